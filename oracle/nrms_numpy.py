@@ -1,0 +1,476 @@
+"""ORACLE -- test infrastructure, NOT product code.
+
+A numpy (float64 by default) restatement of the reference's NRMS / NRMSDocVec
+math, written from SURVEY.md Appendix A.  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this package; the product path (``ebnerd-benchmark_amd/``) never does and
+fails loudly when the HIP library is missing.
+
+PARITY UNPINNED (model math): the reference delegates every arithmetic op of
+this path to TensorFlow/Keras (``tensorflow>=2.12,<2.16``, pyproject.toml:11),
+which is neither vendored under /root/reference nor installable here, and the
+reference has no test, golden vector or known-answer value for any model
+output.  This file therefore restates the published
+semantics of the Keras ops at the reference's call sites; statements that
+depend on Keras behaviour are tagged [KERAS-SEMANTICS].  The evaluation
+metrics, by contrast, ARE pinned against the reference run in this container
+(see oracle/metrics_numpy.py and tests/golden/make_metrics_golden.py).
+
+Every function cites the reference file:line it follows (paths relative to
+/root/reference/src/ebrec/models/newsrec/).
+
+Layout conventions (same as the HIP path):
+  ids   (N, T) int          token ids of N titles
+  X     (N, L, Din)         a batch of N sequences of length L
+  heads are the column blocks [a*d, (a+1)*d) of the E = h*d projection output
+"""
+from __future__ import annotations
+
+import numpy as np
+
+EPS_KERAS = 1e-7  # K.epsilon()  (layers.py:75-77)
+
+# --------------------------------------------------------------------------
+# Counter-based dropout stream shared bit-for-bit with the HIP kernels
+# (csrc/ebn_common.h: ebn_lowbias32 / ebn_dropout_keep).  TF's RNG stream is
+# not reproducible outside TF ("Dropout RNG cannot match
+# TF"), so the build defines its own and tests training-mode parity with it.
+# --------------------------------------------------------------------------
+_U32 = np.uint32
+
+
+def lowbias32(x):
+    x = np.asarray(x, dtype=np.uint32).copy()
+    with np.errstate(over="ignore"):
+        x ^= x >> _U32(16)
+        x *= _U32(0x7FEB352D)
+        x ^= x >> _U32(15)
+        x *= _U32(0x846CA68B)
+        x ^= x >> _U32(16)
+    return x
+
+
+def dropout_key(seed: int, step: int, site: int) -> int:
+    """One 32-bit key per (model seed, optimizer step, dropout call site)."""
+    with np.errstate(over="ignore"):
+        k = lowbias32(_U32(seed & 0xFFFFFFFF) ^ _U32(0x9E3779B9))
+        k = k + _U32(step & 0xFFFFFFFF) * _U32(0x85EBCA6B) + _U32(site & 0xFFFFFFFF) * _U32(0xC2B2AE35)
+        k = lowbias32(k)
+    return int(k)
+
+
+def dropout_threshold(p: float) -> int:
+    return int(min(max(int(p * 4294967296.0), 0), 4294967295))
+
+
+def dropout_keep_mask(key: int, n_elem: int, p: float, start: int = 0) -> np.ndarray:
+    """keep[i] for flat element index start+i; an element is dropped with prob p."""
+    idx = np.arange(start, start + n_elem, dtype=np.uint64)
+    lo = (idx & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    hi = (idx >> np.uint64(32)).astype(np.uint32)
+    with np.errstate(over="ignore"):
+        h = lowbias32(lo ^ _U32(key))
+        h = lowbias32(h + hi * _U32(0x27D4EB2F) + _U32(0x165667B1))
+    return h >= _U32(dropout_threshold(p))
+
+
+def dropout_apply(x: np.ndarray, key: int, p: float):
+    """Inverted dropout (nrms.py:136,154) [KERAS-SEMANTICS: scale 1/(1-p)]."""
+    if p <= 0.0:
+        return x, None
+    keep = dropout_keep_mask(key, x.size, p).reshape(x.shape)
+    scale = x.dtype.type(np.float32(1.0) / np.float32(1.0 - p)) if x.dtype == np.float32 else 1.0 / (1.0 - p)
+    m = keep.astype(x.dtype) * scale
+    return x * m, m
+
+
+# --------------------------------------------------------------------------
+# initialisers  [KERAS-SEMANTICS]
+# --------------------------------------------------------------------------
+def glorot_uniform(shape, rng: np.random.Generator, dtype=np.float64):
+    fan_in, fan_out = shape[0], shape[-1]
+    lim = np.sqrt(6.0 / (fan_in + fan_out))
+    return rng.uniform(-lim, lim, size=shape).astype(dtype)
+
+
+def init_nrms_params(V, D, h, d, A, seed=0, dtype=np.float64, table=None):
+    """13 arrays in the A.6 interchange order.  Quirk 5 (layers.py:155-172,38,50):
+    with a seed, WQ/WK/WV of one layer share one GlorotUniform(seed) draw."""
+    E = h * d
+    r = lambda: np.random.default_rng(seed)
+    P = {}
+    P["emb"] = glorot_uniform((V, D), np.random.default_rng(seed + 1), dtype) if table is None else np.asarray(table, dtype)
+    w = glorot_uniform((D, E), r(), dtype)
+    P["n_WQ"], P["n_WK"], P["n_WV"] = w.copy(), w.copy(), w.copy()
+    P["n_W"] = glorot_uniform((E, A), r(), dtype)
+    P["n_b"] = np.zeros((A,), dtype)
+    P["n_q"] = glorot_uniform((A, 1), r(), dtype)
+    w = glorot_uniform((E, E), r(), dtype)
+    P["u_WQ"], P["u_WK"], P["u_WV"] = w.copy(), w.copy(), w.copy()
+    P["u_W"] = glorot_uniform((E, A), r(), dtype)
+    P["u_b"] = np.zeros((A,), dtype)
+    P["u_q"] = glorot_uniform((A, 1), r(), dtype)
+    return P
+
+
+def random_nrms_params(V, D, h, d, A, seed=0, dtype=np.float64, scale=1.0):
+    """Independent random weights (breaks the WQ=WK=WV symmetry so that a
+    Q/K/V mix-up in a kernel cannot hide)."""
+    rng = np.random.default_rng(seed)
+    E = h * d
+    P = {"emb": glorot_uniform((V, D), rng, dtype) * (3.0 * scale)}
+    for pre, din in (("n", D), ("u", E)):
+        for nm in ("WQ", "WK", "WV"):
+            P[f"{pre}_{nm}"] = glorot_uniform((din, E), rng, dtype) * (2.0 * scale)
+        P[f"{pre}_W"] = glorot_uniform((E, A), rng, dtype) * (2.0 * scale)
+        P[f"{pre}_b"] = (rng.standard_normal(A) * 0.1).astype(dtype)
+        P[f"{pre}_q"] = glorot_uniform((A, 1), rng, dtype) * (2.0 * scale)
+    return P
+
+
+PARAM_ORDER = ["emb", "n_WQ", "n_WK", "n_WV", "n_W", "n_b", "n_q",
+               "u_WQ", "u_WK", "u_WV", "u_W", "u_b", "u_q"]
+
+
+# --------------------------------------------------------------------------
+# A.1 Embedding (nrms.py:125-134): plain row gather, no mask_zero.
+# --------------------------------------------------------------------------
+def embedding_fwd(ids, table):
+    ids = np.asarray(ids)
+    if ids.size and (ids.min() < 0 or ids.max() >= table.shape[0]):
+        raise IndexError("token id out of range for the embedding table")
+    return table[ids]
+
+
+def embedding_bwd(ids, dX, V):
+    dT = np.zeros((V, dX.shape[-1]), dX.dtype)
+    np.add.at(dT, np.asarray(ids).reshape(-1), dX.reshape(-1, dX.shape[-1]))
+    return dT
+
+
+# --------------------------------------------------------------------------
+# A.2 SelfAttention (layers.py:200-254).  Quirks: no bias, no output
+# projection (155-172); O = softmax(QK^T/sqrt(d))^T . V (249, adjoint_a=True);
+# no mask (209-211, 186-187).
+# --------------------------------------------------------------------------
+def self_attention_fwd(X, WQ, WK, WV, h, d):
+    N, L, _ = X.shape
+    Q = X @ WQ  # layers.py:214
+    K = X @ WK  # layers.py:220
+    V = X @ WV  # layers.py:226
+    Qh = Q.reshape(N, L, h, d).transpose(0, 2, 1, 3)  # layers.py:215-218
+    Kh = K.reshape(N, L, h, d).transpose(0, 2, 1, 3)
+    Vh = V.reshape(N, L, h, d).transpose(0, 2, 1, 3)
+    inv = X.dtype.type(1.0) / np.sqrt(X.dtype.type(d))
+    S = (Qh @ Kh.transpose(0, 1, 3, 2)) * inv  # layers.py:231-233
+    S = S - S.max(axis=-1, keepdims=True)
+    P = np.exp(S)
+    P = P / P.sum(axis=-1, keepdims=True)  # K.softmax, last axis; layers.py:247
+    Oh = P.transpose(0, 1, 3, 2) @ Vh  # P^T V; layers.py:249
+    O = Oh.transpose(0, 2, 1, 3).reshape(N, L, h * d)  # layers.py:250-252
+    return O, (X, WQ, WK, WV, Qh, Kh, Vh, P, h, d)
+
+
+def self_attention_bwd(dO, cache):
+    X, WQ, WK, WV, Qh, Kh, Vh, P, h, d = cache
+    N, L, _ = X.shape
+    inv = X.dtype.type(1.0) / np.sqrt(X.dtype.type(d))
+    dOh = dO.reshape(N, L, h, d).transpose(0, 2, 1, 3)  # (N,h,L(j),d)
+    dVh = P @ dOh  # dV[i] = sum_j P[i,j] dO[j]
+    dP = Vh @ dOh.transpose(0, 1, 3, 2)  # dP[i,j] = V[i].dO[j]
+    dS = P * (dP - (P * dP).sum(axis=-1, keepdims=True))
+    dQh = (dS @ Kh) * inv
+    dKh = (dS.transpose(0, 1, 3, 2) @ Qh) * inv
+    back = lambda Z: Z.transpose(0, 2, 1, 3).reshape(N * L, h * d)
+    dQ, dK, dV = back(dQh), back(dKh), back(dVh)
+    X2 = X.reshape(N * L, -1)
+    dWQ, dWK, dWV = X2.T @ dQ, X2.T @ dK, X2.T @ dV
+    dX = (dQ @ WQ.T + dK @ WK.T + dV @ WV.T).reshape(X.shape)
+    return dX, dWQ, dWK, dWV
+
+
+# --------------------------------------------------------------------------
+# A.3 AttLayer2 (layers.py:55-81).  Quirk 4: exp without max-subtraction and
+# a +1e-7 in the denominator (layers.py:71-77).
+# --------------------------------------------------------------------------
+def att_layer2_fwd(X, W, b, q):
+    U = np.tanh(X @ W + b)  # layers.py:65
+    e = (U @ q)[..., 0]  # layers.py:66-68
+    a = np.exp(e)  # layers.py:71
+    w = a / (a.sum(axis=-1, keepdims=True) + X.dtype.type(EPS_KERAS))  # layers.py:75-77
+    out = (X * w[..., None]).sum(axis=1)  # layers.py:79-81
+    return out, (X, W, q, U, w)
+
+
+def att_layer2_bwd(dout, cache):
+    X, W, q, U, w = cache
+    N, L, E = X.shape
+    dw = (X * dout[:, None, :]).sum(-1)  # (N,L)
+    de = w * (dw - (w * dw).sum(-1, keepdims=True))
+    dU = de[..., None] * q[:, 0]
+    dq = (U * de[..., None]).sum((0, 1))[:, None]
+    dpre = dU * (1 - U * U)
+    db = dpre.sum((0, 1))
+    dW = X.reshape(N * L, E).T @ dpre.reshape(N * L, -1)
+    dX = w[..., None] * dout[:, None, :] + dpre @ W.T
+    return dX, dW, db, dq
+
+
+# --------------------------------------------------------------------------
+# A.4 wiring (nrms.py:92-210)
+# --------------------------------------------------------------------------
+class Drop:
+    """Dropout spec for one optimizer step: p, model seed, step."""
+
+    def __init__(self, p, seed, step):
+        self.p, self.seed, self.step = float(p), int(seed), int(step)
+
+    def key(self, site):
+        return dropout_key(self.seed, self.step, site)
+
+
+SITE_NEWS_IN, SITE_NEWS_ATT = 0, 1
+SITE_MLP0 = 8  # DocVec / optional NRMS MLP: site 8 + layer index
+
+
+def news_encoder_fwd(ids, P, h, d, drop: Drop | None = None):
+    """nrms.py:116-159 (units_per_layer=None branch)."""
+    X = embedding_fwd(ids, P["emb"])  # nrms.py:134
+    m0 = m1 = None
+    if drop is not None and drop.p > 0:
+        X, m0 = dropout_apply(X, drop.key(SITE_NEWS_IN), drop.p)  # nrms.py:136
+    O, c_sa = self_attention_fwd(X, P["n_WQ"], P["n_WK"], P["n_WV"], h, d)  # nrms.py:137-139
+    Y = O
+    if drop is not None and drop.p > 0:
+        Y, m1 = dropout_apply(O, drop.key(SITE_NEWS_ATT), drop.p)  # nrms.py:154
+    out, c_al = att_layer2_fwd(Y, P["n_W"], P["n_b"], P["n_q"])  # nrms.py:156
+    return out, (ids, m0, m1, c_sa, c_al, O, Y)
+
+
+def news_encoder_bwd(dout, cache, V, need_emb_grad=True):
+    ids, m0, m1, c_sa, c_al, _, _ = cache
+    dY, dW, db, dq = att_layer2_bwd(dout, c_al)
+    dO = dY if m1 is None else dY * m1
+    dX, dWQ, dWK, dWV = self_attention_bwd(dO, c_sa)
+    if m0 is not None:
+        dX = dX * m0
+    g = {"n_WQ": dWQ, "n_WK": dWK, "n_WV": dWV, "n_W": dW, "n_b": db, "n_q": dq}
+    if need_emb_grad:
+        g["emb"] = embedding_bwd(ids, dX, V)
+    return g
+
+
+def user_encoder_from_news_fwd(NEh, P, h, d):
+    """nrms.py:108-111 on already-encoded history (B,H,E)."""
+    O, c_sa = self_attention_fwd(NEh, P["u_WQ"], P["u_WK"], P["u_WV"], h, d)
+    out, c_al = att_layer2_fwd(O, P["u_W"], P["u_b"], P["u_q"])
+    return out, (c_sa, c_al)
+
+
+def user_encoder_from_news_bwd(duser, cache):
+    c_sa, c_al = cache
+    dO, dW, db, dq = att_layer2_bwd(duser, c_al)
+    dNEh, dWQ, dWK, dWV = self_attention_bwd(dO, c_sa)
+    return dNEh, {"u_WQ": dWQ, "u_WK": dWK, "u_WV": dWV, "u_W": dW, "u_b": db, "u_q": dq}
+
+
+def softmax_rows(s):
+    s = s - s.max(-1, keepdims=True)
+    e = np.exp(s)
+    return e / e.sum(-1, keepdims=True)
+
+
+def sigmoid(x):
+    return 1.0 / (1.0 + np.exp(-x))
+
+
+def nrms_forward(his, pred, P, h, d, drop: Drop | None = None):
+    """model: softmax_c(news(pred) . user(his))  (nrms.py:195-202).  Returns
+    (probs (B,C), scores (B,C), cache)."""
+    B, H, T = his.shape
+    C = pred.shape[1]
+    ids = np.concatenate([his.reshape(B * H, T), pred.reshape(B * C, T)], 0)
+    NE, c_news = news_encoder_fwd(ids, P, h, d, drop)
+    NEh = NE[: B * H].reshape(B, H, -1)
+    NEc = NE[B * H:].reshape(B, C, -1)
+    user, c_user = user_encoder_from_news_fwd(NEh, P, h, d)
+    s = np.einsum("bce,be->bc", NEc, user)  # Dot(axes=-1), nrms.py:201
+    return softmax_rows(s), s, (B, H, C, c_news, c_user, NEc, user)
+
+
+def scorer_forward(his, pred_one, P, h, d):
+    """scorer: sigmoid(news(pred_one) . user(his)) -> (B,1)  (nrms.py:204-205)."""
+    _, s, _ = nrms_forward(his, pred_one, P, h, d, None)
+    return sigmoid(s)
+
+
+# A.5 losses [KERAS-SEMANTICS, unverified]: both Keras cross-entropies recover
+# the cached logits of the softmax Activation (output._keras_logits).
+def loss_fwd_bwd(s, y, kind="cross_entropy_loss"):
+    """Returns (loss, dL/ds).  nrms.py:56-67."""
+    y = np.asarray(y, dtype=s.dtype)
+    B, C = s.shape
+    if kind == "cross_entropy_loss":  # categorical_crossentropy on logits
+        m = s.max(-1, keepdims=True)
+        lse = m + np.log(np.exp(s - m).sum(-1, keepdims=True))
+        logp = s - lse
+        L = -(y * logp).sum(-1).mean()
+        ds = (np.exp(logp) * y.sum(-1, keepdims=True) - y) / B
+        return L, ds
+    if kind == "log_loss":  # binary_crossentropy -> sigmoid CE on the logits
+        L = (np.maximum(s, 0) - s * y + np.log1p(np.exp(-np.abs(s)))).mean()
+        ds = (sigmoid(s) - y) / (B * C)
+        return L, ds
+    raise ValueError(f"this loss not defined {kind}")
+
+
+def nrms_loss_and_grads(his, pred, y, P, h, d, loss="cross_entropy_loss",
+                        drop: Drop | None = None, need_emb_grad=True):
+    probs, s, cache = nrms_forward(his, pred, P, h, d, drop)
+    B, H, C, c_news, c_user, NEc, user = cache
+    L, ds = loss_fwd_bwd(s, y, loss)
+    dNEc = ds[..., None] * user[:, None, :]
+    duser = np.einsum("bc,bce->be", ds, NEc)
+    dNEh, g_user = user_encoder_from_news_bwd(duser, c_user)
+    dNE = np.concatenate([dNEh.reshape(B * H, -1), dNEc.reshape(B * C, -1)], 0)
+    g = news_encoder_bwd(dNE, c_news, P["emb"].shape[0], need_emb_grad)
+    g.update(g_user)
+    return L, probs, g
+
+
+def adam_keras_step(theta, g, m, v, t, lr=1e-4, b1=0.9, b2=0.999, eps=1e-7):
+    """Keras>=2.11 Adam (A.5) [KERAS-SEMANTICS]: eps added to sqrt(v) before the
+    bias correction is folded into the step size.  t starts at 1.  In place."""
+    dt = theta.dtype.type
+    m += (g - m) * dt(1 - b1)
+    v += (g * g - v) * dt(1 - b2)
+    alpha = dt(lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t))
+    theta -= alpha * m / (np.sqrt(v) + dt(eps))
+
+
+# --------------------------------------------------------------------------
+# NRMSDocVec (nrms_docvec.py:99-188)
+# --------------------------------------------------------------------------
+BN_EPS, BN_MOM = 1e-3, 0.99  # Keras BatchNormalization defaults [KERAS-SEMANTICS]
+
+
+def init_docvec_params(Din, units, h, d, A, seed=0, dtype=np.float64, randomize_bn=False):
+    rng = np.random.default_rng(seed)
+    E = h * d
+    P = {"units": list(units)}
+    prev = Din
+    for l, u in enumerate(units):
+        P[f"d{l}_W"] = glorot_uniform((prev, u), rng, dtype)
+        P[f"d{l}_b"] = (rng.standard_normal(u) * (0.1 if randomize_bn else 0.0)).astype(dtype)
+        P[f"bn{l}_g"] = (1 + 0.1 * rng.standard_normal(u) * randomize_bn).astype(dtype)
+        P[f"bn{l}_b"] = (0.1 * rng.standard_normal(u) * randomize_bn).astype(dtype)
+        P[f"bn{l}_mean"] = np.zeros(u, dtype)
+        P[f"bn{l}_var"] = np.ones(u, dtype)
+        prev = u
+    P["out_W"] = glorot_uniform((prev, E), rng, dtype)
+    P["out_b"] = (rng.standard_normal(E) * (0.1 if randomize_bn else 0.0)).astype(dtype)
+    for nm in ("WQ", "WK", "WV"):
+        P[f"u_{nm}"] = glorot_uniform((E, E), rng, dtype)
+    P["u_W"] = glorot_uniform((E, A), rng, dtype)
+    P["u_b"] = np.zeros(A, dtype)
+    P["u_q"] = glorot_uniform((A, 1), rng, dtype)
+    return P
+
+
+def docvec_news_encoder_fwd(X, P, training=False, drop: Drop | None = None, site_offset=0,
+                            row_offset=0):
+    """nrms_docvec.py:113-135.  X (R, Din) = all rows of ONE call site (batch
+    statistics are per call site [KERAS-SEMANTICS]).  Returns out, cache, and the
+    new moving statistics (list of (mean, var)) when training."""
+    caches, new_stats = [], []
+    x = X
+    for l, u in enumerate(P["units"]):
+        pre = x @ P[f"d{l}_W"] + P[f"d{l}_b"]
+        r = np.maximum(pre, 0)  # Dense(relu), nrms_docvec.py:116-122
+        if training:
+            mu, var = r.mean(0), r.var(0)  # biased batch variance
+            new_stats.append((mu, var))
+        else:
+            mu, var = P[f"bn{l}_mean"], P[f"bn{l}_var"]
+        istd = 1.0 / np.sqrt(var + x.dtype.type(BN_EPS))
+        xh = (r - mu) * istd
+        bn = xh * P[f"bn{l}_g"] + P[f"bn{l}_b"]  # nrms_docvec.py:123
+        msk = None
+        y = bn
+        if training and drop is not None and drop.p > 0:  # nrms_docvec.py:124
+            keep = dropout_keep_mask(drop.key(SITE_MLP0 + l + site_offset), bn.size, drop.p,
+                                     start=row_offset * u).reshape(bn.shape)
+            msk = keep.astype(bn.dtype) * (1.0 / (1.0 - drop.p))
+            y = bn * msk
+        caches.append((x, pre, xh, istd, msk))
+        x = y
+    pre = x @ P["out_W"] + P["out_b"]
+    out = np.maximum(pre, 0)  # nrms_docvec.py:130
+    return out, (caches, x, pre, training), new_stats
+
+
+def docvec_news_encoder_bwd(dout, cache, P):
+    caches, xl, pre, training = cache
+    g = {}
+    dpre = dout * (pre > 0)
+    g["out_W"] = xl.T @ dpre
+    g["out_b"] = dpre.sum(0)
+    dx = dpre @ P["out_W"].T
+    for l in reversed(range(len(P["units"]))):
+        x, pre_l, xh, istd, msk = caches[l]
+        if msk is not None:
+            dx = dx * msk
+        g[f"bn{l}_g"] = (dx * xh).sum(0)
+        g[f"bn{l}_b"] = dx.sum(0)
+        dxh = dx * P[f"bn{l}_g"]
+        if training:
+            R = x.shape[0]
+            dr = istd / R * (R * dxh - dxh.sum(0) - xh * (dxh * xh).sum(0))
+        else:
+            dr = dxh * istd
+        dpre_l = dr * (pre_l > 0)
+        g[f"d{l}_W"] = x.T @ dpre_l
+        g[f"d{l}_b"] = dpre_l.sum(0)
+        dx = dpre_l @ P[f"d{l}_W"].T
+    return g, dx
+
+
+def docvec_forward(his, pred, P, h, d, training=False, drop: Drop | None = None):
+    """nrms_docvec.py:139-188: his (B,H,Din), pred (B,C,Din) float."""
+    B, H, Din = his.shape
+    C = pred.shape[1]
+    # two call sites -> two sets of batch statistics (TimeDistributed at 88-90 and 176-178)
+    NEh, ch, st_h = docvec_news_encoder_fwd(his.reshape(B * H, Din), P, training, drop, 0, 0)
+    NEc, cc, st_c = docvec_news_encoder_fwd(pred.reshape(B * C, Din), P, training, drop, 0, B * H)
+    user, c_user = user_encoder_from_news_fwd(NEh.reshape(B, H, -1), P, h, d)
+    NEc3 = NEc.reshape(B, C, -1)
+    s = np.einsum("bce,be->bc", NEc3, user)
+    return softmax_rows(s), s, (B, H, C, ch, cc, c_user, NEc3, user, st_h, st_c)
+
+
+def docvec_loss_and_grads(his, pred, y, P, h, d, loss="cross_entropy_loss", l2=0.0,
+                          training=True, drop: Drop | None = None):
+    probs, s, cache = docvec_forward(his, pred, P, h, d, training, drop)
+    B, H, C, ch, cc, c_user, NEc3, user, st_h, st_c = cache
+    L, ds = loss_fwd_bwd(s, y, loss)
+    dNEc = (ds[..., None] * user[:, None, :]).reshape(B * C, -1)
+    duser = np.einsum("bc,bce->be", ds, NEc3)
+    dNEh, g = user_encoder_from_news_bwd(duser, c_user)
+    g_h, _ = docvec_news_encoder_bwd(dNEh.reshape(B * H, -1), ch, P)
+    g_c, _ = docvec_news_encoder_bwd(dNEc, cc, P)
+    for k in g_h:
+        g[k] = g_h[k] + g_c[k]
+    # kernel_regularizer=l2(lambda) on the hidden Dense kernels only (116-122; not 130)
+    for l in range(len(P["units"])):
+        W = P[f"d{l}_W"]
+        L = L + l2 * (W * W).sum()
+        g[f"d{l}_W"] = g[f"d{l}_W"] + 2 * l2 * W
+    return L, probs, g, (st_h, st_c)
+
+
+def bn_update_moving(P, stats_seq):
+    """moving = moving*0.99 + batch*0.01, one update per call site, in call order."""
+    for stats in stats_seq:
+        for l, (mu, var) in enumerate(stats):
+            P[f"bn{l}_mean"] = P[f"bn{l}_mean"] * BN_MOM + mu * (1 - BN_MOM)
+            P[f"bn{l}_var"] = P[f"bn{l}_var"] * BN_MOM + var * (1 - BN_MOM)
