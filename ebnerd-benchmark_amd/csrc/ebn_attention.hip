@@ -1,0 +1,294 @@
+// a3 / a6: core of the reference SelfAttention layer after the Q/K/V projections
+// (layers.py:231-252): S = QK^T/sqrt(d), P = softmax_rows(S), O = P^T V  -- the TRANSPOSED
+// attention matrix multiplies V (adjoint_a=True, layers.py:249); no mask (layers.py:209-211).
+//
+// Sequences are tiny (L = title_size 30 or history_size 20..50, d = 16/20), so one
+// (sequence, head) problem is an L x L tile that lives in LDS next to its Q/K/V tiles; this
+// is latency/LDS-bound VALU work (6 % of the projection FLOPs), not MFMA work.  One 64-lane
+// wave per workgroup; when L <= 32 the two 32-lane halves of the wave work on two independent
+// (sequence, head) problems (ds_read_b32 serves the halves as separate lane groups, so their
+// broadcast reads never conflict).  Lane i owns row i of S/P (softmax + dQ/dV), lane j owns
+// column j (O, dK): row accesses use an odd row stride, column accesses are unit-stride.
+#include "ebn_common.h"
+
+namespace {
+
+constexpr int DMAX = 32;  // head_dim <= 32 (reference configs: 20, 16)
+
+struct AttnArgs {
+  const float* qkv;
+  int64_t ld_qkv;
+  const float* dout;  // bwd only
+  int64_t ld_dout;
+  float* out;  // fwd: out, bwd: dqkv
+  int64_t ld_out;
+  int64_t n_prob;  // n_seq * h
+  int32_t L, h, d;
+  const uint32_t* key_ptr;
+  uint32_t thresh;
+  float scale;
+};
+
+// cooperative tile load by the GW lanes of one group: tile[l*d + c] = src[(row0+l)*ld + col0 + c]
+template <int GW>
+__device__ __forceinline__ void load_tile(float* __restrict__ tile, const float* __restrict__ src,
+                                          int64_t ld, int64_t row0, int col0, int L, int d, int gl) {
+  const int n = L * d;
+  for (int e = gl; e < n; e += GW) {
+    const int l = e / d;
+    const int c = e - l * d;
+    tile[e] = src[(row0 + l) * ld + col0 + c];
+  }
+}
+
+// Computes normalised P (row-major, stride LP) for one problem; lane gl = row i.
+template <int GW>
+__device__ __forceinline__ void softmax_scores(const float* __restrict__ sQ, const float* __restrict__ sK,
+                                               float* __restrict__ sP, int L, int LP, int d, int gl) {
+  if (gl < L) {
+    float q[DMAX];
+#pragma unroll
+    for (int c = 0; c < DMAX; ++c) q[c] = (c < d) ? sQ[gl * d + c] : 0.f;
+    const float inv = 1.0f / sqrtf(static_cast<float>(d));
+    float mx = -INFINITY;
+    for (int j = 0; j < L; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < DMAX; ++c)
+        if (c < d) s = fmaf(q[c], sK[j * d + c], s);
+      s *= inv;
+      sP[gl * LP + j] = s;
+      mx = fmaxf(mx, s);
+    }
+    float sum = 0.f;
+    for (int j = 0; j < L; ++j) {
+      const float p = expf(sP[gl * LP + j] - mx);
+      sP[gl * LP + j] = p;
+      sum += p;
+    }
+    for (int j = 0; j < L; ++j) sP[gl * LP + j] = sP[gl * LP + j] / sum;
+  }
+}
+
+template <int GW>
+__global__ __launch_bounds__(64) void attn_fwd_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int G = 64 / GW;
+  const int lane = threadIdx.x;
+  const int g = lane / GW;
+  const int gl = lane % GW;
+  const int L = a.L, d = a.d;
+  const int LP = (L & 1) ? L + 2 : L + 1;  // odd row stride
+  const int tile = L * d;
+  const int per_group = 3 * tile + L * LP;
+  float* base = smem + g * per_group;
+  float* sQ = base;
+  float* sK = base + tile;
+  float* sV = base + 2 * tile;
+  float* sP = base + 3 * tile;
+
+  const int64_t prob = static_cast<int64_t>(blockIdx.x) * G + g;
+  const bool active = prob < a.n_prob;
+  const int64_t seq = active ? prob / a.h : 0;
+  const int head = active ? static_cast<int>(prob - seq * a.h) : 0;
+  const int E = a.h * d;
+  const int64_t row0 = seq * L;
+  if (active) {
+    load_tile<GW>(sQ, a.qkv, a.ld_qkv, row0, head * d, L, d, gl);
+    load_tile<GW>(sK, a.qkv, a.ld_qkv, row0, E + head * d, L, d, gl);
+    load_tile<GW>(sV, a.qkv, a.ld_qkv, row0, 2 * E + head * d, L, d, gl);
+  }
+  __syncthreads();
+  if (active) softmax_scores<GW>(sQ, sK, sP, L, LP, d, gl);
+  __syncthreads();
+  if (active && gl < L) {
+    const int j = gl;
+    float o[DMAX];
+#pragma unroll
+    for (int c = 0; c < DMAX; ++c) o[c] = 0.f;
+    for (int i = 0; i < L; ++i) {
+      const float p = sP[i * LP + j];
+#pragma unroll
+      for (int c = 0; c < DMAX; ++c)
+        if (c < d) o[c] = fmaf(p, sV[i * d + c], o[c]);
+    }
+    const bool do_drop = a.key_ptr != nullptr;
+    const uint32_t key = do_drop ? *a.key_ptr : 0u;
+    float* dst = a.out + (row0 + j) * a.ld_out + head * d;
+    const uint64_t e0 = static_cast<uint64_t>(row0 + j) * E + head * d;  // logical (n,l,e) index
+#pragma unroll
+    for (int c = 0; c < DMAX; ++c) {
+      if (c < d) {
+        float v = o[c];
+        if (do_drop) v *= ebn_drop_mult(key, e0 + c, a.thresh, a.scale);
+        dst[c] = v;
+      }
+    }
+  }
+}
+
+template <int GW>
+__global__ __launch_bounds__(64) void attn_bwd_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int G = 64 / GW;
+  const int lane = threadIdx.x;
+  const int g = lane / GW;
+  const int gl = lane % GW;
+  const int L = a.L, d = a.d;
+  const int LP = (L & 1) ? L + 2 : L + 1;
+  const int tile = L * d;
+  const int per_group = 4 * tile + 2 * L * LP;
+  float* base = smem + g * per_group;
+  float* sQ = base;
+  float* sK = base + tile;
+  float* sV = base + 2 * tile;
+  float* sG = base + 3 * tile;  // dO (after dropout mask)
+  float* sP = base + 4 * tile;
+  float* sD = sP + L * LP;  // dP then dS
+
+  const int64_t prob = static_cast<int64_t>(blockIdx.x) * G + g;
+  const bool active = prob < a.n_prob;
+  const int64_t seq = active ? prob / a.h : 0;
+  const int head = active ? static_cast<int>(prob - seq * a.h) : 0;
+  const int E = a.h * d;
+  const int64_t row0 = seq * L;
+  const float inv = 1.0f / sqrtf(static_cast<float>(d));
+  if (active) {
+    load_tile<GW>(sQ, a.qkv, a.ld_qkv, row0, head * d, L, d, gl);
+    load_tile<GW>(sK, a.qkv, a.ld_qkv, row0, E + head * d, L, d, gl);
+    load_tile<GW>(sV, a.qkv, a.ld_qkv, row0, 2 * E + head * d, L, d, gl);
+    const bool do_drop = a.key_ptr != nullptr;
+    const uint32_t key = do_drop ? *a.key_ptr : 0u;
+    for (int e = gl; e < tile; e += GW) {
+      const int l = e / d;
+      const int c = e - l * d;
+      float v = a.dout[(row0 + l) * a.ld_dout + head * d + c];
+      if (do_drop) v *= ebn_drop_mult(key, static_cast<uint64_t>(row0 + l) * E + head * d + c, a.thresh, a.scale);
+      sG[e] = v;
+    }
+  }
+  __syncthreads();
+  if (active) softmax_scores<GW>(sQ, sK, sP, L, LP, d, gl);
+  __syncthreads();
+  float* dq_dst = a.out;  // dqkv
+  if (active && gl < L) {
+    const int i = gl;
+    // dV[i,:] = sum_j P[i,j] dO[j,:]
+    float acc[DMAX];
+#pragma unroll
+    for (int c = 0; c < DMAX; ++c) acc[c] = 0.f;
+    for (int j = 0; j < L; ++j) {
+      const float p = sP[i * LP + j];
+#pragma unroll
+      for (int c = 0; c < DMAX; ++c)
+        if (c < d) acc[c] = fmaf(p, sG[j * d + c], acc[c]);
+    }
+    float* dv = dq_dst + (row0 + i) * a.ld_out + 2 * E + head * d;
+#pragma unroll
+    for (int c = 0; c < DMAX; ++c)
+      if (c < d) dv[c] = acc[c];
+    // dP[i,j] = V[i,:].dO[j,:] ; dS = P*(dP - sum_j P dP)
+    float v[DMAX];
+#pragma unroll
+    for (int c = 0; c < DMAX; ++c) v[c] = (c < d) ? sV[i * d + c] : 0.f;
+    float rowdot = 0.f;
+    for (int j = 0; j < L; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < DMAX; ++c)
+        if (c < d) s = fmaf(v[c], sG[j * d + c], s);
+      sD[i * LP + j] = s;
+      rowdot = fmaf(sP[i * LP + j], s, rowdot);
+    }
+    for (int j = 0; j < L; ++j) sD[i * LP + j] = sP[i * LP + j] * (sD[i * LP + j] - rowdot);
+    // dQ[i,:] = inv * sum_j dS[i,j] K[j,:]
+#pragma unroll
+    for (int c = 0; c < DMAX; ++c) acc[c] = 0.f;
+    for (int j = 0; j < L; ++j) {
+      const float s = sD[i * LP + j];
+#pragma unroll
+      for (int c = 0; c < DMAX; ++c)
+        if (c < d) acc[c] = fmaf(s, sK[j * d + c], acc[c]);
+    }
+    float* dq = dq_dst + (row0 + i) * a.ld_out + head * d;
+#pragma unroll
+    for (int c = 0; c < DMAX; ++c)
+      if (c < d) dq[c] = acc[c] * inv;
+  }
+  __syncthreads();
+  if (active && gl < L) {
+    const int j = gl;
+    // dK[j,:] = inv * sum_i dS[i,j] Q[i,:]
+    float acc[DMAX];
+#pragma unroll
+    for (int c = 0; c < DMAX; ++c) acc[c] = 0.f;
+    for (int i = 0; i < L; ++i) {
+      const float s = sD[i * LP + j];
+#pragma unroll
+      for (int c = 0; c < DMAX; ++c)
+        if (c < d) acc[c] = fmaf(s, sQ[i * d + c], acc[c]);
+    }
+    float* dk = dq_dst + (row0 + j) * a.ld_out + E + head * d;
+#pragma unroll
+    for (int c = 0; c < DMAX; ++c)
+      if (c < d) dk[c] = acc[c] * inv;
+  }
+}
+
+int check_attn_args(const void* qkv, const void* out, int64_t n_seq, int32_t L, int32_t h, int32_t d) {
+  EBN_REQUIRE(qkv && out, EBN_ERR_BAD_ARG);
+  EBN_REQUIRE(n_seq >= 0 && L > 0 && h > 0 && d > 0, EBN_ERR_BAD_ARG);
+  EBN_REQUIRE(L <= 64 && d <= DMAX, EBN_ERR_UNSUPPORTED);
+  return EBN_OK;
+}
+
+}  // namespace
+
+extern "C" int ebn_attn_fwd_f32(const float* qkv, int64_t ld_qkv, float* out, int64_t ld_out, int64_t n_seq,
+                                int32_t L, int32_t h, int32_t d, const ebn_step_state* st, int32_t site,
+                                float drop_p, ebn_stream_t stream) {
+  int rc = check_attn_args(qkv, out, n_seq, L, h, d);
+  if (rc != EBN_OK) return rc;
+  if (n_seq == 0) return EBN_OK;
+  EBN_REQUIRE(ld_qkv >= 3 * h * d && ld_out >= h * d, EBN_ERR_BAD_ARG);
+  const EbnDrop dr = ebn_make_drop(st, site, drop_p);
+  AttnArgs a{qkv, ld_qkv, nullptr, 0, out, ld_out, n_seq * h, L, h, d, dr.key_ptr, dr.thresh, dr.scale};
+  const int LP = (L & 1) ? L + 2 : L + 1;
+  const int per_group = 3 * L * d + L * LP;
+  EBN_REQUIRE(static_cast<size_t>((L <= 32 ? 2 : 1) * per_group) * sizeof(float) <= 65536, EBN_ERR_UNSUPPORTED);
+  if (L <= 32) {
+    const int64_t grid = ebn_ceil_div(a.n_prob, 2);
+    hipLaunchKernelGGL(attn_fwd_kernel<32>, dim3(static_cast<unsigned>(grid)), dim3(64),
+                       2 * per_group * sizeof(float), ebn_stream(stream), a);
+  } else {
+    hipLaunchKernelGGL(attn_fwd_kernel<64>, dim3(static_cast<unsigned>(a.n_prob)), dim3(64),
+                       per_group * sizeof(float), ebn_stream(stream), a);
+  }
+  EBN_CHECK_LAUNCH();
+  return EBN_OK;
+}
+
+extern "C" int ebn_attn_bwd_f32(const float* qkv, int64_t ld_qkv, const float* dout, int64_t ld_dout,
+                                float* dqkv, int64_t ld_dqkv, int64_t n_seq, int32_t L, int32_t h, int32_t d,
+                                const ebn_step_state* st, int32_t site, float drop_p, ebn_stream_t stream) {
+  int rc = check_attn_args(qkv, dqkv, n_seq, L, h, d);
+  if (rc != EBN_OK) return rc;
+  EBN_REQUIRE(dout, EBN_ERR_BAD_ARG);
+  if (n_seq == 0) return EBN_OK;
+  EBN_REQUIRE(ld_qkv >= 3 * h * d && ld_dqkv >= 3 * h * d && ld_dout >= h * d, EBN_ERR_BAD_ARG);
+  const EbnDrop dr = ebn_make_drop(st, site, drop_p);
+  AttnArgs a{qkv, ld_qkv, dout, ld_dout, dqkv, ld_dqkv, n_seq * h, L, h, d, dr.key_ptr, dr.thresh, dr.scale};
+  const int LP = (L & 1) ? L + 2 : L + 1;
+  const int per_group = 4 * L * d + 2 * L * LP;
+  EBN_REQUIRE(static_cast<size_t>((L <= 32 ? 2 : 1) * per_group) * sizeof(float) <= 65536, EBN_ERR_UNSUPPORTED);
+  if (L <= 32) {
+    const int64_t grid = ebn_ceil_div(a.n_prob, 2);
+    hipLaunchKernelGGL(attn_bwd_kernel<32>, dim3(static_cast<unsigned>(grid)), dim3(64),
+                       2 * per_group * sizeof(float), ebn_stream(stream), a);
+  } else {
+    hipLaunchKernelGGL(attn_bwd_kernel<64>, dim3(static_cast<unsigned>(a.n_prob)), dim3(64),
+                       per_group * sizeof(float), ebn_stream(stream), a);
+  }
+  EBN_CHECK_LAUNCH();
+  return EBN_OK;
+}

@@ -1,0 +1,144 @@
+// a1: title-token embedding gather (+ fused inverted dropout) and its backward scatter.
+// Replaces tf.keras.layers.Embedding at nrms.py:125-134 and Dropout at nrms.py:136.
+//
+// HBM-bound: per token the kernel reads 4 B of id + D*4 B of table row and writes D*4 B.
+// Work items are 16-byte vectors; consecutive lanes take consecutive vectors of a row so a
+// wave covers whole 128-B lines of the (V x D) table; each thread keeps UNROLL independent
+// row loads in flight before the first store (random rows -> latency-bound otherwise).
+#include "ebn_common.h"
+
+namespace {
+
+constexpr int GATHER_THREADS = 256;
+constexpr int GATHER_UNROLL = 4;
+
+__global__ __launch_bounds__(GATHER_THREADS) void gather_rows_vec4_kernel(
+    const int32_t* __restrict__ ids, const float4* __restrict__ table, float4* __restrict__ out,
+    int64_t n_items, int32_t vpr, int64_t V, const uint32_t* __restrict__ key_ptr, uint32_t thresh,
+    float scale, int32_t* __restrict__ oob_flag) {
+  const int64_t base = (static_cast<int64_t>(blockIdx.x) * GATHER_UNROLL) * GATHER_THREADS + threadIdx.x;
+  const bool do_drop = key_ptr != nullptr;
+  const uint32_t key = do_drop ? *key_ptr : 0u;
+  float4 v[GATHER_UNROLL];
+  int64_t item[GATHER_UNROLL];
+  bool ok[GATHER_UNROLL];
+#pragma unroll
+  for (int u = 0; u < GATHER_UNROLL; ++u) {
+    item[u] = base + static_cast<int64_t>(u) * GATHER_THREADS;
+    ok[u] = item[u] < n_items;
+    v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok[u]) {
+      const int64_t row = item[u] / vpr;
+      const int32_t col = static_cast<int32_t>(item[u] - row * vpr);
+      const int64_t id = ids[row];
+      if (id >= 0 && id < V) {
+        v[u] = table[id * vpr + col];
+      } else if (oob_flag != nullptr) {
+        *oob_flag = 1;
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < GATHER_UNROLL; ++u) {
+    if (!ok[u]) continue;
+    if (do_drop) {
+      const uint64_t e0 = static_cast<uint64_t>(item[u]) * 4u;
+      v[u].x *= ebn_drop_mult(key, e0 + 0, thresh, scale);
+      v[u].y *= ebn_drop_mult(key, e0 + 1, thresh, scale);
+      v[u].z *= ebn_drop_mult(key, e0 + 2, thresh, scale);
+      v[u].w *= ebn_drop_mult(key, e0 + 3, thresh, scale);
+    }
+    out[item[u]] = v[u];
+  }
+}
+
+// D not a multiple of 4 (or unaligned base): one float per work item.
+__global__ __launch_bounds__(GATHER_THREADS) void gather_rows_scalar_kernel(
+    const int32_t* __restrict__ ids, const float* __restrict__ table, float* __restrict__ out,
+    int64_t n_items, int32_t D, int64_t V, const uint32_t* __restrict__ key_ptr, uint32_t thresh,
+    float scale, int32_t* __restrict__ oob_flag) {
+  const bool do_drop = key_ptr != nullptr;
+  const uint32_t key = do_drop ? *key_ptr : 0u;
+  for (int64_t it = static_cast<int64_t>(blockIdx.x) * GATHER_THREADS + threadIdx.x; it < n_items;
+       it += static_cast<int64_t>(gridDim.x) * GATHER_THREADS) {
+    const int64_t row = it / D;
+    const int32_t col = static_cast<int32_t>(it - row * D);
+    const int64_t id = ids[row];
+    float x = 0.f;
+    if (id >= 0 && id < V) {
+      x = table[id * D + col];
+    } else if (oob_flag != nullptr) {
+      *oob_flag = 1;
+    }
+    if (do_drop) x *= ebn_drop_mult(key, static_cast<uint64_t>(it), thresh, scale);
+    out[it] = x;
+  }
+}
+
+// Backward: dense dTable[ids[r],:] += dX[r,:]*mult. Hardware fp32 atomics (global_atomic_add_f32);
+// hot rows (token 0 of padded history) serialise in L2, not in HBM.
+__global__ __launch_bounds__(GATHER_THREADS) void scatter_add_rows_kernel(
+    const int32_t* __restrict__ ids, const float* __restrict__ dX, float* __restrict__ dTable,
+    int64_t n_items, int32_t D, int64_t V, const uint32_t* __restrict__ key_ptr, uint32_t thresh,
+    float scale) {
+  const bool do_drop = key_ptr != nullptr;
+  const uint32_t key = do_drop ? *key_ptr : 0u;
+  for (int64_t it = static_cast<int64_t>(blockIdx.x) * GATHER_THREADS + threadIdx.x; it < n_items;
+       it += static_cast<int64_t>(gridDim.x) * GATHER_THREADS) {
+    const int64_t row = it / D;
+    const int32_t col = static_cast<int32_t>(it - row * D);
+    const int64_t id = ids[row];
+    if (id < 0 || id >= V) continue;
+    float g = dX[it];
+    if (do_drop) g *= ebn_drop_mult(key, static_cast<uint64_t>(it), thresh, scale);
+    if (g != 0.f) unsafeAtomicAdd(&dTable[id * D + col], g);
+  }
+}
+
+}  // namespace
+
+extern "C" int ebn_gather_rows_f32(const int32_t* ids, const float* table, float* out, int64_t n_tok,
+                                   int32_t D, int64_t V, const ebn_step_state* st, int32_t site,
+                                   float drop_p, int32_t* oob_flag, ebn_stream_t stream) {
+  EBN_REQUIRE(ids && table && out, EBN_ERR_BAD_ARG);
+  EBN_REQUIRE(n_tok >= 0 && D > 0 && V > 0, EBN_ERR_BAD_ARG);
+  if (n_tok == 0) return EBN_OK;
+  const EbnDrop dr = ebn_make_drop(st, site, drop_p);
+  if ((D % 4) == 0 && ebn_aligned16(table) && ebn_aligned16(out)) {
+    const int32_t vpr = D / 4;
+    const int64_t n_items = n_tok * vpr;
+    const int64_t per_block = static_cast<int64_t>(GATHER_THREADS) * GATHER_UNROLL;
+    const int64_t grid = ebn_ceil_div(n_items, per_block);
+    EBN_REQUIRE(grid <= 0x7FFFFFFF, EBN_ERR_UNSUPPORTED);
+    hipLaunchKernelGGL(gather_rows_vec4_kernel, dim3(static_cast<unsigned>(grid)), dim3(GATHER_THREADS),
+                       0, ebn_stream(stream), ids, reinterpret_cast<const float4*>(table),
+                       reinterpret_cast<float4*>(out), n_items, vpr, V, dr.key_ptr, dr.thresh, dr.scale,
+                       oob_flag);
+  } else {
+    const int64_t n_items = n_tok * D;
+    int64_t grid = ebn_ceil_div(n_items, GATHER_THREADS);
+    if (grid > 256 * 32) grid = 256 * 32;
+    hipLaunchKernelGGL(gather_rows_scalar_kernel, dim3(static_cast<unsigned>(grid)), dim3(GATHER_THREADS),
+                       0, ebn_stream(stream), ids, table, out, n_items, D, V, dr.key_ptr, dr.thresh,
+                       dr.scale, oob_flag);
+  }
+  EBN_CHECK_LAUNCH();
+  return EBN_OK;
+}
+
+extern "C" int ebn_embedding_grad_scatter_f32(const int32_t* ids, const float* dX, float* dTable,
+                                              int64_t n_tok, int32_t D, int64_t V,
+                                              const ebn_step_state* st, int32_t site, float drop_p,
+                                              ebn_stream_t stream) {
+  EBN_REQUIRE(ids && dX && dTable, EBN_ERR_BAD_ARG);
+  EBN_REQUIRE(n_tok >= 0 && D > 0 && V > 0, EBN_ERR_BAD_ARG);
+  if (n_tok == 0) return EBN_OK;
+  const EbnDrop dr = ebn_make_drop(st, site, drop_p);
+  const int64_t n_items = n_tok * D;
+  int64_t grid = ebn_ceil_div(n_items, GATHER_THREADS);
+  if (grid > 256 * 32) grid = 256 * 32;
+  hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(static_cast<unsigned>(grid)), dim3(GATHER_THREADS), 0,
+                     ebn_stream(stream), ids, dX, dTable, n_items, D, V, dr.key_ptr, dr.thresh, dr.scale);
+  EBN_CHECK_LAUNCH();
+  return EBN_OK;
+}

@@ -1,0 +1,68 @@
+// Stage-level composition: SelfAttention + AttLayer2 over a batch of sequences, forward and
+// backward -- the news encoder after its gather (nrms.py:137-156) and the user encoder
+// (nrms.py:108-111).  Host code only: enqueues the kernels of the other translation units on
+// the caller's stream in dependency order; no allocation, no sync (hipGraph-capturable).
+#include "ebn_common.h"
+
+#define EBN_TRY(call)            \
+  do {                           \
+    int rc__ = (call);           \
+    if (rc__ != EBN_OK) return rc__; \
+  } while (0)
+
+static int check_dims(const ebn_encoder_dims* d) {
+  EBN_REQUIRE(d, EBN_ERR_BAD_ARG);
+  EBN_REQUIRE(d->n_seq >= 0 && d->L > 0 && d->Din > 0 && d->h > 0 && d->d > 0 && d->A > 0, EBN_ERR_BAD_ARG);
+  return EBN_OK;
+}
+
+extern "C" int ebn_encoder_fwd_f32(const ebn_encoder_dims* dims, const ebn_encoder_params* p,
+                                   const ebn_encoder_acts* a, const ebn_step_state* st, ebn_stream_t stream) {
+  EBN_TRY(check_dims(dims));
+  EBN_REQUIRE(p && a && p->Wqkv && p->W && p->b && p->q, EBN_ERR_BAD_ARG);
+  EBN_REQUIRE(a->X && a->QKV && a->Y && a->U && a->w && a->out, EBN_ERR_BAD_ARG);
+  const int64_t R = dims->n_seq * dims->L;
+  const int E = dims->h * dims->d;
+  if (R == 0) return EBN_OK;
+  // Q|K|V = X.Wqkv   (layers.py:214,220,226)
+  EBN_TRY(ebn_gemm_f32(0, 0, R, 3 * E, dims->Din, 1.0f, a->X, dims->Din, p->Wqkv, 3 * E, 0.0f, a->QKV, 3 * E, stream));
+  // Y = dropout(P^T V)   (layers.py:231-252, nrms.py:154)
+  EBN_TRY(ebn_attn_fwd_f32(a->QKV, 3 * E, a->Y, E, dims->n_seq, dims->L, dims->h, dims->d, st, dims->drop_site,
+                           dims->drop_p, stream));
+  // U = Y.W ; AttLayer2 tail   (layers.py:65-81)
+  EBN_TRY(ebn_gemm_f32(0, 0, R, dims->A, E, 1.0f, a->Y, E, p->W, dims->A, 0.0f, a->U, dims->A, stream));
+  EBN_TRY(ebn_attpool_fwd_f32(a->U, p->b, p->q, a->Y, a->out, a->w, dims->n_seq, dims->L, E, dims->A, stream));
+  return EBN_OK;
+}
+
+extern "C" int ebn_encoder_bwd_f32(const ebn_encoder_dims* dims, const ebn_encoder_params* p,
+                                   const ebn_encoder_acts* a, const float* dout, const ebn_encoder_grads* g,
+                                   const ebn_encoder_scratch* s, float* dX, int32_t accumulate,
+                                   const ebn_step_state* st, ebn_stream_t stream) {
+  EBN_TRY(check_dims(dims));
+  EBN_REQUIRE(p && a && g && s && dout, EBN_ERR_BAD_ARG);
+  EBN_REQUIRE(p->Wqkv && p->W && p->q, EBN_ERR_BAD_ARG);
+  EBN_REQUIRE(a->X && a->QKV && a->Y && a->U && a->w, EBN_ERR_BAD_ARG);
+  EBN_REQUIRE(g->dWqkv && g->dW && g->db && g->dq, EBN_ERR_BAD_ARG);
+  EBN_REQUIRE(s->dY && s->dQKV && s->de && s->partials, EBN_ERR_BAD_ARG);
+  const int64_t R = dims->n_seq * dims->L;
+  const int E = dims->h * dims->d;
+  const int A = dims->A;
+  if (R == 0) return EBN_OK;
+  const float beta = accumulate ? 1.0f : 0.0f;
+  // AttLayer2 backward: dY = w*dout, de; then dq, db and U <- d(pre-tanh)
+  EBN_TRY(ebn_attpool_bwd_pool_f32(a->Y, a->w, dout, s->dY, s->de, dims->n_seq, dims->L, E, stream));
+  EBN_TRY(ebn_attpool_bwd_dpre_f32(a->U, p->q, s->de, g->dq, g->db, s->partials, R, A, accumulate, stream));
+  // dW = Y^T . dpre ; dY += dpre . W^T
+  EBN_TRY(ebn_gemm_f32_ws(1, 0, E, A, R, 1.0f, a->Y, E, a->U, A, beta, g->dW, A, s->gemm_ws, s->gemm_ws_floats, stream));
+  EBN_TRY(ebn_gemm_f32(0, 1, R, E, A, 1.0f, a->U, A, p->W, A, 1.0f, s->dY, E, stream));
+  // self-attention core backward (re-derives the dropout mask of Y)
+  EBN_TRY(ebn_attn_bwd_f32(a->QKV, 3 * E, s->dY, E, s->dQKV, 3 * E, dims->n_seq, dims->L, dims->h, dims->d, st,
+                           dims->drop_site, dims->drop_p, stream));
+  // dWqkv = X^T . dQKV ; dX = dQKV . Wqkv^T
+  EBN_TRY(ebn_gemm_f32_ws(1, 0, dims->Din, 3 * E, R, 1.0f, a->X, dims->Din, s->dQKV, 3 * E, beta, g->dWqkv, 3 * E,
+                          s->gemm_ws, s->gemm_ws_floats, stream));
+  if (dX != nullptr)
+    EBN_TRY(ebn_gemm_f32(0, 1, R, dims->Din, 3 * E, 1.0f, s->dQKV, 3 * E, p->Wqkv, 3 * E, 0.0f, dX, dims->Din, stream));
+  return EBN_OK;
+}

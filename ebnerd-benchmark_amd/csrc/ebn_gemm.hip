@@ -1,0 +1,307 @@
+// Exact-fp32 MFMA GEMM for the projection matmuls of the hot path
+// (K.dot at layers.py:65,214,220,226; Dense at nrms_docvec.py:116,130; and their backward).
+//
+//   C[M,N] = alpha * op(A)[M,K] * op(B)[K,N] + beta * C       (row-major)
+//
+// MFMA-bound (v_mfma_f32_32x32x2_f32: 64 cycles / 4096 FLOP per SIMD -> 157 TFLOP/s chip
+// peak, bitwise an fp32 fma chain -> keeps the 1e-4 parity budget of north_star).
+// Block tile BM x BN x 16, 4 waves as 2x2, each wave (BM/2)x(BN/2) in 32x32 MFMA tiles.
+// Operands are staged k-major in LDS ([k][m] / [k][n], +4 pad) so that the MFMA operand
+// fetch (lane l: A[i=l&31][k=l>>5]) is a conflict-free ds_read_b32; the next K-slab is
+// prefetched into registers while the current one is multiplied (2 LDS buffers, one
+// barrier per slab).  Skinny outputs (weight gradients: M,N ~ 1e3, K ~ 2e4) use split-K with
+// deterministic slab partials in the caller's workspace -- never atomics.
+#include "ebn_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 16;
+constexpr int PAD = 4;
+constexpr int GEMM_THREADS = 256;
+
+// One operand tile of R_MN x BK (mn = m or n index). KCONTIG: memory is [mn][k] (k fastest);
+// else memory is [k][mn] (mn fastest).
+template <int BMN, bool KCONTIG>
+struct TileLoader {
+  static constexpr int VECS = BMN * BK / 4;            // float4 per tile
+  static constexpr int PER_THREAD = VECS / GEMM_THREADS;  // 2 (BMN=128) or 1 (BMN=64)
+  static_assert(VECS % GEMM_THREADS == 0, "tile/thread mismatch");
+
+  // returns 4 consecutive elements along the contiguous axis (guarded, zero-filled)
+  __device__ static __forceinline__ float4 load(const float* __restrict__ P, int64_t ld, int64_t mn0,
+                                                int64_t k0, int64_t MN, int64_t Kdim, int v, bool vec_ok) {
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (KCONTIG) {
+      const int mn = v / (BK / 4);
+      const int kq = v % (BK / 4);
+      const int64_t gmn = mn0 + mn;
+      const int64_t gk = k0 + kq * 4;
+      if (gmn < MN) {
+        const float* p = P + gmn * ld + gk;
+        if (vec_ok && gk + 3 < Kdim) {
+          r = *reinterpret_cast<const float4*>(p);
+        } else {
+          if (gk + 0 < Kdim) r.x = p[0];
+          if (gk + 1 < Kdim) r.y = p[1];
+          if (gk + 2 < Kdim) r.z = p[2];
+          if (gk + 3 < Kdim) r.w = p[3];
+        }
+      }
+    } else {
+      const int k = v / (BMN / 4);
+      const int mq = v % (BMN / 4);
+      const int64_t gk = k0 + k;
+      const int64_t gmn = mn0 + mq * 4;
+      if (gk < Kdim) {
+        const float* p = P + gk * ld + gmn;
+        if (vec_ok && gmn + 3 < MN) {
+          r = *reinterpret_cast<const float4*>(p);
+        } else {
+          if (gmn + 0 < MN) r.x = p[0];
+          if (gmn + 1 < MN) r.y = p[1];
+          if (gmn + 2 < MN) r.z = p[2];
+          if (gmn + 3 < MN) r.w = p[3];
+        }
+      }
+    }
+    return r;
+  }
+
+  // LDS image: S[k][mn], row stride BMN+PAD
+  __device__ static __forceinline__ void store(float* __restrict__ S, int v, float4 r) {
+    constexpr int LD = BMN + PAD;
+    if (KCONTIG) {
+      const int mn = v / (BK / 4);
+      const int kq = v % (BK / 4);
+      S[(kq * 4 + 0) * LD + mn] = r.x;
+      S[(kq * 4 + 1) * LD + mn] = r.y;
+      S[(kq * 4 + 2) * LD + mn] = r.z;
+      S[(kq * 4 + 3) * LD + mn] = r.w;
+    } else {
+      const int k = v / (BMN / 4);
+      const int mq = v % (BMN / 4);
+      *reinterpret_cast<float4*>(&S[k * LD + mq * 4]) = r;
+    }
+  }
+};
+
+// TA: A stored [K,M]; TB: B stored [N,K].
+// gridDim.z = split-K factor; when > 1 each z-slice writes alpha*partial to
+// Cpart + z*M*N (dense ld = N) and a reduce kernel finishes; else writes C directly.
+template <int BM, int BN, bool TA, bool TB>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
+    int64_t M, int64_t N, int64_t K, float alpha, const float* __restrict__ A, int64_t lda,
+    const float* __restrict__ B, int64_t ldb, float beta, float* __restrict__ C, int64_t ldc,
+    int vecA, int vecB, int64_t k_per_split, float* __restrict__ Cpart) {
+  constexpr int TM = BM / 64;  // 32x32 tiles per wave along m
+  constexpr int TN = BN / 64;
+  constexpr int LDA_S = BM + PAD;
+  constexpr int LDB_S = BN + PAD;
+  using LA = TileLoader<BM, !TA>;
+  using LB = TileLoader<BN, TB>;
+
+  __shared__ __attribute__((aligned(16))) float As[2][BK * LDA_S];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB_S];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1;
+  const int wn = wave & 1;
+  const int64_t m0 = static_cast<int64_t>(blockIdx.y) * BM;
+  const int64_t n0 = static_cast<int64_t>(blockIdx.x) * BN;
+  const int64_t kbeg = static_cast<int64_t>(blockIdx.z) * k_per_split;
+  const int64_t kend = (kbeg + k_per_split < K) ? (kbeg + k_per_split) : K;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra[LA::PER_THREAD], rb[LB::PER_THREAD];
+  const int nk = static_cast<int>((kend - kbeg + BK - 1) / BK);
+
+  // prologue: slab 0 -> LDS buffer 0
+  if (nk > 0) {
+#pragma unroll
+    for (int i = 0; i < LA::PER_THREAD; ++i)
+      ra[i] = LA::load(A, lda, m0, kbeg, M, kend, tid + i * GEMM_THREADS, vecA);
+#pragma unroll
+    for (int i = 0; i < LB::PER_THREAD; ++i)
+      rb[i] = LB::load(B, ldb, n0, kbeg, N, kend, tid + i * GEMM_THREADS, vecB);
+#pragma unroll
+    for (int i = 0; i < LA::PER_THREAD; ++i) LA::store(As[0], tid + i * GEMM_THREADS, ra[i]);
+#pragma unroll
+    for (int i = 0; i < LB::PER_THREAD; ++i) LB::store(Bs[0], tid + i * GEMM_THREADS, rb[i]);
+  }
+  __syncthreads();
+
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool has_next = (kt + 1) < nk;
+    if (has_next) {
+      const int64_t k0 = kbeg + static_cast<int64_t>(kt + 1) * BK;
+#pragma unroll
+      for (int i = 0; i < LA::PER_THREAD; ++i)
+        ra[i] = LA::load(A, lda, m0, k0, M, kend, tid + i * GEMM_THREADS, vecA);
+#pragma unroll
+      for (int i = 0; i < LB::PER_THREAD; ++i)
+        rb[i] = LB::load(B, ldb, n0, k0, N, kend, tid + i * GEMM_THREADS, vecB);
+    }
+    const float* as = As[cur];
+    const float* bs = Bs[cur];
+    const int kl = lane >> 5;
+    const int il = lane & 31;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = as[(kk + kl) * LDA_S + wm * (BM / 2) + i * 32 + il];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = bs[(kk + kl) * LDB_S + wn * (BN / 2) + j * 32 + il];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (has_next) {
+#pragma unroll
+      for (int i = 0; i < LA::PER_THREAD; ++i) LA::store(As[cur ^ 1], tid + i * GEMM_THREADS, ra[i]);
+#pragma unroll
+      for (int i = 0; i < LB::PER_THREAD; ++i) LB::store(Bs[cur ^ 1], tid + i * GEMM_THREADS, rb[i]);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // epilogue. C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+  const bool split = gridDim.z > 1;
+  float* out = split ? (Cpart + static_cast<int64_t>(blockIdx.z) * M * N) : C;
+  const int64_t ldo = split ? N : ldc;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int64_t col = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+      if (col >= N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row >= M) continue;
+        float v = alpha * acc[i][j][r];
+        if (!split && beta != 0.f) v += beta * out[row * ldo + col];
+        out[row * ldo + col] = v;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int splits,
+                                                            int64_t M, int64_t N, float beta,
+                                                            float* __restrict__ C, int64_t ldc) {
+  const int64_t total = M * N;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < total;
+       i += static_cast<int64_t>(gridDim.x) * 256) {
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += part[static_cast<int64_t>(z) * total + i];
+    const int64_t row = i / N;
+    const int64_t col = i - row * N;
+    float* c = C + row * ldc + col;
+    *c = (beta != 0.f) ? (s + beta * *c) : s;
+  }
+}
+
+template <int BM, int BN>
+int launch_gemm(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha, const float* A,
+                int64_t lda, const float* B, int64_t ldb, float beta, float* C, int64_t ldc, int vecA,
+                int vecB, int splits, int64_t k_per_split, float* part, hipStream_t s) {
+  dim3 grid(static_cast<unsigned>(ebn_ceil_div(N, BN)), static_cast<unsigned>(ebn_ceil_div(M, BM)),
+            static_cast<unsigned>(splits));
+  dim3 block(GEMM_THREADS);
+#define EBN_GEMM_LAUNCH(TA, TB)                                                                        \
+  hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB>), grid, block, 0, s, M, N, K, alpha, A, lda, B, \
+                     ldb, beta, C, ldc, vecA, vecB, k_per_split, part)
+  if (!transA && !transB) EBN_GEMM_LAUNCH(false, false);
+  else if (!transA && transB) EBN_GEMM_LAUNCH(false, true);
+  else if (transA && !transB) EBN_GEMM_LAUNCH(true, false);
+  else EBN_GEMM_LAUNCH(true, true);
+#undef EBN_GEMM_LAUNCH
+  EBN_CHECK_LAUNCH();
+  return EBN_OK;
+}
+
+}  // namespace
+
+// Split-K plan shared by the workspace query and the launcher.
+static void gemm_plan(int64_t M, int64_t N, int64_t K, int64_t ws_floats, int* bm, int* splits,
+                      int64_t* k_per_split) {
+  int64_t max_split = K / (8 * BK);  // keep >= 8 slabs per split
+  if (max_split > 64) max_split = 64;
+  const int64_t max_by_ws = (M * N > 0) ? ws_floats / (M * N) : 0;
+  if (max_split > max_by_ws) max_split = max_by_ws;
+  if (max_split < 1) max_split = 1;
+  const int64_t tiles128 = ebn_ceil_div(M, 128) * ebn_ceil_div(N, 128);
+  // 128x128 tiles (2x the arithmetic intensity) whenever they can still fill 256 CUs x 2
+  *bm = (tiles128 * max_split >= 512) ? 128 : 64;
+  const int64_t tiles = ebn_ceil_div(M, *bm) * ebn_ceil_div(N, *bm);
+  int64_t s = 1;
+  if (tiles < 512) {
+    s = ebn_ceil_div(1024, tiles);
+    if (s > max_split) s = max_split;
+  }
+  int64_t kps = ebn_ceil_div(ebn_ceil_div(K > 0 ? K : 1, s), BK) * BK;
+  s = ebn_ceil_div(K > 0 ? K : 1, kps);
+  *splits = static_cast<int>(s < 1 ? 1 : s);
+  *k_per_split = kps;
+}
+
+extern "C" int64_t ebn_gemm_workspace_floats(int64_t M, int64_t N, int64_t K) {
+  int bm, s;
+  int64_t kps;
+  gemm_plan(M, N, K, INT64_MAX / 4, &bm, &s, &kps);
+  return (s > 1) ? static_cast<int64_t>(s) * M * N : 0;
+}
+
+extern "C" int ebn_gemm_f32_ws(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K, float alpha,
+                               const float* A, int64_t lda, const float* B, int64_t ldb, float beta,
+                               float* C, int64_t ldc, float* workspace, int64_t workspace_floats,
+                               ebn_stream_t stream) {
+  EBN_REQUIRE(M >= 0 && N >= 0 && K >= 0, EBN_ERR_BAD_ARG);
+  if (M == 0 || N == 0) return EBN_OK;
+  EBN_REQUIRE(A && B && C, EBN_ERR_BAD_ARG);
+  EBN_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, EBN_ERR_BAD_ARG);
+  hipStream_t s = ebn_stream(stream);
+  const int vecA = ((lda % 4) == 0 && ebn_aligned16(A)) ? 1 : 0;
+  const int vecB = ((ldb % 4) == 0 && ebn_aligned16(B)) ? 1 : 0;
+  int bm, splits;
+  int64_t kps;
+  gemm_plan(M, N, K, workspace ? workspace_floats : 0, &bm, &splits, &kps);
+  int rc;
+  if (bm == 128)
+    rc = launch_gemm<128, 128>(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, vecA, vecB,
+                               splits, kps, workspace, s);
+  else
+    rc = launch_gemm<64, 64>(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, vecA, vecB,
+                             splits, kps, workspace, s);
+  if (rc != EBN_OK) return rc;
+  if (splits > 1) {
+    int64_t grid = ebn_ceil_div(M * N, 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(static_cast<unsigned>(grid)), dim3(256), 0, s, workspace,
+                       splits, M, N, beta, C, ldc);
+    EBN_CHECK_LAUNCH();
+  }
+  return EBN_OK;
+}
+
+extern "C" int ebn_gemm_f32(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K, float alpha,
+                            const float* A, int64_t lda, const float* B, int64_t ldb, float beta, float* C,
+                            int64_t ldc, ebn_stream_t stream) {
+  return ebn_gemm_f32_ws(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, nullptr, 0, stream);
+}

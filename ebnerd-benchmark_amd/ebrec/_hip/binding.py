@@ -1,0 +1,131 @@
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+import threading
+from pathlib import Path
+
+_PKG_ROOT = Path(__file__).resolve().parents[2]  # .../ebnerd-benchmark_amd
+_REPO_ROOT = _PKG_ROOT.parent
+
+
+def library_path() -> Path:
+    return Path(os.environ.get("EBNERD_HIP_LIB", _PKG_ROOT / "csrc" / "libebnerd_hip.so"))
+
+
+def header_path() -> Path:
+    return _REPO_ROOT / "include" / "ebnerd_hip.h"
+
+
+class HipError(RuntimeError):
+    pass
+
+
+# ---- struct mirrors of include/ebnerd_hip.h --------------------------------
+EBN_N_SITES = 12
+
+
+class StepState(ctypes.Structure):
+    _fields_ = [("step", ctypes.c_uint32), ("seed", ctypes.c_uint32), ("adam_alpha", ctypes.c_float),
+                ("lr", ctypes.c_float), ("drop_key", ctypes.c_uint32 * EBN_N_SITES)]
+
+
+class EncoderDims(ctypes.Structure):
+    _fields_ = [("n_seq", ctypes.c_int64), ("L", ctypes.c_int32), ("Din", ctypes.c_int32),
+                ("h", ctypes.c_int32), ("d", ctypes.c_int32), ("A", ctypes.c_int32),
+                ("drop_site", ctypes.c_int32), ("drop_p", ctypes.c_float)]
+
+
+class EncoderParams(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ("Wqkv", "W", "b", "q")]
+
+
+class EncoderActs(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ("X", "QKV", "Y", "U", "w", "out")]
+
+
+class EncoderGrads(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ("dWqkv", "dW", "db", "dq")]
+
+
+class EncoderScratch(ctypes.Structure):
+    _fields_ = [("dY", ctypes.c_void_p), ("dQKV", ctypes.c_void_p), ("de", ctypes.c_void_p),
+                ("partials", ctypes.c_void_p), ("gemm_ws", ctypes.c_void_p),
+                ("gemm_ws_floats", ctypes.c_int64)]
+
+
+# ---- header parser -------------------------------------------------------
+_PROTO = re.compile(r"^(int64_t|int|const char\*)\s+(ebn_\w+)\s*\(([^;{}]*?)\)\s*;", re.M | re.S)
+
+
+def _ctype(decl: str):
+    decl = decl.strip()
+    if decl in ("void", ""):
+        return None
+    if "*" in decl or decl.startswith("ebn_stream_t"):
+        return ctypes.c_void_p
+    base = decl.rsplit(" ", 1)[0].replace("const", "").strip()
+    return {"int64_t": ctypes.c_int64, "int32_t": ctypes.c_int32, "int": ctypes.c_int32,
+            "uint32_t": ctypes.c_uint32, "float": ctypes.c_float}[base]
+
+
+def declared_functions() -> dict:
+    """{name: (restype, [argtypes])} for every prototype in ebnerd_hip.h."""
+    text = re.sub(r"/\*.*?\*/", "", header_path().read_text(), flags=re.S)
+    out = {}
+    for ret, name, args in _PROTO.findall(text):
+        argt = [t for t in (_ctype(a) for a in args.replace("\n", " ").split(",")) if t is not None]
+        res = {"int": ctypes.c_int32, "int64_t": ctypes.c_int64, "const char*": ctypes.c_char_p}[ret]
+        out[name] = (res, argt)
+    return out
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib() -> ctypes.CDLL:
+    """Load (once) and type the C-ABI library.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            path = library_path()
+            if not path.exists():
+                raise HipError(
+                    f"{path} not found: the MI355X HIP extension is not built. Run "
+                    "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C "
+                    "ebnerd-benchmark_amd/csrc`). There is no CPU fallback for the model path.")
+            handle = ctypes.CDLL(str(path))
+            for name, (res, argt) in declared_functions().items():
+                fn = getattr(handle, name)  # AttributeError -> header/library mismatch
+                fn.restype = res
+                fn.argtypes = argt
+            if handle.ebn_abi_version() != 1:
+                raise HipError("libebnerd_hip.so ABI version mismatch")
+            _lib = handle
+    return _lib
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_handle():
+    import torch
+
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def call(name: str, *args):
+    """Invoke an int-returning entry point; raise HipError on a non-zero code."""
+    handle = lib()
+    rc = getattr(handle, name)(*args)
+    if rc != 0:
+        msg = handle.ebn_error_string(rc)
+        raise HipError(f"{name} failed with code {rc}: {msg.decode() if msg else '?'}")

@@ -1,0 +1,242 @@
+/*
+ * ebnerd_hip.h -- C ABI of the MI355X (gfx950) NRMS / NRMSDocVec hot path.
+ *
+ * The reference (ebanalyse/ebnerd-benchmark) has no FFI: its hot path is Python
+ * calling TensorFlow ops.  This header is the boundary a maintainer would bind
+ * instead (ctypes stub in INTEGRATION.md).  Every entry point names the reference
+ * interface it replaces (paths relative to src/ebrec/models/newsrec/).
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers owned by the caller (e.g. torch tensors'
+ *     data_ptr()); all matrices are row-major fp32 unless stated otherwise;
+ *   - `stream` is a hipStream_t passed as void*; calls only ENQUEUE work on it and
+ *     return immediately (no host sync, no allocation -> hipGraph-capturable);
+ *   - return 0 on success, a positive hipError_t from the launch, or a negative
+ *     EBN_ERR_* argument code (the host layer raises on non-zero);
+ *   - no global mutable state: re-entrant, callable from several host threads on
+ *     different streams;
+ *   - step-dependent scalars (Adam step size, dropout keys) live in a DEVICE
+ *     `ebn_step_state` so a captured graph replays with fresh values.
+ */
+#ifndef EBNERD_HIP_H
+#define EBNERD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EBN_ABI_VERSION 1
+
+#define EBN_OK 0
+#define EBN_ERR_BAD_ARG (-1)     /* null pointer / negative size */
+#define EBN_ERR_UNSUPPORTED (-2) /* shape outside what the kernels are built for */
+#define EBN_ERR_ALIGN (-3)       /* pointer or leading dimension not 16-byte friendly */
+
+typedef void* ebn_stream_t;
+
+/* Dropout call sites (keys in ebn_step_state.drop_key). nrms.py:136 / nrms.py:154 /
+ * nrms_docvec.py:124 (site EBN_SITE_MLP0 + layer). */
+#define EBN_SITE_NEWS_IN 0
+#define EBN_SITE_NEWS_ATT 1
+#define EBN_SITE_MLP0 8
+#define EBN_N_SITES 12
+
+/* 64-byte device-resident per-step state. */
+typedef struct ebn_step_state {
+  uint32_t step;       /* optimizer step t, 1-based after the first advance */
+  uint32_t seed;       /* model seed (NRMSModel(seed=...), nrms.py:33) */
+  float adam_alpha;    /* lr*sqrt(1-b2^t)/(1-b1^t), refreshed by ebn_step_advance */
+  float lr;            /* current learning rate (ReduceLROnPlateau rewrites it) */
+  uint32_t drop_key[EBN_N_SITES];
+} ebn_step_state;
+
+int ebn_abi_version(void);
+const char* ebn_error_string(int code);
+
+/* step++ ; adam_alpha and the dropout keys for the new step. One tiny kernel. */
+int ebn_step_advance(ebn_step_state* st, float beta1, float beta2, ebn_stream_t stream);
+
+/* ---- a1  tf.keras.layers.Embedding (nrms.py:125-134) ---------------------------
+ * out[r,:] = table[ids[r],:] (* inverted-dropout multiplier of nrms.py:136 when
+ * drop_p > 0 and st != NULL).  ids outside [0,V) write a zero row and set *oob_flag
+ * (may be NULL) to 1: the host layer turns that into an IndexError.               */
+int ebn_gather_rows_f32(const int32_t* ids, const float* table, float* out, int64_t n_tok,
+                        int32_t D, int64_t V, const ebn_step_state* st, int32_t site,
+                        float drop_p, int32_t* oob_flag, ebn_stream_t stream);
+
+/* Backward of a1: dTable[ids[r],:] += dX[r,:] * dropout multiplier. dTable must be
+ * zeroed by the caller (dense gradient, Keras-Adam dense semantics).   */
+int ebn_embedding_grad_scatter_f32(const int32_t* ids, const float* dX, float* dTable,
+                                   int64_t n_tok, int32_t D, int64_t V,
+                                   const ebn_step_state* st, int32_t site, float drop_p,
+                                   ebn_stream_t stream);
+
+/* ---- K.dot / Dense matmuls (layers.py:65,214,220,226; nrms_docvec.py:116,130) ----
+ * C[M,N] = alpha * op(A)[M,K] * op(B)[K,N] + beta * C, exact-fp32 MFMA
+ * (v_mfma_f32_32x32x2_f32). transA=0: A is [M,K] (lda>=K); transA=1: A is [K,M].
+ * transB=0: B is [K,N]; transB=1: B is [N,K].                                      */
+int ebn_gemm_f32(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K, float alpha,
+                 const float* A, int64_t lda, const float* B, int64_t ldb, float beta, float* C,
+                 int64_t ldc, ebn_stream_t stream);
+/* Same, with a caller-owned scratch buffer that enables deterministic split-K for skinny
+ * outputs (weight gradients: M,N ~ 1e3, K = all tokens of the batch).
+ * ebn_gemm_workspace_floats() returns the size the planner can use for (M,N,K).        */
+int64_t ebn_gemm_workspace_floats(int64_t M, int64_t N, int64_t K);
+int ebn_gemm_f32_ws(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K, float alpha,
+                    const float* A, int64_t lda, const float* B, int64_t ldb, float beta, float* C,
+                    int64_t ldc, float* workspace, int64_t workspace_floats, ebn_stream_t stream);
+
+/* ---- a3/a6  SelfAttention core (layers.py:231-252) -------------------------------
+ * qkv [n_seq*L, ld_qkv] holds Q | K | V in column blocks [0,E) [E,2E) [2E,3E), E=h*d.
+ * out[n,j,a*d+c] = sum_i softmax_j'(Q_i.K_j'/sqrt(d))[i,j] * V[i,c]   (P^T V, line 249)
+ * times the dropout multiplier of nrms.py:154 when drop_p > 0.                      */
+int ebn_attn_fwd_f32(const float* qkv, int64_t ld_qkv, float* out, int64_t ld_out, int64_t n_seq,
+                     int32_t L, int32_t h, int32_t d, const ebn_step_state* st, int32_t site,
+                     float drop_p, ebn_stream_t stream);
+/* dqkv (same layout as qkv) from d(out); the dropout multiplier is re-derived.     */
+int ebn_attn_bwd_f32(const float* qkv, int64_t ld_qkv, const float* dout, int64_t ld_dout,
+                     float* dqkv, int64_t ld_dqkv, int64_t n_seq, int32_t L, int32_t h, int32_t d,
+                     const ebn_step_state* st, int32_t site, float drop_p, ebn_stream_t stream);
+
+/* ---- a4/a7  AttLayer2 (layers.py:55-81) after the x.W matmul ----------------------
+ * fwd: U <- tanh(U + b) in place ([R,A], R = n_seq*L); e = U.q; a = exp(e);
+ *      w = a/(sum_l a + 1e-7); out[n,:] = sum_l w[n,l] X[n,l,:].                    */
+int ebn_attpool_fwd_f32(float* U, const float* b, const float* q, const float* X, float* out,
+                        float* w, int64_t n_seq, int32_t L, int32_t E, int32_t A,
+                        ebn_stream_t stream);
+/* bwd step 1: dX[n,l,:] = w[n,l]*dout[n,:]; de[n,l] = w (dw - sum w dw), dw = dout.X */
+int ebn_attpool_bwd_pool_f32(const float* X, const float* w, const float* dout, float* dX,
+                             float* de, int64_t n_seq, int32_t L, int32_t E,
+                             ebn_stream_t stream);
+/* bwd step 2: dq[k] = sum_r de[r] U[r,k]; U <- dpre = de*q*(1-U^2) in place;
+ * db[k] = sum_r dpre[r,k].  `partials` is scratch of ebn_attpool_partials_len(R, A)
+ * floats; dq/db are ACCUMULATED into when accumulate != 0 (else overwritten).       */
+int64_t ebn_attpool_partials_len(int64_t R, int32_t A);
+int ebn_attpool_bwd_dpre_f32(float* U, const float* q, const float* de, float* dq, float* db,
+                             float* partials, int64_t R, int32_t A, int32_t accumulate,
+                             ebn_stream_t stream);
+
+/* ---- stage level: SelfAttention + AttLayer2 over a batch of sequences -----------------
+ * The news encoder after its embedding gather (nrms.py:137-156, L = title_size,
+ * Din = word_emb_dim) and the user encoder after TimeDistributed(news encoder)
+ * (nrms.py:108-111, L = history_size, Din = E) are the same stage:
+ *   QKV = X.Wqkv ; Y = drop(P^T V) ; U = tanh(Y.W + b) ; w = exp(U.q)/(sum+1e-7) ; out = sum w Y
+ * Wqkv is [Din, 3E] = WQ | WK | WV side by side (layers.py:155-172 have no bias).
+ * All activation buffers are caller-allocated and are what the backward needs.          */
+typedef struct ebn_encoder_dims {
+  int64_t n_seq; /* sequences in this call */
+  int32_t L;     /* sequence length */
+  int32_t Din;   /* input feature width */
+  int32_t h, d;  /* heads, head width; E = h*d */
+  int32_t A;     /* attention_hidden_dim */
+  int32_t drop_site; /* EBN_SITE_* of the dropout after self-attention, or -1 */
+  float drop_p;
+} ebn_encoder_dims;
+
+typedef struct ebn_encoder_params {
+  const float* Wqkv; /* [Din, 3E] */
+  const float* W;    /* [E, A]  */
+  const float* b;    /* [A]     */
+  const float* q;    /* [A]     */
+} ebn_encoder_params;
+
+typedef struct ebn_encoder_acts {
+  const float* X; /* [R, Din] input rows, R = n_seq*L */
+  float* QKV;     /* [R, 3E] */
+  float* Y;       /* [R, E]  (after dropout) */
+  float* U;       /* [R, A]  tanh output */
+  float* w;       /* [R]     attention weights */
+  float* out;     /* [n_seq, E] */
+} ebn_encoder_acts;
+
+typedef struct ebn_encoder_grads {
+  float* dWqkv; /* [Din, 3E] */
+  float* dW;    /* [E, A] */
+  float* db;    /* [A] */
+  float* dq;    /* [A] */
+} ebn_encoder_grads;
+
+typedef struct ebn_encoder_scratch {
+  float* dY;    /* [R, E]  */
+  float* dQKV;  /* [R, 3E] */
+  float* de;    /* [R]     */
+  float* partials;        /* ebn_attpool_partials_len(R, A) floats */
+  float* gemm_ws;         /* split-K scratch, may be NULL */
+  int64_t gemm_ws_floats;
+} ebn_encoder_scratch;
+
+int ebn_encoder_fwd_f32(const ebn_encoder_dims* dims, const ebn_encoder_params* params,
+                        const ebn_encoder_acts* acts, const ebn_step_state* st,
+                        ebn_stream_t stream);
+/* dout [n_seq, E] -> parameter gradients (accumulated when accumulate != 0) and, when dX is
+ * non-NULL, dX [R, Din] (overwritten).  acts->U is consumed (overwritten with d(pre-tanh)). */
+int ebn_encoder_bwd_f32(const ebn_encoder_dims* dims, const ebn_encoder_params* params,
+                        const ebn_encoder_acts* acts, const float* dout,
+                        const ebn_encoder_grads* grads, const ebn_encoder_scratch* scratch,
+                        float* dX, int32_t accumulate, const ebn_step_state* st,
+                        ebn_stream_t stream);
+
+/* ---- a8/a9  Dot + softmax/sigmoid + loss (nrms.py:201-205, 56-67) ------------------
+ * scores[b,c] = cand[b,c,:].user[b,:]; probs = softmax_c (mode 0) or sigmoid (mode 1). */
+int ebn_score_fwd_f32(const float* cand, const float* user, float* scores, float* probs,
+                      int64_t B, int32_t C, int32_t E, int32_t mode, ebn_stream_t stream);
+/* loss_kind 0: categorical CE on the softmax logits; 1: sigmoid CE on the same logits
+ * ([KERAS-SEMANTICS] _keras_logits path).  Writes loss_rows[b] (already divided so that
+ * sum_b loss_rows = batch loss), dscores, dcand[b,c,:], duser[b,:].                   */
+int ebn_score_loss_bwd_f32(const float* cand, const float* user, const float* scores,
+                           const float* labels, float* loss_rows, float* dcand, float* duser,
+                           int64_t B, int32_t C, int32_t E, int32_t loss_kind, float inv_batch,
+                           ebn_stream_t stream);
+/* ragged scoring for the eval path (dataloader.py:94-107 + nrms.py:204-205):
+ * out[p] = act(user[u_idx[p],:] . news[n_idx[p],:]), act = sigmoid (mode 1) or id (0). */
+int ebn_pair_score_f32(const float* user, const float* news, const int32_t* u_idx,
+                       const int32_t* n_idx, float* out, int64_t n_pairs, int32_t E, int32_t mode,
+                       ebn_stream_t stream);
+
+/* ---- a10  tf.keras.optimizers.Adam (nrms.py:69-80), Keras update form -------------
+ * m += (g-m)(1-b1); v += (g^2-v)(1-b2); theta -= alpha_t * m/(sqrt(v)+eps), dense over
+ * n elements; g is multiplied by grad_scale first (1/world_size after an all-reduce sum). */
+int ebn_adam_keras_step_f32(float* theta, const float* g, float* m, float* v, int64_t n,
+                            const ebn_step_state* st, float beta1, float beta2, float eps,
+                            float grad_scale, ebn_stream_t stream);
+
+/* ---- small dense helpers used by the DocVec encoder (nrms_docvec.py:113-135) ------- */
+/* Y = relu(X + bias) row-wise, in place allowed (Dense(relu)).                        */
+int ebn_bias_relu_f32(const float* X, const float* bias, float* Y, int64_t R, int32_t Ccols,
+                      ebn_stream_t stream);
+/* dX = dY * (Y > 0); dbias[c] = sum_r dX[r,c] (partials scratch: ebn_colsum_partials_len). */
+int64_t ebn_colsum_partials_len(int64_t R, int32_t Ccols);
+int ebn_bias_relu_bwd_f32(const float* Y, const float* dY, float* dX, float* dbias,
+                          float* partials, int64_t R, int32_t Ccols, int32_t accumulate,
+                          ebn_stream_t stream);
+/* BatchNormalization(axis=-1, momentum .99, eps 1e-3) over the R rows of one call site.
+ * training != 0: batch statistics (biased var), saved to mean_out/istd_out, moving stats
+ * updated in place; else moving statistics.  Optional fused dropout (site, drop_p) with
+ * flat element offset elem_offset.                                                     */
+int ebn_batchnorm_fwd_f32(const float* X, const float* gamma, const float* beta,
+                          float* moving_mean, float* moving_var, float* Y, float* xhat,
+                          float* mean_out, float* istd_out, float* partials, int64_t R,
+                          int32_t Ccols, int32_t training, const ebn_step_state* st,
+                          int32_t site, float drop_p, int64_t elem_offset,
+                          ebn_stream_t stream);
+int ebn_batchnorm_bwd_f32(const float* dY, const float* xhat, const float* gamma,
+                          const float* istd, float* dX, float* dgamma, float* dbeta,
+                          float* partials, int64_t R, int32_t Ccols, int32_t training,
+                          int32_t accumulate, const ebn_step_state* st, int32_t site,
+                          float drop_p, int64_t elem_offset, ebn_stream_t stream);
+
+/* y = a*x + y over n elements (L2 kernel-regulariser gradient, gradient accumulation). */
+int ebn_axpy_f32(float a, const float* x, float* y, int64_t n, ebn_stream_t stream);
+/* out[0] (+)= scale * sum(x[0..n)) -- deterministic single-block reduction.            */
+int ebn_sum_f32(const float* x, int64_t n, float scale, float* out, int32_t accumulate,
+                ebn_stream_t stream);
+/* out[0] (+)= scale * sum(x^2).                                                         */
+int ebn_sumsq_f32(const float* x, int64_t n, float scale, float* out, int32_t accumulate,
+                  ebn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EBNERD_HIP_H */

@@ -1,0 +1,63 @@
+"""Helpers shared by the gpu-marked parity tests (all calls go through the C ABI)."""
+import ctypes
+
+import numpy as np
+import torch
+
+from ebrec import _hip
+from oracle import nrms_numpy as on
+
+
+def dev(a, dtype=torch.float32):
+    return torch.as_tensor(np.ascontiguousarray(a)).to(dtype).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy().astype(np.float64)
+
+
+def make_state(seed=0, step=0, lr=1e-4, alpha=0.0, advance=False):
+    """Device ebn_step_state with the oracle's keys for (seed, step)."""
+    st = _hip.StepState()
+    st.step, st.seed, st.lr, st.adam_alpha = step, seed & 0xFFFFFFFF, lr, alpha
+    for s in range(_hip.binding.EBN_N_SITES):
+        st.drop_key[s] = on.dropout_key(seed, step, s)
+    t = torch.frombuffer(bytearray(bytes(st)), dtype=torch.uint8).cuda()
+    return t
+
+
+def read_state(t):
+    return _hip.StepState.from_buffer_copy(bytes(t.cpu().numpy().tobytes()))
+
+
+def P(t):
+    return _hip.ptr(t)
+
+
+def S():
+    return _hip.stream_handle()
+
+
+def i64(x):
+    return ctypes.c_int64(int(x))
+
+
+def gemm(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, ws=None):
+    if ws is None:
+        _hip.call("ebn_gemm_f32", transA, transB, M, N, K, alpha, P(A), lda, P(B), ldb, beta, P(C), ldc, S())
+    else:
+        _hip.call("ebn_gemm_f32_ws", transA, transB, M, N, K, alpha, P(A), lda, P(B), ldb, beta, P(C), ldc,
+                  P(ws), ws.numel(), S())
+
+
+def assert_close(got, want, rtol=1e-5, atol=1e-6, what=""):
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    err = np.abs(got - want)
+    tol = atol + rtol * np.abs(want)
+    bad = err > tol
+    if bad.any():
+        i = np.unravel_index(np.argmax(err - tol), err.shape)
+        raise AssertionError(f"{what}: {bad.sum()}/{bad.size} elements off; worst at {i}: got {got[i]!r} want "
+                             f"{want[i]!r} (abs err {err[i]:.3e}, tol {tol[i]:.3e}); max abs err {err.max():.3e}")

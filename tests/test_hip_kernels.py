@@ -1,0 +1,503 @@
+"""Parity of every low-level C-ABI entry point against the float64 oracle (gpu-marked).
+
+Tolerances: the kernels compute in fp32 (exact-fp32 MFMA / VALU); the oracle is float64.
+rtol 2e-5 / atol scaled to the magnitude of each quantity -- an order tighter than the 1e-4
+forward-score budget of BASELINE.json's north_star.  Gather/scatter-without-dropout, dropout
+masks and the step-state keys are bit-exact.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nrms_numpy as on
+from tests.hip_testutil import P, S, assert_close, dev, gemm, host, make_state, read_state
+
+pytestmark = pytest.mark.gpu
+
+
+# ---------------------------------------------------------------- step state
+def test_step_advance_matches_oracle_keys_and_alpha(hip):
+    st = make_state(seed=42, step=0, lr=1e-4)
+    for t in range(1, 4):
+        hip.call("ebn_step_advance", P(st), 0.9, 0.999, S())
+        got = read_state(st)
+        assert got.step == t and got.seed == 42
+        want_alpha = 1e-4 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+        assert abs(got.adam_alpha - want_alpha) <= 1e-6 * want_alpha
+        for s in range(12):
+            assert got.drop_key[s] == on.dropout_key(42, t, s)
+
+
+# ---------------------------------------------------------------- a1 gather / scatter
+@pytest.mark.parametrize("V,D,n_tok", [(1000, 300, 750), (5000, 1024, 1500), (37, 7, 129), (64, 4, 1), (100, 768, 25)])
+def test_gather_bit_exact(hip, V, D, n_tok):
+    rng = np.random.default_rng(0)
+    table = rng.standard_normal((V, D)).astype(np.float32)
+    ids = rng.integers(0, V, n_tok).astype(np.int32)
+    ids[0] = 0
+    ids[-1] = V - 1
+    out = torch.empty(n_tok, D, device="cuda")
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    hip.call("ebn_gather_rows_f32", P(dev(ids, torch.int32)), P(dev(table)), P(out), n_tok, D, V, None, -1, 0.0,
+             P(flag), S())
+    assert np.array_equal(out.cpu().numpy(), table[ids])
+    assert int(flag.item()) == 0
+
+
+def test_gather_oob_sets_flag_and_writes_zero_row(hip):
+    V, D = 10, 8
+    table = np.ones((V, D), np.float32)
+    ids = np.array([1, 10, -1, 3], np.int32)
+    out = torch.full((4, D), 7.0, device="cuda")
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    hip.call("ebn_gather_rows_f32", P(dev(ids, torch.int32)), P(dev(table)), P(out), 4, D, V, None, -1, 0.0,
+             P(flag), S())
+    o = out.cpu().numpy()
+    assert int(flag.item()) == 1
+    assert (o[0] == 1).all() and (o[3] == 1).all() and (o[1] == 0).all() and (o[2] == 0).all()
+
+
+@pytest.mark.parametrize("D", [300, 10])
+def test_gather_dropout_mask_bit_exact(hip, D):
+    rng = np.random.default_rng(1)
+    V, n_tok, p, seed, step = 200, 333, 0.2, 7, 5
+    table = rng.standard_normal((V, D)).astype(np.float32)
+    ids = rng.integers(0, V, n_tok).astype(np.int32)
+    st = make_state(seed=seed, step=step)
+    out = torch.empty(n_tok, D, device="cuda")
+    hip.call("ebn_gather_rows_f32", P(dev(ids, torch.int32)), P(dev(table)), P(out), n_tok, D, V, P(st), 0,
+             ctypes.c_float(p), None, S())
+    keep = on.dropout_keep_mask(on.dropout_key(seed, step, 0), n_tok * D, p).reshape(n_tok, D)
+    want = table[ids] * keep.astype(np.float32) * (np.float32(1.0) / np.float32(1.0 - p))
+    assert np.array_equal(out.cpu().numpy(), want.astype(np.float32))
+    assert 0.75 < keep.mean() < 0.85
+
+
+@pytest.mark.parametrize("p", [0.0, 0.3])
+def test_embedding_grad_scatter(hip, p):
+    rng = np.random.default_rng(2)
+    V, D, n_tok, seed, step = 50, 12, 400, 3, 9
+    ids = rng.integers(0, V, n_tok).astype(np.int32)
+    ids[:100] = 0  # hot row (padded history)
+    dX = rng.standard_normal((n_tok, D)).astype(np.float32)
+    st = make_state(seed=seed, step=step)
+    dT = torch.zeros(V, D, device="cuda")
+    hip.call("ebn_embedding_grad_scatter_f32", P(dev(ids, torch.int32)), P(dev(dX)), P(dT), n_tok, D, V, P(st), 0,
+             ctypes.c_float(p), S())
+    m = np.ones((n_tok, D))
+    if p > 0:
+        m = on.dropout_keep_mask(on.dropout_key(seed, step, 0), n_tok * D, p).reshape(n_tok, D) / (1 - p)
+    want = on.embedding_bwd(ids, dX.astype(np.float64) * m, V)
+    assert_close(host(dT), want, rtol=1e-5, atol=1e-4, what="dTable")  # atomics: order-dependent rounding
+
+
+# ---------------------------------------------------------------- GEMM
+GEMM_SHAPES = [(1, 1, 1), (5, 7, 3), (64, 64, 16), (130, 70, 33), (257, 129, 300), (750, 1200, 300),
+               (640, 200, 400), (300, 1200, 2000), (96, 100, 4096), (1, 400, 400), (513, 5, 64)]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+@pytest.mark.parametrize("tA,tB", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_all_layouts(hip, M, N, K, tA, tB):
+    rng = np.random.default_rng(M * 131 + N * 17 + K)
+    A = rng.standard_normal((K, M) if tA else (M, K)).astype(np.float32)
+    B = rng.standard_normal((N, K) if tB else (K, N)).astype(np.float32)
+    C0 = rng.standard_normal((M, N)).astype(np.float32)
+    opA = A.T if tA else A
+    opB = B.T if tB else B
+    ref = opA.astype(np.float64) @ opB.astype(np.float64)
+    scale = np.sqrt(K)
+    for alpha, beta, use_ws in ((1.0, 0.0, False), (0.5, 1.0, False), (1.0, 0.0, True), (2.0, -0.5, True)):
+        C = dev(C0)
+        ws = None
+        if use_ws:
+            n = hip.lib().ebn_gemm_workspace_floats(M, N, K)
+            ws = torch.empty(max(int(n), 1), device="cuda")
+        gemm(tA, tB, M, N, K, alpha, dev(A), A.shape[1], dev(B), B.shape[1], beta, C, N, ws)
+        want = alpha * ref + beta * C0
+        assert_close(host(C), want, rtol=2e-6, atol=3e-6 * scale, what=f"gemm {M}x{N}x{K} tA={tA} tB={tB} a={alpha} b={beta} ws={use_ws}")
+
+
+def test_gemm_is_asymmetric_safe_and_respects_ld(hip):
+    """A = I against an asymmetric B, with padded leading dimensions (catches C^T / operand swaps)."""
+    M = N = K = 96
+    lda, ldb, ldc = 100, 104, 128
+    A = np.zeros((M, lda), np.float32)
+    A[:, :K] = np.eye(M, dtype=np.float32)
+    B = np.zeros((K, ldb), np.float32)
+    B[:, :N] = np.arange(K * N, dtype=np.float32).reshape(K, N) / 100.0
+    C = torch.full((M, ldc), -1.0, device="cuda")
+    gemm(0, 0, M, N, K, 1.0, dev(A), lda, dev(B), ldb, 0.0, C, ldc)
+    c = C.cpu().numpy()
+    assert np.array_equal(c[:, :N], B[:, :N])
+    assert (c[:, N:] == -1).all()
+
+
+def test_gemm_unaligned_pointers_take_the_scalar_path(hip):
+    rng = np.random.default_rng(5)
+    M, N, K = 33, 45, 27  # ld not multiples of 4
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    B = rng.standard_normal((K, N)).astype(np.float32)
+    C = torch.zeros(M, N, device="cuda")
+    gemm(0, 0, M, N, K, 1.0, dev(A), K, dev(B), N, 0.0, C, N)
+    assert_close(host(C), A.astype(np.float64) @ B.astype(np.float64), rtol=2e-6, atol=2e-5, what="odd gemm")
+
+
+# ---------------------------------------------------------------- a3/a6 attention core
+ATTN_CASES = [(4, 30, 20, 20), (3, 20, 20, 20), (2, 50, 16, 16), (5, 1, 2, 4), (2, 33, 3, 32), (3, 32, 2, 5),
+              (1, 64, 2, 8)]
+
+
+def _qkv_case(n_seq, L, h, d, seed):
+    rng = np.random.default_rng(seed)
+    E = h * d
+    qkv = (rng.standard_normal((n_seq, L, 3 * E)) * 0.8).astype(np.float32)
+    Qh = qkv[..., :E].reshape(n_seq, L, h, d).transpose(0, 2, 1, 3).astype(np.float64)
+    Kh = qkv[..., E:2 * E].reshape(n_seq, L, h, d).transpose(0, 2, 1, 3).astype(np.float64)
+    Vh = qkv[..., 2 * E:].reshape(n_seq, L, h, d).transpose(0, 2, 1, 3).astype(np.float64)
+    S_ = Qh @ Kh.transpose(0, 1, 3, 2) / np.sqrt(d)
+    Pm = on.softmax_rows(S_)
+    return qkv, Qh, Kh, Vh, Pm
+
+
+@pytest.mark.parametrize("n_seq,L,h,d", ATTN_CASES)
+@pytest.mark.parametrize("p", [0.0, 0.2])
+def test_attention_forward_is_transposed_softmax_times_v(hip, n_seq, L, h, d, p):
+    E = h * d
+    qkv, Qh, Kh, Vh, Pm = _qkv_case(n_seq, L, h, d, 11)
+    O = (Pm.transpose(0, 1, 3, 2) @ Vh).transpose(0, 2, 1, 3).reshape(n_seq, L, E)  # P^T V (layers.py:249)
+    wrong = (Pm @ Vh).transpose(0, 2, 1, 3).reshape(n_seq, L, E)  # standard attention
+    seed, step = 5, 2
+    if p > 0:
+        O = O * on.dropout_keep_mask(on.dropout_key(seed, step, 1), O.size, p).reshape(O.shape) / (1 - p)
+    st = make_state(seed=seed, step=step)
+    out = torch.empty(n_seq * L, E, device="cuda")
+    hip.call("ebn_attn_fwd_f32", P(dev(qkv.reshape(n_seq * L, 3 * E))), 3 * E, P(out), E, n_seq, L, h, d, P(st), 1,
+             ctypes.c_float(p), S())
+    assert_close(host(out).reshape(n_seq, L, E), O, rtol=2e-5, atol=2e-6, what="attn fwd")
+    if L > 2 and p == 0:
+        assert np.abs(host(out).reshape(n_seq, L, E) - wrong).max() > 1e-3  # the quirk is observable
+
+
+@pytest.mark.parametrize("n_seq,L,h,d", ATTN_CASES)
+@pytest.mark.parametrize("p", [0.0, 0.2])
+def test_attention_backward(hip, n_seq, L, h, d, p):
+    E = h * d
+    qkv, Qh, Kh, Vh, Pm = _qkv_case(n_seq, L, h, d, 12)
+    rng = np.random.default_rng(13)
+    dY = rng.standard_normal((n_seq, L, E)).astype(np.float32)
+    seed, step = 8, 3
+    dO = dY.astype(np.float64)
+    if p > 0:
+        dO = dO * on.dropout_keep_mask(on.dropout_key(seed, step, 1), dO.size, p).reshape(dO.shape) / (1 - p)
+    dOh = dO.reshape(n_seq, L, h, d).transpose(0, 2, 1, 3)
+    dVh = Pm @ dOh
+    dP = Vh @ dOh.transpose(0, 1, 3, 2)
+    dS = Pm * (dP - (Pm * dP).sum(-1, keepdims=True))
+    dQh = dS @ Kh / np.sqrt(d)
+    dKh = dS.transpose(0, 1, 3, 2) @ Qh / np.sqrt(d)
+    back = lambda Z: Z.transpose(0, 2, 1, 3).reshape(n_seq * L, E)
+    want = np.concatenate([back(dQh), back(dKh), back(dVh)], 1)
+    st = make_state(seed=seed, step=step)
+    dqkv = torch.full((n_seq * L, 3 * E), float("nan"), device="cuda")
+    hip.call("ebn_attn_bwd_f32", P(dev(qkv.reshape(n_seq * L, 3 * E))), 3 * E, P(dev(dY.reshape(n_seq * L, E))), E,
+             P(dqkv), 3 * E, n_seq, L, h, d, P(st), 1, ctypes.c_float(p), S())
+    assert_close(host(dqkv), want, rtol=3e-5, atol=5e-6, what="attn bwd")
+
+
+def test_attention_rejects_unsupported_shapes(hip):
+    x = torch.zeros(10, device="cuda")
+    with pytest.raises(hip.HipError):
+        hip.call("ebn_attn_fwd_f32", P(x), 300, P(x), 100, 1, 65, 2, 8, None, -1, ctypes.c_float(0), S())
+    with pytest.raises(hip.HipError):
+        hip.call("ebn_attn_fwd_f32", P(x), 300, P(x), 100, 1, 10, 2, 33, None, -1, ctypes.c_float(0), S())
+
+
+# ---------------------------------------------------------------- a4/a7 AttLayer2 tail
+@pytest.mark.parametrize("n_seq,L,E,A", [(6, 30, 400, 200), (3, 20, 256, 200), (2, 50, 40, 7), (4, 1, 8, 3), (1, 70, 64, 300)])
+def test_attpool_forward_and_backward(hip, n_seq, L, E, A):
+    rng = np.random.default_rng(21)
+    X = rng.standard_normal((n_seq, L, E)) * 0.7
+    W = on.glorot_uniform((E, A), rng) * 2
+    b = rng.standard_normal(A) * 0.1
+    q = on.glorot_uniform((A, 1), rng) * 2
+    out, cache = on.att_layer2_fwd(X, W, b, q)
+    R = n_seq * L
+    Xd, Wd = dev(X.reshape(R, E)), dev(W)
+    U = torch.empty(R, A, device="cuda")
+    gemm(0, 0, R, A, E, 1.0, Xd, E, Wd, A, 0.0, U, A)
+    o = torch.empty(n_seq, E, device="cuda")
+    w = torch.empty(R, device="cuda")
+    hip.call("ebn_attpool_fwd_f32", P(U), P(dev(b)), P(dev(q)), P(Xd), P(o), P(w), n_seq, L, E, A, S())
+    assert_close(host(U).reshape(n_seq, L, A), cache[3], rtol=2e-5, atol=3e-6, what="tanh U")
+    assert_close(host(w).reshape(n_seq, L), cache[4], rtol=3e-5, atol=1e-7, what="attention weights")
+    assert_close(host(o), out, rtol=3e-5, atol=3e-6, what="pooled out")
+    # the +1e-7 of layers.py:75-77 is there: weights sum to slightly less than one
+    dout = rng.standard_normal((n_seq, E))
+    dX, dW, db, dq = on.att_layer2_bwd(dout, cache)
+    dXd = torch.empty(R, E, device="cuda")
+    de = torch.empty(R, device="cuda")
+    hip.call("ebn_attpool_bwd_pool_f32", P(Xd), P(w), P(dev(dout)), P(dXd), P(de), n_seq, L, E, S())
+    part = torch.empty(int(hip.lib().ebn_attpool_partials_len(R, A)), device="cuda")
+    dqd = torch.full((A,), 5.0, device="cuda")
+    dbd = torch.full((A,), 5.0, device="cuda")
+    hip.call("ebn_attpool_bwd_dpre_f32", P(U), P(dev(q)), P(de), P(dqd), P(dbd), P(part), R, A, 0, S())
+    assert_close(host(dqd), dq[:, 0], rtol=3e-5, atol=2e-5, what="dq")
+    assert_close(host(dbd), db, rtol=3e-5, atol=2e-5, what="db")
+    dWd = torch.empty(E, A, device="cuda")
+    gemm(1, 0, E, A, R, 1.0, Xd, E, U, A, 0.0, dWd, A)
+    gemm(0, 1, R, E, A, 1.0, U, A, Wd, A, 1.0, dXd, E)
+    assert_close(host(dWd), dW, rtol=3e-5, atol=3e-5, what="dW")
+    assert_close(host(dXd).reshape(n_seq, L, E), dX, rtol=3e-5, atol=1e-5, what="dX")
+    # accumulate flag adds on top
+    hip.call("ebn_attpool_bwd_dpre_f32", P(U), P(dev(q)), P(torch.zeros_like(de)), P(dqd), P(dbd), P(part), R, A, 1, S())
+    assert_close(host(dqd), dq[:, 0], rtol=3e-5, atol=2e-5, what="dq accumulate(0)")
+
+
+def test_attpool_epsilon_bias_is_reproduced(hip):
+    """Quirk 4: exp without max-subtraction and +1e-7 in the denominator (layers.py:71-77)."""
+    n_seq, L, E, A = 1, 3, 4, 2
+    U = torch.full((L, A), -30.0, device="cuda")  # tanh -> -1; e = -q.sum ~ -20 -> exp ~ 2e-9
+    b = torch.zeros(A, device="cuda")
+    q = torch.full((A,), 10.0, device="cuda")
+    X = torch.ones(L, E, device="cuda")
+    o = torch.empty(1, E, device="cuda")
+    w = torch.empty(L, device="cuda")
+    hip.call("ebn_attpool_fwd_f32", P(U), P(b), P(q), P(X), P(o), P(w), n_seq, L, E, A, S())
+    a = np.exp(np.float64(-20.0))
+    want = a / (3 * a + 1e-7)
+    assert_close(host(w), np.full(L, want), rtol=1e-4, atol=0, what="eps-biased weights")
+    assert host(w).sum() < 0.2  # far from 1: a stabilised softmax would give 1/3 each
+
+
+# ---------------------------------------------------------------- stage: encoder fwd/bwd
+def _run_encoder(hip, X, Wqkv, W, b, q, h, d, A, drop_p, st, dout=None, need_dx=True):
+    n_seq, L, Din = X.shape
+    E = h * d
+    R = n_seq * L
+    t = {"X": dev(X.reshape(R, Din)), "QKV": torch.empty(R, 3 * E, device="cuda"), "Y": torch.empty(R, E, device="cuda"),
+         "U": torch.empty(R, A, device="cuda"), "w": torch.empty(R, device="cuda"),
+         "out": torch.empty(n_seq, E, device="cuda")}
+    prm = {"Wqkv": dev(Wqkv), "W": dev(W), "b": dev(b), "q": dev(q)}
+    dims = hip.EncoderDims(n_seq, L, Din, h, d, A, 1 if drop_p > 0 else -1, drop_p)
+    params = hip.EncoderParams(*[t_.data_ptr() for t_ in (prm["Wqkv"], prm["W"], prm["b"], prm["q"])])
+    acts = hip.EncoderActs(*[t[k].data_ptr() for k in ("X", "QKV", "Y", "U", "w", "out")])
+    hip.call("ebn_encoder_fwd_f32", ctypes.byref(dims), ctypes.byref(params), ctypes.byref(acts), P(st), S())
+    res = {"out": host(t["out"]), "Y": host(t["Y"])}
+    if dout is not None:
+        g = {"dWqkv": torch.zeros(Din, 3 * E, device="cuda"), "dW": torch.zeros(E, A, device="cuda"),
+             "db": torch.zeros(A, device="cuda"), "dq": torch.zeros(A, device="cuda")}
+        ws_n = max(int(hip.lib().ebn_gemm_workspace_floats(Din, 3 * E, R)), int(hip.lib().ebn_gemm_workspace_floats(E, A, R)), 1)
+        sc = {"dY": torch.empty(R, E, device="cuda"), "dQKV": torch.empty(R, 3 * E, device="cuda"),
+              "de": torch.empty(R, device="cuda"),
+              "partials": torch.empty(int(hip.lib().ebn_attpool_partials_len(R, A)), device="cuda"),
+              "ws": torch.empty(ws_n, device="cuda")}
+        grads = hip.EncoderGrads(*[g[k].data_ptr() for k in ("dWqkv", "dW", "db", "dq")])
+        scratch = hip.EncoderScratch(sc["dY"].data_ptr(), sc["dQKV"].data_ptr(), sc["de"].data_ptr(),
+                                     sc["partials"].data_ptr(), sc["ws"].data_ptr(), ws_n)
+        dX = torch.empty(R, Din, device="cuda") if need_dx else None
+        hip.call("ebn_encoder_bwd_f32", ctypes.byref(dims), ctypes.byref(params), ctypes.byref(acts), P(dev(dout)),
+                 ctypes.byref(grads), ctypes.byref(scratch), P(dX), 0, P(st), S())
+        res.update({k: host(v) for k, v in g.items()})
+        if need_dx:
+            res["dX"] = host(dX).reshape(n_seq, L, Din)
+    return res
+
+
+@pytest.mark.parametrize("n_seq,L,Din,h,d,A,p", [(8, 30, 300, 20, 20, 200, 0.0), (8, 30, 300, 20, 20, 200, 0.2),
+                                                 (5, 20, 400, 20, 20, 200, 0.0), (3, 50, 256, 16, 16, 200, 0.0),
+                                                 (2, 7, 12, 3, 4, 5, 0.3)])
+def test_encoder_stage_forward_backward_matches_oracle(hip, n_seq, L, Din, h, d, A, p):
+    rng = np.random.default_rng(31)
+    E = h * d
+    X = rng.standard_normal((n_seq, L, Din)) * 0.5
+    WQ, WK, WV = (on.glorot_uniform((Din, E), rng) * 2 for _ in range(3))
+    W = on.glorot_uniform((E, A), rng) * 2
+    b = rng.standard_normal(A) * 0.1
+    q = on.glorot_uniform((A, 1), rng) * 2
+    seed, step = 4, 6
+    O, c_sa = on.self_attention_fwd(X, WQ, WK, WV, h, d)
+    m1 = None
+    Y = O
+    if p > 0:
+        Y, m1 = on.dropout_apply(O, on.dropout_key(seed, step, 1), p)
+    out, c_al = on.att_layer2_fwd(Y, W, b, q)
+    dout = rng.standard_normal((n_seq, E))
+    dY, dW, db, dq = on.att_layer2_bwd(dout, c_al)
+    dO = dY if m1 is None else dY * m1
+    dX, dWQ, dWK, dWV = on.self_attention_bwd(dO, c_sa)
+    st = make_state(seed=seed, step=step)
+    got = _run_encoder(hip, X, np.concatenate([WQ, WK, WV], 1), W, b, q, h, d, A, p, st, dout)
+    assert_close(got["Y"].reshape(Y.shape), Y, rtol=3e-5, atol=3e-6, what="Y")
+    assert_close(got["out"], out, rtol=3e-5, atol=3e-6, what="encoder out")
+    assert_close(got["dWqkv"], np.concatenate([dWQ, dWK, dWV], 1), rtol=5e-5, atol=2e-5, what="dWqkv")
+    assert_close(got["dW"], dW, rtol=5e-5, atol=2e-5, what="dW")
+    assert_close(got["db"], db, rtol=5e-5, atol=2e-5, what="db")
+    assert_close(got["dq"], dq[:, 0], rtol=5e-5, atol=2e-5, what="dq")
+    assert_close(got["dX"], dX, rtol=5e-5, atol=5e-6, what="dX")
+
+
+# ---------------------------------------------------------------- a8/a9 scorer + loss
+@pytest.mark.parametrize("B,C,E", [(32, 5, 400), (3, 1, 16), (2, 250, 256), (1, 70, 33)])
+def test_score_forward_softmax_and_sigmoid(hip, B, C, E):
+    rng = np.random.default_rng(41)
+    cand = rng.standard_normal((B, C, E)) * 0.3
+    user = rng.standard_normal((B, E)) * 0.3
+    s = np.einsum("bce,be->bc", cand, user)
+    for mode, want in ((0, on.softmax_rows(s)), (1, on.sigmoid(s))):
+        sc = torch.empty(B, C, device="cuda")
+        pr = torch.empty(B, C, device="cuda")
+        hip.call("ebn_score_fwd_f32", P(dev(cand)), P(dev(user)), P(sc), P(pr), B, C, E, mode, S())
+        assert_close(host(sc), s, rtol=2e-5, atol=2e-6, what="scores")
+        assert_close(host(pr), want, rtol=3e-5, atol=1e-7, what=f"probs mode {mode}")
+
+
+@pytest.mark.parametrize("kind", ["cross_entropy_loss", "log_loss"])
+@pytest.mark.parametrize("B,C,E", [(32, 5, 400), (4, 9, 20)])
+def test_loss_and_backward_into_representations(hip, kind, B, C, E):
+    rng = np.random.default_rng(43)
+    cand = rng.standard_normal((B, C, E)) * 0.4
+    user = rng.standard_normal((B, E)) * 0.4
+    y = np.zeros((B, C))
+    y[np.arange(B), rng.integers(0, C, B)] = 1
+    s = np.einsum("bce,be->bc", cand, user)
+    L, ds = on.loss_fwd_bwd(s, y, kind)
+    dcand = ds[..., None] * user[:, None, :]
+    duser = np.einsum("bc,bce->be", ds, cand)
+    rows = torch.empty(B, device="cuda")
+    dc = torch.empty(B, C, E, device="cuda")
+    du = torch.empty(B, E, device="cuda")
+    hip.call("ebn_score_loss_bwd_f32", P(dev(cand)), P(dev(user)), P(dev(s)), P(dev(y)), P(rows), P(dc), P(du), B, C, E,
+             0 if kind == "cross_entropy_loss" else 1, ctypes.c_float(1.0 / B), S())
+    assert abs(host(rows).sum() - L) <= 3e-6 * max(1, abs(L))
+    assert_close(host(dc), dcand, rtol=3e-5, atol=1e-7, what="dcand")
+    assert_close(host(du), duser, rtol=3e-5, atol=1e-7, what="duser")
+    tot = torch.zeros(1, device="cuda")
+    hip.call("ebn_sum_f32", P(rows), B, ctypes.c_float(1.0), P(tot), 0, S())
+    assert abs(float(tot.item()) - L) <= 3e-6 * max(1, abs(L))
+
+
+def test_pair_score_ragged(hip):
+    rng = np.random.default_rng(47)
+    nu, nn, E, n_pairs = 7, 13, 400, 101
+    user = rng.standard_normal((nu, E)) * 0.2
+    news = rng.standard_normal((nn, E)) * 0.2
+    ui = rng.integers(0, nu, n_pairs).astype(np.int32)
+    ni = rng.integers(0, nn, n_pairs).astype(np.int32)
+    want = (user[ui] * news[ni]).sum(-1)
+    for mode, w in ((0, want), (1, on.sigmoid(want))):
+        out = torch.empty(n_pairs, device="cuda")
+        hip.call("ebn_pair_score_f32", P(dev(user)), P(dev(news)), P(dev(ui, torch.int32)), P(dev(ni, torch.int32)),
+                 P(out), n_pairs, E, mode, S())
+        assert_close(host(out), w, rtol=2e-5, atol=2e-6, what="pair score")
+
+
+# ---------------------------------------------------------------- a10 Adam (Keras form)
+@pytest.mark.parametrize("n", [1, 1000, 4097, 120007])
+def test_adam_keras_multi_step(hip, n):
+    rng = np.random.default_rng(51)
+    theta = rng.standard_normal(n)
+    m = np.zeros(n)
+    v = np.zeros(n)
+    th_d, m_d, v_d = dev(theta), dev(m), dev(v)
+    st = make_state(seed=0, step=0, lr=1e-3)
+    for t in range(1, 6):
+        g = rng.standard_normal(n) * (0.1 if t % 2 else 3.0)
+        g[: n // 3] = 0.0  # untouched embedding rows still get the dense moment decay
+        hip.call("ebn_step_advance", P(st), 0.9, 0.999, S())
+        hip.call("ebn_adam_keras_step_f32", P(th_d), P(dev(g * 2.0)), P(m_d), P(v_d), n, P(st), 0.9, 0.999,
+                 ctypes.c_float(1e-7), ctypes.c_float(0.5), S())
+        on.adam_keras_step(theta, g, m, v, t, lr=1e-3)
+    assert_close(host(th_d), theta, rtol=1e-5, atol=2e-6, what="theta")
+    assert_close(host(m_d), m, rtol=1e-5, atol=1e-7, what="m")
+    assert_close(host(v_d), v, rtol=1e-5, atol=1e-9, what="v")
+
+
+# ---------------------------------------------------------------- DocVec dense helpers
+def test_bias_relu_forward_backward(hip):
+    rng = np.random.default_rng(61)
+    R, C = 160, 512
+    X = rng.standard_normal((R, C))
+    b = rng.standard_normal(C) * 0.2
+    Y = torch.empty(R, C, device="cuda")
+    hip.call("ebn_bias_relu_f32", P(dev(X)), P(dev(b)), P(Y), R, C, S())
+    want = np.maximum(X.astype(np.float32) + b.astype(np.float32), 0)
+    assert np.array_equal(Y.cpu().numpy(), want)
+    dY = rng.standard_normal((R, C))
+    dX = torch.empty(R, C, device="cuda")
+    dbias = torch.zeros(C, device="cuda")
+    part = torch.empty(int(hip.lib().ebn_colsum_partials_len(R, C)), device="cuda")
+    hip.call("ebn_bias_relu_bwd_f32", P(Y), P(dev(dY)), P(dX), P(dbias), P(part), R, C, 0, S())
+    wdx = dY * (want > 0)
+    assert_close(host(dX), wdx, rtol=1e-6, atol=1e-7, what="relu dX")
+    assert_close(host(dbias), wdx.sum(0), rtol=2e-5, atol=2e-5, what="dbias")
+
+
+@pytest.mark.parametrize("training,p", [(1, 0.0), (1, 0.2), (0, 0.0)])
+def test_batchnorm_forward_backward(hip, training, p):
+    rng = np.random.default_rng(67)
+    R, C = 640, 96
+    X = np.maximum(rng.standard_normal((R, C)) + 0.3, 0)
+    gamma = 1 + 0.1 * rng.standard_normal(C)
+    beta = 0.1 * rng.standard_normal(C)
+    mm0 = 0.05 * rng.standard_normal(C)
+    mv0 = 1 + 0.1 * rng.random(C)
+    seed, step, site, off = 3, 4, 9, 1000
+    if training:
+        mu, var = X.mean(0), X.var(0)
+    else:
+        mu, var = mm0, mv0
+    istd = 1 / np.sqrt(var + 1e-3)
+    xh = (X - mu) * istd
+    Yw = xh * gamma + beta
+    msk = np.ones_like(Yw)
+    if training and p > 0:
+        msk = on.dropout_keep_mask(on.dropout_key(seed, step, site), Yw.size, p, start=off).reshape(Yw.shape) / (1 - p)
+    Yw = Yw * msk
+    st = make_state(seed=seed, step=step)
+    mm, mv = dev(mm0), dev(mv0)
+    Y = torch.empty(R, C, device="cuda")
+    xhat = torch.empty(R, C, device="cuda")
+    mean_o = torch.empty(C, device="cuda")
+    istd_o = torch.empty(C, device="cuda")
+    part = torch.empty(int(hip.lib().ebn_colsum_partials_len(R, C)), device="cuda")
+    hip.call("ebn_batchnorm_fwd_f32", P(dev(X)), P(dev(gamma)), P(dev(beta)), P(mm), P(mv), P(Y), P(xhat), P(mean_o),
+             P(istd_o), P(part), R, C, training, P(st), site, ctypes.c_float(p), ctypes.c_int64(off), S())
+    assert_close(host(Y), Yw, rtol=3e-5, atol=3e-6, what="bn Y")
+    assert_close(host(istd_o), istd, rtol=2e-5, atol=0, what="istd")
+    if training:
+        assert_close(host(mm), mm0 * 0.99 + mu * 0.01, rtol=1e-5, atol=1e-7, what="moving mean")
+        assert_close(host(mv), mv0 * 0.99 + var * 0.01, rtol=1e-5, atol=1e-7, what="moving var")
+    else:
+        assert_close(host(mm), mm0, rtol=0, atol=1e-7, what="moving mean untouched")
+    dY = rng.standard_normal((R, C))
+    g = dY * msk
+    dgamma, dbeta = (g * xh).sum(0), g.sum(0)
+    dxh = g * gamma
+    if training:
+        dXw = istd / R * (R * dxh - dxh.sum(0) - xh * (dxh * xh).sum(0))
+    else:
+        dXw = dxh * istd
+    dX = torch.empty(R, C, device="cuda")
+    dg = torch.ones(C, device="cuda")
+    dbt = torch.ones(C, device="cuda")
+    hip.call("ebn_batchnorm_bwd_f32", P(dev(dY)), P(xhat), P(dev(gamma)), P(istd_o), P(dX), P(dg), P(dbt), P(part), R, C,
+             training, 1, P(st), site, ctypes.c_float(p), ctypes.c_int64(off), S())
+    assert_close(host(dg), dgamma + 1, rtol=3e-5, atol=3e-5, what="dgamma (accumulated onto 1)")
+    assert_close(host(dbt), dbeta + 1, rtol=3e-5, atol=3e-5, what="dbeta")
+    assert_close(host(dX), dXw, rtol=5e-5, atol=5e-6, what="bn dX")
+
+
+def test_axpy_and_sumsq(hip):
+    rng = np.random.default_rng(71)
+    n = 262145
+    x = rng.standard_normal(n)
+    y = rng.standard_normal(n)
+    yd = dev(y)
+    hip.call("ebn_axpy_f32", ctypes.c_float(0.25), P(dev(x)), P(yd), n, S())
+    assert_close(host(yd), 0.25 * x + y, rtol=1e-6, atol=1e-6, what="axpy")
+    out = torch.full((1,), 2.0, device="cuda")
+    hip.call("ebn_sumsq_f32", P(dev(x)), n, ctypes.c_float(0.5), P(out), 1, S())
+    assert abs(float(out.item()) - (2.0 + 0.5 * (x.astype(np.float32).astype(np.float64) ** 2).sum())) < 2e-4 * n ** 0.5
