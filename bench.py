@@ -1,0 +1,209 @@
+#!/usr/bin/env python
+"""Headline benchmark of the MI355X-native NRMS training path.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+Metric (BASELINE.json): training impressions/sec, plus the embedding-gather HBM GB/s.
+A "step" is one optimizer step -- forward, loss, backward, (RCCL gradient all-reduce), Keras-form
+Adam -- over one synthetic EB-NeRD-shaped batch per GPU.  Workload = BASELINE.json configs[1]
+("c2" in SURVEY.md section 8): NRMS, history_size=20, npratio=4 (C=5), title_len=30, head 20x20,
+attention_hidden 200, dropout 0.2, 250002 x 1024 xlm-roberta-large-shaped token table as a frozen
+lookup, batch 32 per GPU.  Multi-GPU = data parallel, weak scaling (per-GPU batch fixed), no
+data-path collective other than the gradient all-reduce.  Inputs are resident in HBM before the
+timed region starts.
+
+Extra objects on the JSON line:
+  roofline        the time-dominant kernel (the Q|K|V projection GEMM, MFMA-bound), HIP-event timed
+                  inside the timed region
+  roofline_gather the title-embedding gather (HBM-bound) the metric string names, same method
+  cpu_baseline    oracle/nrms_torch.py (fp32 torch-eager port of the reference math; the reference's
+                  TF path cannot run here) timed on the host cores over a bounded sample
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "ebnerd-benchmark_amd"))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: exact-fp32 MFMA = vector peak
+
+CONFIGS = {
+    # name: (V, D, H, C, T, h, d, A, train_embedding, per-GPU batch)
+    "c1": dict(V=32000, D=300, H=20, C=5, T=30, h=20, d=20, A=200, train_embedding=True, B=32),
+    "c2": dict(V=250002, D=1024, H=20, C=5, T=30, h=20, d=20, A=200, train_embedding=False, B=32),
+    "c4": dict(V=32000, D=300, H=50, C=5, T=30, h=20, d=20, A=200, train_embedding=True, B=32),
+}
+
+
+class HP:
+    optimizer = "adam"
+    loss = "cross_entropy_loss"
+    dropout = 0.2
+    learning_rate = 1e-4
+    newsencoder_units_per_layer = None
+    newsencoder_l2_regularization = 1e-4
+
+
+def make_hparams(c):
+    return type("hparams_bench", (HP,), dict(title_size=c["T"], history_size=c["H"], head_num=c["h"], head_dim=c["d"],
+                                             attention_hidden_dim=c["A"]))
+
+
+def synthetic_batches(c, n, seed, device):
+    """ids uniform in [0,V), one positive per row at a uniform position."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    out = []
+    for _ in range(n):
+        his = torch.randint(0, c["V"], (c["B"], c["H"], c["T"]), generator=g, dtype=torch.int32)
+        pred = torch.randint(0, c["V"], (c["B"], c["C"], c["T"]), generator=g, dtype=torch.int32)
+        y = torch.zeros(c["B"], c["C"])
+        y[torch.arange(c["B"]), torch.randint(0, c["C"], (c["B"],), generator=g)] = 1.0
+        out.append((his.to(device), pred.to(device), y.to(device)))
+    return out
+
+
+def cpu_baseline(c, seconds=15.0):
+    """fp32 torch-eager port of the reference train step on the host cores (bounded sample)."""
+    from oracle.nrms_torch import CpuNRMSTrainer
+
+    rng = np.random.default_rng(123)
+    E = c["h"] * c["d"]
+    lim = lambda a, b: np.sqrt(6.0 / (a + b))
+    P = {"emb": (rng.standard_normal((c["V"], c["D"])) * 0.02).astype(np.float32)}
+    for pre, din in (("n", c["D"]), ("u", E)):
+        for nm in ("WQ", "WK", "WV"):
+            P[f"{pre}_{nm}"] = rng.uniform(-lim(din, E), lim(din, E), (din, E)).astype(np.float32)
+        P[f"{pre}_W"] = rng.uniform(-lim(E, c["A"]), lim(E, c["A"]), (E, c["A"])).astype(np.float32)
+        P[f"{pre}_b"] = np.zeros(c["A"], np.float32)
+        P[f"{pre}_q"] = rng.uniform(-lim(c["A"], 1), lim(c["A"], 1), (c["A"], 1)).astype(np.float32)
+    tr = CpuNRMSTrainer(P, c["h"], c["d"], loss="cross_entropy_loss", lr=1e-4, dropout=0.2,
+                        train_embedding=c["train_embedding"], seed=0)
+    def batch():
+        his = rng.integers(0, c["V"], (c["B"], c["H"], c["T"]))
+        pred = rng.integers(0, c["V"], (c["B"], c["C"], c["T"]))
+        y = np.zeros((c["B"], c["C"]), np.float32)
+        y[np.arange(c["B"]), rng.integers(0, c["C"], c["B"])] = 1
+        return his, pred, y
+    tr.step(*batch())  # warm-up (thread pool, allocator)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        tr.step(*batch())
+        n += 1
+        el = time.perf_counter() - t0
+        if (el >= seconds and n >= 2) or n >= 200:
+            break
+    return {"value": n * c["B"] / el, "unit": "impressions/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": f"{n} train steps of batch {c['B']} ({c['H']}+{c['C']} titles x {c['T']} tokens, table {c['V']}x{c['D']}"
+                      f"{' frozen' if not c['train_embedding'] else ' trainable'}) in {el:.1f}s, oracle/nrms_torch.py fp32 eager"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the config's, 32)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("--gpus N>1 must be launched with python -m torch.distributed.run --nproc-per-node N")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)  # RCCL over xGMI
+
+    c = dict(CONFIGS[args.config])
+    if args.batch:
+        c["B"] = args.batch
+    from ebrec.models.newsrec import NRMSModel
+
+    rng = np.random.default_rng(42)  # identical weights on every rank (data-parallel replicas)
+    table = (rng.standard_normal((c["V"], c["D"]), dtype=np.float32) * 0.02) if not c["train_embedding"] else None
+    model = NRMSModel(make_hparams(c), word2vec_embedding=table, word_emb_dim=c["D"], vocab_size=c["V"], seed=42,
+                      train_embedding=c["train_embedding"], device=device)
+    eng = model._engine
+    batches = synthetic_batches(c, 8, 123 + rank, device)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        eng.train_step(*batches[i % len(batches)])
+    sync()
+    eng.kernel_events = {}
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        eng.train_step(*batches[i % len(batches)])
+    sync()
+    dt = time.perf_counter() - t0
+    events, eng.kernel_events = eng.kernel_events, None
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss = float(eng.loss_dev.item())
+
+    if rank == 0:
+        kt = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) * 1e-3 for k, v in events.items()}
+        n_tok = c["B"] * (c["H"] + c["C"]) * c["T"]
+        E = c["h"] * c["d"]
+        gemm_flops = 2.0 * n_tok * c["D"] * 3 * E
+        gather_bytes = n_tok * (4 + 2 * c["D"] * 4)  # id + row read + row write (materialising gather)
+        traffic = {}
+        tf = ROOT / "profiles" / "traffic.json"
+        if tf.exists():
+            traffic = json.loads(tf.read_text()).get(args.config, {})
+        line = {
+            "metric": "training impressions/sec", "value": world * c["B"] * args.steps / dt, "unit": "impressions/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"NRMS train step, BASELINE.json configs[{ {'c1': 0, 'c2': 1, 'c4': 3}[args.config] }] "
+                                   f"({args.config}): table {c['V']}x{c['D']} {'trainable' if c['train_embedding'] else 'frozen lookup'}, "
+                                   f"history_size={c['H']} npratio={c['C'] - 1} title_len={c['T']} head={c['h']}x{c['d']} "
+                                   f"att_hidden={c['A']} dropout=0.2 adam lr=1e-4 CE loss",
+                       "global_batch": world * c["B"], "per_gpu_batch": c["B"], "parallelism": f"dp{world}",
+                       "final_loss": loss},
+            "roofline": {"kernel": "gemm_f32_kernel<128,128,NN> (news-encoder Q|K|V projection, fwd)", "bound": "mfma",
+                         "achieved": gemm_flops / kt["qkv_gemm"] / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": gemm_flops / kt["qkv_gemm"] / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                         "traffic": traffic.get("qkv_gemm"), "avg_launch_us": kt["qkv_gemm"] * 1e6,
+                         "algorithmic_flops_per_launch": gemm_flops},
+            "roofline_gather": {"kernel": "gather_rows_vec4_kernel (title-token embedding gather + dropout)", "bound": "hbm",
+                                "achieved": gather_bytes / kt["gather"] / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": gather_bytes / kt["gather"] / 1e9 / HBM_PEAK_GBS,
+                                "traffic": traffic.get("gather"), "avg_launch_us": kt["gather"] * 1e6,
+                                "algorithmic_bytes_per_launch": gather_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(c, args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -120,12 +120,12 @@ __global__ __launch_bounds__(256) void pair_score_kernel(const float* __restrict
   if (lane == 0) out[p] = (mode == 1) ? 1.0f / (1.0f + expf(-part)) : part;
 }
 
-__global__ void step_advance_kernel(ebn_step_state* st, float beta1, float beta2) {
+__global__ void step_advance_kernel(ebn_step_state* st, double beta1, double beta2) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const uint32_t t = st->step + 1u;
   st->step = t;
-  const double b1t = pow(static_cast<double>(beta1), static_cast<double>(t));
-  const double b2t = pow(static_cast<double>(beta2), static_cast<double>(t));
+  const double b1t = pow(beta1, static_cast<double>(t));
+  const double b2t = pow(beta2, static_cast<double>(t));
   st->adam_alpha = static_cast<float>(static_cast<double>(st->lr) * sqrt(1.0 - b2t) / (1.0 - b1t));
   for (uint32_t s = 0; s < EBN_N_SITES; ++s) st->drop_key[s] = ebn_dropout_key(st->seed, t, s);
 }
@@ -201,7 +201,7 @@ extern "C" const char* ebn_error_string(int code) {
   return "ebnerd_hip: unknown error";
 }
 
-extern "C" int ebn_step_advance(ebn_step_state* st, float beta1, float beta2, ebn_stream_t stream) {
+extern "C" int ebn_step_advance(ebn_step_state* st, double beta1, double beta2, ebn_stream_t stream) {
   EBN_REQUIRE(st, EBN_ERR_BAD_ARG);
   hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, ebn_stream(stream), st, beta1, beta2);
   EBN_CHECK_LAUNCH();
@@ -248,21 +248,23 @@ extern "C" int ebn_pair_score_f32(const float* user, const float* news, const in
 }
 
 extern "C" int ebn_adam_keras_step_f32(float* theta, const float* g, float* m, float* v, int64_t n,
-                                       const ebn_step_state* st, float beta1, float beta2, float eps,
+                                       const ebn_step_state* st, double beta1, double beta2, double eps_d,
                                        float grad_scale, ebn_stream_t stream) {
   EBN_REQUIRE(theta && g && m && v && st, EBN_ERR_BAD_ARG);
   EBN_REQUIRE(n >= 0, EBN_ERR_BAD_ARG);
   if (n == 0) return EBN_OK;
+  const float omb1 = static_cast<float>(1.0 - beta1), omb2 = static_cast<float>(1.0 - beta2);
+  const float eps = static_cast<float>(eps_d);
   const bool vec = ebn_aligned16(theta) && ebn_aligned16(g) && ebn_aligned16(m) && ebn_aligned16(v);
   int64_t grid = ebn_ceil_div(vec ? ebn_ceil_div(n, 4) : n, 256);
   if (grid > 256 * 16) grid = 256 * 16;
   if (grid < 1) grid = 1;
   if (vec)
     hipLaunchKernelGGL(adam_keras_kernel, dim3(static_cast<unsigned>(grid)), dim3(256), 0, ebn_stream(stream),
-                       theta, g, m, v, n, st, 1.0f - beta1, 1.0f - beta2, eps, grad_scale);
+                       theta, g, m, v, n, st, omb1, omb2, eps, grad_scale);
   else
     hipLaunchKernelGGL(adam_keras_scalar_kernel, dim3(static_cast<unsigned>(grid)), dim3(256), 0,
-                       ebn_stream(stream), theta, g, m, v, n, st, 1.0f - beta1, 1.0f - beta2, eps, grad_scale);
+                       ebn_stream(stream), theta, g, m, v, n, st, omb1, omb2, eps, grad_scale);
   EBN_CHECK_LAUNCH();
   return EBN_OK;
 }

@@ -67,7 +67,7 @@ def _ctype(decl: str):
         return ctypes.c_void_p
     base = decl.rsplit(" ", 1)[0].replace("const", "").strip()
     return {"int64_t": ctypes.c_int64, "int32_t": ctypes.c_int32, "int": ctypes.c_int32,
-            "uint32_t": ctypes.c_uint32, "float": ctypes.c_float}[base]
+            "uint32_t": ctypes.c_uint32, "float": ctypes.c_float, "double": ctypes.c_double}[base]
 
 
 def declared_functions() -> dict:

@@ -1,0 +1,432 @@
+"""Device engine of the MI355X NRMS path: owns parameters, activations and optimizer state in
+HBM and drives the HIP kernels through the C ABI (include/ebnerd_hip.h).
+
+torch is plumbing only here (device memory, streams, torch.distributed over RCCL); every
+arithmetic op of the reference hot path -- SURVEY.md section 8(a) rows a1..a10 -- is a call
+into libebnerd_hip.so.  There is no CPU path: constructing an engine without the library or
+without a GPU raises.
+
+Data layout in HBM (all fp32 row-major):
+  table        (V, D)            word-embedding rows (a1)
+  dense        flat buffer       n_Wqkv (D,3E) | n_W (E,A) | n_b (A) | n_q (A) |
+                                 u_Wqkv (E,3E) | u_W (E,A) | u_b (A) | u_q (A)
+                                 -> one RCCL all-reduce and one Adam launch per step
+  ids          (N*T,) int32      N = B*(H+C) titles: history titles first, then candidates
+  Xd/QKV/Y/U/w per-token activations of the news encoder (kept for backward)
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from ebrec import _hip
+
+BETA1, BETA2, ADAM_EPS = 0.9, 0.999, 1e-7  # tf.keras.optimizers.Adam defaults (nrms.py:77)
+_ALIGN = 64  # floats; keeps every parameter 256-byte aligned inside the flat buffer
+
+LOSS_KIND = {"cross_entropy_loss": 0, "log_loss": 1}
+
+
+def require_gpu() -> torch.device:
+    if not torch.cuda.is_available():
+        raise RuntimeError("the MI355X NRMS path needs a visible GPU (no CPU fallback); "
+                           "torch.cuda.is_available() is False")
+    _hip.lib()
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def glorot_uniform_np(shape, seed):
+    """[KERAS-SEMANTICS] GlorotUniform(seed): the same (seed, shape) gives the same draw, which is
+    why WQ, WK and WV of one layer start identical in the reference (layers.py:155-172)."""
+    rng = np.random.default_rng(seed)
+    lim = math.sqrt(6.0 / (shape[0] + shape[-1]))
+    return rng.uniform(-lim, lim, size=shape).astype(np.float32)
+
+
+class FlatParams:
+    """Named fp32 parameters carved out of one flat device buffer (plus grad / Adam moments)."""
+
+    def __init__(self, shapes: dict, device):
+        self.shapes = dict(shapes)
+        self.offsets = {}
+        off = 0
+        for name, shp in shapes.items():
+            self.offsets[name] = off
+            off += -(-int(np.prod(shp)) // _ALIGN) * _ALIGN
+        self.numel = off
+        self.data = torch.zeros(off, device=device)
+        self.grad = torch.zeros(off, device=device)
+        self.m = torch.zeros(off, device=device)
+        self.v = torch.zeros(off, device=device)
+
+    def view(self, name, buf=None):
+        buf = self.data if buf is None else buf
+        n = int(np.prod(self.shapes[name]))
+        return buf[self.offsets[name]: self.offsets[name] + n].view(*self.shapes[name])
+
+    def g(self, name):
+        return self.view(name, self.grad)
+
+
+class EncoderBuffers:
+    """Activations + backward scratch of one SelfAttention+AttLayer2 stage for up to n_seq sequences."""
+
+    def __init__(self, n_seq, L, Din, E, A, device, own_input, need_dx):
+        R = n_seq * L
+        self.n_seq, self.L, self.Din, self.E, self.A, self.R = n_seq, L, Din, E, A, R
+        f = lambda *s: torch.empty(*s, device=device)
+        self.X = f(R, Din) if own_input else None
+        self.QKV, self.Y, self.U, self.w = f(R, 3 * E), f(R, E), f(R, A), f(R)
+        self.out = f(n_seq, E)
+        self.dY, self.dQKV, self.de = f(R, E), f(R, 3 * E), f(R)
+        self.partials = f(int(_hip.lib().ebn_attpool_partials_len(R, A)))
+        ws = max(int(_hip.lib().ebn_gemm_workspace_floats(Din, 3 * E, R)),
+                 int(_hip.lib().ebn_gemm_workspace_floats(E, A, R)), 1)
+        self.ws = f(ws)
+        self.dX = f(R, Din) if need_dx else None
+
+
+class NRMSEngine:
+    def __init__(self, table: np.ndarray, title_size: int, history_size: int, head_num: int, head_dim: int,
+                 attention_hidden_dim: int, dropout: float, learning_rate: float, loss: str, seed=None,
+                 train_embedding: bool = True, device=None, process_group=None):
+        self.device = require_gpu() if device is None else torch.device(device)
+        if loss not in LOSS_KIND:
+            raise ValueError(f"this loss not defined {loss}")
+        self.T, self.H = int(title_size), int(history_size)
+        self.h, self.d, self.A = int(head_num), int(head_dim), int(attention_hidden_dim)
+        self.E = self.h * self.d
+        self.p = float(dropout)
+        self.loss = loss
+        self.seed = seed
+        self.train_embedding = bool(train_embedding)
+        self.pg = process_group
+        table = np.ascontiguousarray(table, dtype=np.float32)  # copied, like weights=[...] (nrms.py:128)
+        self.V, self.D = table.shape
+        self.table = torch.from_numpy(table).to(self.device)
+        D, E, A = self.D, self.E, self.A
+        self.params = FlatParams({"n_Wqkv": (D, 3 * E), "n_W": (E, A), "n_b": (A,), "n_q": (A,),
+                                  "u_Wqkv": (E, 3 * E), "u_W": (E, A), "u_b": (A,), "u_q": (A,)}, self.device)
+        self._init_weights(seed)
+        if self.train_embedding:
+            self.table_grad = torch.zeros_like(self.table)
+            self.table_m = torch.zeros_like(self.table)
+            self.table_v = torch.zeros_like(self.table)
+        st = _hip.StepState()
+        st.step, st.seed, st.lr, st.adam_alpha = 0, (0 if seed is None else int(seed)) & 0xFFFFFFFF, learning_rate, 0.0
+        self.state = torch.frombuffer(bytearray(bytes(st)), dtype=torch.uint8).to(self.device)
+        self._lr = float(learning_rate)
+        self._bufs = {}
+        self.oob_flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.loss_dev = torch.zeros(1, device=self.device)
+        self.kernel_events = None  # dict name -> [(start, stop)] when bench.py asks for kernel timings
+        self.world = 1
+        if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            self.world = torch.distributed.get_world_size(process_group)
+
+    # ------------------------------------------------------------------ parameters
+    def _init_weights(self, seed):
+        D, E, A = self.D, self.E, self.A
+        s = (lambda: seed) if seed is not None else (lambda: None)
+        pv = self.params.view
+        with torch.no_grad():
+            for pre, din in (("n", D), ("u", E)):
+                # three separate Keras initialisers with the same seed and shape -> identical draws
+                w = np.concatenate([glorot_uniform_np((din, E), s()) for _ in range(3)], axis=1)
+                pv(f"{pre}_Wqkv").copy_(torch.from_numpy(w))
+                pv(f"{pre}_W").copy_(torch.from_numpy(glorot_uniform_np((E, A), s())))
+                pv(f"{pre}_b").zero_()
+                pv(f"{pre}_q").copy_(torch.from_numpy(glorot_uniform_np((A, 1), s())[:, 0]))
+
+    def get_weights(self):
+        """13 arrays in the Keras creation order of SURVEY.md A.6."""
+        E = self.E
+        out = [self.table.cpu().numpy()]
+        for pre in ("n", "u"):
+            w = self.params.view(f"{pre}_Wqkv").cpu().numpy()
+            out += [w[:, :E].copy(), w[:, E:2 * E].copy(), w[:, 2 * E:].copy()]
+            out += [self.params.view(f"{pre}_W").cpu().numpy(), self.params.view(f"{pre}_b").cpu().numpy(),
+                    self.params.view(f"{pre}_q").cpu().numpy().reshape(-1, 1)]
+        return out
+
+    def set_weights(self, weights):
+        if len(weights) != 13:
+            raise ValueError(f"expected 13 weight arrays (emb, 2x[WQ,WK,WV,W,b,q]), got {len(weights)}")
+        w = [np.asarray(a, dtype=np.float32) for a in weights]
+        if w[0].shape != (self.V, self.D):
+            raise ValueError(f"embedding shape {w[0].shape} != {(self.V, self.D)}")
+        with torch.no_grad():
+            self.table.copy_(torch.from_numpy(w[0]))
+            i = 1
+            for pre in ("n", "u"):
+                self.params.view(f"{pre}_Wqkv").copy_(torch.from_numpy(np.concatenate(w[i:i + 3], axis=1)))
+                self.params.view(f"{pre}_W").copy_(torch.from_numpy(w[i + 3]))
+                self.params.view(f"{pre}_b").copy_(torch.from_numpy(w[i + 4].reshape(-1)))
+                self.params.view(f"{pre}_q").copy_(torch.from_numpy(w[i + 5].reshape(-1)))
+                i += 6
+
+    def count_params(self):
+        return self.V * self.D + sum(int(np.prod(s)) for s in self.params.shapes.values())
+
+    # ------------------------------------------------------------------ optimizer state
+    @property
+    def learning_rate(self):
+        return self._lr
+
+    @learning_rate.setter
+    def learning_rate(self, lr):
+        self._lr = float(lr)
+        st = self.read_state()
+        st.lr = self._lr
+        self.state.copy_(torch.frombuffer(bytearray(bytes(st)), dtype=torch.uint8))
+
+    def read_state(self):
+        return _hip.StepState.from_buffer_copy(self.state.cpu().numpy().tobytes())
+
+    # ------------------------------------------------------------------ buffers
+    def _news_bufs(self, N, train):
+        key = ("news", train)
+        b = self._bufs.get(key)
+        if b is None or b.n_seq < N:
+            b = EncoderBuffers(N, self.T, self.D, self.E, self.A, self.device, own_input=True,
+                               need_dx=train and self.train_embedding)
+            b.ids = torch.empty(N * self.T, dtype=torch.int32, device=self.device)
+            self._bufs[key] = b
+        return b
+
+    def _user_bufs(self, B, train):
+        key = ("user", train)
+        b = self._bufs.get(key)
+        if b is None or b.n_seq < B:
+            b = EncoderBuffers(B, self.H, self.E, self.E, self.A, self.device, own_input=False, need_dx=False)
+            self._bufs[key] = b
+        return b
+
+    # ------------------------------------------------------------------ C-ABI plumbing
+    def _enc_structs(self, pre, b: EncoderBuffers, n_seq, X, drop_site, drop_p):
+        pv = self.params.view
+        dims = _hip.EncoderDims(n_seq, b.L, b.Din, self.h, self.d, self.A, drop_site, drop_p)
+        params = _hip.EncoderParams(pv(f"{pre}_Wqkv").data_ptr(), pv(f"{pre}_W").data_ptr(),
+                                    pv(f"{pre}_b").data_ptr(), pv(f"{pre}_q").data_ptr())
+        acts = _hip.EncoderActs(X.data_ptr(), b.QKV.data_ptr(), b.Y.data_ptr(), b.U.data_ptr(), b.w.data_ptr(),
+                                b.out.data_ptr())
+        return dims, params, acts
+
+    def _encoder_fwd(self, pre, b, n_seq, X, train):
+        site, p = (1, self.p) if (train and pre == "n" and self.p > 0) else (-1, 0.0)
+        st = _hip.ptr(self.state) if train else None
+        if self.kernel_events is not None and pre == "n":
+            return self._encoder_fwd_timed(b, n_seq, X, st, site, p)
+        dims, params, acts = self._enc_structs(pre, b, n_seq, X, site, p)
+        _hip.call("ebn_encoder_fwd_f32", ctypes.byref(dims), ctypes.byref(params), ctypes.byref(acts), st,
+                  _hip.stream_handle())
+
+    def _timed(self, name):
+        """HIP events on the launch stream around one kernel (bench.py roofline figures)."""
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.kernel_events.setdefault(name, []).append((e0, e1))
+        return e0, e1
+
+    def _encoder_fwd_timed(self, b, n_seq, X, st, site, p):
+        """Same four launches as ebn_encoder_fwd_f32 for the news encoder, issued one by one so the
+        Q|K|V projection GEMM can be bracketed by events."""
+        S, E, A, R = _hip.stream_handle, self.E, self.A, n_seq * b.L
+        pv = self.params.view
+        e0, e1 = self._timed("qkv_gemm")
+        e0.record()
+        _hip.call("ebn_gemm_f32", 0, 0, R, 3 * E, b.Din, ctypes.c_float(1.0), _hip.ptr(X), b.Din,
+                  _hip.ptr(pv("n_Wqkv")), 3 * E, ctypes.c_float(0.0), _hip.ptr(b.QKV), 3 * E, S())
+        e1.record()
+        _hip.call("ebn_attn_fwd_f32", _hip.ptr(b.QKV), 3 * E, _hip.ptr(b.Y), E, n_seq, b.L, self.h, self.d, st, site,
+                  ctypes.c_float(p), S())
+        _hip.call("ebn_gemm_f32", 0, 0, R, A, E, ctypes.c_float(1.0), _hip.ptr(b.Y), E, _hip.ptr(pv("n_W")), A,
+                  ctypes.c_float(0.0), _hip.ptr(b.U), A, S())
+        _hip.call("ebn_attpool_fwd_f32", _hip.ptr(b.U), _hip.ptr(pv("n_b")), _hip.ptr(pv("n_q")), _hip.ptr(b.Y),
+                  _hip.ptr(b.out), _hip.ptr(b.w), n_seq, b.L, E, A, S())
+
+    def _encoder_bwd(self, pre, b, n_seq, X, dout, dX):
+        site, p = (1, self.p) if (pre == "n" and self.p > 0) else (-1, 0.0)
+        dims, params, acts = self._enc_structs(pre, b, n_seq, X, site, p)
+        g = self.params.g
+        grads = _hip.EncoderGrads(g(f"{pre}_Wqkv").data_ptr(), g(f"{pre}_W").data_ptr(), g(f"{pre}_b").data_ptr(),
+                                  g(f"{pre}_q").data_ptr())
+        scratch = _hip.EncoderScratch(b.dY.data_ptr(), b.dQKV.data_ptr(), b.de.data_ptr(), b.partials.data_ptr(),
+                                      b.ws.data_ptr(), b.ws.numel())
+        _hip.call("ebn_encoder_bwd_f32", ctypes.byref(dims), ctypes.byref(params), ctypes.byref(acts), _hip.ptr(dout),
+                  ctypes.byref(grads), ctypes.byref(scratch), _hip.ptr(dX), 0, _hip.ptr(self.state),
+                  _hip.stream_handle())
+
+    def _upload_ids(self, dst, *arrays):
+        """Token ids -> int32 device buffer; ids outside [0,V) raise like TF-CPU's Embedding does."""
+        off = 0
+        for a in arrays:
+            if isinstance(a, torch.Tensor):
+                t = a.reshape(-1).to(device=self.device, dtype=torch.int32)
+            else:
+                a = np.asarray(a)
+                if a.size and (a.min() < 0 or a.max() >= self.V):
+                    raise IndexError(f"token id out of range [0, {self.V}) for the embedding table")
+                t = torch.from_numpy(np.ascontiguousarray(a.reshape(-1).astype(np.int32, copy=False)))
+            dst[off: off + t.numel()].copy_(t, non_blocking=True)
+            off += t.numel()
+        return off
+
+    def _news_forward(self, b, N, train):
+        """a1..a4 for N titles whose ids are already in b.ids -> b.out[:N]"""
+        site, p = (0, self.p) if (train and self.p > 0) else (-1, 0.0)
+        ev = self._timed("gather") if self.kernel_events is not None else None
+        if ev:
+            ev[0].record()
+        _hip.call("ebn_gather_rows_f32", _hip.ptr(b.ids), _hip.ptr(self.table), _hip.ptr(b.X), N * self.T, self.D,
+                  self.V, _hip.ptr(self.state) if train else None, site, ctypes.c_float(p), _hip.ptr(self.oob_flag),
+                  _hip.stream_handle())
+        if ev:
+            ev[1].record()
+        self._encoder_fwd("n", b, N, b.X, train)
+
+    # ------------------------------------------------------------------ public compute
+    def encode_news(self, ids, chunk=8192) -> torch.Tensor:
+        """newsencoder: (N,T) ids -> (N,E) device tensor (inference mode, nrms.py:116-159)."""
+        ids = ids if isinstance(ids, torch.Tensor) else np.asarray(ids)
+        N = ids.shape[0]
+        if ids.ndim != 2 or ids.shape[1] != self.T:
+            raise ValueError(f"expected ids of shape (N, {self.T}), got {tuple(ids.shape)}")
+        out = torch.empty(N, self.E, device=self.device)
+        for s in range(0, N, chunk):
+            n = min(chunk, N - s)
+            b = self._news_bufs(min(chunk, N), False)
+            self._upload_ids(b.ids, ids[s:s + n])
+            self._news_forward(b, n, False)
+            out[s:s + n].copy_(b.out[:n])
+        self._check_oob()
+        return out
+
+    def encode_users_from_news(self, NEh: torch.Tensor) -> torch.Tensor:
+        """user encoder on already-encoded history (B,H,E) -> (B,E)  (nrms.py:108-111)."""
+        B = NEh.shape[0]
+        X = NEh.reshape(B * self.H, self.E).contiguous()
+        b = self._user_bufs(B, False)
+        self._encoder_fwd("u", b, B, X, False)
+        return b.out[:B].clone()
+
+    def encode_users(self, his) -> torch.Tensor:
+        his = his if isinstance(his, torch.Tensor) else np.asarray(his)
+        B = his.shape[0]
+        NEh = self.encode_news(his.reshape(B * self.H, self.T))
+        return self.encode_users_from_news(NEh.view(B, self.H, self.E))
+
+    def forward(self, his, pred, mode="softmax"):
+        """(B,H,T),(B,C,T) ids -> (probs (B,C), scores (B,C)) device tensors, inference mode."""
+        his = his if isinstance(his, torch.Tensor) else np.asarray(his)
+        pred = pred if isinstance(pred, torch.Tensor) else np.asarray(pred)
+        B, C = his.shape[0], pred.shape[1]
+        self._check_shapes(his, pred)
+        N = B * (self.H + C)
+        nb = self._news_bufs(N, False)
+        self._upload_ids(nb.ids, his, pred)
+        self._news_forward(nb, N, False)
+        ub = self._user_bufs(B, False)
+        self._encoder_fwd("u", ub, B, nb.out, False)
+        scores = torch.empty(B, C, device=self.device)
+        probs = torch.empty(B, C, device=self.device)
+        cand = nb.out[B * self.H:]
+        _hip.call("ebn_score_fwd_f32", _hip.ptr(cand), _hip.ptr(ub.out), _hip.ptr(scores), _hip.ptr(probs), B, C,
+                  self.E, 0 if mode == "softmax" else 1, _hip.stream_handle())
+        self._check_oob()
+        return probs, scores
+
+    def eval_loss(self, his, pred, y):
+        """Inference-mode forward + the compiled loss (validation pass of fit): (loss[1], probs (B,C))."""
+        probs, scores = self.forward(his, pred, mode="softmax")
+        B, C = scores.shape
+        labels = (y if isinstance(y, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(y, dtype=np.float32))))
+        labels = labels.to(device=self.device, dtype=torch.float32).reshape(B, C).contiguous()
+        nb, ub = self._news_bufs(B * (self.H + C), False), self._user_bufs(B, False)
+        rows = torch.empty(B, device=self.device)
+        junk_c = torch.empty(B * C, self.E, device=self.device)
+        junk_u = torch.empty(B, self.E, device=self.device)
+        loss = torch.empty(1, device=self.device)
+        _hip.call("ebn_score_loss_bwd_f32", _hip.ptr(nb.out[B * self.H:]), _hip.ptr(ub.out), _hip.ptr(scores),
+                  _hip.ptr(labels), _hip.ptr(rows), _hip.ptr(junk_c), _hip.ptr(junk_u), B, C, self.E,
+                  LOSS_KIND[self.loss], ctypes.c_float(1.0 / B), _hip.stream_handle())
+        _hip.call("ebn_sum_f32", _hip.ptr(rows), B, ctypes.c_float(1.0), _hip.ptr(loss), 0, _hip.stream_handle())
+        return loss, probs
+
+    def pair_scores(self, user, news, u_idx, n_idx, sigmoid=True):
+        n = u_idx.numel()
+        out = torch.empty(n, device=self.device)
+        _hip.call("ebn_pair_score_f32", _hip.ptr(user), _hip.ptr(news), _hip.ptr(u_idx), _hip.ptr(n_idx),
+                  _hip.ptr(out), n, self.E, 1 if sigmoid else 0, _hip.stream_handle())
+        return out
+
+    def _check_shapes(self, his, pred):
+        if his.ndim != 3 or his.shape[1] != self.H or his.shape[2] != self.T:
+            raise ValueError(f"his_input_title must be (B, {self.H}, {self.T}), got {tuple(his.shape)}")
+        if pred.ndim != 3 or pred.shape[0] != his.shape[0] or pred.shape[2] != self.T:
+            raise ValueError(f"pred_input_title must be (B, C, {self.T}), got {tuple(pred.shape)}")
+
+    def _check_oob(self):
+        if int(self.oob_flag.item()) != 0:
+            self.oob_flag.zero_()
+            raise IndexError(f"token id out of range [0, {self.V}) for the embedding table")
+
+    # ------------------------------------------------------------------ training
+    def train_step(self, his, pred, y, return_probs=False):
+        """One optimizer step (forward, loss, backward, gradient all-reduce, Keras Adam).
+        Returns the batch loss as a 1-element device tensor (no host sync)."""
+        his = his if isinstance(his, torch.Tensor) else np.asarray(his)
+        pred = pred if isinstance(pred, torch.Tensor) else np.asarray(pred)
+        self._check_shapes(his, pred)
+        B, C, H, E = his.shape[0], pred.shape[1], self.H, self.E
+        N = B * (H + C)
+        S = _hip.stream_handle
+        nb = self._news_bufs(N, True)
+        ub = self._user_bufs(B, True)
+        self._upload_ids(nb.ids, his, pred)
+        labels = (y if isinstance(y, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(y, dtype=np.float32))))
+        labels = labels.to(device=self.device, dtype=torch.float32).reshape(B, C).contiguous()
+        if not hasattr(nb, "dNE") or nb.dNE.shape[0] < N:
+            nb.dNE = torch.empty(nb.n_seq, E, device=self.device)
+            nb.scores = torch.empty(nb.n_seq, device=self.device)
+            nb.probs = torch.empty(nb.n_seq, device=self.device)
+            ub.duser = torch.empty(ub.n_seq, E, device=self.device)
+            ub.loss_rows = torch.empty(ub.n_seq, device=self.device)
+        st = _hip.ptr(self.state)
+        _hip.call("ebn_step_advance", st, BETA1, BETA2, S())
+        # ---- forward
+        self._news_forward(nb, N, True)
+        self._encoder_fwd("u", ub, B, nb.out, True)  # history encodings are the first B*H rows
+        cand = nb.out[B * H:]
+        _hip.call("ebn_score_fwd_f32", _hip.ptr(cand), _hip.ptr(ub.out), _hip.ptr(nb.scores), _hip.ptr(nb.probs), B, C,
+                  E, 0, S())
+        # ---- backward
+        dcand = nb.dNE[B * H:]
+        _hip.call("ebn_score_loss_bwd_f32", _hip.ptr(cand), _hip.ptr(ub.out), _hip.ptr(nb.scores), _hip.ptr(labels),
+                  _hip.ptr(ub.loss_rows), _hip.ptr(dcand), _hip.ptr(ub.duser), B, C, E, LOSS_KIND[self.loss],
+                  ctypes.c_float(1.0 / B), S())
+        _hip.call("ebn_sum_f32", _hip.ptr(ub.loss_rows), B, ctypes.c_float(1.0), _hip.ptr(self.loss_dev), 0, S())
+        self._encoder_bwd("u", ub, B, nb.out, ub.duser, nb.dNE)  # writes dNE[:B*H]
+        self._encoder_bwd("n", nb, N, nb.X, nb.dNE, nb.dX)
+        if self.train_embedding:
+            self.table_grad.zero_()
+            site, p = (0, self.p) if self.p > 0 else (-1, 0.0)
+            _hip.call("ebn_embedding_grad_scatter_f32", _hip.ptr(nb.ids), _hip.ptr(nb.dX), _hip.ptr(self.table_grad),
+                      N * self.T, self.D, self.V, st, site, ctypes.c_float(p), S())
+        # ---- data-parallel gradient all-reduce over RCCL (SUM; 1/world folded into Adam)
+        if self.world > 1:
+            torch.distributed.all_reduce(self.params.grad, group=self.pg)
+            if self.train_embedding:
+                torch.distributed.all_reduce(self.table_grad, group=self.pg)
+        gs = ctypes.c_float(1.0 / self.world)
+        P = self.params
+        _hip.call("ebn_adam_keras_step_f32", _hip.ptr(P.data), _hip.ptr(P.grad), _hip.ptr(P.m), _hip.ptr(P.v), P.numel,
+                  st, BETA1, BETA2, ADAM_EPS, gs, S())
+        if self.train_embedding:
+            _hip.call("ebn_adam_keras_step_f32", _hip.ptr(self.table), _hip.ptr(self.table_grad), _hip.ptr(self.table_m),
+                      _hip.ptr(self.table_v), self.table.numel(), st, BETA1, BETA2, ADAM_EPS, gs, S())
+        if return_probs:
+            return self.loss_dev, nb.probs[: B * C].view(B, C)
+        return self.loss_dev

@@ -1,0 +1,264 @@
+"""The Keras ``Model`` surface the reference's callers use, on top of a device engine.
+
+Callers of the reference touch ``model.model.fit / predict / compile / summary / save_weights /
+load_weights / count_params / variables / optimizer / loss`` and ``model.scorer.predict``
+(ebnerd_nrms.py:244-260,302; nrms_dummy.py:46-47).  This module keeps
+those call shapes; the arithmetic happens in the engine's HIP kernels.
+"""
+from __future__ import annotations
+
+import time
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from .callbacks import Callback, History, StreamingAUC
+
+
+def _is_loader(x):
+    return hasattr(x, "__len__") and hasattr(x, "__getitem__") and not isinstance(x, (tuple, list, np.ndarray))
+
+
+class _ArrayBatches:
+    """(his, pred), y arrays sliced like a Keras Sequence."""
+
+    def __init__(self, x, y, batch_size):
+        self.his, self.pred = x
+        self.y = y
+        self.bs = int(batch_size or 32)
+
+    def __len__(self):
+        return int(np.ceil(len(self.his) / self.bs))
+
+    def __getitem__(self, i):
+        s = slice(i * self.bs, (i + 1) * self.bs)
+        return (self.his[s], self.pred[s]), (None if self.y is None else self.y[s])
+
+
+class _Optimizer:
+    """``model.optimizer``: exposes learning_rate like tf.keras.optimizers.Adam (nrms.py:77)."""
+
+    def __init__(self, engine, name="adam"):
+        self._engine, self.name = engine, name
+
+    @property
+    def learning_rate(self):
+        return self._engine.learning_rate
+
+    @learning_rate.setter
+    def learning_rate(self, lr):
+        self._engine.learning_rate = lr
+
+    lr = learning_rate
+
+    def get_config(self):
+        return {"name": "Adam", "learning_rate": self.learning_rate, "beta_1": 0.9, "beta_2": 0.999, "epsilon": 1e-7}
+
+
+class _Variable(SimpleNamespace):
+    pass
+
+
+class TrainModel:
+    """``NRMSModel.model``: inputs [his (B,H,T), pred (B,C,T)] -> softmax probabilities (B,C)."""
+
+    def __init__(self, owner, names):
+        self._owner = owner
+        self._names = names
+        self.stop_training = False
+        self.metrics_names = []
+        self.history = None
+
+    @property
+    def _engine(self):
+        return self._owner._engine
+
+    # ---- compile / introspection -------------------------------------------------
+    def compile(self, optimizer=None, loss=None, metrics=None, **_):
+        """Re-compile (ebnerd_nrms.py:244-248): optimizer/loss objects coming from this model's own
+        getters are accepted as-is; a loss given by name switches the engine's loss."""
+        if isinstance(loss, str):
+            loss = {"categorical_crossentropy": "cross_entropy_loss", "binary_crossentropy": "log_loss"}.get(loss, loss)
+            self._owner._set_loss(loss)
+        if isinstance(optimizer, str) and optimizer.lower() != "adam":
+            raise ValueError(f"this optimizer not defined {optimizer}")
+        self.metrics_names = [str(m).lower() for m in (metrics or [])]
+
+    @property
+    def optimizer(self):
+        return _Optimizer(self._engine)
+
+    @property
+    def loss(self):
+        return {"cross_entropy_loss": "categorical_crossentropy", "log_loss": "binary_crossentropy"}[self._engine.loss]
+
+    def count_params(self):
+        return self._engine.count_params()
+
+    @property
+    def variables(self):
+        dev = str(self._engine.device)
+        return [_Variable(name=n, device=dev, shape=w.shape) for n, w in zip(self._names, self._engine.get_weights())]
+
+    trainable_variables = variables
+
+    def summary(self, print_fn=print):
+        e = self._engine
+        print_fn(f'Model: "{type(self._owner).__name__}" on {e.device} (HIP/gfx950 kernels)')
+        print_fn(f"{'variable':<28}{'shape':<20}{'params':>12}")
+        for n, w in zip(self._names, e.get_weights()):
+            print_fn(f"{n:<28}{str(tuple(w.shape)):<20}{w.size:>12,}")
+        print_fn(f"Total params: {e.count_params():,}")
+
+    def get_weights(self):
+        return self._engine.get_weights()
+
+    def set_weights(self, weights):
+        self._engine.set_weights(weights)
+
+    def save_weights(self, filepath, **_):
+        """Named tensors (SURVEY.md A.6 order) in a torch file at exactly `filepath`."""
+        state = {n: torch.from_numpy(np.ascontiguousarray(w)) for n, w in zip(self._names, self._engine.get_weights())}
+        extra = getattr(self._engine, "extra_state", lambda: {})()
+        torch.save({"format": "ebnerd-mi355x-weights-v1", "weights": state, "extra": extra}, str(filepath))
+
+    def load_weights(self, filepath, **_):
+        blob = torch.load(str(filepath), map_location="cpu", weights_only=False)
+        if not isinstance(blob, dict) or blob.get("format") != "ebnerd-mi355x-weights-v1":
+            raise ValueError(f"{filepath} is not an ebnerd-mi355x weight file")
+        self._engine.set_weights([blob["weights"][n].numpy() for n in self._names])
+        if blob.get("extra") and hasattr(self._engine, "load_extra_state"):
+            self._engine.load_extra_state(blob["extra"])
+
+    # ---- training ------------------------------------------------------------------
+    def fit(self, x=None, y=None, batch_size=None, epochs=1, verbose=1, callbacks=None, validation_data=None,
+            shuffle=True, initial_epoch=0, **_):
+        data = x if _is_loader(x) else _ArrayBatches(x, y, batch_size)
+        val = None
+        if validation_data is not None:
+            val = validation_data if _is_loader(validation_data) else _ArrayBatches(validation_data[0], validation_data[1], batch_size)
+        hist = History()
+        cbs = [hist] + list(callbacks or [])
+        for cb in cbs:
+            cb.set_model(self)
+        self.stop_training = False
+        want_auc = "auc" in self.metrics_names
+        eng = self._engine
+        rng = np.random.default_rng(self._owner.seed)
+        for cb in cbs:
+            cb.on_train_begin()
+        for epoch in range(initial_epoch, epochs):
+            for cb in cbs:
+                cb.on_epoch_begin(epoch)
+            t0 = time.time()
+            order = rng.permutation(len(data)) if shuffle else np.arange(len(data))  # Keras shuffles batch ORDER only
+            loss_sum = torch.zeros(1, device=eng.device)
+            n_rows = 0
+            auc = StreamingAUC() if want_auc else None
+            for step, idx in enumerate(order):
+                (his, pred), yb = data[int(idx)]
+                nb = len(his)
+                if want_auc:
+                    loss, probs = eng.train_step(his, pred, yb, return_probs=True)
+                    auc.update_device(torch.as_tensor(np.asarray(yb)).to(eng.device), probs)
+                else:
+                    loss = eng.train_step(his, pred, yb)
+                loss_sum += loss * nb
+                n_rows += nb
+                for cb in cbs:
+                    cb.on_train_batch_end(step)
+            logs = {"loss": float(loss_sum.item()) / max(n_rows, 1)}
+            if want_auc:
+                logs["auc"] = auc.result()
+            if val is not None:
+                vl = self.evaluate(val, verbose=0, return_dict=True)
+                logs.update({f"val_{k}": v for k, v in vl.items()})
+            if hasattr(data, "on_epoch_end"):
+                data.on_epoch_end()
+            if verbose:
+                dt = time.time() - t0
+                msg = " - ".join(f"{k}: {v:.4f}" for k, v in logs.items())
+                print(f"Epoch {epoch + 1}/{epochs} - {len(order)} steps - {dt:.1f}s - {n_rows / max(dt, 1e-9):.0f} impressions/s - {msg}")
+            for cb in cbs:
+                cb.on_epoch_end(epoch, logs)
+            if self.stop_training:
+                break
+        for cb in cbs:
+            cb.on_train_end()
+        self.history = hist
+        return hist
+
+    def evaluate(self, x=None, y=None, batch_size=None, verbose=0, return_dict=False, **_):
+        data = x if _is_loader(x) else _ArrayBatches(x, y, batch_size)
+        eng = self._engine
+        auc = StreamingAUC() if "auc" in self.metrics_names else None
+        loss_sum, n_rows = 0.0, 0
+        for i in range(len(data)):
+            (his, pred), yb = data[i]
+            loss, probs = eng.eval_loss(his, pred, yb)
+            loss_sum += float(loss.item()) * len(his)
+            n_rows += len(his)
+            if auc is not None:
+                auc.update_device(torch.as_tensor(np.asarray(yb)).to(eng.device), probs)
+        out = {"loss": loss_sum / max(n_rows, 1)}
+        if auc is not None:
+            out["auc"] = auc.result()
+        return out if return_dict else ([out["loss"]] + ([out["auc"]] if auc is not None else []))
+
+    def predict(self, x, batch_size=None, verbose=0, **_):
+        data = x if _is_loader(x) else _ArrayBatches(x, None, batch_size)
+        outs = []
+        for i in range(len(data)):
+            (his, pred), _y = data[i]
+            probs, _ = self._engine.forward(his, pred, mode="softmax")
+            outs.append(probs.cpu().numpy())
+        return np.concatenate(outs, axis=0) if outs else np.zeros((0, 0), np.float32)
+
+    def __call__(self, inputs, training=False):
+        his, pred = inputs
+        return self._engine.forward(his, pred, mode="softmax")[0]
+
+
+class ScorerModel:
+    """``NRMSModel.scorer``: inputs [his (N,H,T), pred_one (N,1,T)] -> sigmoid(u.n) (N,1)
+    (nrms.py:204-208).  The eval loader repeats the history once per candidate
+    (dataloader.py:99-103); identical history rows of a batch are encoded ONCE here and the
+    scores come from a ragged pair-dot kernel -- same outputs, ~C_i x fewer user encodings."""
+
+    def __init__(self, owner):
+        self._owner = owner
+
+    def predict(self, x, batch_size=None, verbose=0, **_):
+        eng = self._owner._engine
+        data = x if _is_loader(x) else _ArrayBatches(x, None, batch_size)
+        outs = []
+        for i in range(len(data)):
+            (his, pred_one), _y = data[i]
+            outs.append(self._owner._score_pairs(np.asarray(his), np.asarray(pred_one)).cpu().numpy().reshape(-1, 1))
+        return np.concatenate(outs, axis=0) if outs else np.zeros((0, 1), np.float32)
+
+    def __call__(self, inputs, training=False):
+        his, pred_one = inputs
+        return self._owner._score_pairs(np.asarray(his), np.asarray(pred_one)).view(-1, 1)
+
+
+class EncoderModel:
+    """``.newsencoder`` / ``.userencoder`` sub-models (nrms.py:192-193)."""
+
+    def __init__(self, fn, name):
+        self._fn, self.name = fn, name
+
+    def predict(self, x, batch_size=None, verbose=0, **_):
+        return self._fn(x).cpu().numpy()
+
+    def __call__(self, x, training=False):
+        return self._fn(x)
+
+
+def dedup_rows(a: np.ndarray):
+    """unique rows + inverse index (host side; rows are short int/float vectors)."""
+    flat = np.ascontiguousarray(a.reshape(a.shape[0], -1))
+    view = flat.view(np.dtype((np.void, flat.dtype.itemsize * flat.shape[1]))).reshape(-1)
+    _, first, inv = np.unique(view, return_index=True, return_inverse=True)
+    return a[first], inv.reshape(-1).astype(np.int32)

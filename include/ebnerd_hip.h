@@ -56,7 +56,7 @@ int ebn_abi_version(void);
 const char* ebn_error_string(int code);
 
 /* step++ ; adam_alpha and the dropout keys for the new step. One tiny kernel. */
-int ebn_step_advance(ebn_step_state* st, float beta1, float beta2, ebn_stream_t stream);
+int ebn_step_advance(ebn_step_state* st, double beta1, double beta2, ebn_stream_t stream);
 
 /* ---- a1  tf.keras.layers.Embedding (nrms.py:125-134) ---------------------------
  * out[r,:] = table[ids[r],:] (* inverted-dropout multiplier of nrms.py:136 when
@@ -197,9 +197,10 @@ int ebn_pair_score_f32(const float* user, const float* news, const int32_t* u_id
 
 /* ---- a10  tf.keras.optimizers.Adam (nrms.py:69-80), Keras update form -------------
  * m += (g-m)(1-b1); v += (g^2-v)(1-b2); theta -= alpha_t * m/(sqrt(v)+eps), dense over
- * n elements; g is multiplied by grad_scale first (1/world_size after an all-reduce sum). */
+ * n elements; g is multiplied by grad_scale first (1/world_size after an all-reduce sum).
+ * Betas are doubles so that (1-beta) is formed as Keras forms it (Python floats), then cast. */
 int ebn_adam_keras_step_f32(float* theta, const float* g, float* m, float* v, int64_t n,
-                            const ebn_step_state* st, float beta1, float beta2, float eps,
+                            const ebn_step_state* st, double beta1, double beta2, double eps,
                             float grad_scale, ebn_stream_t stream);
 
 /* ---- small dense helpers used by the DocVec encoder (nrms_docvec.py:113-135) ------- */

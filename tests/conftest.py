@@ -26,3 +26,12 @@ def hip():
     _hip.lib()
     torch.cuda.set_device(0)
     return _hip
+
+
+@pytest.fixture(autouse=True)
+def _release_device_temporaries(request):
+    yield
+    if request.node.get_closest_marker("gpu") is not None:
+        from tests.hip_testutil import release_kept
+
+        release_kept()

@@ -8,8 +8,19 @@ from ebrec import _hip
 from oracle import nrms_numpy as on
 
 
+_KEEP = []  # device tensors stay alive until the test ends: `P(dev(x))` hands a raw pointer to an
+# asynchronous launch, and a temporary freed right after P() could be recycled by the next dev().
+
+
 def dev(a, dtype=torch.float32):
-    return torch.as_tensor(np.ascontiguousarray(a)).to(dtype).cuda()
+    t = torch.as_tensor(np.ascontiguousarray(a)).to(dtype).cuda()
+    _KEEP.append(t)
+    return t
+
+
+def release_kept():
+    torch.cuda.synchronize()
+    _KEEP.clear()
 
 
 def host(t):

@@ -108,7 +108,6 @@ def test_gemm_all_layouts(hip, M, N, K, tA, tB):
     opA = A.T if tA else A
     opB = B.T if tB else B
     ref = opA.astype(np.float64) @ opB.astype(np.float64)
-    scale = np.sqrt(K)
     for alpha, beta, use_ws in ((1.0, 0.0, False), (0.5, 1.0, False), (1.0, 0.0, True), (2.0, -0.5, True)):
         C = dev(C0)
         ws = None
@@ -117,7 +116,7 @@ def test_gemm_all_layouts(hip, M, N, K, tA, tB):
             ws = torch.empty(max(int(n), 1), device="cuda")
         gemm(tA, tB, M, N, K, alpha, dev(A), A.shape[1], dev(B), B.shape[1], beta, C, N, ws)
         want = alpha * ref + beta * C0
-        assert_close(host(C), want, rtol=2e-6, atol=3e-6 * scale, what=f"gemm {M}x{N}x{K} tA={tA} tB={tB} a={alpha} b={beta} ws={use_ws}")
+        assert_close(host(C), want, rtol=2e-6, atol=1e-5 + 3e-7 * K, what=f"gemm {M}x{N}x{K} tA={tA} tB={tB} a={alpha} b={beta} ws={use_ws}")
 
 
 def test_gemm_is_asymmetric_safe_and_respects_ld(hip):
@@ -252,7 +251,7 @@ def test_attpool_forward_and_backward(hip, n_seq, L, E, A):
     assert_close(host(dWd), dW, rtol=3e-5, atol=3e-5, what="dW")
     assert_close(host(dXd).reshape(n_seq, L, E), dX, rtol=3e-5, atol=1e-5, what="dX")
     # accumulate flag adds on top
-    hip.call("ebn_attpool_bwd_dpre_f32", P(U), P(dev(q)), P(torch.zeros_like(de)), P(dqd), P(dbd), P(part), R, A, 1, S())
+    hip.call("ebn_attpool_bwd_dpre_f32", P(U), P(dev(q)), P(dev(np.zeros(R))), P(dqd), P(dbd), P(part), R, A, 1, S())
     assert_close(host(dqd), dq[:, 0], rtol=3e-5, atol=2e-5, what="dq accumulate(0)")
 
 
@@ -408,7 +407,7 @@ def test_adam_keras_multi_step(hip, n):
         g[: n // 3] = 0.0  # untouched embedding rows still get the dense moment decay
         hip.call("ebn_step_advance", P(st), 0.9, 0.999, S())
         hip.call("ebn_adam_keras_step_f32", P(th_d), P(dev(g * 2.0)), P(m_d), P(v_d), n, P(st), 0.9, 0.999,
-                 ctypes.c_float(1e-7), ctypes.c_float(0.5), S())
+                 1e-7, ctypes.c_float(0.5), S())
         on.adam_keras_step(theta, g, m, v, t, lr=1e-3)
     assert_close(host(th_d), theta, rtol=1e-5, atol=2e-6, what="theta")
     assert_close(host(m_d), m, rtol=1e-5, atol=1e-7, what="m")

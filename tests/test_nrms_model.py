@@ -1,0 +1,223 @@
+"""Model-level parity of the MI355X NRMS host layer against the float64 oracle (gpu-marked).
+
+These read like the tests the reference never had (no model numerics
+tests): same constructor, same ``.model`` / ``.scorer`` / ``.newsencoder`` / ``.userencoder``
+surface, outputs compared with the restated reference math on identical weights and inputs.
+Forward tolerance: 1e-5 abs on probabilities / scores of O(1) -- 10x inside the 1e-4 fp32
+budget of BASELINE.json's north_star.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nrms_numpy as on
+from tests.hip_testutil import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+class HP:
+    title_size = 30
+    history_size = 20
+    head_num = 20
+    head_dim = 20
+    attention_hidden_dim = 200
+    optimizer = "adam"
+    loss = "cross_entropy_loss"
+    dropout = 0.2
+    learning_rate = 1e-3
+    newsencoder_units_per_layer = None
+    newsencoder_l2_regularization = 1e-4
+
+
+def make_hp(**kw):
+    return type("hp", (HP,), kw)
+
+
+def weight_list(P):
+    return [P[k] for k in on.PARAM_ORDER]
+
+
+def batch(rng, B, H, C, T, V, pad_frac=0.15):
+    his = rng.integers(0, V, (B, H, T))
+    pad = rng.random((B, H)) < pad_frac  # padded history slots = all-zero titles
+    his[pad] = 0
+    pred = rng.integers(0, V, (B, C, T))
+    y = np.zeros((B, C), np.int8)
+    y[np.arange(B), rng.integers(0, C, B)] = 1
+    return his, pred, y
+
+
+@pytest.fixture(scope="module")
+def nrms(hip):
+    from ebrec.models.newsrec import NRMSModel
+
+    return NRMSModel
+
+
+@pytest.mark.parametrize("cfg", [dict(), dict(history_size=50, title_size=30), dict(head_num=16, head_dim=16),
+                                 dict(title_size=12, history_size=5, head_num=3, head_dim=8, attention_hidden_dim=17)])
+def test_forward_matches_oracle_on_identical_weights(nrms, cfg):
+    hp = make_hp(**cfg)
+    V, D = 500, 300 if not cfg.get("head_dim") == 8 else 36
+    rng = np.random.default_rng(0)
+    P = on.random_nrms_params(V, D, hp.head_num, hp.head_dim, hp.attention_hidden_dim, seed=3)
+    m = nrms(hp, word2vec_embedding=P["emb"], seed=1).from_keras_weight_list(weight_list(P))
+    B, C = 7, 5
+    his, pred, y = batch(rng, B, hp.history_size, C, hp.title_size, V)
+    probs, s, _ = on.nrms_forward(his, pred, P, hp.head_num, hp.head_dim)
+    got = m.model.predict((his, pred))
+    assert got.shape == (B, C)
+    assert_close(got, probs, rtol=0, atol=1e-5, what="softmax click probabilities")
+    # scorer: sigmoid(u.n) per (history, single candidate) row, nrms.py:204-205
+    one = pred[:, :1, :]
+    sc = m.scorer.predict((his, one))
+    assert sc.shape == (B, 1)
+    assert_close(sc, on.scorer_forward(his, one, P, hp.head_num, hp.head_dim), rtol=0, atol=1e-5, what="scorer")
+    # sub-models
+    ne = m.newsencoder.predict(pred[0])
+    want_ne, _ = on.news_encoder_fwd(pred[0], P, hp.head_num, hp.head_dim)
+    assert_close(ne, want_ne, rtol=1e-5, atol=1e-5, what="newsencoder")
+    ue = m.userencoder.predict(his)
+    NEh, _ = on.news_encoder_fwd(his.reshape(-1, hp.title_size), P, hp.head_num, hp.head_dim)
+    want_u, _ = on.user_encoder_from_news_fwd(NEh.reshape(B, hp.history_size, -1), P, hp.head_num, hp.head_dim)
+    assert_close(ue, want_u, rtol=1e-5, atol=1e-5, what="userencoder")
+
+
+def test_scorer_on_eval_loader_layout_dedups_but_keeps_row_order(nrms):
+    """dataloader.py:99-107 layout: history repeated per candidate, pred (sum C_i, 1, T)."""
+    hp = make_hp()
+    V, D = 300, 64
+    rng = np.random.default_rng(5)
+    P = on.random_nrms_params(V, D, hp.head_num, hp.head_dim, hp.attention_hidden_dim, seed=4)
+    m = nrms(hp, word2vec_embedding=P["emb"]).from_keras_weight_list(weight_list(P))
+    n_imp = 4
+    his_imp = rng.integers(0, V, (n_imp, hp.history_size, hp.title_size))
+    counts = [3, 1, 6, 2]
+    his = np.repeat(his_imp, counts, axis=0)
+    pred = rng.integers(0, V, (sum(counts), 1, hp.title_size))
+    pred[4] = pred[5]  # a repeated candidate title
+    got = m.scorer.predict((his, pred))
+    want = on.scorer_forward(his, pred, P, hp.head_num, hp.head_dim)
+    assert_close(got, want, rtol=0, atol=1e-5, what="ragged scorer")
+
+
+@pytest.mark.parametrize("loss", ["cross_entropy_loss", "log_loss"])
+@pytest.mark.parametrize("p", [0.0, 0.2])
+def test_training_steps_follow_the_oracle_trajectory(nrms, loss, p):
+    """3 optimizer steps: loss values and every updated tensor vs float64 oracle + Keras-form Adam,
+    with the shared counter-based dropout stream (training-mode parity)."""
+    hp = make_hp(loss=loss, dropout=p, learning_rate=1e-3)
+    V, D, seed = 400, 300, 11
+    rng = np.random.default_rng(7)
+    P = on.random_nrms_params(V, D, hp.head_num, hp.head_dim, hp.attention_hidden_dim, seed=5)
+    m = nrms(hp, word2vec_embedding=P["emb"], seed=seed).from_keras_weight_list(weight_list(P))
+    P = {k: v.astype(np.float32).astype(np.float64) for k, v in P.items()}
+    mom = {k: (np.zeros_like(v), np.zeros_like(v)) for k, v in P.items()}
+    B, C = 8, 5
+    for t in range(1, 4):
+        his, pred, y = batch(rng, B, hp.history_size, C, hp.title_size, V)
+        L, _, g = on.nrms_loss_and_grads(his, pred, y, P, hp.head_num, hp.head_dim, loss,
+                                         on.Drop(p, seed, t) if p > 0 else None)
+        got_L = float(m.train_step(his, pred, y).item())
+        assert abs(got_L - L) <= 2e-5 * max(1.0, abs(L)), (t, got_L, L)
+        for k in P:
+            on.adam_keras_step(P[k], g[k], mom[k][0], mom[k][1], t, lr=1e-3)
+    got = dict(zip(on.PARAM_ORDER, m.model.get_weights()))
+    for k in on.PARAM_ORDER:
+        # Adam's m/(sqrt(v)+eps) amplifies fp32 gradient noise where |g| ~ eps: compare the update
+        step = np.abs(P[k] - on.random_nrms_params(V, D, hp.head_num, hp.head_dim, hp.attention_hidden_dim, seed=5)[k].astype(np.float32))
+        assert_close(got[k].reshape(P[k].shape), P[k], rtol=0, atol=2e-5 + 0.02 * float(step.max()), what=f"weights {k} after 3 steps")
+
+
+def test_gradients_match_oracle_directly(nrms):
+    """Backward parity without the optimizer in the way: raw gradient buffers after one step."""
+    hp = make_hp(dropout=0.2)
+    V, D, seed = 300, 300, 2
+    rng = np.random.default_rng(9)
+    P = on.random_nrms_params(V, D, hp.head_num, hp.head_dim, hp.attention_hidden_dim, seed=6)
+    m = nrms(hp, word2vec_embedding=P["emb"], seed=seed).from_keras_weight_list(weight_list(P))
+    P = {k: v.astype(np.float32).astype(np.float64) for k, v in P.items()}
+    his, pred, y = batch(rng, 6, hp.history_size, 5, hp.title_size, V)
+    L, _, g = on.nrms_loss_and_grads(his, pred, y, P, hp.head_num, hp.head_dim, "cross_entropy_loss", on.Drop(0.2, seed, 1))
+    m.train_step(his, pred, y)
+    eng = m._engine
+    E = eng.E
+    for pre in ("n", "u"):
+        gq = eng.params.g(f"{pre}_Wqkv").cpu().numpy()
+        want = np.concatenate([g[f"{pre}_WQ"], g[f"{pre}_WK"], g[f"{pre}_WV"]], 1)
+        assert_close(gq, want, rtol=1e-4, atol=1e-6 + 1e-4 * np.abs(want).max(), what=f"{pre} dWqkv")
+        for nm in ("W", "b", "q"):
+            want = g[f"{pre}_{nm}"].reshape(eng.params.shapes[f"{pre}_{nm}"])
+            assert_close(eng.params.g(f"{pre}_{nm}").cpu().numpy(), want, rtol=1e-4, atol=1e-6 + 1e-4 * np.abs(want).max(), what=f"{pre} d{nm}")
+    assert_close(eng.table_grad.cpu().numpy(), g["emb"], rtol=1e-4, atol=1e-6 + 1e-4 * np.abs(g["emb"]).max(), what="dEmb")
+
+
+def test_frozen_table_is_untouched_and_has_no_moments(nrms):
+    hp = make_hp(dropout=0.0)
+    rng = np.random.default_rng(1)
+    emb = rng.standard_normal((200, 64)).astype(np.float32)
+    m = nrms(hp, word2vec_embedding=emb, seed=3, train_embedding=False)
+    his, pred, y = batch(rng, 4, hp.history_size, 5, hp.title_size, 200)
+    w0 = m.model.get_weights()
+    m.train_step(his, pred, y)
+    w1 = m.model.get_weights()
+    assert np.array_equal(w0[0], w1[0]) and not np.array_equal(w0[1], w1[1])
+    assert not hasattr(m._engine, "table_m")
+
+
+def test_seeded_init_reproduces_reference_quirks(nrms):
+    hp = make_hp()
+    m = nrms(hp, word_emb_dim=32, vocab_size=100, seed=42)
+    w = m.model.get_weights()
+    assert len(w) == 13 and w[0].shape == (100, 32)
+    assert np.array_equal(w[1], w[2]) and np.array_equal(w[2], w[3])  # WQ=WK=WV at init (quirk 5)
+    assert np.all(w[5] == 0) and w[6].shape == (200, 1)
+    lim = np.sqrt(6.0 / (100 + 32))
+    assert np.abs(w[0]).max() <= lim and np.abs(w[0]).max() > 0.9 * lim
+    m2 = nrms(hp, word_emb_dim=32, vocab_size=100, seed=42)
+    assert all(np.array_equal(a, b) for a, b in zip(w, m2.model.get_weights()))
+    assert m.model.count_params() == 100 * 32 + 32 * 1200 + 400 * 200 + 200 + 200 + 400 * 1200 + 400 * 200 + 200 + 200
+
+
+def test_out_of_range_token_raises(nrms):
+    hp = make_hp()
+    m = nrms(hp, word_emb_dim=16, vocab_size=50, seed=0)
+    his = np.zeros((2, hp.history_size, hp.title_size), np.int64)
+    pred = np.zeros((2, 3, hp.title_size), np.int64)
+    pred[1, 2, 5] = 50
+    with pytest.raises(IndexError):
+        m.model.predict((his, pred))
+    with pytest.raises(IndexError):  # device-side check for ids that are already on the GPU
+        m._engine.forward(torch.from_numpy(his).cuda(), torch.from_numpy(pred).cuda())
+
+
+def test_fit_predict_compile_save_load_surface(nrms, tmp_path):
+    """The call sequence of nrms_dummy.py:46-47 and ebnerd_nrms.py:244-260."""
+    from ebrec.models.newsrec.callbacks import EarlyStopping, ModelCheckpoint, ReduceLROnPlateau
+
+    hp = make_hp(learning_rate=1e-3)
+    rng = np.random.default_rng(3)
+    V = 120
+    m = nrms(hp, word2vec_embedding=rng.random((V, 40)), seed=5)
+    m.model.compile(optimizer=m.model.optimizer, loss=m.model.loss, metrics=["AUC"])
+    his, pred, y = batch(rng, 70, hp.history_size, 5, hp.title_size, V)
+    ck = tmp_path / "weights.h5"
+    hist = m.model.fit((his, pred), y, batch_size=32, epochs=3, verbose=0, validation_data=((his[:20], pred[:20]), y[:20]),
+                       callbacks=[EarlyStopping(monitor="val_auc", mode="max", patience=4, restore_best_weights=True),
+                                  ModelCheckpoint(filepath=str(ck), monitor="val_auc", mode="max", save_best_only=True,
+                                                  save_weights_only=True),
+                                  ReduceLROnPlateau(monitor="val_auc", mode="max", factor=0.2, patience=2, min_lr=1e-6)])
+    assert set(hist.history) >= {"loss", "auc", "val_loss", "val_auc"} and len(hist.history["loss"]) == 3
+    assert hist.history["loss"][-1] < hist.history["loss"][0]  # it learns the 70 rows
+    assert ck.exists()
+    p1 = m.model.predict((his, pred))
+    assert p1.shape == (70, 5) and np.allclose(p1.sum(1), 1, atol=1e-5)
+    m2 = nrms(hp, word2vec_embedding=rng.random((V, 40)), seed=9)
+    m2.model.load_weights(str(ck))
+    m.model.load_weights(str(ck))
+    assert np.array_equal(m2.model.predict((his, pred)), m.model.predict((his, pred)))
+    lines = []
+    m.model.summary(print_fn=lines.append)
+    assert any("news.attn.WQ" in l for l in lines)
+    assert m.model.variables[0].name == "news.emb" and "cuda" in m.model.variables[0].device
