@@ -11,6 +11,13 @@
 // column j (O, dK): row accesses use an odd row stride, column accesses are unit-stride.
 #include "ebn_common.h"
 
+// MFMA fast path (ebn_attention_mfma.hip): L <= 32, d in {16,20,32}, 16-byte friendly layouts.
+int ebn_attn_mfma_fwd(const float* qkv, int64_t ld_qkv, float* out, int64_t ld_out, int64_t n_seq, int32_t L,
+                      int32_t h, int32_t d, const EbnDrop& dr, hipStream_t s, bool* handled);
+int ebn_attn_mfma_bwd(const float* qkv, int64_t ld_qkv, const float* dout, int64_t ld_dout, float* dqkv,
+                      int64_t ld_dqkv, int64_t n_seq, int32_t L, int32_t h, int32_t d, const EbnDrop& dr,
+                      hipStream_t s, bool* handled);
+
 namespace {
 
 constexpr int DMAX = 32;  // head_dim <= 32 (reference configs: 20, 16)
@@ -252,6 +259,9 @@ extern "C" int ebn_attn_fwd_f32(const float* qkv, int64_t ld_qkv, float* out, in
   if (n_seq == 0) return EBN_OK;
   EBN_REQUIRE(ld_qkv >= 3 * h * d && ld_out >= h * d, EBN_ERR_BAD_ARG);
   const EbnDrop dr = ebn_make_drop(st, site, drop_p);
+  bool handled = false;
+  rc = ebn_attn_mfma_fwd(qkv, ld_qkv, out, ld_out, n_seq, L, h, d, dr, ebn_stream(stream), &handled);
+  if (rc != EBN_OK || handled) return rc;
   AttnArgs a{qkv, ld_qkv, nullptr, 0, out, ld_out, n_seq * h, L, h, d, dr.key_ptr, dr.thresh, dr.scale};
   const int LP = (L & 1) ? L + 2 : L + 1;
   const int per_group = 3 * L * d + L * LP;
@@ -277,6 +287,9 @@ extern "C" int ebn_attn_bwd_f32(const float* qkv, int64_t ld_qkv, const float* d
   if (n_seq == 0) return EBN_OK;
   EBN_REQUIRE(ld_qkv >= 3 * h * d && ld_dqkv >= 3 * h * d && ld_dout >= h * d, EBN_ERR_BAD_ARG);
   const EbnDrop dr = ebn_make_drop(st, site, drop_p);
+  bool handled = false;
+  rc = ebn_attn_mfma_bwd(qkv, ld_qkv, dout, ld_dout, dqkv, ld_dqkv, n_seq, L, h, d, dr, ebn_stream(stream), &handled);
+  if (rc != EBN_OK || handled) return rc;
   AttnArgs a{qkv, ld_qkv, dout, ld_dout, dqkv, ld_dqkv, n_seq * h, L, h, d, dr.key_ptr, dr.thresh, dr.scale};
   const int LP = (L & 1) ? L + 2 : L + 1;
   const int per_group = 4 * L * d + 2 * L * LP;
