@@ -23,47 +23,49 @@ constexpr int GEMM_THREADS = 256;
 
 // One operand tile of R_MN x BK (mn = m or n index). KCONTIG: memory is [mn][k] (k fastest);
 // else memory is [k][mn] (mn fastest).
-template <int BMN, bool KCONTIG>
+template <int BMN, bool KCONTIG, bool VEC>
 struct TileLoader {
   static constexpr int VECS = BMN * BK / 4;            // float4 per tile
   static constexpr int PER_THREAD = VECS / GEMM_THREADS;  // 2 (BMN=128) or 1 (BMN=64)
   static_assert(VECS % GEMM_THREADS == 0, "tile/thread mismatch");
 
-  // returns 4 consecutive elements along the contiguous axis (guarded, zero-filled)
+  // returns 4 consecutive elements along the contiguous axis, zero-filled outside the matrix.
+  // vec_ok (host-checked: 16-byte aligned base, ld % 4 == 0, extent of the contiguous axis % 4 == 0)
+  // makes every float4 all-in or all-out, so the load is BRANCH-FREE: an out-of-range lane reads the
+  // (always valid) first 16 bytes of the matrix and the value is replaced by a select.  Guarded
+  // per-element loads make hipcc branch around each one and serialise them on vmcnt(0).
   __device__ static __forceinline__ float4 load(const float* __restrict__ P, int64_t ld, int64_t mn0,
-                                                int64_t k0, int64_t MN, int64_t Kdim, int v, bool vec_ok) {
+                                                int64_t k0, int64_t MN, int64_t Kdim, int v) {
+    int64_t gmn, gk;
+    if (KCONTIG) {
+      gmn = mn0 + v / (BK / 4);
+      gk = k0 + (v % (BK / 4)) * 4;
+    } else {
+      gk = k0 + v / (BMN / 4);
+      gmn = mn0 + (v % (BMN / 4)) * 4;
+    }
+    const int64_t off = KCONTIG ? (gmn * ld + gk) : (gk * ld + gmn);
+    if (VEC) {
+      const bool valid = (gmn < MN) && (gk < Kdim);
+      const float4 r = *reinterpret_cast<const float4*>(valid ? (P + off) : P);
+      return valid ? r : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
     if (KCONTIG) {
-      const int mn = v / (BK / 4);
-      const int kq = v % (BK / 4);
-      const int64_t gmn = mn0 + mn;
-      const int64_t gk = k0 + kq * 4;
       if (gmn < MN) {
-        const float* p = P + gmn * ld + gk;
-        if (vec_ok && gk + 3 < Kdim) {
-          r = *reinterpret_cast<const float4*>(p);
-        } else {
-          if (gk + 0 < Kdim) r.x = p[0];
-          if (gk + 1 < Kdim) r.y = p[1];
-          if (gk + 2 < Kdim) r.z = p[2];
-          if (gk + 3 < Kdim) r.w = p[3];
-        }
+        const float* p = P + off;
+        if (gk + 0 < Kdim) r.x = p[0];
+        if (gk + 1 < Kdim) r.y = p[1];
+        if (gk + 2 < Kdim) r.z = p[2];
+        if (gk + 3 < Kdim) r.w = p[3];
       }
     } else {
-      const int k = v / (BMN / 4);
-      const int mq = v % (BMN / 4);
-      const int64_t gk = k0 + k;
-      const int64_t gmn = mn0 + mq * 4;
       if (gk < Kdim) {
-        const float* p = P + gk * ld + gmn;
-        if (vec_ok && gmn + 3 < MN) {
-          r = *reinterpret_cast<const float4*>(p);
-        } else {
-          if (gmn + 0 < MN) r.x = p[0];
-          if (gmn + 1 < MN) r.y = p[1];
-          if (gmn + 2 < MN) r.z = p[2];
-          if (gmn + 3 < MN) r.w = p[3];
-        }
+        const float* p = P + off;
+        if (gmn + 0 < MN) r.x = p[0];
+        if (gmn + 1 < MN) r.y = p[1];
+        if (gmn + 2 < MN) r.z = p[2];
+        if (gmn + 3 < MN) r.w = p[3];
       }
     }
     return r;
@@ -90,17 +92,17 @@ struct TileLoader {
 // TA: A stored [K,M]; TB: B stored [N,K].
 // gridDim.z = split-K factor; when > 1 each z-slice writes alpha*partial to
 // Cpart + z*M*N (dense ld = N) and a reduce kernel finishes; else writes C directly.
-template <int BM, int BN, bool TA, bool TB>
+template <int BM, int BN, bool TA, bool TB, bool VEC>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
     int64_t M, int64_t N, int64_t K, float alpha, const float* __restrict__ A, int64_t lda,
     const float* __restrict__ B, int64_t ldb, float beta, float* __restrict__ C, int64_t ldc,
-    int vecA, int vecB, int64_t k_per_split, float* __restrict__ Cpart) {
+    int64_t k_per_split, float* __restrict__ Cpart) {
   constexpr int TM = BM / 64;  // 32x32 tiles per wave along m
   constexpr int TN = BN / 64;
   constexpr int LDA_S = BM + PAD;
   constexpr int LDB_S = BN + PAD;
-  using LA = TileLoader<BM, !TA>;
-  using LB = TileLoader<BN, TB>;
+  using LA = TileLoader<BM, !TA, VEC>;
+  using LB = TileLoader<BN, TB, VEC>;
 
   __shared__ __attribute__((aligned(16))) float As[2][BK * LDA_S];
   __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB_S];
@@ -130,10 +132,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
   if (nk > 0) {
 #pragma unroll
     for (int i = 0; i < LA::PER_THREAD; ++i)
-      ra[i] = LA::load(A, lda, m0, kbeg, M, kend, tid + i * GEMM_THREADS, vecA);
+      ra[i] = LA::load(A, lda, m0, kbeg, M, kend, tid + i * GEMM_THREADS);
 #pragma unroll
     for (int i = 0; i < LB::PER_THREAD; ++i)
-      rb[i] = LB::load(B, ldb, n0, kbeg, N, kend, tid + i * GEMM_THREADS, vecB);
+      rb[i] = LB::load(B, ldb, n0, kbeg, N, kend, tid + i * GEMM_THREADS);
 #pragma unroll
     for (int i = 0; i < LA::PER_THREAD; ++i) LA::store(As[0], tid + i * GEMM_THREADS, ra[i]);
 #pragma unroll
@@ -148,10 +150,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
       const int64_t k0 = kbeg + static_cast<int64_t>(kt + 1) * BK;
 #pragma unroll
       for (int i = 0; i < LA::PER_THREAD; ++i)
-        ra[i] = LA::load(A, lda, m0, k0, M, kend, tid + i * GEMM_THREADS, vecA);
+        ra[i] = LA::load(A, lda, m0, k0, M, kend, tid + i * GEMM_THREADS);
 #pragma unroll
       for (int i = 0; i < LB::PER_THREAD; ++i)
-        rb[i] = LB::load(B, ldb, n0, k0, N, kend, tid + i * GEMM_THREADS, vecB);
+        rb[i] = LB::load(B, ldb, n0, k0, N, kend, tid + i * GEMM_THREADS);
     }
     const float* as = As[cur];
     const float* bs = Bs[cur];
@@ -224,9 +226,15 @@ int launch_gemm(int transA, int transB, int64_t M, int64_t N, int64_t K, float a
   dim3 grid(static_cast<unsigned>(ebn_ceil_div(N, BN)), static_cast<unsigned>(ebn_ceil_div(M, BM)),
             static_cast<unsigned>(splits));
   dim3 block(GEMM_THREADS);
-#define EBN_GEMM_LAUNCH(TA, TB)                                                                        \
-  hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB>), grid, block, 0, s, M, N, K, alpha, A, lda, B, \
-                     ldb, beta, C, ldc, vecA, vecB, k_per_split, part)
+#define EBN_GEMM_LAUNCH(TA, TB)                                                                            \
+  do {                                                                                                    \
+    if (vecA && vecB)                                                                                     \
+      hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB, true>), grid, block, 0, s, M, N, K, alpha, A, lda, \
+                         B, ldb, beta, C, ldc, k_per_split, part);                                        \
+    else                                                                                                  \
+      hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB, false>), grid, block, 0, s, M, N, K, alpha, A,  \
+                         lda, B, ldb, beta, C, ldc, k_per_split, part);                                   \
+  } while (0)
   if (!transA && !transB) EBN_GEMM_LAUNCH(false, false);
   else if (!transA && transB) EBN_GEMM_LAUNCH(false, true);
   else if (transA && !transB) EBN_GEMM_LAUNCH(true, false);
@@ -277,8 +285,9 @@ extern "C" int ebn_gemm_f32_ws(int32_t transA, int32_t transB, int64_t M, int64_
   EBN_REQUIRE(A && B && C, EBN_ERR_BAD_ARG);
   EBN_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, EBN_ERR_BAD_ARG);
   hipStream_t s = ebn_stream(stream);
-  const int vecA = ((lda % 4) == 0 && ebn_aligned16(A)) ? 1 : 0;
-  const int vecB = ((ldb % 4) == 0 && ebn_aligned16(B)) ? 1 : 0;
+  // contiguous-axis extent must be a multiple of 4 too (K for k-contiguous operands, M/N otherwise)
+  const int vecA = ((lda % 4) == 0 && ebn_aligned16(A) && ((transA ? M : K) % 4) == 0) ? 1 : 0;
+  const int vecB = ((ldb % 4) == 0 && ebn_aligned16(B) && ((transB ? K : N) % 4) == 0) ? 1 : 0;
   int bm, splits;
   int64_t kps;
   gemm_plan(M, N, K, workspace ? workspace_floats : 0, &bm, &splits, &kps);
