@@ -119,6 +119,7 @@ def main():
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the config's, 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch kernel by kernel instead of hipGraph replay")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -151,15 +152,24 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    eng.enable_graphs(not args.no_graph)
     for i in range(args.warmup):
         eng.train_step(*batches[i % len(batches)])
     sync()
-    eng.kernel_events = {}
     t0 = time.perf_counter()
     for i in range(args.steps):
         eng.train_step(*batches[i % len(batches)])
     sync()
     dt = time.perf_counter() - t0
+    # Kernel-level rooflines: the same K steps once more, launched kernel by kernel (identical kernels and
+    # arguments; a captured graph cannot carry per-kernel events) with HIP events on the launch stream
+    # around the gather and the Q|K|V projection GEMM.
+    eng.kernel_events = {}
+    t1 = time.perf_counter()
+    for i in range(args.steps):
+        eng.train_step(*batches[i % len(batches)])
+    sync()
+    dt_eager = time.perf_counter() - t1
     events, eng.kernel_events = eng.kernel_events, None
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -180,6 +190,7 @@ def main():
         line = {
             "metric": "training impressions/sec", "value": world * c["B"] * args.steps / dt, "unit": "impressions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step_kernel_by_kernel": dt_eager / args.steps * 1e3, "launch": "eager" if args.no_graph else "hipGraph replay",
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"NRMS train step, BASELINE.json configs[{ {'c1': 0, 'c2': 1, 'c4': 3}[args.config] }] "
                                    f"({args.config}): table {c['V']}x{c['D']} {'trainable' if c['train_embedding'] else 'frozen lookup'}, "

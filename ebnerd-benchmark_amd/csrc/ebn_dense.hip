@@ -218,7 +218,7 @@ extern "C" int ebn_bias_relu_bwd_f32(const float* Y, const float* dY, float* dX,
   hipLaunchKernelGGL(bias_relu_bwd_kernel, dim3(static_cast<unsigned>(nb)), dim3(256), 0, s, Y, dY, dX, partials, R,
                      Ccols, rpb);
   EBN_CHECK_LAUNCH();
-  hipLaunchKernelGGL(ebn_reduce_partials_kernel, dim3(static_cast<unsigned>(ebn_ceil_div(2 * Ccols, 256))),
+  hipLaunchKernelGGL(ebn_reduce_partials_kernel, dim3(static_cast<unsigned>(ebn_ceil_div(2 * Ccols, 32))),
                      dim3(256), 0, s, partials, static_cast<int>(nb), 2, Ccols, dbias,
                      static_cast<float*>(nullptr), accumulate);
   EBN_CHECK_LAUNCH();
@@ -240,7 +240,7 @@ extern "C" int ebn_batchnorm_fwd_f32(const float* X, const float* gamma, const f
   if (training) {
     const int64_t nb = ebn_colred_blocks(R);
     const int64_t rpb = ebn_ceil_div(R, nb);
-    const unsigned rgrid = static_cast<unsigned>(ebn_ceil_div(2 * C, 256));
+    const unsigned rgrid = static_cast<unsigned>(ebn_ceil_div(2 * C, 32));
     hipLaunchKernelGGL((col_moment_kernel<1>), dim3(static_cast<unsigned>(nb)), dim3(256), 0, s, X,
                        static_cast<const float*>(nullptr), partials, R, C, rpb);
     hipLaunchKernelGGL(ebn_reduce_partials_kernel, dim3(rgrid), dim3(256), 0, s, partials, static_cast<int>(nb), 2, C,
@@ -281,7 +281,7 @@ extern "C" int ebn_batchnorm_bwd_f32(const float* dY, const float* xhat, const f
   float* site_db = site_dg + C;
   hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(static_cast<unsigned>(nb)), dim3(256), 0, s, dY, xhat, partials, R, C,
                      rpb, dr.key_ptr, dr.thresh, dr.scale, elem_offset);
-  hipLaunchKernelGGL(ebn_reduce_partials_kernel, dim3(static_cast<unsigned>(ebn_ceil_div(2 * C, 256))), dim3(256), 0,
+  hipLaunchKernelGGL(ebn_reduce_partials_kernel, dim3(static_cast<unsigned>(ebn_ceil_div(2 * C, 32))), dim3(256), 0,
                      s, partials, static_cast<int>(nb), 2, C, site_dg, site_db, 0);
   EBN_CHECK_LAUNCH();
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(R * C)), dim3(256), 0, s, dY, xhat, gamma, istd, site_dg,

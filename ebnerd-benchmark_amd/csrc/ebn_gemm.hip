@@ -17,6 +17,13 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifndef EBN_GEMM_XCD
+#define EBN_GEMM_XCD 0
+#endif
+#ifndef EBN_GEMM_PIPE
+#define EBN_GEMM_PIPE 0
+#endif
+
 constexpr int BK = 16;
 constexpr int PAD = 4;
 constexpr int GEMM_THREADS = 256;
@@ -112,8 +119,20 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
   const int wave = tid >> 6;
   const int wm = wave >> 1;
   const int wn = wave & 1;
-  const int64_t m0 = static_cast<int64_t>(blockIdx.y) * BM;
-  const int64_t n0 = static_cast<int64_t>(blockIdx.x) * BN;
+  // XCD-aware tile order: hardware deals consecutive workgroups round-robin to the 8 XCDs (private
+  // L2s); remap so that each XCD walks a CONTIGUOUS run of tiles (neighbouring tiles share their A
+  // row-panel / B column-panel in one L2).  Bijective for any grid size; speed only, never correctness.
+  int64_t tile_id = static_cast<int64_t>(blockIdx.y) * gridDim.x + blockIdx.x;
+#if EBN_GEMM_XCD
+  {
+    const int64_t nwg = static_cast<int64_t>(gridDim.x) * gridDim.y;
+    const int64_t orig = static_cast<int64_t>(blockIdx.y) * gridDim.x + blockIdx.x;
+    const int64_t q = nwg / 8, r = nwg % 8, xcd = orig % 8, idx = orig / 8;
+    tile_id = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+#endif
+  const int64_t m0 = (tile_id / gridDim.x) * BM;
+  const int64_t n0 = (tile_id % gridDim.x) * BN;
   const int64_t kbeg = static_cast<int64_t>(blockIdx.z) * k_per_split;
   const int64_t kend = (kbeg + k_per_split < K) ? (kbeg + k_per_split) : K;
 
@@ -128,59 +147,73 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
   float4 ra[LA::PER_THREAD], rb[LB::PER_THREAD];
   const int nk = static_cast<int>((kend - kbeg + BK - 1) / BK);
 
-  // prologue: slab 0 -> LDS buffer 0
-  if (nk > 0) {
-#pragma unroll
-    for (int i = 0; i < LA::PER_THREAD; ++i)
-      ra[i] = LA::load(A, lda, m0, kbeg, M, kend, tid + i * GEMM_THREADS);
-#pragma unroll
-    for (int i = 0; i < LB::PER_THREAD; ++i)
-      rb[i] = LB::load(B, ldb, n0, kbeg, N, kend, tid + i * GEMM_THREADS);
-#pragma unroll
-    for (int i = 0; i < LA::PER_THREAD; ++i) LA::store(As[0], tid + i * GEMM_THREADS, ra[i]);
-#pragma unroll
-    for (int i = 0; i < LB::PER_THREAD; ++i) LB::store(Bs[0], tid + i * GEMM_THREADS, rb[i]);
+#define EBN_LOAD_SLAB(KT)                                                              \
+  {                                                                                    \
+    const int64_t k0__ = kbeg + static_cast<int64_t>(KT) * BK;                         \
+    _Pragma("unroll") for (int i = 0; i < LA::PER_THREAD; ++i)                         \
+        ra[i] = LA::load(A, lda, m0, k0__, M, kend, tid + i * GEMM_THREADS);           \
+    _Pragma("unroll") for (int i = 0; i < LB::PER_THREAD; ++i)                         \
+        rb[i] = LB::load(B, ldb, n0, k0__, N, kend, tid + i * GEMM_THREADS);           \
   }
+#define EBN_STORE_SLAB(BUF)                                                                              \
+  {                                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < LA::PER_THREAD; ++i) LA::store(As[BUF], tid + i * GEMM_THREADS, ra[i]); \
+    _Pragma("unroll") for (int i = 0; i < LB::PER_THREAD; ++i) LB::store(Bs[BUF], tid + i * GEMM_THREADS, rb[i]); \
+  }
+
+  // Pipeline (issue-early / write-late): registers hold slab kt+1 (fetched one whole iteration ago),
+  // LDS buffer `cur` holds slab kt.  Each iteration: registers -> LDS[cur^1], re-issue the loads of
+  // slab kt+2 into the same registers, multiply slab kt, one barrier.  The vmcnt wait is an iteration
+  // old by the time it is needed, and the LDS writes overlap the other waves' MFMAs.
+#if EBN_GEMM_PIPE
+  if (nk > 0) {
+    EBN_LOAD_SLAB(0);
+    EBN_STORE_SLAB(0);
+    if (nk > 1) EBN_LOAD_SLAB(1);
+  }
+#else
+  if (nk > 0) {
+    EBN_LOAD_SLAB(0);
+    EBN_STORE_SLAB(0);
+  }
+#endif
   __syncthreads();
 
+  const int kl = lane >> 5;
+  const int il = lane & 31;
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    const bool has_next = (kt + 1) < nk;
-    if (has_next) {
-      const int64_t k0 = kbeg + static_cast<int64_t>(kt + 1) * BK;
-#pragma unroll
-      for (int i = 0; i < LA::PER_THREAD; ++i)
-        ra[i] = LA::load(A, lda, m0, k0, M, kend, tid + i * GEMM_THREADS);
-#pragma unroll
-      for (int i = 0; i < LB::PER_THREAD; ++i)
-        rb[i] = LB::load(B, ldb, n0, k0, N, kend, tid + i * GEMM_THREADS);
+#if EBN_GEMM_PIPE
+    if (kt + 1 < nk) {
+      EBN_STORE_SLAB(cur ^ 1);
+      if (kt + 2 < nk) EBN_LOAD_SLAB(kt + 2);
     }
-    const float* as = As[cur];
-    const float* bs = Bs[cur];
-    const int kl = lane >> 5;
-    const int il = lane & 31;
+#else
+    if (kt + 1 < nk) EBN_LOAD_SLAB(kt + 1);
+#endif
+    const float* as = As[cur] + kl * LDA_S + wm * (BM / 2) + il;
+    const float* bs = Bs[cur] + kl * LDB_S + wn * (BN / 2) + il;
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
       float a[TM], b[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = as[(kk + kl) * LDA_S + wm * (BM / 2) + i * 32 + il];
+      for (int i = 0; i < TM; ++i) a[i] = as[kk * LDA_S + i * 32];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = bs[(kk + kl) * LDB_S + wn * (BN / 2) + j * 32 + il];
+      for (int j = 0; j < TN; ++j) b[j] = bs[kk * LDB_S + j * 32];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
-    if (has_next) {
-#pragma unroll
-      for (int i = 0; i < LA::PER_THREAD; ++i) LA::store(As[cur ^ 1], tid + i * GEMM_THREADS, ra[i]);
-#pragma unroll
-      for (int i = 0; i < LB::PER_THREAD; ++i) LB::store(Bs[cur ^ 1], tid + i * GEMM_THREADS, rb[i]);
-    }
+#if !EBN_GEMM_PIPE
+    if (kt + 1 < nk) EBN_STORE_SLAB(cur ^ 1);
+#endif
     __syncthreads();
     cur ^= 1;
   }
+#undef EBN_LOAD_SLAB
+#undef EBN_STORE_SLAB
 
   // epilogue. C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
   const bool split = gridDim.z > 1;

@@ -122,6 +122,8 @@ class NRMSEngine:
         self._bufs = {}
         self.oob_flag = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.loss_dev = torch.zeros(1, device=self.device)
+        self.use_graph = False  # capture the per-shape kernel sequence into hipGraphs (enable_graphs())
+        self._graphs = {}
         self.kernel_events = None  # dict name -> [(start, stop)] when bench.py asks for kernel timings
         self.world = 1
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
@@ -171,6 +173,12 @@ class NRMSEngine:
     def count_params(self):
         return self.V * self.D + sum(int(np.prod(s)) for s in self.params.shapes.values())
 
+    def enable_graphs(self, flag=True):
+        self.use_graph = bool(flag)
+        if not flag:
+            self._graphs = {}
+        return self
+
     # ------------------------------------------------------------------ optimizer state
     @property
     def learning_rate(self):
@@ -195,6 +203,7 @@ class NRMSEngine:
                                need_dx=train and self.train_embedding)
             b.ids = torch.empty(N * self.T, dtype=torch.int32, device=self.device)
             self._bufs[key] = b
+            self._graphs.clear()  # captured graphs hold raw pointers into the old buffers
         return b
 
     def _user_bufs(self, B, train):
@@ -203,6 +212,7 @@ class NRMSEngine:
         if b is None or b.n_seq < B:
             b = EncoderBuffers(B, self.H, self.E, self.E, self.A, self.device, own_input=False, need_dx=False)
             self._bufs[key] = b
+            self._graphs.clear()
         return b
 
     # ------------------------------------------------------------------ C-ABI plumbing
@@ -376,24 +386,62 @@ class NRMSEngine:
     # ------------------------------------------------------------------ training
     def train_step(self, his, pred, y, return_probs=False):
         """One optimizer step (forward, loss, backward, gradient all-reduce, Keras Adam).
-        Returns the batch loss as a 1-element device tensor (no host sync)."""
+        Returns the batch loss as a 1-element device tensor (no host sync).  With
+        ``use_graph`` the kernel sequence of a (B, C) shape is captured once into hipGraphs and
+        replayed: ~50 launches per step become two graph launches (step-dependent scalars live in
+        the device ebn_step_state, so the replay sees fresh dropout keys / Adam step sizes)."""
         his = his if isinstance(his, torch.Tensor) else np.asarray(his)
         pred = pred if isinstance(pred, torch.Tensor) else np.asarray(pred)
         self._check_shapes(his, pred)
-        B, C, H, E = his.shape[0], pred.shape[1], self.H, self.E
-        N = B * (H + C)
-        S = _hip.stream_handle
-        nb = self._news_bufs(N, True)
-        ub = self._user_bufs(B, True)
+        B, C = his.shape[0], pred.shape[1]
+        nb, ub = self._train_bufs(B, C)
         self._upload_ids(nb.ids, his, pred)
         labels = (y if isinstance(y, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(y, dtype=np.float32))))
-        labels = labels.to(device=self.device, dtype=torch.float32).reshape(B, C).contiguous()
-        if not hasattr(nb, "dNE") or nb.dNE.shape[0] < N:
+        nb.labels[: B * C].copy_(labels.reshape(-1).to(device=self.device, dtype=torch.float32), non_blocking=True)
+        if self.use_graph and self.kernel_events is None:
+            graphs = self._graphs.get((B, C))
+            if graphs is None:
+                graphs = self._capture(B, C)
+            graphs[0].replay()
+            self._allreduce_grads()
+            graphs[1].replay()
+        else:
+            self._fwd_bwd_kernels(B, C)
+            self._allreduce_grads()
+            self._optimizer_kernels()
+        if return_probs:
+            return self.loss_dev, nb.probs[: B * C].view(B, C)
+        return self.loss_dev
+
+    def _train_bufs(self, B, C):
+        N, E = B * (self.H + C), self.E
+        nb = self._news_bufs(N, True)
+        ub = self._user_bufs(B, True)
+        if not hasattr(nb, "dNE"):
             nb.dNE = torch.empty(nb.n_seq, E, device=self.device)
             nb.scores = torch.empty(nb.n_seq, device=self.device)
             nb.probs = torch.empty(nb.n_seq, device=self.device)
+            nb.labels = torch.empty(nb.n_seq, device=self.device)
+        if not hasattr(ub, "duser"):
             ub.duser = torch.empty(ub.n_seq, E, device=self.device)
             ub.loss_rows = torch.empty(ub.n_seq, device=self.device)
+        return nb, ub
+
+    def _capture(self, B, C):
+        torch.cuda.synchronize()
+        g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1):
+            self._fwd_bwd_kernels(B, C)
+        with torch.cuda.graph(g2, pool=g1.pool()):
+            self._optimizer_kernels()
+        self._graphs[(B, C)] = (g1, g2)
+        return g1, g2
+
+    def _fwd_bwd_kernels(self, B, C):
+        H, E = self.H, self.E
+        N = B * (H + C)
+        S = _hip.stream_handle
+        nb, ub = self._train_bufs(B, C)
         st = _hip.ptr(self.state)
         _hip.call("ebn_step_advance", st, BETA1, BETA2, S())
         # ---- forward
@@ -404,7 +452,7 @@ class NRMSEngine:
                   E, 0, S())
         # ---- backward
         dcand = nb.dNE[B * H:]
-        _hip.call("ebn_score_loss_bwd_f32", _hip.ptr(cand), _hip.ptr(ub.out), _hip.ptr(nb.scores), _hip.ptr(labels),
+        _hip.call("ebn_score_loss_bwd_f32", _hip.ptr(cand), _hip.ptr(ub.out), _hip.ptr(nb.scores), _hip.ptr(nb.labels),
                   _hip.ptr(ub.loss_rows), _hip.ptr(dcand), _hip.ptr(ub.duser), B, C, E, LOSS_KIND[self.loss],
                   ctypes.c_float(1.0 / B), S())
         _hip.call("ebn_sum_f32", _hip.ptr(ub.loss_rows), B, ctypes.c_float(1.0), _hip.ptr(self.loss_dev), 0, S())
@@ -415,11 +463,17 @@ class NRMSEngine:
             site, p = (0, self.p) if self.p > 0 else (-1, 0.0)
             _hip.call("ebn_embedding_grad_scatter_f32", _hip.ptr(nb.ids), _hip.ptr(nb.dX), _hip.ptr(self.table_grad),
                       N * self.T, self.D, self.V, st, site, ctypes.c_float(p), S())
-        # ---- data-parallel gradient all-reduce over RCCL (SUM; 1/world folded into Adam)
+
+    def _allreduce_grads(self):
+        """Data-parallel gradient all-reduce over RCCL (SUM; the 1/world is folded into Adam)."""
         if self.world > 1:
             torch.distributed.all_reduce(self.params.grad, group=self.pg)
             if self.train_embedding:
                 torch.distributed.all_reduce(self.table_grad, group=self.pg)
+
+    def _optimizer_kernels(self):
+        S = _hip.stream_handle
+        st = _hip.ptr(self.state)
         gs = ctypes.c_float(1.0 / self.world)
         P = self.params
         _hip.call("ebn_adam_keras_step_f32", _hip.ptr(P.data), _hip.ptr(P.grad), _hip.ptr(P.m), _hip.ptr(P.v), P.numel,
@@ -427,6 +481,3 @@ class NRMSEngine:
         if self.train_embedding:
             _hip.call("ebn_adam_keras_step_f32", _hip.ptr(self.table), _hip.ptr(self.table_grad), _hip.ptr(self.table_m),
                       _hip.ptr(self.table_v), self.table.numel(), st, BETA1, BETA2, ADAM_EPS, gs, S())
-        if return_probs:
-            return self.loss_dev, nb.probs[: B * C].view(B, C)
-        return self.loss_dev

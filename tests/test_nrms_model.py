@@ -221,3 +221,30 @@ def test_fit_predict_compile_save_load_surface(nrms, tmp_path):
     m.model.summary(print_fn=lines.append)
     assert any("news.attn.WQ" in l for l in lines)
     assert m.model.variables[0].name == "news.emb" and "cuda" in m.model.variables[0].device
+
+
+@pytest.mark.parametrize("train_embedding", [False, True])
+def test_hipgraph_replay_equals_kernel_by_kernel_launch(nrms, train_embedding):
+    """enable_graphs(): same kernels replayed from a captured graph, dropout keys / Adam step sizes read
+    from the device step state -> same trajectory as eager launches (bitwise with a frozen table; the
+    trainable table goes through fp32 atomics, so only to rounding)."""
+    hp = make_hp(dropout=0.2, learning_rate=1e-3)
+    rng = np.random.default_rng(21)
+    V = 300
+    emb = rng.standard_normal((V, 64)).astype(np.float32)
+    ms = [nrms(hp, word2vec_embedding=emb, seed=13, train_embedding=train_embedding) for _ in range(2)]
+    ms[1]._engine.enable_graphs()
+    batches = [batch(rng, 6, hp.history_size, 5, hp.title_size, V) for _ in range(4)]
+    losses = [[float(m.train_step(*b).item()) for b in batches] for m in ms]
+    w0, w1 = ms[0].model.get_weights(), ms[1].model.get_weights()
+    if train_embedding:
+        assert np.allclose(losses[0], losses[1], rtol=1e-5)
+        assert all(np.allclose(a, b, rtol=1e-4, atol=1e-6) for a, b in zip(w0, w1))
+    else:
+        assert losses[0] == losses[1]
+        assert all(np.array_equal(a, b) for a, b in zip(w0, w1))
+    assert ms[1]._engine.read_state().step == 4
+    # a different batch shape captures its own graph and keeps working
+    b2 = batch(rng, 3, hp.history_size, 4, hp.title_size, V)
+    l0, l1 = (float(m.train_step(*b2).item()) for m in ms)
+    assert abs(l0 - l1) <= 1e-5 * max(1.0, abs(l0))
