@@ -18,7 +18,7 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #ifndef EBN_GEMM_XCD
-#define EBN_GEMM_XCD 0
+#define EBN_GEMM_XCD 1
 #endif
 #ifndef EBN_GEMM_PIPE
 #define EBN_GEMM_PIPE 0
@@ -123,17 +123,21 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
   // L2s); remap so that each XCD walks a CONTIGUOUS run of tiles (neighbouring tiles share their A
   // row-panel / B column-panel in one L2).  Bijective for any grid size; speed only, never correctness.
   int64_t tile_id = static_cast<int64_t>(blockIdx.y) * gridDim.x + blockIdx.x;
+  int64_t zsplit = blockIdx.z;
 #if EBN_GEMM_XCD
   {
-    const int64_t nwg = static_cast<int64_t>(gridDim.x) * gridDim.y;
-    const int64_t orig = static_cast<int64_t>(blockIdx.y) * gridDim.x + blockIdx.x;
+    const int64_t per_z = static_cast<int64_t>(gridDim.x) * gridDim.y;
+    const int64_t nwg = per_z * gridDim.z;
+    const int64_t orig = tile_id + per_z * blockIdx.z;  // hardware dispatch order
     const int64_t q = nwg / 8, r = nwg % 8, xcd = orig % 8, idx = orig / 8;
-    tile_id = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int64_t lin = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    zsplit = lin / per_z;  // tiles of one K-split share their A/B K-range: keep them on one XCD too
+    tile_id = lin - zsplit * per_z;
   }
 #endif
   const int64_t m0 = (tile_id / gridDim.x) * BM;
   const int64_t n0 = (tile_id % gridDim.x) * BN;
-  const int64_t kbeg = static_cast<int64_t>(blockIdx.z) * k_per_split;
+  const int64_t kbeg = zsplit * k_per_split;
   const int64_t kend = (kbeg + k_per_split < K) ? (kbeg + k_per_split) : K;
 
   f32x16 acc[TM][TN];
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
 
   // epilogue. C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
   const bool split = gridDim.z > 1;
-  float* out = split ? (Cpart + static_cast<int64_t>(blockIdx.z) * M * N) : C;
+  float* out = split ? (Cpart + zsplit * M * N) : C;
   const int64_t ldo = split ? N : ldc;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
