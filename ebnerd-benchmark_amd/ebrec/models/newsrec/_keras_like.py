@@ -233,9 +233,15 @@ class ScorerModel:
         eng = self._owner._engine
         data = x if _is_loader(x) else _ArrayBatches(x, None, batch_size)
         outs = []
+        compact = getattr(data, "compact_eval_batch", None) if getattr(data, "eval_mode", False) else None
         for i in range(len(data)):
-            (his, pred_one), _y = data[i]
-            outs.append(self._owner._score_pairs(np.asarray(his), np.asarray(pred_one)).cpu().numpy().reshape(-1, 1))
+            if compact is not None:  # this repo's loaders: history rows are NOT materialised per candidate
+                his, cand, rows, _y = compact(i)
+                s = self._owner._score_compact(np.asarray(his), np.asarray(cand), np.asarray(rows))
+            else:
+                (his, pred_one), _y = data[i]
+                s = self._owner._score_pairs(np.asarray(his), np.asarray(pred_one))
+            outs.append(s.cpu().numpy().reshape(-1, 1))
         return np.concatenate(outs, axis=0) if outs else np.zeros((0, 1), np.float32)
 
     def __call__(self, inputs, training=False):

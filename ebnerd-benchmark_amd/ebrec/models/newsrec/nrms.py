@@ -101,6 +101,17 @@ class NRMSModel:
         ci = torch.from_numpy(c_inv).to(eng.device)
         return eng.pair_scores(user, news, ui, ci, sigmoid=True)
 
+    def _score_compact(self, his: np.ndarray, cands: np.ndarray, rows: np.ndarray) -> torch.Tensor:
+        """Same scores for the loader's compact eval layout: his (b,H,T) once per impression, cands (n,T),
+        rows[i] = impression of candidate i."""
+        eng = self._engine
+        cand_u, c_inv = dedup_rows(cands)
+        user = eng.encode_users(his)
+        news = eng.encode_news(cand_u)
+        ui = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.int32)).to(eng.device)
+        ci = torch.from_numpy(c_inv).to(eng.device)
+        return eng.pair_scores(user, news, ui, ci, sigmoid=True)
+
     # -- interchange ------------------------------------------------------------------
     def from_keras_weight_list(self, weights):
         """Load ``tf_model.model.get_weights()`` (13 arrays, SURVEY.md A.6 order)."""
