@@ -92,7 +92,8 @@ class EncoderBuffers:
 class NRMSEngine:
     def __init__(self, table: np.ndarray, title_size: int, history_size: int, head_num: int, head_dim: int,
                  attention_hidden_dim: int, dropout: float, learning_rate: float, loss: str, seed=None,
-                 train_embedding: bool = True, device=None, process_group=None):
+                 train_embedding: bool = True, device=None, process_group=None, shard_table: bool = False,
+                 shard_mode: str = "alltoall"):
         self.device = require_gpu() if device is None else torch.device(device)
         if loss not in LOSS_KIND:
             raise ValueError(f"this loss not defined {loss}")
@@ -106,7 +107,14 @@ class NRMSEngine:
         self.pg = process_group
         table = np.ascontiguousarray(table, dtype=np.float32)  # copied, like weights=[...] (nrms.py:128)
         self.V, self.D = table.shape
-        self.table = torch.from_numpy(table).to(self.device)
+        self.exchange = None
+        if shard_table:
+            # BASELINE config 5: each rank keeps only its contiguous block of rows in HBM
+            from ._dist import ShardedTableExchange
+
+            self.exchange = ShardedTableExchange(self.V, self.D, group=process_group, mode=shard_mode)
+            table = table[self.exchange.lo: self.exchange.hi]
+        self.table = torch.from_numpy(np.ascontiguousarray(table)).to(self.device)
         D, E, A = self.D, self.E, self.A
         self.params = FlatParams({"n_Wqkv": (D, 3 * E), "n_W": (E, A), "n_b": (A,), "n_q": (A,),
                                   "u_Wqkv": (E, 3 * E), "u_W": (E, A), "u_b": (A,), "u_q": (A,)}, self.device)
@@ -146,7 +154,7 @@ class NRMSEngine:
     def get_weights(self):
         """13 arrays in the Keras creation order of SURVEY.md A.6."""
         E = self.E
-        out = [self.table.cpu().numpy()]
+        out = [self._full_table().cpu().numpy()]
         for pre in ("n", "u"):
             w = self.params.view(f"{pre}_Wqkv").cpu().numpy()
             out += [w[:, :E].copy(), w[:, E:2 * E].copy(), w[:, 2 * E:].copy()]
@@ -161,7 +169,8 @@ class NRMSEngine:
         if w[0].shape != (self.V, self.D):
             raise ValueError(f"embedding shape {w[0].shape} != {(self.V, self.D)}")
         with torch.no_grad():
-            self.table.copy_(torch.from_numpy(w[0]))
+            t0 = w[0] if self.exchange is None else w[0][self.exchange.lo: self.exchange.hi]
+            self.table.copy_(torch.from_numpy(np.ascontiguousarray(t0)))
             i = 1
             for pre in ("n", "u"):
                 self.params.view(f"{pre}_Wqkv").copy_(torch.from_numpy(np.concatenate(w[i:i + 3], axis=1)))
@@ -169,6 +178,17 @@ class NRMSEngine:
                 self.params.view(f"{pre}_b").copy_(torch.from_numpy(w[i + 4].reshape(-1)))
                 self.params.view(f"{pre}_q").copy_(torch.from_numpy(w[i + 5].reshape(-1)))
                 i += 6
+
+    def _full_table(self) -> torch.Tensor:
+        """The whole (V, D) table; with a row-sharded table the shards are all-gathered (save / export only)."""
+        if self.exchange is None or self.exchange.world == 1:
+            return self.table
+        per = self.exchange.per
+        mine = torch.zeros(per, self.D, device=self.device)
+        mine[: self.table.shape[0]] = self.table
+        parts = [torch.empty_like(mine) for _ in range(self.exchange.world)]
+        torch.distributed.all_gather(parts, mine, group=self.pg)
+        return torch.cat(parts)[: self.V]
 
     def count_params(self):
         return self.V * self.D + sum(int(np.prod(s)) for s in self.params.shapes.values())
@@ -287,15 +307,38 @@ class NRMSEngine:
     def _news_forward(self, b, N, train):
         """a1..a4 for N titles whose ids are already in b.ids -> b.out[:N]"""
         site, p = (0, self.p) if (train and self.p > 0) else (-1, 0.0)
+        st = _hip.ptr(self.state) if train else None
+        if self.exchange is not None:
+            # row-sharded table: route the distinct ids to their owners, fetch the rows over RCCL, then the same
+            # gather kernel expands them to token order (ids = positions in the unique list) with dropout fused
+            b.plan = self.exchange.plan(b.ids[: N * self.T])
+            b.rows_uniq = self.exchange.lookup(b.plan, self._local_gather)
+            _hip.call("ebn_gather_rows_f32", _hip.ptr(b.plan.inv), _hip.ptr(b.rows_uniq), _hip.ptr(b.X), N * self.T,
+                      self.D, b.rows_uniq.shape[0], st, site, ctypes.c_float(p), _hip.ptr(self.oob_flag),
+                      _hip.stream_handle())
+            return self._encoder_fwd("n", b, N, b.X, train)
         ev = self._timed("gather") if self.kernel_events is not None else None
         if ev:
             ev[0].record()
         _hip.call("ebn_gather_rows_f32", _hip.ptr(b.ids), _hip.ptr(self.table), _hip.ptr(b.X), N * self.T, self.D,
-                  self.V, _hip.ptr(self.state) if train else None, site, ctypes.c_float(p), _hip.ptr(self.oob_flag),
-                  _hip.stream_handle())
+                  self.V, st, site, ctypes.c_float(p), _hip.ptr(self.oob_flag), _hip.stream_handle())
         if ev:
             ev[1].record()
         self._encoder_fwd("n", b, N, b.X, train)
+
+    def _local_gather(self, local_rows: torch.Tensor) -> torch.Tensor:
+        m = local_rows.numel()
+        out = torch.empty(m, self.D, device=self.device)
+        if m:
+            _hip.call("ebn_gather_rows_f32", _hip.ptr(local_rows), _hip.ptr(self.table), _hip.ptr(out), m, self.D,
+                      self.table.shape[0], None, -1, ctypes.c_float(0.0), _hip.ptr(self.oob_flag), _hip.stream_handle())
+        return out
+
+    def _local_scatter_add(self, local_rows: torch.Tensor, grads: torch.Tensor) -> None:
+        m = local_rows.numel()
+        if m:
+            _hip.call("ebn_embedding_grad_scatter_f32", _hip.ptr(local_rows), _hip.ptr(grads), _hip.ptr(self.table_grad),
+                      m, self.D, self.table.shape[0], None, -1, ctypes.c_float(0.0), _hip.stream_handle())
 
     # ------------------------------------------------------------------ public compute
     def encode_news(self, ids, chunk=8192) -> torch.Tensor:
@@ -398,7 +441,7 @@ class NRMSEngine:
         self._upload_ids(nb.ids, his, pred)
         labels = (y if isinstance(y, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(y, dtype=np.float32))))
         nb.labels[: B * C].copy_(labels.reshape(-1).to(device=self.device, dtype=torch.float32), non_blocking=True)
-        if self.use_graph and self.kernel_events is None:
+        if self.use_graph and self.kernel_events is None and self.exchange is None:  # sharded lookups have data-dependent sizes
             graphs = self._graphs.get((B, C))
             if graphs is None:
                 graphs = self._capture(B, C)
@@ -461,14 +504,21 @@ class NRMSEngine:
         if self.train_embedding:
             self.table_grad.zero_()
             site, p = (0, self.p) if self.p > 0 else (-1, 0.0)
-            _hip.call("ebn_embedding_grad_scatter_f32", _hip.ptr(nb.ids), _hip.ptr(nb.dX), _hip.ptr(self.table_grad),
-                      N * self.T, self.D, self.V, st, site, ctypes.c_float(p), S())
+            if self.exchange is not None:
+                # reduce to one gradient row per distinct id locally, send each to its owner, owners accumulate
+                d_uniq = torch.zeros_like(nb.rows_uniq)
+                _hip.call("ebn_embedding_grad_scatter_f32", _hip.ptr(nb.plan.inv), _hip.ptr(nb.dX), _hip.ptr(d_uniq),
+                          N * self.T, self.D, d_uniq.shape[0], st, site, ctypes.c_float(p), S())
+                self.exchange.scatter_grads(nb.plan, d_uniq, self._local_scatter_add)
+            else:
+                _hip.call("ebn_embedding_grad_scatter_f32", _hip.ptr(nb.ids), _hip.ptr(nb.dX), _hip.ptr(self.table_grad),
+                          N * self.T, self.D, self.V, st, site, ctypes.c_float(p), S())
 
     def _allreduce_grads(self):
         """Data-parallel gradient all-reduce over RCCL (SUM; the 1/world is folded into Adam)."""
         if self.world > 1:
             torch.distributed.all_reduce(self.params.grad, group=self.pg)
-            if self.train_embedding:
+            if self.train_embedding and self.exchange is None:  # a sharded table's gradients already sit at their owner
                 torch.distributed.all_reduce(self.table_grad, group=self.pg)
 
     def _optimizer_kernels(self):

@@ -1,0 +1,338 @@
+"""Device engine of NRMSDocVec (reference nrms_docvec.py:99-188): news encoder = per-article MLP
+``[Dense(u, relu, l2) -> BatchNormalization -> Dropout] x len(units) -> Dense(E, relu)`` over pre-computed
+document vectors, then the same user encoder, scorer, loss and Keras-form Adam as NRMS.
+
+Layout: the B*H history vectors and the B*C candidate vectors of a step are ONE (N, Din) row block (history
+first).  Dense layers run over all N rows in one GEMM; BatchNormalization runs per CALL SITE (rows [0,B*H) and
+[B*H,N) separately: TimeDistributed(newsencoder) is applied twice, nrms_docvec.py:88-90 and 176-178), each
+with its own batch statistics and its own moving-average update [KERAS-SEMANTICS].  The dropout stream is
+indexed by (row, column) of the whole block, so both sites draw from one mask.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from ebrec import _hip
+
+from ._engine import ADAM_EPS, BETA1, BETA2, LOSS_KIND, EncoderBuffers, FlatParams, glorot_uniform_np, require_gpu
+
+SITE_MLP0 = 8
+
+
+class DocVecEngine:
+    def __init__(self, doc_dim: int, units, history_size: int, head_num: int, head_dim: int, attention_hidden_dim: int,
+                 dropout: float, learning_rate: float, loss: str, l2: float, seed=None, device=None, process_group=None):
+        self.device = require_gpu() if device is None else torch.device(device)
+        if loss not in LOSS_KIND:
+            raise ValueError(f"this loss not defined {loss}")
+        self.Din, self.units, self.H = int(doc_dim), [int(u) for u in (units or [])], int(history_size)
+        self.h, self.d, self.A = int(head_num), int(head_dim), int(attention_hidden_dim)
+        self.E = self.h * self.d
+        self.p, self.loss, self.l2, self.seed, self.pg = float(dropout), loss, float(l2), seed, process_group
+        if len(self.units) > 4:
+            raise ValueError("at most 4 hidden Dense layers (dropout sites 8..11 of ebn_step_state)")
+        E, A = self.E, self.A
+        shapes, prev = {}, self.Din
+        for l, u in enumerate(self.units):
+            shapes.update({f"d{l}_W": (prev, u), f"d{l}_b": (u,), f"bn{l}_g": (u,), f"bn{l}_b": (u,)})
+            prev = u
+        shapes.update({"out_W": (prev, E), "out_b": (E,), "u_Wqkv": (E, 3 * E), "u_W": (E, A), "u_b": (A,), "u_q": (A,)})
+        self.params = FlatParams(shapes, self.device)
+        self.bn_mean = [torch.zeros(u, device=self.device) for u in self.units]
+        self.bn_var = [torch.ones(u, device=self.device) for u in self.units]
+        self._init_weights(seed)
+        st = _hip.StepState()
+        st.step, st.seed, st.lr, st.adam_alpha = 0, (0 if seed is None else int(seed)) & 0xFFFFFFFF, learning_rate, 0.0
+        self.state = torch.frombuffer(bytearray(bytes(st)), dtype=torch.uint8).to(self.device)
+        self._lr = float(learning_rate)
+        self._bufs = {}
+        self.loss_dev = torch.zeros(1, device=self.device)
+        self.reg_dev = torch.zeros(1, device=self.device)
+        self.world = 1
+        if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            self.world = torch.distributed.get_world_size(process_group)
+
+    # ------------------------------------------------------------------ parameters
+    def _init_weights(self, seed):
+        rng_seed = (lambda k: None) if seed is None else (lambda k: int(seed) * 1000 + k)
+        pv = self.params.view
+        with torch.no_grad():
+            prev = self.Din
+            for l, u in enumerate(self.units):  # Dense: GlorotUniform kernel, zero bias; BN: gamma 1, beta 0
+                pv(f"d{l}_W").copy_(torch.from_numpy(glorot_uniform_np((prev, u), rng_seed(l))))
+                pv(f"bn{l}_g").fill_(1.0)
+                prev = u
+            pv("out_W").copy_(torch.from_numpy(glorot_uniform_np((prev, self.E), rng_seed(99))))
+            s = (lambda: seed) if seed is not None else (lambda: None)
+            pv("u_Wqkv").copy_(torch.from_numpy(np.concatenate([glorot_uniform_np((self.E, self.E), s()) for _ in range(3)], 1)))
+            pv("u_W").copy_(torch.from_numpy(glorot_uniform_np((self.E, self.A), s())))
+            pv("u_q").copy_(torch.from_numpy(glorot_uniform_np((self.A, 1), s())[:, 0]))
+
+    def weight_names(self):
+        names = []
+        for l in range(len(self.units)):
+            names += [f"news.dense{l}.kernel", f"news.dense{l}.bias", f"news.bn{l}.gamma", f"news.bn{l}.beta",
+                      f"news.bn{l}.moving_mean", f"news.bn{l}.moving_variance"]
+        return names + ["news.out.kernel", "news.out.bias", "user.attn.WQ", "user.attn.WK", "user.attn.WV", "user.att.W",
+                        "user.att.b", "user.att.q"]
+
+    def get_weights(self):
+        pv, E = self.params.view, self.E
+        out = []
+        for l in range(len(self.units)):
+            out += [pv(f"d{l}_W").cpu().numpy(), pv(f"d{l}_b").cpu().numpy(), pv(f"bn{l}_g").cpu().numpy(),
+                    pv(f"bn{l}_b").cpu().numpy(), self.bn_mean[l].cpu().numpy(), self.bn_var[l].cpu().numpy()]
+        w = pv("u_Wqkv").cpu().numpy()
+        out += [pv("out_W").cpu().numpy(), pv("out_b").cpu().numpy(), w[:, :E].copy(), w[:, E:2 * E].copy(), w[:, 2 * E:].copy(),
+                pv("u_W").cpu().numpy(), pv("u_b").cpu().numpy(), pv("u_q").cpu().numpy().reshape(-1, 1)]
+        return out
+
+    def set_weights(self, weights):
+        n = 6 * len(self.units) + 8
+        if len(weights) != n:
+            raise ValueError(f"expected {n} weight arrays, got {len(weights)}")
+        w = [torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float32))) for a in weights]
+        pv = self.params.view
+        with torch.no_grad():
+            i = 0
+            for l in range(len(self.units)):
+                pv(f"d{l}_W").copy_(w[i]); pv(f"d{l}_b").copy_(w[i + 1]); pv(f"bn{l}_g").copy_(w[i + 2]); pv(f"bn{l}_b").copy_(w[i + 3])
+                self.bn_mean[l].copy_(w[i + 4]); self.bn_var[l].copy_(w[i + 5])
+                i += 6
+            pv("out_W").copy_(w[i]); pv("out_b").copy_(w[i + 1])
+            pv("u_Wqkv").copy_(torch.cat(w[i + 2:i + 5], dim=1))
+            pv("u_W").copy_(w[i + 5]); pv("u_b").copy_(w[i + 6].reshape(-1)); pv("u_q").copy_(w[i + 7].reshape(-1))
+
+    def count_params(self):
+        return sum(int(np.prod(s)) for s in self.params.shapes.values()) + 2 * sum(self.units)
+
+    @property
+    def learning_rate(self):
+        return self._lr
+
+    @learning_rate.setter
+    def learning_rate(self, lr):
+        self._lr = float(lr)
+        st = self.read_state()
+        st.lr = self._lr
+        self.state.copy_(torch.frombuffer(bytearray(bytes(st)), dtype=torch.uint8))
+
+    def read_state(self):
+        return _hip.StepState.from_buffer_copy(self.state.cpu().numpy().tobytes())
+
+    # ------------------------------------------------------------------ buffers
+    def _mlp_bufs(self, N):
+        b = self._bufs.get("mlp")
+        if b is None or b["N"] < N:
+            f = lambda *s: torch.empty(*s, device=self.device)
+            b = {"N": N, "X0": f(N, self.Din), "R": [f(N, u) for u in self.units], "xhat": [f(N, u) for u in self.units],
+                 "Xn": [f(N, u) for u in self.units], "mean": [[f(u), f(u)] for u in self.units],
+                 "istd": [[f(u), f(u)] for u in self.units], "NE": f(N, self.E), "dNE": f(N, self.E),
+                 "dA": [f(N, u) for u in self.units], "dB": [f(N, u) for u in self.units],
+                 "scores": f(N), "probs": f(N), "labels": f(N)}
+            width = max(self.units + [self.E])
+            b["partials"] = f(int(_hip.lib().ebn_colsum_partials_len(N, width)))
+            dims = [self.Din] + self.units
+            ws = max([int(_hip.lib().ebn_gemm_workspace_floats(dims[i], dims[i + 1], N)) for i in range(len(self.units))] +
+                     [int(_hip.lib().ebn_gemm_workspace_floats(dims[-1], self.E, N)), 1])
+            b["ws"] = f(ws)
+            self._bufs["mlp"] = b
+        return b
+
+    def _user_bufs(self, B):
+        b = self._bufs.get("user")
+        if b is None or b.n_seq < B:
+            b = EncoderBuffers(B, self.H, self.E, self.E, self.A, self.device, own_input=False, need_dx=False)
+            b.duser = torch.empty(B, self.E, device=self.device)
+            b.loss_rows = torch.empty(B, device=self.device)
+            self._bufs["user"] = b
+        return b
+
+    # ------------------------------------------------------------------ kernels
+    def _gemm(self, tA, tB, M, N, K, A, lda, B, ldb, beta, C, ldc, ws=None):
+        _hip.call("ebn_gemm_f32_ws", tA, tB, M, N, K, ctypes.c_float(1.0), _hip.ptr(A), lda, _hip.ptr(B), ldb,
+                  ctypes.c_float(beta), _hip.ptr(C), ldc, _hip.ptr(ws), 0 if ws is None else ws.numel(), _hip.stream_handle())
+
+    def _news_forward(self, mb, n_hist, n_cand, train):
+        """MLP over the N = n_hist + n_cand rows already in mb['X0'] -> mb['NE'][:N]."""
+        N = n_hist + n_cand
+        S = _hip.stream_handle
+        pv = self.params.view
+        st = _hip.ptr(self.state) if train else None
+        x, prev = mb["X0"], self.Din
+        for l, u in enumerate(self.units):
+            R = mb["R"][l]
+            self._gemm(0, 0, N, u, prev, x, prev, pv(f"d{l}_W"), u, 0.0, R, u)
+            _hip.call("ebn_bias_relu_f32", _hip.ptr(R), _hip.ptr(pv(f"d{l}_b")), _hip.ptr(R), N, u, S())
+            for site, (r0, nr) in enumerate(((0, n_hist), (n_hist, n_cand))):  # one BN call per TimeDistributed call site
+                if nr == 0:
+                    continue
+                _hip.call("ebn_batchnorm_fwd_f32", _hip.ptr(R[r0:]), _hip.ptr(pv(f"bn{l}_g")), _hip.ptr(pv(f"bn{l}_b")),
+                          _hip.ptr(self.bn_mean[l]), _hip.ptr(self.bn_var[l]), _hip.ptr(mb["Xn"][l][r0:]),
+                          _hip.ptr(mb["xhat"][l][r0:]), _hip.ptr(mb["mean"][l][site]), _hip.ptr(mb["istd"][l][site]),
+                          _hip.ptr(mb["partials"]), nr, u, 1 if train else 0, st, SITE_MLP0 + l,
+                          ctypes.c_float(self.p if train else 0.0), ctypes.c_int64(r0 * u), S())
+            x, prev = mb["Xn"][l], u
+        self._gemm(0, 0, N, self.E, prev, x, prev, pv("out_W"), self.E, 0.0, mb["NE"], self.E)
+        _hip.call("ebn_bias_relu_f32", _hip.ptr(mb["NE"]), _hip.ptr(pv("out_b")), _hip.ptr(mb["NE"]), N, self.E, S())
+
+    def _news_backward(self, mb, n_hist, n_cand):
+        N = n_hist + n_cand
+        S = _hip.stream_handle
+        pv, g = self.params.view, self.params.g
+        st = _hip.ptr(self.state)
+        L = len(self.units)
+        x_last, prev = (mb["Xn"][L - 1], self.units[-1]) if L else (mb["X0"], self.Din)
+        dpre = mb["dNE"]  # relu backward in place
+        _hip.call("ebn_bias_relu_bwd_f32", _hip.ptr(mb["NE"]), _hip.ptr(mb["dNE"]), _hip.ptr(dpre), _hip.ptr(g("out_b")),
+                  _hip.ptr(mb["partials"]), N, self.E, 0, S())
+        self._gemm(1, 0, prev, self.E, N, x_last, prev, dpre, self.E, 0.0, g("out_W"), self.E, mb["ws"])
+        if L:
+            self._gemm(0, 1, N, prev, self.E, dpre, self.E, pv("out_W"), self.E, 0.0, mb["dA"][L - 1], prev)
+        for l in reversed(range(L)):
+            u = self.units[l]
+            x_in, din = (mb["Xn"][l - 1], self.units[l - 1]) if l else (mb["X0"], self.Din)
+            dY, dR = mb["dA"][l], mb["dB"][l]
+            for site, (r0, nr) in enumerate(((0, n_hist), (n_hist, n_cand))):
+                if nr == 0:
+                    continue
+                _hip.call("ebn_batchnorm_bwd_f32", _hip.ptr(dY[r0:]), _hip.ptr(mb["xhat"][l][r0:]), _hip.ptr(pv(f"bn{l}_g")),
+                          _hip.ptr(mb["istd"][l][site]), _hip.ptr(dR[r0:]), _hip.ptr(g(f"bn{l}_g")), _hip.ptr(g(f"bn{l}_b")),
+                          _hip.ptr(mb["partials"]), nr, u, 1, 1 if site else 0, st, SITE_MLP0 + l, ctypes.c_float(self.p),
+                          ctypes.c_int64(r0 * u), S())
+            _hip.call("ebn_bias_relu_bwd_f32", _hip.ptr(mb["R"][l]), _hip.ptr(dR), _hip.ptr(dR), _hip.ptr(g(f"d{l}_b")),
+                      _hip.ptr(mb["partials"]), N, u, 0, S())
+            self._gemm(1, 0, din, u, N, x_in, din, dR, u, 0.0, g(f"d{l}_W"), u, mb["ws"])
+            if self.l2 > 0:  # kernel_regularizer=l2(lambda): d/dW of lambda*sum(W^2)
+                _hip.call("ebn_axpy_f32", ctypes.c_float(2.0 * self.l2), _hip.ptr(pv(f"d{l}_W")), _hip.ptr(g(f"d{l}_W")), din * u, S())
+            if l:
+                self._gemm(0, 1, N, din, u, dR, u, pv(f"d{l}_W"), u, 0.0, mb["dA"][l - 1], din)
+
+    def _enc(self, ub, B, X, dims_only=False):
+        pv = self.params.view
+        dims = _hip.EncoderDims(B, self.H, self.E, self.h, self.d, self.A, -1, 0.0)
+        params = _hip.EncoderParams(pv("u_Wqkv").data_ptr(), pv("u_W").data_ptr(), pv("u_b").data_ptr(), pv("u_q").data_ptr())
+        acts = _hip.EncoderActs(X.data_ptr(), ub.QKV.data_ptr(), ub.Y.data_ptr(), ub.U.data_ptr(), ub.w.data_ptr(), ub.out.data_ptr())
+        return dims, params, acts
+
+    def _upload(self, mb, his, pred):
+        B, C = his.shape[0], pred.shape[1]
+        n_hist, n_cand = B * self.H, B * C
+        for arr, r0, n in ((his, 0, n_hist), (pred, n_hist, n_cand)):
+            t = arr if isinstance(arr, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(arr, dtype=np.float32)))
+            mb["X0"][r0:r0 + n].copy_(t.reshape(n, self.Din).to(device=self.device, dtype=torch.float32), non_blocking=True)
+        return n_hist, n_cand
+
+    def _check_shapes(self, his, pred):
+        if his.ndim != 3 or his.shape[1] != self.H or his.shape[2] != self.Din:
+            raise ValueError(f"his_input_title must be (B, {self.H}, {self.Din}), got {tuple(his.shape)}")
+        if pred.ndim != 3 or pred.shape[0] != his.shape[0] or pred.shape[2] != self.Din:
+            raise ValueError(f"pred_input_title must be (B, C, {self.Din}), got {tuple(pred.shape)}")
+
+    # ------------------------------------------------------------------ public compute
+    def encode_news(self, vecs, chunk=65536) -> torch.Tensor:
+        vecs = vecs if isinstance(vecs, torch.Tensor) else np.asarray(vecs, dtype=np.float32)
+        N = vecs.shape[0]
+        out = torch.empty(N, self.E, device=self.device)
+        for s in range(0, N, chunk):
+            n = min(chunk, N - s)
+            mb = self._mlp_bufs(min(chunk, N))
+            t = vecs[s:s + n] if isinstance(vecs, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(vecs[s:s + n]))
+            mb["X0"][:n].copy_(t.to(device=self.device, dtype=torch.float32))
+            self._news_forward(mb, n, 0, False)
+            out[s:s + n].copy_(mb["NE"][:n])
+        return out
+
+    def encode_users_from_news(self, NEh: torch.Tensor) -> torch.Tensor:
+        B = NEh.shape[0]
+        ub = self._user_bufs(B)
+        X = NEh.reshape(B * self.H, self.E).contiguous()
+        dims, params, acts = self._enc(ub, B, X)
+        _hip.call("ebn_encoder_fwd_f32", ctypes.byref(dims), ctypes.byref(params), ctypes.byref(acts), None, _hip.stream_handle())
+        return ub.out[:B].clone()
+
+    def encode_users(self, his) -> torch.Tensor:
+        his = np.asarray(his, dtype=np.float32) if not isinstance(his, torch.Tensor) else his
+        B = his.shape[0]
+        return self.encode_users_from_news(self.encode_news(his.reshape(B * self.H, self.Din)).view(B, self.H, self.E))
+
+    def forward(self, his, pred, mode="softmax"):
+        his = his if isinstance(his, torch.Tensor) else np.asarray(his)
+        pred = pred if isinstance(pred, torch.Tensor) else np.asarray(pred)
+        self._check_shapes(his, pred)
+        B, C = his.shape[0], pred.shape[1]
+        mb, ub = self._mlp_bufs(B * (self.H + C)), self._user_bufs(B)
+        n_hist, n_cand = self._upload(mb, his, pred)
+        self._news_forward(mb, n_hist, n_cand, False)
+        dims, params, acts = self._enc(ub, B, mb["NE"])
+        _hip.call("ebn_encoder_fwd_f32", ctypes.byref(dims), ctypes.byref(params), ctypes.byref(acts), None, _hip.stream_handle())
+        scores, probs = torch.empty(B, C, device=self.device), torch.empty(B, C, device=self.device)
+        _hip.call("ebn_score_fwd_f32", _hip.ptr(mb["NE"][n_hist:]), _hip.ptr(ub.out), _hip.ptr(scores), _hip.ptr(probs), B, C,
+                  self.E, 0 if mode == "softmax" else 1, _hip.stream_handle())
+        return probs, scores
+
+    def eval_loss(self, his, pred, y):
+        probs, scores = self.forward(his, pred)
+        B, C = scores.shape
+        labels = torch.as_tensor(np.asarray(y, dtype=np.float32)).to(self.device).reshape(B, C).contiguous()
+        mb, ub = self._mlp_bufs(B * (self.H + C)), self._user_bufs(B)
+        rows, jc, ju = torch.empty(B, device=self.device), torch.empty(B * C, self.E, device=self.device), torch.empty(B, self.E, device=self.device)
+        loss = torch.empty(1, device=self.device)
+        _hip.call("ebn_score_loss_bwd_f32", _hip.ptr(mb["NE"][B * self.H:]), _hip.ptr(ub.out), _hip.ptr(scores), _hip.ptr(labels),
+                  _hip.ptr(rows), _hip.ptr(jc), _hip.ptr(ju), B, C, self.E, LOSS_KIND[self.loss], ctypes.c_float(1.0 / B), _hip.stream_handle())
+        _hip.call("ebn_sum_f32", _hip.ptr(rows), B, ctypes.c_float(1.0), _hip.ptr(loss), 0, _hip.stream_handle())
+        return loss, probs
+
+    def pair_scores(self, user, news, u_idx, n_idx, sigmoid=True):
+        n = u_idx.numel()
+        out = torch.empty(n, device=self.device)
+        _hip.call("ebn_pair_score_f32", _hip.ptr(user), _hip.ptr(news), _hip.ptr(u_idx), _hip.ptr(n_idx), _hip.ptr(out), n,
+                  self.E, 1 if sigmoid else 0, _hip.stream_handle())
+        return out
+
+    def train_step(self, his, pred, y, return_probs=False):
+        his = his if isinstance(his, torch.Tensor) else np.asarray(his)
+        pred = pred if isinstance(pred, torch.Tensor) else np.asarray(pred)
+        self._check_shapes(his, pred)
+        B, C, E = his.shape[0], pred.shape[1], self.E
+        S = _hip.stream_handle
+        mb, ub = self._mlp_bufs(B * (self.H + C)), self._user_bufs(B)
+        n_hist, n_cand = self._upload(mb, his, pred)
+        labels = (y if isinstance(y, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(y, dtype=np.float32))))
+        mb["labels"][: B * C].copy_(labels.reshape(-1).to(device=self.device, dtype=torch.float32))
+        st = _hip.ptr(self.state)
+        _hip.call("ebn_step_advance", st, BETA1, BETA2, S())
+        self._news_forward(mb, n_hist, n_cand, True)
+        dims, params, acts = self._enc(ub, B, mb["NE"])
+        _hip.call("ebn_encoder_fwd_f32", ctypes.byref(dims), ctypes.byref(params), ctypes.byref(acts), st, S())
+        cand = mb["NE"][n_hist:]
+        _hip.call("ebn_score_fwd_f32", _hip.ptr(cand), _hip.ptr(ub.out), _hip.ptr(mb["scores"]), _hip.ptr(mb["probs"]), B, C, E, 0, S())
+        _hip.call("ebn_score_loss_bwd_f32", _hip.ptr(cand), _hip.ptr(ub.out), _hip.ptr(mb["scores"]), _hip.ptr(mb["labels"]),
+                  _hip.ptr(ub.loss_rows), _hip.ptr(mb["dNE"][n_hist:]), _hip.ptr(ub.duser), B, C, E, LOSS_KIND[self.loss],
+                  ctypes.c_float(1.0 / B), S())
+        _hip.call("ebn_sum_f32", _hip.ptr(ub.loss_rows), B, ctypes.c_float(1.0), _hip.ptr(self.loss_dev), 0, S())
+        for l in range(len(self.units)):  # + lambda * sum(W^2) per regularised kernel, once (not per call site)
+            if self.l2 > 0:
+                W = self.params.view(f"d{l}_W")
+                _hip.call("ebn_sumsq_f32", _hip.ptr(W), W.numel(), ctypes.c_float(self.l2), _hip.ptr(self.loss_dev), 1, S())
+        g = self.params.g
+        grads = _hip.EncoderGrads(g("u_Wqkv").data_ptr(), g("u_W").data_ptr(), g("u_b").data_ptr(), g("u_q").data_ptr())
+        scratch = _hip.EncoderScratch(ub.dY.data_ptr(), ub.dQKV.data_ptr(), ub.de.data_ptr(), ub.partials.data_ptr(),
+                                      ub.ws.data_ptr(), ub.ws.numel())
+        _hip.call("ebn_encoder_bwd_f32", ctypes.byref(dims), ctypes.byref(params), ctypes.byref(acts), _hip.ptr(ub.duser),
+                  ctypes.byref(grads), ctypes.byref(scratch), _hip.ptr(mb["dNE"]), 0, st, S())
+        self._news_backward(mb, n_hist, n_cand)
+        if self.world > 1:
+            torch.distributed.all_reduce(self.params.grad, group=self.pg)
+        P = self.params
+        _hip.call("ebn_adam_keras_step_f32", _hip.ptr(P.data), _hip.ptr(P.grad), _hip.ptr(P.m), _hip.ptr(P.v), P.numel, st,
+                  BETA1, BETA2, ADAM_EPS, ctypes.c_float(1.0 / self.world), S())
+        if return_probs:
+            return self.loss_dev, mb["probs"][: B * C].view(B, C)
+        return self.loss_dev
+
+    def extra_state(self):
+        return {}

@@ -7,6 +7,8 @@
 
 Differences from the reference that are deliberate and visible:
   * runs on a GPU through libebnerd_hip.so only (RuntimeError otherwise -- no CPU fallback);
+  * ``shard_table=True`` row-shards the word-embedding table over the ranks of the process group
+    (BASELINE config 5) -- rows travel over RCCL, table gradients are never all-reduced;
   * ``train_embedding=False`` freezes the word-embedding table (BASELINE.json config 2,
     "frozen lookup"); the reference always trains it (nrms.py:129);
   * dropout uses the build's own counter-based stream, not TF's (statistical parity only);
@@ -31,7 +33,7 @@ class NRMSModel:
 
     def __init__(self, hparams, word2vec_embedding: np.ndarray = None, word_emb_dim: int = 300,
                  vocab_size: int = 32000, seed: int = None, *, train_embedding: bool = True, device=None,
-                 process_group=None):
+                 process_group=None, shard_table: bool = False, shard_mode: str = "alltoall"):
         self.hparams = hparams
         self.seed = seed
         if seed is not None:
@@ -52,7 +54,8 @@ class NRMSModel:
         self._engine = NRMSEngine(
             np.asarray(self.word2vec_embedding), hparams.title_size, hparams.history_size, hparams.head_num,
             hparams.head_dim, hparams.attention_hidden_dim, hparams.dropout, hparams.learning_rate, hparams.loss,
-            seed=seed, train_embedding=train_embedding, device=device, process_group=process_group)
+            seed=seed, train_embedding=train_embedding, device=device, process_group=process_group,
+            shard_table=shard_table, shard_mode=shard_mode)
         self.model, self.scorer = self._build_graph()
 
     # -- same helper names as the reference ------------------------------------------

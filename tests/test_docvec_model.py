@@ -1,0 +1,113 @@
+"""NRMSDocVec through the C ABI against the float64 oracle (gpu-marked)."""
+import numpy as np
+import pytest
+
+from oracle import nrms_numpy as on
+from tests.hip_testutil import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def make_hp(**kw):
+    base = dict(title_size=768, history_size=20, head_num=16, head_dim=16, attention_hidden_dim=200, optimizer="adam",
+                loss="cross_entropy_loss", dropout=0.2, learning_rate=1e-3, newsencoder_units_per_layer=[512, 512, 512],
+                newsencoder_l2_regularization=1e-4)
+    base.update(kw)
+    return type("hp", (), base)
+
+
+def oracle_params(hp, seed):
+    P = on.init_docvec_params(hp.title_size, hp.newsencoder_units_per_layer, hp.head_num, hp.head_dim, hp.attention_hidden_dim,
+                              seed=seed, randomize_bn=True)
+    rng = np.random.default_rng(seed + 1)
+    for l, u in enumerate(P["units"]):
+        P[f"bn{l}_mean"] = 0.1 * rng.standard_normal(u)
+        P[f"bn{l}_var"] = 1 + 0.2 * rng.random(u)
+    return {k: (v.astype(np.float32).astype(np.float64) if isinstance(v, np.ndarray) else v) for k, v in P.items()}
+
+
+def weight_list(P):
+    out = []
+    for l in range(len(P["units"])):
+        out += [P[f"d{l}_W"], P[f"d{l}_b"], P[f"bn{l}_g"], P[f"bn{l}_b"], P[f"bn{l}_mean"], P[f"bn{l}_var"]]
+    return out + [P["out_W"], P["out_b"], P["u_WQ"], P["u_WK"], P["u_WV"], P["u_W"], P["u_b"], P["u_q"]]
+
+
+def data(rng, B, H, C, Din):
+    his = rng.standard_normal((B, H, Din)).astype(np.float32)
+    his[0, :3] = 0  # padded history slots = the zero "unknown" document vector
+    pred = rng.standard_normal((B, C, Din)).astype(np.float32)
+    y = np.zeros((B, C), np.int8)
+    y[np.arange(B), rng.integers(0, C, B)] = 1
+    return his, pred, y
+
+
+@pytest.fixture(scope="module")
+def docvec(hip):
+    from ebrec.models.newsrec import NRMSDocVec
+
+    return NRMSDocVec
+
+
+@pytest.mark.parametrize("cfg", [dict(), dict(title_size=40, newsencoder_units_per_layer=[24, 20], head_num=4, head_dim=8, attention_hidden_dim=9, history_size=6)])
+def test_forward_eval_mode_uses_moving_statistics(docvec, cfg):
+    hp = make_hp(**cfg)
+    P = oracle_params(hp, 3)
+    m = docvec(hp, seed=1)
+    m.model.set_weights(weight_list(P))
+    rng = np.random.default_rng(0)
+    his, pred, y = data(rng, 6, hp.history_size, 5, hp.title_size)
+    probs, s, _ = on.docvec_forward(his.astype(np.float64), pred.astype(np.float64), P, hp.head_num, hp.head_dim, training=False)
+    assert_close(m.model.predict((his, pred)), probs, rtol=0, atol=2e-5, what="docvec probabilities")
+    one = pred[:, :1]
+    _, s1, _ = on.docvec_forward(his.astype(np.float64), one.astype(np.float64), P, hp.head_num, hp.head_dim, training=False)
+    assert_close(m.scorer.predict((his, one)), on.sigmoid(s1), rtol=0, atol=2e-5, what="docvec scorer")
+    ne = m.newsencoder.predict(pred[0])
+    want, _, _ = on.docvec_news_encoder_fwd(pred[0].astype(np.float64), P, training=False)
+    assert_close(ne, want, rtol=2e-5, atol=2e-5, what="docvec newsencoder")
+
+
+@pytest.mark.parametrize("p,l2", [(0.0, 0.0), (0.2, 1e-4)])
+def test_train_step_gradients_loss_and_moving_stats(docvec, p, l2):
+    hp = make_hp(title_size=64, newsencoder_units_per_layer=[48, 40], head_num=4, head_dim=8, attention_hidden_dim=12,
+                 history_size=7, dropout=p, newsencoder_l2_regularization=l2)
+    seed = 5
+    P = oracle_params(hp, 9)
+    m = docvec(hp, seed=seed)
+    m.model.set_weights(weight_list(P))
+    rng = np.random.default_rng(2)
+    his, pred, y = data(rng, 8, hp.history_size, 5, hp.title_size)
+    L, _, g, stats = on.docvec_loss_and_grads(his.astype(np.float64), pred.astype(np.float64), y, P, hp.head_num, hp.head_dim,
+                                              l2=l2, training=True, drop=on.Drop(p, seed, 1) if p > 0 else None)
+    got = float(m.train_step(his, pred, y).item())
+    assert abs(got - L) <= 3e-5 * max(1.0, abs(L)), (got, L)
+    eng = m._engine
+    E = eng.E
+    for k in [f"d{l}_{s}" for l in range(2) for s in ("W", "b")] + [f"bn{l}_{s}" for l in range(2) for s in ("g", "b")] + ["out_W", "out_b", "u_W", "u_b"]:
+        want = g[k].reshape(eng.params.shapes[k])
+        assert_close(eng.params.g(k).cpu().numpy(), want, rtol=2e-4, atol=1e-6 + 2e-4 * np.abs(want).max(), what=f"d{k}")
+    want = np.concatenate([g["u_WQ"], g["u_WK"], g["u_WV"]], 1)
+    assert_close(eng.params.g("u_Wqkv").cpu().numpy(), want, rtol=2e-4, atol=1e-6 + 2e-4 * np.abs(want).max(), what="du_Wqkv")
+    Pn = dict(P)
+    on.bn_update_moving(Pn, stats)  # history call site first, then candidates: two updates per step
+    for l in range(2):
+        assert_close(eng.bn_mean[l].cpu().numpy(), Pn[f"bn{l}_mean"], rtol=1e-5, atol=1e-6, what=f"moving mean {l}")
+        assert_close(eng.bn_var[l].cpu().numpy(), Pn[f"bn{l}_var"], rtol=1e-5, atol=1e-6, what=f"moving var {l}")
+
+
+def test_docvec_fit_surface_and_weights_roundtrip(docvec, tmp_path):
+    hp = make_hp(title_size=32, newsencoder_units_per_layer=[16], head_num=2, head_dim=8, attention_hidden_dim=6, history_size=4)
+    m = docvec(hp, seed=3)
+    rng = np.random.default_rng(4)
+    his, pred, y = data(rng, 40, 4, 5, 32)
+    m.model.compile(optimizer=m.model.optimizer, loss=m.model.loss, metrics=["AUC"])
+    h = m.model.fit((his, pred), y, batch_size=16, epochs=4, verbose=0, validation_data=((his, pred), y))
+    assert h.history["loss"][-1] < h.history["loss"][0] and "val_auc" in h.history
+    w = m.model.get_weights()
+    assert len(w) == 6 * 1 + 8 and w[4].shape == (16,) and not np.allclose(w[4], 0)  # moving mean moved
+    path = tmp_path / "docvec.weights"
+    m.model.save_weights(str(path))
+    m2 = docvec(hp, seed=77)
+    m2.model.load_weights(str(path))
+    assert np.array_equal(m2.model.predict((his, pred)), m.model.predict((his, pred)))
+    assert m.model.count_params() == sum(a.size for a in w)

@@ -248,3 +248,22 @@ def test_hipgraph_replay_equals_kernel_by_kernel_launch(nrms, train_embedding):
     b2 = batch(rng, 3, hp.history_size, 4, hp.title_size, V)
     l0, l1 = (float(m.train_step(*b2).item()) for m in ms)
     assert abs(l0 - l1) <= 1e-5 * max(1.0, abs(l0))
+
+
+@pytest.mark.parametrize("train_embedding", [False, True])
+def test_row_sharded_table_path_on_one_gpu_equals_replicated(nrms, train_embedding):
+    """shard_table=True at world size 1 exercises the whole routed-lookup code path (dedup, local gather,
+    expand-with-dropout, per-unique-row gradient, owner scatter) against the replicated-table path."""
+    hp = make_hp(dropout=0.2, learning_rate=1e-3)
+    rng = np.random.default_rng(31)
+    V = 257
+    emb = rng.standard_normal((V, 64)).astype(np.float32)
+    a = nrms(hp, word2vec_embedding=emb, seed=3, train_embedding=train_embedding)
+    b = nrms(hp, word2vec_embedding=emb, seed=3, train_embedding=train_embedding, shard_table=True)
+    his, pred, y = batch(rng, 5, hp.history_size, 5, hp.title_size, V)
+    assert np.array_equal(a.model.predict((his, pred)), b.model.predict((his, pred)))
+    for _ in range(2):
+        la, lb = float(a.train_step(his, pred, y).item()), float(b.train_step(his, pred, y).item())
+        assert abs(la - lb) <= 1e-6 * max(1.0, abs(la))
+    for wa, wb in zip(a.model.get_weights(), b.model.get_weights()):
+        assert np.allclose(wa, wb, rtol=1e-4, atol=1e-6)
