@@ -20,9 +20,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef EBN_GEMM_XCD
 #define EBN_GEMM_XCD 1
 #endif
-#ifndef EBN_GEMM_PIPE
-#define EBN_GEMM_PIPE 0
-#endif
 
 constexpr int BK = 16;
 constexpr int PAD = 4;
@@ -165,36 +162,21 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
     _Pragma("unroll") for (int i = 0; i < LB::PER_THREAD; ++i) LB::store(Bs[BUF], tid + i * GEMM_THREADS, rb[i]); \
   }
 
-  // Pipeline (issue-early / write-late): registers hold slab kt+1 (fetched one whole iteration ago),
-  // LDS buffer `cur` holds slab kt.  Each iteration: registers -> LDS[cur^1], re-issue the loads of
-  // slab kt+2 into the same registers, multiply slab kt, one barrier.  The vmcnt wait is an iteration
-  // old by the time it is needed, and the LDS writes overlap the other waves' MFMAs.
-#if EBN_GEMM_PIPE
-  if (nk > 0) {
-    EBN_LOAD_SLAB(0);
-    EBN_STORE_SLAB(0);
-    if (nk > 1) EBN_LOAD_SLAB(1);
-  }
-#else
+  // Pipeline: LDS buffer `cur` holds slab kt; slab kt+1 is fetched into registers while slab kt is multiplied
+  // and written to LDS[cur^1] afterwards; one barrier per slab.  Variants measured and rejected on MI355X
+  // (profiles/r01_gemm_tuning.md): two-slab-deep prefetch, BK=32, k-contiguous LDS image with burst b128
+  // operand reads, s_setprio around the MFMA cluster / per-workgroup static priority -- all within +-3 %.
   if (nk > 0) {
     EBN_LOAD_SLAB(0);
     EBN_STORE_SLAB(0);
   }
-#endif
   __syncthreads();
 
   const int kl = lane >> 5;
   const int il = lane & 31;
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
-#if EBN_GEMM_PIPE
-    if (kt + 1 < nk) {
-      EBN_STORE_SLAB(cur ^ 1);
-      if (kt + 2 < nk) EBN_LOAD_SLAB(kt + 2);
-    }
-#else
-    if (kt + 1 < nk) EBN_LOAD_SLAB(kt + 1);
-#endif
+    if (kt + 1 < nk) EBN_LOAD_SLAB(kt + 1);  // next slab into registers while this one is multiplied
     const float* as = As[cur] + kl * LDA_S + wm * (BM / 2) + il;
     const float* bs = Bs[cur] + kl * LDB_S + wn * (BN / 2) + il;
 #pragma unroll
@@ -210,9 +192,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
-#if !EBN_GEMM_PIPE
     if (kt + 1 < nk) EBN_STORE_SLAB(cur ^ 1);
-#endif
     __syncthreads();
     cur ^= 1;
   }
