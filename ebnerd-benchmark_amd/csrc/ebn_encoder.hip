@@ -17,20 +17,24 @@ static int check_dims(const ebn_encoder_dims* d) {
 }
 
 extern "C" int ebn_encoder_fwd_f32(const ebn_encoder_dims* dims, const ebn_encoder_params* p,
-                                   const ebn_encoder_acts* a, const ebn_step_state* st, ebn_stream_t stream) {
+                                   const ebn_encoder_acts* a, const ebn_encoder_scratch* s,
+                                   const ebn_step_state* st, ebn_stream_t stream) {
   EBN_TRY(check_dims(dims));
   EBN_REQUIRE(p && a && p->Wqkv && p->W && p->b && p->q, EBN_ERR_BAD_ARG);
   EBN_REQUIRE(a->X && a->QKV && a->Y && a->U && a->w && a->out, EBN_ERR_BAD_ARG);
   const int64_t R = dims->n_seq * dims->L;
   const int E = dims->h * dims->d;
   if (R == 0) return EBN_OK;
+  float* ws = s ? s->gemm_ws : nullptr;
+  const int64_t ws_n = s ? s->gemm_ws_floats : 0;
   // Q|K|V = X.Wqkv   (layers.py:214,220,226)
-  EBN_TRY(ebn_gemm_f32(0, 0, R, 3 * E, dims->Din, 1.0f, a->X, dims->Din, p->Wqkv, 3 * E, 0.0f, a->QKV, 3 * E, stream));
+  EBN_TRY(ebn_gemm_f32_ws(0, 0, R, 3 * E, dims->Din, 1.0f, a->X, dims->Din, p->Wqkv, 3 * E, 0.0f, a->QKV, 3 * E, ws, ws_n,
+                          stream));
   // Y = dropout(P^T V)   (layers.py:231-252, nrms.py:154)
   EBN_TRY(ebn_attn_fwd_f32(a->QKV, 3 * E, a->Y, E, dims->n_seq, dims->L, dims->h, dims->d, st, dims->drop_site,
                            dims->drop_p, stream));
   // U = Y.W ; AttLayer2 tail   (layers.py:65-81)
-  EBN_TRY(ebn_gemm_f32(0, 0, R, dims->A, E, 1.0f, a->Y, E, p->W, dims->A, 0.0f, a->U, dims->A, stream));
+  EBN_TRY(ebn_gemm_f32_ws(0, 0, R, dims->A, E, 1.0f, a->Y, E, p->W, dims->A, 0.0f, a->U, dims->A, ws, ws_n, stream));
   EBN_TRY(ebn_attpool_fwd_f32(a->U, p->b, p->q, a->Y, a->out, a->w, dims->n_seq, dims->L, E, dims->A, stream));
   return EBN_OK;
 }
@@ -55,7 +59,7 @@ extern "C" int ebn_encoder_bwd_f32(const ebn_encoder_dims* dims, const ebn_encod
   EBN_TRY(ebn_attpool_bwd_dpre_f32(a->U, p->q, s->de, g->dq, g->db, s->partials, R, A, accumulate, stream));
   // dW = Y^T . dpre ; dY += dpre . W^T
   EBN_TRY(ebn_gemm_f32_ws(1, 0, E, A, R, 1.0f, a->Y, E, a->U, A, beta, g->dW, A, s->gemm_ws, s->gemm_ws_floats, stream));
-  EBN_TRY(ebn_gemm_f32(0, 1, R, E, A, 1.0f, a->U, A, p->W, A, 1.0f, s->dY, E, stream));
+  EBN_TRY(ebn_gemm_f32_ws(0, 1, R, E, A, 1.0f, a->U, A, p->W, A, 1.0f, s->dY, E, s->gemm_ws, s->gemm_ws_floats, stream));
   // self-attention core backward (re-derives the dropout mask of Y)
   EBN_TRY(ebn_attn_bwd_f32(a->QKV, 3 * E, s->dY, E, s->dQKV, 3 * E, dims->n_seq, dims->L, dims->h, dims->d, st,
                            dims->drop_site, dims->drop_p, stream));
@@ -63,6 +67,7 @@ extern "C" int ebn_encoder_bwd_f32(const ebn_encoder_dims* dims, const ebn_encod
   EBN_TRY(ebn_gemm_f32_ws(1, 0, dims->Din, 3 * E, R, 1.0f, a->X, dims->Din, s->dQKV, 3 * E, beta, g->dWqkv, 3 * E,
                           s->gemm_ws, s->gemm_ws_floats, stream));
   if (dX != nullptr)
-    EBN_TRY(ebn_gemm_f32(0, 1, R, dims->Din, 3 * E, 1.0f, s->dQKV, 3 * E, p->Wqkv, 3 * E, 0.0f, dX, dims->Din, stream));
+    EBN_TRY(ebn_gemm_f32_ws(0, 1, R, dims->Din, 3 * E, 1.0f, s->dQKV, 3 * E, p->Wqkv, 3 * E, 0.0f, dX, dims->Din, s->gemm_ws,
+                            s->gemm_ws_floats, stream));
   return EBN_OK;
 }

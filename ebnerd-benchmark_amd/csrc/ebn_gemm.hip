@@ -266,7 +266,7 @@ int launch_gemm(int transA, int transB, int64_t M, int64_t N, int64_t K, float a
 // Split-K plan shared by the workspace query and the launcher.
 static void gemm_plan(int64_t M, int64_t N, int64_t K, int64_t ws_floats, int* bm, int* splits,
                       int64_t* k_per_split) {
-  int64_t max_split = K / (8 * BK);  // keep >= 8 slabs per split
+  int64_t max_split = K / (4 * BK);  // keep >= 4 slabs per split
   if (max_split > 64) max_split = 64;
   const int64_t max_by_ws = (M * N > 0) ? ws_floats / (M * N) : 0;
   if (max_split > max_by_ws) max_split = max_by_ws;

@@ -83,9 +83,11 @@ class EncoderBuffers:
         self.out = f(n_seq, E)
         self.dY, self.dQKV, self.de = f(R, E), f(R, 3 * E), f(R)
         self.partials = f(int(_hip.lib().ebn_attpool_partials_len(R, A)))
-        ws = max(int(_hip.lib().ebn_gemm_workspace_floats(Din, 3 * E, R)),
-                 int(_hip.lib().ebn_gemm_workspace_floats(E, A, R)), 1)
+        wsf = _hip.lib().ebn_gemm_workspace_floats  # split-K scratch for every GEMM shape of the stage (fwd and bwd)
+        ws = max(int(wsf(Din, 3 * E, R)), int(wsf(E, A, R)), int(wsf(R, 3 * E, Din)), int(wsf(R, A, E)), int(wsf(R, E, A)),
+                 int(wsf(R, Din, 3 * E)), 1)
         self.ws = f(ws)
+        self.fwd_scratch = _hip.EncoderScratch(None, None, None, None, self.ws.data_ptr(), self.ws.numel())
         self.dX = f(R, Din) if need_dx else None
 
 
@@ -251,8 +253,12 @@ class NRMSEngine:
         if self.kernel_events is not None and pre == "n":
             return self._encoder_fwd_timed(b, n_seq, X, st, site, p)
         dims, params, acts = self._enc_structs(pre, b, n_seq, X, site, p)
-        _hip.call("ebn_encoder_fwd_f32", ctypes.byref(dims), ctypes.byref(params), ctypes.byref(acts), st,
-                  _hip.stream_handle())
+        _hip.call("ebn_encoder_fwd_f32", ctypes.byref(dims), ctypes.byref(params), ctypes.byref(acts),
+                  ctypes.byref(self._fwd_scratch(b)), st, _hip.stream_handle())
+
+    @staticmethod
+    def _fwd_scratch(b):
+        return b.fwd_scratch
 
     def _timed(self, name):
         """HIP events on the launch stream around one kernel (bench.py roofline figures)."""

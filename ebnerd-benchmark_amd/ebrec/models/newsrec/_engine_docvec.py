@@ -211,6 +211,10 @@ class DocVecEngine:
             if l:
                 self._gemm(0, 1, N, din, u, dR, u, pv(f"d{l}_W"), u, 0.0, mb["dA"][l - 1], din)
 
+    @staticmethod
+    def _fwd_scratch(b):
+        return b.fwd_scratch
+
     def _enc(self, ub, B, X, dims_only=False):
         pv = self.params.view
         dims = _hip.EncoderDims(B, self.H, self.E, self.h, self.d, self.A, -1, 0.0)
@@ -251,7 +255,7 @@ class DocVecEngine:
         ub = self._user_bufs(B)
         X = NEh.reshape(B * self.H, self.E).contiguous()
         dims, params, acts = self._enc(ub, B, X)
-        _hip.call("ebn_encoder_fwd_f32", ctypes.byref(dims), ctypes.byref(params), ctypes.byref(acts), None, _hip.stream_handle())
+        _hip.call("ebn_encoder_fwd_f32", ctypes.byref(dims), ctypes.byref(params), ctypes.byref(acts), ctypes.byref(self._fwd_scratch(ub)), None, _hip.stream_handle())
         return ub.out[:B].clone()
 
     def encode_users(self, his) -> torch.Tensor:
@@ -268,7 +272,7 @@ class DocVecEngine:
         n_hist, n_cand = self._upload(mb, his, pred)
         self._news_forward(mb, n_hist, n_cand, False)
         dims, params, acts = self._enc(ub, B, mb["NE"])
-        _hip.call("ebn_encoder_fwd_f32", ctypes.byref(dims), ctypes.byref(params), ctypes.byref(acts), None, _hip.stream_handle())
+        _hip.call("ebn_encoder_fwd_f32", ctypes.byref(dims), ctypes.byref(params), ctypes.byref(acts), ctypes.byref(self._fwd_scratch(ub)), None, _hip.stream_handle())
         scores, probs = torch.empty(B, C, device=self.device), torch.empty(B, C, device=self.device)
         _hip.call("ebn_score_fwd_f32", _hip.ptr(mb["NE"][n_hist:]), _hip.ptr(ub.out), _hip.ptr(scores), _hip.ptr(probs), B, C,
                   self.E, 0 if mode == "softmax" else 1, _hip.stream_handle())
@@ -307,7 +311,7 @@ class DocVecEngine:
         _hip.call("ebn_step_advance", st, BETA1, BETA2, S())
         self._news_forward(mb, n_hist, n_cand, True)
         dims, params, acts = self._enc(ub, B, mb["NE"])
-        _hip.call("ebn_encoder_fwd_f32", ctypes.byref(dims), ctypes.byref(params), ctypes.byref(acts), st, S())
+        _hip.call("ebn_encoder_fwd_f32", ctypes.byref(dims), ctypes.byref(params), ctypes.byref(acts), ctypes.byref(self._fwd_scratch(ub)), st, S())
         cand = mb["NE"][n_hist:]
         _hip.call("ebn_score_fwd_f32", _hip.ptr(cand), _hip.ptr(ub.out), _hip.ptr(mb["scores"]), _hip.ptr(mb["probs"]), B, C, E, 0, S())
         _hip.call("ebn_score_loss_bwd_f32", _hip.ptr(cand), _hip.ptr(ub.out), _hip.ptr(mb["scores"]), _hip.ptr(mb["labels"]),

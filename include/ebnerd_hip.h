@@ -167,9 +167,11 @@ typedef struct ebn_encoder_scratch {
   int64_t gemm_ws_floats;
 } ebn_encoder_scratch;
 
+/* scratch may be NULL; when given, its gemm_ws lets the two projection GEMMs of a SMALL batch of sequences
+ * (the user encoder: B*H rows) use split-K to fill the chip (only gemm_ws / gemm_ws_floats are read).    */
 int ebn_encoder_fwd_f32(const ebn_encoder_dims* dims, const ebn_encoder_params* params,
-                        const ebn_encoder_acts* acts, const ebn_step_state* st,
-                        ebn_stream_t stream);
+                        const ebn_encoder_acts* acts, const ebn_encoder_scratch* scratch,
+                        const ebn_step_state* st, ebn_stream_t stream);
 /* dout [n_seq, E] -> parameter gradients (accumulated when accumulate != 0) and, when dX is
  * non-NULL, dX [R, Din] (overwritten).  acts->U is consumed (overwritten with d(pre-tanh)). */
 int ebn_encoder_bwd_f32(const ebn_encoder_dims* dims, const ebn_encoder_params* params,

@@ -283,7 +283,7 @@ def _run_encoder(hip, X, Wqkv, W, b, q, h, d, A, drop_p, st, dout=None, need_dx=
     dims = hip.EncoderDims(n_seq, L, Din, h, d, A, 1 if drop_p > 0 else -1, drop_p)
     params = hip.EncoderParams(*[t_.data_ptr() for t_ in (prm["Wqkv"], prm["W"], prm["b"], prm["q"])])
     acts = hip.EncoderActs(*[t[k].data_ptr() for k in ("X", "QKV", "Y", "U", "w", "out")])
-    hip.call("ebn_encoder_fwd_f32", ctypes.byref(dims), ctypes.byref(params), ctypes.byref(acts), P(st), S())
+    hip.call("ebn_encoder_fwd_f32", ctypes.byref(dims), ctypes.byref(params), ctypes.byref(acts), None, P(st), S())
     res = {"out": host(t["out"]), "Y": host(t["Y"])}
     if dout is not None:
         g = {"dWqkv": torch.zeros(Din, 3 * E, device="cuda"), "dW": torch.zeros(E, A, device="cuda"),
