@@ -275,10 +275,23 @@ static void gemm_plan(int64_t M, int64_t N, int64_t K, int64_t ws_floats, int* b
   // 128x128 tiles (2x the arithmetic intensity) whenever they can still fill 256 CUs x 2
   *bm = (tiles128 * max_split >= 512) ? 128 : 64;
   const int64_t tiles = ebn_ceil_div(M, *bm) * ebn_ceil_div(N, *bm);
+  // Workgroups are dealt round-robin to 256 CUs and all cost the same, so the launch takes ceil(n_wg/256) "turns":
+  // among the split factors that give the chip 2..8 workgroups per CU pick the one that wastes the least of its
+  // last turn (e.g. 80 tiles: 16 splits = exactly 5 turns, where 13 splits would idle 19 % of a 5th turn).
   int64_t s = 1;
-  if (tiles < 512) {
-    s = ebn_ceil_div(1024, tiles);
-    if (s > max_split) s = max_split;
+  if (tiles < 512 && max_split > 1) {
+    int64_t lo = ebn_ceil_div(512, tiles), hi = ebn_ceil_div(2048, tiles);
+    if (lo > max_split) lo = max_split;
+    if (hi > max_split) hi = max_split;
+    double best = -1.0;
+    for (int64_t c = lo; c <= hi; ++c) {
+      const double turns = static_cast<double>(tiles * c) / 256.0;
+      const double eff = turns / static_cast<double>(ebn_ceil_div(tiles * c, 256));
+      if (eff > best + 1e-9) {
+        best = eff;
+        s = c;
+      }
+    }
   }
   int64_t kps = ebn_ceil_div(ebn_ceil_div(K > 0 ? K : 1, s), BK) * BK;
   s = ebn_ceil_div(K > 0 ? K : 1, kps);
