@@ -198,7 +198,7 @@ def main():
                                    f"att_hidden={c['A']} dropout=0.2 adam lr=1e-4 CE loss",
                        "global_batch": world * c["B"], "per_gpu_batch": c["B"], "parallelism": f"dp{world}",
                        "final_loss": loss},
-            "roofline": {"kernel": "gemm_f32_kernel<128,128,NN> (news-encoder Q|K|V projection, fwd)", "bound": "mfma",
+            "roofline": {"kernel": "gemm_f32_kernel<128, 128, false, false, true, 1> (news-encoder Q|K|V projection, fwd)", "bound": "mfma",
                          "achieved": gemm_flops / kt["qkv_gemm"] / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": gemm_flops / kt["qkv_gemm"] / 1e12 / MFMA_F32_PEAK_TFLOPS,
                          "traffic": traffic.get("qkv_gemm"), "avg_launch_us": kt["qkv_gemm"] * 1e6,

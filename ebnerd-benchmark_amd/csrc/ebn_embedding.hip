@@ -95,7 +95,42 @@ __global__ __launch_bounds__(GATHER_THREADS) void scatter_add_rows_kernel(
   }
 }
 
+__global__ __launch_bounds__(GATHER_THREADS) void expand_titles_kernel(const int32_t* __restrict__ art_idx,
+                                                                       const int32_t* __restrict__ token_matrix,
+                                                                       int32_t* __restrict__ ids_out, int64_t n_items,
+                                                                       int32_t T, int64_t n_rows,
+                                                                       int32_t* __restrict__ oob_flag) {
+  for (int64_t it = static_cast<int64_t>(blockIdx.x) * GATHER_THREADS + threadIdx.x; it < n_items;
+       it += static_cast<int64_t>(gridDim.x) * GATHER_THREADS) {
+    const int64_t r = it / T;
+    const int32_t t = static_cast<int32_t>(it - r * T);
+    const int64_t a = art_idx[r];
+    int32_t v = 0;
+    if (a >= 0 && a < n_rows) {
+      v = token_matrix[a * T + t];
+    } else if (oob_flag != nullptr) {
+      *oob_flag = 1;
+    }
+    ids_out[it] = v;
+  }
+}
+
 }  // namespace
+
+extern "C" int ebn_expand_titles_i32(const int32_t* art_idx, const int32_t* token_matrix, int32_t* ids_out,
+                                     int64_t n_titles, int32_t T, int64_t n_rows, int32_t* oob_flag,
+                                     ebn_stream_t stream) {
+  EBN_REQUIRE(art_idx && token_matrix && ids_out, EBN_ERR_BAD_ARG);
+  EBN_REQUIRE(n_titles >= 0 && T > 0 && n_rows > 0, EBN_ERR_BAD_ARG);
+  if (n_titles == 0) return EBN_OK;
+  const int64_t n_items = n_titles * T;
+  int64_t grid = ebn_ceil_div(n_items, GATHER_THREADS);
+  if (grid > 256 * 32) grid = 256 * 32;
+  hipLaunchKernelGGL(expand_titles_kernel, dim3(static_cast<unsigned>(grid)), dim3(GATHER_THREADS), 0,
+                     ebn_stream(stream), art_idx, token_matrix, ids_out, n_items, T, n_rows, oob_flag);
+  EBN_CHECK_LAUNCH();
+  return EBN_OK;
+}
 
 extern "C" int ebn_gather_rows_f32(const int32_t* ids, const float* table, float* out, int64_t n_tok,
                                    int32_t D, int64_t V, const ebn_step_state* st, int32_t site,

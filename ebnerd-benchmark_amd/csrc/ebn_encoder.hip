@@ -28,8 +28,8 @@ extern "C" int ebn_encoder_fwd_f32(const ebn_encoder_dims* dims, const ebn_encod
   float* ws = s ? s->gemm_ws : nullptr;
   const int64_t ws_n = s ? s->gemm_ws_floats : 0;
   // Q|K|V = X.Wqkv   (layers.py:214,220,226)
-  EBN_TRY(ebn_gemm_f32_ws(0, 0, R, 3 * E, dims->Din, 1.0f, a->X, dims->Din, p->Wqkv, 3 * E, 0.0f, a->QKV, 3 * E, ws, ws_n,
-                          stream));
+  EBN_TRY(ebn_gemm_f32_site(0, 0, R, 3 * E, dims->Din, 1.0f, a->X, dims->Din, p->Wqkv, 3 * E, 0.0f, a->QKV, 3 * E, ws, ws_n,
+                            1, stream));
   // Y = dropout(P^T V)   (layers.py:231-252, nrms.py:154)
   EBN_TRY(ebn_attn_fwd_f32(a->QKV, 3 * E, a->Y, E, dims->n_seq, dims->L, dims->h, dims->d, st, dims->drop_site,
                            dims->drop_p, stream));

@@ -96,7 +96,9 @@ struct TileLoader {
 // TA: A stored [K,M]; TB: B stored [N,K].
 // gridDim.z = split-K factor; when > 1 each z-slice writes alpha*partial to
 // Cpart + z*M*N (dense ld = N) and a reduce kernel finishes; else writes C directly.
-template <int BM, int BN, bool TA, bool TB, bool VEC>
+// SITE only labels the instantiation (0 = generic, 1 = the encoders' Q|K|V projection) so that per-kernel profiler
+// summaries separate the roofline kernel of bench.py from the other GEMM call sites of the same shape class.
+template <int BM, int BN, bool TA, bool TB, bool VEC, int SITE>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
     int64_t M, int64_t N, int64_t K, float alpha, const float* __restrict__ A, int64_t lda,
     const float* __restrict__ B, int64_t ldb, float beta, float* __restrict__ C, int64_t ldc,
@@ -239,20 +241,23 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 template <int BM, int BN>
 int launch_gemm(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha, const float* A,
                 int64_t lda, const float* B, int64_t ldb, float beta, float* C, int64_t ldc, int vecA,
-                int vecB, int splits, int64_t k_per_split, float* part, hipStream_t s) {
+                int vecB, int splits, int64_t k_per_split, float* part, hipStream_t s, int site) {
   dim3 grid(static_cast<unsigned>(ebn_ceil_div(N, BN)), static_cast<unsigned>(ebn_ceil_div(M, BM)),
             static_cast<unsigned>(splits));
   dim3 block(GEMM_THREADS);
 #define EBN_GEMM_LAUNCH(TA, TB)                                                                            \
   do {                                                                                                    \
     if (vecA && vecB)                                                                                     \
-      hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB, true>), grid, block, 0, s, M, N, K, alpha, A, lda, \
+      hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB, true, 0>), grid, block, 0, s, M, N, K, alpha, A, lda, \
                          B, ldb, beta, C, ldc, k_per_split, part);                                        \
     else                                                                                                  \
-      hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB, false>), grid, block, 0, s, M, N, K, alpha, A,  \
+      hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB, false, 0>), grid, block, 0, s, M, N, K, alpha, A,  \
                          lda, B, ldb, beta, C, ldc, k_per_split, part);                                   \
   } while (0)
-  if (!transA && !transB) EBN_GEMM_LAUNCH(false, false);
+  if (!transA && !transB && site == 1 && vecA && vecB)
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, false, true, 1>), grid, block, 0, s, M, N, K, alpha, A, lda, B,
+                       ldb, beta, C, ldc, k_per_split, part);
+  else if (!transA && !transB) EBN_GEMM_LAUNCH(false, false);
   else if (!transA && transB) EBN_GEMM_LAUNCH(false, true);
   else if (transA && !transB) EBN_GEMM_LAUNCH(true, false);
   else EBN_GEMM_LAUNCH(true, true);
@@ -306,10 +311,10 @@ extern "C" int64_t ebn_gemm_workspace_floats(int64_t M, int64_t N, int64_t K) {
   return (s > 1) ? static_cast<int64_t>(s) * M * N : 0;
 }
 
-extern "C" int ebn_gemm_f32_ws(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K, float alpha,
-                               const float* A, int64_t lda, const float* B, int64_t ldb, float beta,
-                               float* C, int64_t ldc, float* workspace, int64_t workspace_floats,
-                               ebn_stream_t stream) {
+extern "C" int ebn_gemm_f32_site(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K, float alpha,
+                                 const float* A, int64_t lda, const float* B, int64_t ldb, float beta, float* C,
+                                 int64_t ldc, float* workspace, int64_t workspace_floats, int32_t site,
+                                 ebn_stream_t stream) {
   EBN_REQUIRE(M >= 0 && N >= 0 && K >= 0, EBN_ERR_BAD_ARG);
   if (M == 0 || N == 0) return EBN_OK;
   EBN_REQUIRE(A && B && C, EBN_ERR_BAD_ARG);
@@ -324,10 +329,10 @@ extern "C" int ebn_gemm_f32_ws(int32_t transA, int32_t transB, int64_t M, int64_
   int rc;
   if (bm == 128)
     rc = launch_gemm<128, 128>(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, vecA, vecB,
-                               splits, kps, workspace, s);
+                               splits, kps, workspace, s, site);
   else
     rc = launch_gemm<64, 64>(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, vecA, vecB,
-                             splits, kps, workspace, s);
+                             splits, kps, workspace, s, site);
   if (rc != EBN_OK) return rc;
   if (splits > 1) {
     int64_t grid = ebn_ceil_div(M * N, 256);
@@ -337,6 +342,14 @@ extern "C" int ebn_gemm_f32_ws(int32_t transA, int32_t transB, int64_t M, int64_
     EBN_CHECK_LAUNCH();
   }
   return EBN_OK;
+}
+
+extern "C" int ebn_gemm_f32_ws(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K, float alpha,
+                               const float* A, int64_t lda, const float* B, int64_t ldb, float beta,
+                               float* C, int64_t ldc, float* workspace, int64_t workspace_floats,
+                               ebn_stream_t stream) {
+  return ebn_gemm_f32_site(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, workspace, workspace_floats, 0,
+                           stream);
 }
 
 extern "C" int ebn_gemm_f32(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K, float alpha,

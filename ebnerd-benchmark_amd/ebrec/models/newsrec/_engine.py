@@ -273,13 +273,13 @@ class NRMSEngine:
         pv = self.params.view
         e0, e1 = self._timed("qkv_gemm")
         e0.record()
-        _hip.call("ebn_gemm_f32", 0, 0, R, 3 * E, b.Din, ctypes.c_float(1.0), _hip.ptr(X), b.Din,
-                  _hip.ptr(pv("n_Wqkv")), 3 * E, ctypes.c_float(0.0), _hip.ptr(b.QKV), 3 * E, S())
+        _hip.call("ebn_gemm_f32_site", 0, 0, R, 3 * E, b.Din, ctypes.c_float(1.0), _hip.ptr(X), b.Din,
+                  _hip.ptr(pv("n_Wqkv")), 3 * E, ctypes.c_float(0.0), _hip.ptr(b.QKV), 3 * E, _hip.ptr(b.ws), b.ws.numel(), 1, S())
         e1.record()
         _hip.call("ebn_attn_fwd_f32", _hip.ptr(b.QKV), 3 * E, _hip.ptr(b.Y), E, n_seq, b.L, self.h, self.d, st, site,
                   ctypes.c_float(p), S())
-        _hip.call("ebn_gemm_f32", 0, 0, R, A, E, ctypes.c_float(1.0), _hip.ptr(b.Y), E, _hip.ptr(pv("n_W")), A,
-                  ctypes.c_float(0.0), _hip.ptr(b.U), A, S())
+        _hip.call("ebn_gemm_f32_ws", 0, 0, R, A, E, ctypes.c_float(1.0), _hip.ptr(b.Y), E, _hip.ptr(pv("n_W")), A,
+                  ctypes.c_float(0.0), _hip.ptr(b.U), A, _hip.ptr(b.ws), b.ws.numel(), S())
         _hip.call("ebn_attpool_fwd_f32", _hip.ptr(b.U), _hip.ptr(pv("n_b")), _hip.ptr(pv("n_q")), _hip.ptr(b.Y),
                   _hip.ptr(b.out), _hip.ptr(b.w), n_seq, b.L, E, A, S())
 
@@ -433,7 +433,33 @@ class NRMSEngine:
             raise IndexError(f"token id out of range [0, {self.V}) for the embedding table")
 
     # ------------------------------------------------------------------ training
-    def train_step(self, his, pred, y, return_probs=False):
+    # ------------------------------------------------------------------ device-side batch assembly (a13)
+    def set_article_matrix(self, matrix) -> None:
+        """Keep the loader's (n_articles+1, T) token matrix in HBM; batches can then be given as article-row
+        numbers (``train_step(..., indexed=True)``) and expanded to token ids on the device."""
+        m = np.asarray(matrix)
+        if m.ndim != 2 or m.shape[1] != self.T or not np.issubdtype(m.dtype, np.integer):
+            raise ValueError(f"article matrix must be integer (n_articles+1, {self.T}), got {m.dtype} {m.shape}")
+        if m.size and (m.min() < 0 or m.max() >= self.V):
+            raise IndexError(f"token id out of range [0, {self.V}) for the embedding table")
+        self.article_matrix = torch.from_numpy(np.ascontiguousarray(m.astype(np.int32))).to(self.device)
+        self._article_matrix_src = matrix
+
+    def _stage_indexed(self, nb, his_idx, pred_idx):
+        B, C = his_idx.shape[0], pred_idx.shape[1]
+        n_titles = B * (self.H + C)
+        if not hasattr(nb, "art_idx") or nb.art_idx.numel() < n_titles:
+            nb.art_idx = torch.empty(nb.n_seq, dtype=torch.int32, device=self.device)
+        off = 0
+        for a in (his_idx, pred_idx):
+            t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(a).reshape(-1).astype(np.int32, copy=False)))
+            t = t.reshape(-1)
+            nb.art_idx[off: off + t.numel()].copy_(t.to(device=self.device, dtype=torch.int32), non_blocking=True)
+            off += t.numel()
+        _hip.call("ebn_expand_titles_i32", _hip.ptr(nb.art_idx), _hip.ptr(self.article_matrix), _hip.ptr(nb.ids), n_titles,
+                  self.T, self.article_matrix.shape[0], _hip.ptr(self.oob_flag), _hip.stream_handle())
+
+    def train_step(self, his, pred, y, return_probs=False, indexed=False):
         """One optimizer step (forward, loss, backward, gradient all-reduce, Keras Adam).
         Returns the batch loss as a 1-element device tensor (no host sync).  With
         ``use_graph`` the kernel sequence of a (B, C) shape is captured once into hipGraphs and
@@ -441,10 +467,16 @@ class NRMSEngine:
         the device ebn_step_state, so the replay sees fresh dropout keys / Adam step sizes)."""
         his = his if isinstance(his, torch.Tensor) else np.asarray(his)
         pred = pred if isinstance(pred, torch.Tensor) else np.asarray(pred)
-        self._check_shapes(his, pred)
         B, C = his.shape[0], pred.shape[1]
-        nb, ub = self._train_bufs(B, C)
-        self._upload_ids(nb.ids, his, pred)
+        if indexed:  # (B,H) / (B,C) article-row numbers of the matrix given to set_article_matrix()
+            if his.ndim != 2 or his.shape[1] != self.H or pred.ndim != 2 or pred.shape[0] != B:
+                raise ValueError(f"indexed batches must be (B, {self.H}) and (B, C), got {tuple(his.shape)} {tuple(pred.shape)}")
+            nb, ub = self._train_bufs(B, C)
+            self._stage_indexed(nb, his, pred)
+        else:
+            self._check_shapes(his, pred)
+            nb, ub = self._train_bufs(B, C)
+            self._upload_ids(nb.ids, his, pred)
         labels = (y if isinstance(y, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(y, dtype=np.float32))))
         nb.labels[: B * C].copy_(labels.reshape(-1).to(device=self.device, dtype=torch.float32), non_blocking=True)
         if self.use_graph and self.kernel_events is None and self.exchange is None:  # sharded lookups have data-dependent sizes

@@ -156,14 +156,19 @@ class TrainModel:
             loss_sum = torch.zeros(1, device=eng.device)
             n_rows = 0
             auc = StreamingAUC() if want_auc else None
+            # loaders of this repo + an engine that can hold the token matrix in HBM: ship article-row numbers only
+            indexed = (hasattr(data, "index_batch") and hasattr(eng, "set_article_matrix") and not getattr(data, "eval_mode", False)
+                       and np.issubdtype(np.asarray(data.lookup_article_matrix).dtype, np.integer))
+            if indexed and getattr(eng, "_article_matrix_src", None) is not data.lookup_article_matrix:
+                eng.set_article_matrix(data.lookup_article_matrix)
             for step, idx in enumerate(order):
-                (his, pred), yb = data[int(idx)]
+                (his, pred), yb = data.index_batch(int(idx)) if indexed else data[int(idx)]
                 nb = len(his)
                 if want_auc:
-                    loss, probs = eng.train_step(his, pred, yb, return_probs=True)
+                    loss, probs = eng.train_step(his, pred, yb, return_probs=True, **({"indexed": True} if indexed else {}))
                     auc.update_device(torch.as_tensor(np.asarray(yb)).to(eng.device), probs)
                 else:
-                    loss = eng.train_step(his, pred, yb)
+                    loss = eng.train_step(his, pred, yb, **({"indexed": True} if indexed else {}))
                 loss_sum += loss * nb
                 n_rows += nb
                 for cb in cbs:

@@ -119,6 +119,17 @@ class NRMSDataLoader(NewsrecDataLoader):
             pred_input_title = self.lookup_article_matrix[inv.reshape(hi - lo, C)]
         return (his_input_title, pred_input_title), batch_y
 
+    def index_batch(self, idx):
+        """Train batch as article-row numbers of ``lookup_article_matrix`` -- ((his (B,H), pred (B,C)) int32, y (B,C)):
+        what a model that keeps the matrix in HBM needs per step (device-side batch assembly)."""
+        lo, hi = self._rows(idx)
+        lens = np.diff(self._inv_off[lo: hi + 1])
+        if len(lens) and lens.min() != lens.max():
+            raise ValueError("train mode needs equal-length in-view lists (sampling_strategy_wu2019)")
+        C = int(lens[0]) if len(lens) else 0
+        sl = slice(self._inv_off[lo], self._inv_off[hi])
+        return (self._history_rows(lo, hi), self._inv_flat[sl].reshape(hi - lo, C)), self._y_flat[sl].reshape(hi - lo, C)
+
     def compact_eval_batch(self, idx):
         """Eval batch WITHOUT the per-candidate repetition of the history: (his (b,H,T), pred (sum C_i, T),
         impression_of_row (sum C_i,), y (sum C_i, 1)).  Scores are identical to the repeated layout."""

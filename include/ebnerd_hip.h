@@ -66,6 +66,14 @@ int ebn_gather_rows_f32(const int32_t* ids, const float* table, float* out, int6
                         int32_t D, int64_t V, const ebn_step_state* st, int32_t site,
                         float drop_p, int32_t* oob_flag, ebn_stream_t stream);
 
+/* ---- a13  device-side batch assembly (dataloader.py:169-179: lookup_article_matrix[article rows]) ----------
+ * ids_out[r*T + t] = token_matrix[art_idx[r]*T + t]: the loader ships B*(H+C) article-row numbers per step
+ * instead of B*(H+C)*T token ids; row 0 of the matrix is the "unknown / padded article" title.  Integer copy,
+ * bit-exact.  art_idx outside [0, n_rows) writes zeros and sets *oob_flag (may be NULL).                       */
+int ebn_expand_titles_i32(const int32_t* art_idx, const int32_t* token_matrix, int32_t* ids_out,
+                          int64_t n_titles, int32_t T, int64_t n_rows, int32_t* oob_flag,
+                          ebn_stream_t stream);
+
 /* Backward of a1: dTable[ids[r],:] += dX[r,:] * dropout multiplier. dTable must be
  * zeroed by the caller (dense gradient, Keras-Adam dense semantics).   */
 int ebn_embedding_grad_scatter_f32(const int32_t* ids, const float* dX, float* dTable,
@@ -87,6 +95,13 @@ int64_t ebn_gemm_workspace_floats(int64_t M, int64_t N, int64_t K);
 int ebn_gemm_f32_ws(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K, float alpha,
                     const float* A, int64_t lda, const float* B, int64_t ldb, float beta, float* C,
                     int64_t ldc, float* workspace, int64_t workspace_floats, ebn_stream_t stream);
+
+/* Same again; `site` only labels the kernel instantiation (0 generic, 1 = Q|K|V projection of an encoder) so that
+ * per-kernel profiler summaries keep the roofline kernel of bench.py apart from other call sites.               */
+int ebn_gemm_f32_site(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K, float alpha,
+                      const float* A, int64_t lda, const float* B, int64_t ldb, float beta, float* C,
+                      int64_t ldc, float* workspace, int64_t workspace_floats, int32_t site,
+                      ebn_stream_t stream);
 
 /* ---- a3/a6  SelfAttention core (layers.py:231-252) -------------------------------
  * qkv [n_seq*L, ld_qkv] holds Q | K | V in column blocks [0,E) [E,2E) [2E,3E), E=h*d.

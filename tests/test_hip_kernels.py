@@ -500,3 +500,20 @@ def test_axpy_and_sumsq(hip):
     out = torch.full((1,), 2.0, device="cuda")
     hip.call("ebn_sumsq_f32", P(dev(x)), n, ctypes.c_float(0.5), P(out), 1, S())
     assert abs(float(out.item()) - (2.0 + 0.5 * (x.astype(np.float32).astype(np.float64) ** 2).sum())) < 2e-4 * n ** 0.5
+
+
+# ---------------------------------------------------------------- a13 device-side batch assembly
+def test_expand_titles_is_the_loader_gather_bit_exact(hip):
+    rng = np.random.default_rng(81)
+    n_rows, T, n_titles = 300, 30, 800
+    matrix = rng.integers(0, 250002, (n_rows, T)).astype(np.int32)
+    matrix[0] = 0  # the unknown / padded article
+    idx = rng.integers(0, n_rows, n_titles).astype(np.int32)
+    idx[:50] = 0
+    out = torch.full((n_titles * T,), -7, dtype=torch.int32, device="cuda")
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    hip.call("ebn_expand_titles_i32", P(dev(idx, torch.int32)), P(dev(matrix, torch.int32)), P(out), n_titles, T, n_rows, P(flag), S())
+    assert np.array_equal(out.cpu().numpy().reshape(n_titles, T), matrix[idx]) and int(flag.item()) == 0
+    idx[3] = n_rows
+    hip.call("ebn_expand_titles_i32", P(dev(idx, torch.int32)), P(dev(matrix, torch.int32)), P(out), n_titles, T, n_rows, P(flag), S())
+    assert int(flag.item()) == 1 and (out.cpu().numpy().reshape(n_titles, T)[3] == 0).all()

@@ -267,3 +267,39 @@ def test_row_sharded_table_path_on_one_gpu_equals_replicated(nrms, train_embeddi
         assert abs(la - lb) <= 1e-6 * max(1.0, abs(la))
     for wa, wb in zip(a.model.get_weights(), b.model.get_weights()):
         assert np.allclose(wa, wb, rtol=1e-4, atol=1e-6)
+
+
+def test_indexed_batches_equal_token_batches(nrms):
+    """Device-side batch assembly: article-row numbers + the loader's token matrix in HBM give the same step as the
+    host-gathered token batches (dataloader.py:169-179), bit for bit with a frozen table."""
+    import pandas as pd
+
+    from ebrec.models.newsrec.dataloader import NRMSDataLoader
+
+    hp = make_hp(dropout=0.2, learning_rate=1e-3, history_size=6, title_size=8)
+    rng = np.random.default_rng(41)
+    V, n_art, n = 120, 50, 64
+    art_ids = np.arange(1000, 1000 + n_art)
+    mapping = {int(a): rng.integers(1, V, 8).tolist() for a in art_ids}
+    df = pd.DataFrame({"user_id": rng.integers(0, 9, n), "article_id_fixed": [rng.choice(np.append(art_ids, 0), 6).tolist() for _ in range(n)],
+                       "article_ids_inview": [rng.choice(np.append(art_ids, 7), 5).tolist() for _ in range(n)],
+                       "labels": [np.eye(5, dtype=int)[rng.integers(0, 5)].tolist() for _ in range(n)]})
+    loader = NRMSDataLoader(behaviors=df, article_dict=mapping, history_column="article_id_fixed", unknown_representation="zeros", batch_size=16)
+    emb = rng.standard_normal((V, 32)).astype(np.float32)
+    a = nrms(hp, word2vec_embedding=emb, seed=3, train_embedding=False)
+    b = nrms(hp, word2vec_embedding=emb, seed=3, train_embedding=False)
+    b._engine.set_article_matrix(loader.lookup_article_matrix)
+    for i in range(len(loader)):
+        (his, pred), y = loader[i]
+        (hi, pi), yi = loader.index_batch(i)
+        assert np.array_equal(loader.lookup_article_matrix[hi], his) and np.array_equal(loader.lookup_article_matrix[pi], pred) and np.array_equal(y, yi)
+        la = float(a.train_step(his, pred, y).item())
+        lb = float(b._engine.train_step(hi, pi, yi, indexed=True).item())
+        assert la == lb
+    assert all(np.array_equal(x, z) for x, z in zip(a.model.get_weights(), b.model.get_weights()))
+    c = nrms(hp, word2vec_embedding=emb, seed=3, train_embedding=False)
+    c.model.fit(loader, epochs=1, verbose=0, shuffle=False)  # fit() picks the indexed path by itself
+    assert c._engine._article_matrix_src is loader.lookup_article_matrix
+    assert all(np.array_equal(x, z) for x, z in zip(a.model.get_weights(), c.model.get_weights()))
+    with pytest.raises(IndexError):
+        b._engine.set_article_matrix(np.full((3, 8), V))
