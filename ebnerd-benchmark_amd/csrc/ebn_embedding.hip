@@ -95,6 +95,39 @@ __global__ __launch_bounds__(GATHER_THREADS) void scatter_add_rows_kernel(
   }
 }
 
+constexpr double FIXED_SCALE = 1099511627776.0;  // 2^40
+
+// Deterministic backward: 64-bit integer atomics on a fixed-point accumulator (order-independent sums).
+__global__ __launch_bounds__(GATHER_THREADS) void scatter_add_rows_fixed_kernel(
+    const int32_t* __restrict__ ids, const float* __restrict__ dX, long long* __restrict__ acc, int64_t n_items,
+    int32_t D, int64_t V, const uint32_t* __restrict__ key_ptr, uint32_t thresh, float scale) {
+  const bool do_drop = key_ptr != nullptr;
+  const uint32_t key = do_drop ? *key_ptr : 0u;
+  for (int64_t it = static_cast<int64_t>(blockIdx.x) * GATHER_THREADS + threadIdx.x; it < n_items;
+       it += static_cast<int64_t>(gridDim.x) * GATHER_THREADS) {
+    const int64_t row = it / D;
+    const int32_t col = static_cast<int32_t>(it - row * D);
+    const int64_t id = ids[row];
+    if (id < 0 || id >= V) continue;
+    float g = dX[it];
+    if (do_drop) g *= ebn_drop_mult(key, static_cast<uint64_t>(it), thresh, scale);
+    if (g != 0.f) {
+      const long long q = __double2ll_rn(static_cast<double>(g) * FIXED_SCALE);
+      atomicAdd(reinterpret_cast<unsigned long long*>(&acc[id * D + col]), static_cast<unsigned long long>(q));
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void fixed_to_f32_kernel(long long* __restrict__ acc, float* __restrict__ out,
+                                                           int64_t n) {
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * 256) {
+    const long long q = acc[i];
+    out[i] = static_cast<float>(static_cast<double>(q) * (1.0 / FIXED_SCALE));
+    if (q != 0) acc[i] = 0;
+  }
+}
+
 __global__ __launch_bounds__(GATHER_THREADS) void expand_titles_kernel(const int32_t* __restrict__ art_idx,
                                                                        const int32_t* __restrict__ token_matrix,
                                                                        int32_t* __restrict__ ids_out, int64_t n_items,
@@ -116,6 +149,34 @@ __global__ __launch_bounds__(GATHER_THREADS) void expand_titles_kernel(const int
 }
 
 }  // namespace
+
+extern "C" int ebn_embedding_grad_scatter_fixed(const int32_t* ids, const float* dX, int64_t* acc, int64_t n_tok,
+                                                int32_t D, int64_t V, const ebn_step_state* st, int32_t site,
+                                                float drop_p, ebn_stream_t stream) {
+  EBN_REQUIRE(ids && dX && acc, EBN_ERR_BAD_ARG);
+  EBN_REQUIRE(n_tok >= 0 && D > 0 && V > 0, EBN_ERR_BAD_ARG);
+  if (n_tok == 0) return EBN_OK;
+  const EbnDrop dr = ebn_make_drop(st, site, drop_p);
+  const int64_t n_items = n_tok * D;
+  int64_t grid = ebn_ceil_div(n_items, GATHER_THREADS);
+  if (grid > 256 * 32) grid = 256 * 32;
+  hipLaunchKernelGGL(scatter_add_rows_fixed_kernel, dim3(static_cast<unsigned>(grid)), dim3(GATHER_THREADS), 0,
+                     ebn_stream(stream), ids, dX, reinterpret_cast<long long*>(acc), n_items, D, V, dr.key_ptr,
+                     dr.thresh, dr.scale);
+  EBN_CHECK_LAUNCH();
+  return EBN_OK;
+}
+
+extern "C" int ebn_fixed_to_f32(int64_t* acc, float* out, int64_t n, ebn_stream_t stream) {
+  EBN_REQUIRE(acc && out && n >= 0, EBN_ERR_BAD_ARG);
+  if (n == 0) return EBN_OK;
+  int64_t grid = ebn_ceil_div(n, 256);
+  if (grid > 256 * 16) grid = 256 * 16;
+  hipLaunchKernelGGL(fixed_to_f32_kernel, dim3(static_cast<unsigned>(grid)), dim3(256), 0, ebn_stream(stream),
+                     reinterpret_cast<long long*>(acc), out, n);
+  EBN_CHECK_LAUNCH();
+  return EBN_OK;
+}
 
 extern "C" int ebn_expand_titles_i32(const int32_t* art_idx, const int32_t* token_matrix, int32_t* ids_out,
                                      int64_t n_titles, int32_t T, int64_t n_rows, int32_t* oob_flag,

@@ -95,7 +95,7 @@ class NRMSEngine:
     def __init__(self, table: np.ndarray, title_size: int, history_size: int, head_num: int, head_dim: int,
                  attention_hidden_dim: int, dropout: float, learning_rate: float, loss: str, seed=None,
                  train_embedding: bool = True, device=None, process_group=None, shard_table: bool = False,
-                 shard_mode: str = "alltoall"):
+                 shard_mode: str = "alltoall", deterministic: bool = True):
         self.device = require_gpu() if device is None else torch.device(device)
         if loss not in LOSS_KIND:
             raise ValueError(f"this loss not defined {loss}")
@@ -121,10 +121,13 @@ class NRMSEngine:
         self.params = FlatParams({"n_Wqkv": (D, 3 * E), "n_W": (E, A), "n_b": (A,), "n_q": (A,),
                                   "u_Wqkv": (E, 3 * E), "u_W": (E, A), "u_b": (A,), "u_q": (A,)}, self.device)
         self._init_weights(seed)
+        self.deterministic = bool(deterministic)
         if self.train_embedding:
             self.table_grad = torch.zeros_like(self.table)
             self.table_m = torch.zeros_like(self.table)
             self.table_v = torch.zeros_like(self.table)
+            if self.deterministic:  # order-independent fixed-point accumulator of the embedding gradient
+                self.table_acc = torch.zeros(self.table.shape, dtype=torch.int64, device=self.device)
         st = _hip.StepState()
         st.step, st.seed, st.lr, st.adam_alpha = 0, (0 if seed is None else int(seed)) & 0xFFFFFFFF, learning_rate, 0.0
         self.state = torch.frombuffer(bytearray(bytes(st)), dtype=torch.uint8).to(self.device)
@@ -540,7 +543,8 @@ class NRMSEngine:
         self._encoder_bwd("u", ub, B, nb.out, ub.duser, nb.dNE)  # writes dNE[:B*H]
         self._encoder_bwd("n", nb, N, nb.X, nb.dNE, nb.dX)
         if self.train_embedding:
-            self.table_grad.zero_()
+            if self.exchange is not None or not self.deterministic:
+                self.table_grad.zero_()
             site, p = (0, self.p) if self.p > 0 else (-1, 0.0)
             if self.exchange is not None:
                 # reduce to one gradient row per distinct id locally, send each to its owner, owners accumulate
@@ -548,6 +552,10 @@ class NRMSEngine:
                 _hip.call("ebn_embedding_grad_scatter_f32", _hip.ptr(nb.plan.inv), _hip.ptr(nb.dX), _hip.ptr(d_uniq),
                           N * self.T, self.D, d_uniq.shape[0], st, site, ctypes.c_float(p), S())
                 self.exchange.scatter_grads(nb.plan, d_uniq, self._local_scatter_add)
+            elif self.deterministic:
+                _hip.call("ebn_embedding_grad_scatter_fixed", _hip.ptr(nb.ids), _hip.ptr(nb.dX), _hip.ptr(self.table_acc),
+                          N * self.T, self.D, self.V, st, site, ctypes.c_float(p), S())
+                _hip.call("ebn_fixed_to_f32", _hip.ptr(self.table_acc), _hip.ptr(self.table_grad), self.table.numel(), S())
             else:
                 _hip.call("ebn_embedding_grad_scatter_f32", _hip.ptr(nb.ids), _hip.ptr(nb.dX), _hip.ptr(self.table_grad),
                           N * self.T, self.D, self.V, st, site, ctypes.c_float(p), S())

@@ -33,7 +33,8 @@ class NRMSModel:
 
     def __init__(self, hparams, word2vec_embedding: np.ndarray = None, word_emb_dim: int = 300,
                  vocab_size: int = 32000, seed: int = None, *, train_embedding: bool = True, device=None,
-                 process_group=None, shard_table: bool = False, shard_mode: str = "alltoall"):
+                 process_group=None, shard_table: bool = False, shard_mode: str = "alltoall",
+                 deterministic: bool = True):
         self.hparams = hparams
         self.seed = seed
         if seed is not None:
@@ -55,7 +56,7 @@ class NRMSModel:
             np.asarray(self.word2vec_embedding), hparams.title_size, hparams.history_size, hparams.head_num,
             hparams.head_dim, hparams.attention_hidden_dim, hparams.dropout, hparams.learning_rate, hparams.loss,
             seed=seed, train_embedding=train_embedding, device=device, process_group=process_group,
-            shard_table=shard_table, shard_mode=shard_mode)
+            shard_table=shard_table, shard_mode=shard_mode, deterministic=deterministic)
         self.model, self.scorer = self._build_graph()
 
     # -- same helper names as the reference ------------------------------------------

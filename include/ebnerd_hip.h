@@ -81,6 +81,15 @@ int ebn_embedding_grad_scatter_f32(const int32_t* ids, const float* dX, float* d
                                    const ebn_step_state* st, int32_t site, float drop_p,
                                    ebn_stream_t stream);
 
+/* Deterministic form of the same backward: gradients are accumulated as 2^40-scaled 64-bit integers (integer
+ * atomics are associative, so the result does not depend on the order in which duplicate tokens arrive -- hot rows
+ * such as token 0 of padded history get the same bits every run), then ebn_fixed_to_f32 converts the accumulator
+ * to the fp32 dense gradient and zeroes it for the next step.  |sum| must stay below 2^23; resolution 9e-13.      */
+int ebn_embedding_grad_scatter_fixed(const int32_t* ids, const float* dX, int64_t* acc, int64_t n_tok,
+                                     int32_t D, int64_t V, const ebn_step_state* st, int32_t site,
+                                     float drop_p, ebn_stream_t stream);
+int ebn_fixed_to_f32(int64_t* acc, float* out, int64_t n, ebn_stream_t stream);
+
 /* ---- K.dot / Dense matmuls (layers.py:65,214,220,226; nrms_docvec.py:116,130) ----
  * C[M,N] = alpha * op(A)[M,K] * op(B)[K,N] + beta * C, exact-fp32 MFMA
  * (v_mfma_f32_32x32x2_f32). transA=0: A is [M,K] (lda>=K); transA=1: A is [K,M].

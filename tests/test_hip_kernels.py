@@ -517,3 +517,23 @@ def test_expand_titles_is_the_loader_gather_bit_exact(hip):
     idx[3] = n_rows
     hip.call("ebn_expand_titles_i32", P(dev(idx, torch.int32)), P(dev(matrix, torch.int32)), P(out), n_titles, T, n_rows, P(flag), S())
     assert int(flag.item()) == 1 and (out.cpu().numpy().reshape(n_titles, T)[3] == 0).all()
+
+
+def test_fixed_point_scatter_is_order_independent_and_accurate(hip):
+    rng = np.random.default_rng(91)
+    V, D, n_tok = 64, 20, 6000
+    ids = rng.integers(0, V, n_tok).astype(np.int32)
+    ids[:3000] = 0  # a very hot row
+    dX = (rng.standard_normal((n_tok, D)) * 10 ** rng.uniform(-6, 0, (n_tok, 1))).astype(np.float32)
+    want = on.embedding_bwd(ids, dX.astype(np.float64), V)
+    outs = []
+    for perm in (np.arange(n_tok), rng.permutation(n_tok)):  # same multiset of (id, grad row), different arrival order
+        acc = torch.zeros(V, D, dtype=torch.int64, device="cuda")
+        g = torch.full((V, D), 3.0, device="cuda")
+        hip.call("ebn_embedding_grad_scatter_fixed", P(dev(ids[perm], torch.int32)), P(dev(dX[perm])), P(acc), n_tok, D, V, None, -1,
+                 ctypes.c_float(0.0), S())
+        hip.call("ebn_fixed_to_f32", P(acc), P(g), V * D, S())
+        assert int(acc.abs().max().item()) == 0  # accumulator is left zeroed for the next step
+        outs.append(g.cpu().numpy())
+    assert np.array_equal(outs[0], outs[1])  # bitwise, whatever the order
+    assert_close(outs[0], want, rtol=2e-7, atol=1e-9, what="fixed-point dTable")
