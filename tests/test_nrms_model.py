@@ -323,3 +323,42 @@ def test_trainable_table_training_is_bitwise_reproducible(nrms):
     m2 = nrms(hp, word2vec_embedding=emb, seed=5, deterministic=False)  # fp32 atomics: same to rounding
     l2 = [float(m2.train_step(*b).item()) for b in batches]
     assert np.allclose(l2, runs[0][0], rtol=1e-5)
+
+
+@pytest.mark.parametrize("B,H,C,T", [(1, 1, 1, 1), (1, 20, 1, 30), (3, 2, 250, 5), (33, 5, 2, 7)])
+def test_edge_shapes_forward_and_one_step(nrms, B, H, C, T):
+    """Degenerate and ragged sizes: single impression / history slot / candidate / token, a 250-wide in-view list
+    (beyond-accuracy rows), a batch that is not a multiple of anything."""
+    hp = make_hp(history_size=H, title_size=T, head_num=4, head_dim=20, attention_hidden_dim=11, dropout=0.1)
+    V, D = 97, 24
+    rng = np.random.default_rng(B * 1000 + C)
+    P = on.random_nrms_params(V, D, hp.head_num, hp.head_dim, hp.attention_hidden_dim, seed=8)
+    m = nrms(hp, word2vec_embedding=P["emb"], seed=4).from_keras_weight_list(weight_list(P))
+    P = {k: v.astype(np.float32).astype(np.float64) for k, v in P.items()}
+    his, pred, y = batch(rng, B, H, C, T, V)
+    probs, _, _ = on.nrms_forward(his, pred, P, hp.head_num, hp.head_dim)
+    assert_close(m.model.predict((his, pred)), probs, rtol=0, atol=1e-5, what="edge forward")
+    L, _, g = on.nrms_loss_and_grads(his, pred, y, P, hp.head_num, hp.head_dim, "cross_entropy_loss", on.Drop(0.1, 4, 1))
+    got = float(m.train_step(his, pred, y).item())
+    assert abs(got - L) <= 2e-5 * max(1.0, abs(L))
+    want = np.concatenate([g["u_WQ"], g["u_WK"], g["u_WV"]], 1)
+    assert_close(m._engine.params.g("u_Wqkv").cpu().numpy(), want, rtol=1e-4, atol=1e-7 + 1e-4 * np.abs(want).max(), what="edge du_Wqkv")
+
+
+def test_varying_batch_sizes_empty_inputs_and_large_eval_batches(nrms):
+    hp = make_hp(history_size=4, title_size=6, head_num=2, head_dim=16, attention_hidden_dim=7, dropout=0.0)
+    rng = np.random.default_rng(61)
+    V = 60
+    P = on.random_nrms_params(V, 16, 2, 16, 7, seed=2)
+    m = nrms(hp, word2vec_embedding=P["emb"], seed=1).from_keras_weight_list(weight_list(P))
+    m._engine.enable_graphs()
+    his, pred, y = batch(rng, 70, 4, 3, 6, V)
+    h = m.model.fit((his, pred), y, batch_size=32, epochs=2, verbose=0)  # batches of 32, 32, 6 -> three graph shapes
+    assert len(h.history["loss"]) == 2 and np.isfinite(h.history["loss"]).all()
+    assert m.model.predict((his[:0], pred[:0])).shape[0] == 0
+    assert m.scorer.predict((his[:0], pred[:0, :1])).shape == (0, 1)
+    # more titles than one encode chunk (8192): chunked path == oracle
+    P2 = dict(zip(on.PARAM_ORDER, [w.astype(np.float64).reshape(P[k].shape) for k, w in zip(on.PARAM_ORDER, m.model.get_weights())]))
+    ids = rng.integers(0, V, (9000, 6))
+    want, _ = on.news_encoder_fwd(ids, P2, 2, 16)
+    assert_close(m.newsencoder.predict(ids), want, rtol=2e-5, atol=2e-5, what="chunked news encoding")
