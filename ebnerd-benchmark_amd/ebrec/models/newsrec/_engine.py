@@ -95,7 +95,7 @@ class NRMSEngine:
     def __init__(self, table: np.ndarray, title_size: int, history_size: int, head_num: int, head_dim: int,
                  attention_hidden_dim: int, dropout: float, learning_rate: float, loss: str, seed=None,
                  train_embedding: bool = True, device=None, process_group=None, shard_table: bool = False,
-                 shard_mode: str = "alltoall", deterministic: bool = True):
+                 shard_mode: str = "alltoall", deterministic: bool = True, units=None, l2: float = 0.0):
         self.device = require_gpu() if device is None else torch.device(device)
         if loss not in LOSS_KIND:
             raise ValueError(f"this loss not defined {loss}")
@@ -118,8 +118,19 @@ class NRMSEngine:
             table = table[self.exchange.lo: self.exchange.hi]
         self.table = torch.from_numpy(np.ascontiguousarray(table)).to(self.device)
         D, E, A = self.D, self.E, self.A
-        self.params = FlatParams({"n_Wqkv": (D, 3 * E), "n_W": (E, A), "n_b": (A,), "n_q": (A,),
-                                  "u_Wqkv": (E, 3 * E), "u_W": (E, A), "u_b": (A,), "u_q": (A,)}, self.device)
+        # optional per-token [Dense-ReLU -> BatchNorm -> Dropout] stack between self-attention and AttLayer2 (nrms.py:142-152)
+        self.units = [int(u) for u in units] if units else []
+        if self.units and self.units[-1] != E:
+            raise ValueError(f"newsencoder_units_per_layer must end with head_num*head_dim = {E} (the news vector is dotted with "
+                             f"the {E}-wide user vector, nrms.py:201), got {self.units}")
+        shapes = {"n_Wqkv": (D, 3 * E)}
+        if self.units:
+            from ._mlp import MLPStack
+
+            shapes.update(MLPStack.shapes("n_", E, self.units))
+        shapes.update({"n_W": (E, A), "n_b": (A,), "n_q": (A,), "u_Wqkv": (E, 3 * E), "u_W": (E, A), "u_b": (A,), "u_q": (A,)})
+        self.params = FlatParams(shapes, self.device)
+        self.mlp = MLPStack(self.params, "n_", E, self.units, self.device, l2) if self.units else None
         self._init_weights(seed)
         self.deterministic = bool(deterministic)
         if self.train_embedding:
@@ -155,6 +166,15 @@ class NRMSEngine:
                 pv(f"{pre}_W").copy_(torch.from_numpy(glorot_uniform_np((E, A), s())))
                 pv(f"{pre}_b").zero_()
                 pv(f"{pre}_q").copy_(torch.from_numpy(glorot_uniform_np((A, 1), s())[:, 0]))
+        if self.mlp is not None:
+            self.mlp.init_weights((lambda k: None) if seed is None else (lambda k: int(seed) * 1000 + k), glorot_uniform_np)
+
+    def weight_names(self):
+        base = ["news.emb", "news.attn.WQ", "news.attn.WK", "news.attn.WV"]
+        if self.mlp is not None:
+            base += self.mlp.weight_names("news")
+        return base + ["news.att.W", "news.att.b", "news.att.q", "user.attn.WQ", "user.attn.WK", "user.attn.WV", "user.att.W",
+                       "user.att.b", "user.att.q"]
 
     def get_weights(self):
         """13 arrays in the Keras creation order of SURVEY.md A.6."""
@@ -163,14 +183,21 @@ class NRMSEngine:
         for pre in ("n", "u"):
             w = self.params.view(f"{pre}_Wqkv").cpu().numpy()
             out += [w[:, :E].copy(), w[:, E:2 * E].copy(), w[:, 2 * E:].copy()]
+            if pre == "n" and self.mlp is not None:  # Keras creation order: Dense/BN layers sit before AttLayer2
+                out += self.mlp.get_weights()
             out += [self.params.view(f"{pre}_W").cpu().numpy(), self.params.view(f"{pre}_b").cpu().numpy(),
                     self.params.view(f"{pre}_q").cpu().numpy().reshape(-1, 1)]
         return out
 
     def set_weights(self, weights):
-        if len(weights) != 13:
-            raise ValueError(f"expected 13 weight arrays (emb, 2x[WQ,WK,WV,W,b,q]), got {len(weights)}")
+        n_mlp = 6 * len(self.units)
+        if len(weights) != 13 + n_mlp:
+            raise ValueError(f"expected {13 + n_mlp} weight arrays (emb, 2x[WQ,WK,WV,W,b,q]{' + 6 per Dense/BN layer' if n_mlp else ''}), "
+                             f"got {len(weights)}")
         w = [np.asarray(a, dtype=np.float32) for a in weights]
+        if n_mlp:
+            self.mlp.set_weights([torch.from_numpy(np.ascontiguousarray(a)) for a in w[4:4 + n_mlp]])
+            w = w[:4] + w[4 + n_mlp:]
         if w[0].shape != (self.V, self.D):
             raise ValueError(f"embedding shape {w[0].shape} != {(self.V, self.D)}")
         with torch.no_grad():
@@ -196,7 +223,7 @@ class NRMSEngine:
         return torch.cat(parts)[: self.V]
 
     def count_params(self):
-        return self.V * self.D + sum(int(np.prod(s)) for s in self.params.shapes.values())
+        return self.V * self.D + sum(int(np.prod(s)) for s in self.params.shapes.values()) + 2 * sum(self.units)
 
     def enable_graphs(self, flag=True):
         self.use_graph = bool(flag)
@@ -250,9 +277,11 @@ class NRMSEngine:
                                 b.out.data_ptr())
         return dims, params, acts
 
-    def _encoder_fwd(self, pre, b, n_seq, X, train):
+    def _encoder_fwd(self, pre, b, n_seq, X, train, n_first=None):
         site, p = (1, self.p) if (train and pre == "n" and self.p > 0) else (-1, 0.0)
         st = _hip.ptr(self.state) if train else None
+        if pre == "n" and self.mlp is not None:
+            return self._news_encoder_fwd_mlp(b, n_seq, X, train, n_seq if n_first is None else n_first)
         if self.kernel_events is not None and pre == "n":
             return self._encoder_fwd_timed(b, n_seq, X, st, site, p)
         dims, params, acts = self._enc_structs(pre, b, n_seq, X, site, p)
@@ -262,6 +291,41 @@ class NRMSEngine:
     @staticmethod
     def _fwd_scratch(b):
         return b.fwd_scratch
+
+    def _news_encoder_fwd_mlp(self, b, n_seq, X, train, n_first):
+        """News encoder with the per-token Dense/BN stack: QKV -> attention (NO dropout here, nrms.py:142-152) ->
+        stack (call sites: titles [0,n_first) and [n_first,n_seq)) -> AttLayer2."""
+        S, E, A, T = _hip.stream_handle, self.E, self.A, b.L
+        R = n_seq * T
+        pv = self.params.view
+        _hip.call("ebn_gemm_f32_site", 0, 0, R, 3 * E, b.Din, ctypes.c_float(1.0), _hip.ptr(X), b.Din, _hip.ptr(pv("n_Wqkv")), 3 * E,
+                  ctypes.c_float(0.0), _hip.ptr(b.QKV), 3 * E, _hip.ptr(b.ws), b.ws.numel(), 1, S())
+        _hip.call("ebn_attn_fwd_f32", _hip.ptr(b.QKV), 3 * E, _hip.ptr(b.Y), E, n_seq, T, self.h, self.d, None, -1, ctypes.c_float(0.0), S())
+        b.Z = self.mlp.forward(b.Y, n_first * T, (n_seq - n_first) * T, train, self.state, self.p)
+        _hip.call("ebn_gemm_f32_ws", 0, 0, R, A, E, ctypes.c_float(1.0), _hip.ptr(b.Z), E, _hip.ptr(pv("n_W")), A, ctypes.c_float(0.0),
+                  _hip.ptr(b.U), A, _hip.ptr(b.ws), b.ws.numel(), S())
+        _hip.call("ebn_attpool_fwd_f32", _hip.ptr(b.U), _hip.ptr(pv("n_b")), _hip.ptr(pv("n_q")), _hip.ptr(b.Z), _hip.ptr(b.out),
+                  _hip.ptr(b.w), n_seq, T, E, A, S())
+
+    def _news_encoder_bwd_mlp(self, b, n_seq, X, dout, dX, n_first):
+        S, E, A, T = _hip.stream_handle, self.E, self.A, b.L
+        R = n_seq * T
+        pv, g = self.params.view, self.params.g
+        ws, wsn = _hip.ptr(b.ws), b.ws.numel()
+        one, zero = ctypes.c_float(1.0), ctypes.c_float(0.0)
+        _hip.call("ebn_attpool_bwd_pool_f32", _hip.ptr(b.Z), _hip.ptr(b.w), _hip.ptr(dout), _hip.ptr(b.dY), _hip.ptr(b.de), n_seq, T, E, S())
+        _hip.call("ebn_attpool_bwd_dpre_f32", _hip.ptr(b.U), _hip.ptr(pv("n_q")), _hip.ptr(b.de), _hip.ptr(g("n_q")), _hip.ptr(g("n_b")),
+                  _hip.ptr(b.partials), R, A, 0, S())
+        _hip.call("ebn_gemm_f32_ws", 1, 0, E, A, R, one, _hip.ptr(b.Z), E, _hip.ptr(b.U), A, zero, _hip.ptr(g("n_W")), A, ws, wsn, S())
+        _hip.call("ebn_gemm_f32_ws", 0, 1, R, E, A, one, _hip.ptr(b.U), A, _hip.ptr(pv("n_W")), A, one, _hip.ptr(b.dY), E, ws, wsn, S())
+        dYattn = self.mlp.backward(b.dY, b.Y, n_first * T, (n_seq - n_first) * T, self.state, self.p, need_dx0=True)
+        _hip.call("ebn_attn_bwd_f32", _hip.ptr(b.QKV), 3 * E, _hip.ptr(dYattn), E, _hip.ptr(b.dQKV), 3 * E, n_seq, T, self.h, self.d,
+                  None, -1, ctypes.c_float(0.0), S())
+        _hip.call("ebn_gemm_f32_ws", 1, 0, b.Din, 3 * E, R, one, _hip.ptr(X), b.Din, _hip.ptr(b.dQKV), 3 * E, zero, _hip.ptr(g("n_Wqkv")),
+                  3 * E, ws, wsn, S())
+        if dX is not None:
+            _hip.call("ebn_gemm_f32_ws", 0, 1, R, b.Din, 3 * E, one, _hip.ptr(b.dQKV), 3 * E, _hip.ptr(pv("n_Wqkv")), 3 * E, zero,
+                      _hip.ptr(dX), b.Din, ws, wsn, S())
 
     def _timed(self, name):
         """HIP events on the launch stream around one kernel (bench.py roofline figures)."""
@@ -286,7 +350,9 @@ class NRMSEngine:
         _hip.call("ebn_attpool_fwd_f32", _hip.ptr(b.U), _hip.ptr(pv("n_b")), _hip.ptr(pv("n_q")), _hip.ptr(b.Y),
                   _hip.ptr(b.out), _hip.ptr(b.w), n_seq, b.L, E, A, S())
 
-    def _encoder_bwd(self, pre, b, n_seq, X, dout, dX):
+    def _encoder_bwd(self, pre, b, n_seq, X, dout, dX, n_first=None):
+        if pre == "n" and self.mlp is not None:
+            return self._news_encoder_bwd_mlp(b, n_seq, X, dout, dX, n_seq if n_first is None else n_first)
         site, p = (1, self.p) if (pre == "n" and self.p > 0) else (-1, 0.0)
         dims, params, acts = self._enc_structs(pre, b, n_seq, X, site, p)
         g = self.params.g
@@ -313,8 +379,9 @@ class NRMSEngine:
             off += t.numel()
         return off
 
-    def _news_forward(self, b, N, train):
-        """a1..a4 for N titles whose ids are already in b.ids -> b.out[:N]"""
+    def _news_forward(self, b, N, train, n_first=None):
+        """a1..a4 for N titles whose ids are already in b.ids -> b.out[:N].  n_first = titles of the first
+        TimeDistributed call site (history); only the BatchNorm of the optional Dense stack cares."""
         site, p = (0, self.p) if (train and self.p > 0) else (-1, 0.0)
         st = _hip.ptr(self.state) if train else None
         if self.exchange is not None:
@@ -325,7 +392,7 @@ class NRMSEngine:
             _hip.call("ebn_gather_rows_f32", _hip.ptr(b.plan.inv), _hip.ptr(b.rows_uniq), _hip.ptr(b.X), N * self.T,
                       self.D, b.rows_uniq.shape[0], st, site, ctypes.c_float(p), _hip.ptr(self.oob_flag),
                       _hip.stream_handle())
-            return self._encoder_fwd("n", b, N, b.X, train)
+            return self._encoder_fwd("n", b, N, b.X, train, n_first)
         ev = self._timed("gather") if self.kernel_events is not None else None
         if ev:
             ev[0].record()
@@ -333,7 +400,7 @@ class NRMSEngine:
                   self.V, st, site, ctypes.c_float(p), _hip.ptr(self.oob_flag), _hip.stream_handle())
         if ev:
             ev[1].record()
-        self._encoder_fwd("n", b, N, b.X, train)
+        self._encoder_fwd("n", b, N, b.X, train, n_first)
 
     def _local_gather(self, local_rows: torch.Tensor) -> torch.Tensor:
         m = local_rows.numel()
@@ -389,7 +456,7 @@ class NRMSEngine:
         N = B * (self.H + C)
         nb = self._news_bufs(N, False)
         self._upload_ids(nb.ids, his, pred)
-        self._news_forward(nb, N, False)
+        self._news_forward(nb, N, False, B * self.H)
         ub = self._user_bufs(B, False)
         self._encoder_fwd("u", ub, B, nb.out, False)
         scores = torch.empty(B, C, device=self.device)
@@ -529,7 +596,7 @@ class NRMSEngine:
         st = _hip.ptr(self.state)
         _hip.call("ebn_step_advance", st, BETA1, BETA2, S())
         # ---- forward
-        self._news_forward(nb, N, True)
+        self._news_forward(nb, N, True, B * H)
         self._encoder_fwd("u", ub, B, nb.out, True)  # history encodings are the first B*H rows
         cand = nb.out[B * H:]
         _hip.call("ebn_score_fwd_f32", _hip.ptr(cand), _hip.ptr(ub.out), _hip.ptr(nb.scores), _hip.ptr(nb.probs), B, C,
@@ -541,7 +608,9 @@ class NRMSEngine:
                   ctypes.c_float(1.0 / B), S())
         _hip.call("ebn_sum_f32", _hip.ptr(ub.loss_rows), B, ctypes.c_float(1.0), _hip.ptr(self.loss_dev), 0, S())
         self._encoder_bwd("u", ub, B, nb.out, ub.duser, nb.dNE)  # writes dNE[:B*H]
-        self._encoder_bwd("n", nb, N, nb.X, nb.dNE, nb.dX)
+        self._encoder_bwd("n", nb, N, nb.X, nb.dNE, nb.dX, B * H)
+        if self.mlp is not None:
+            self.mlp.add_l2_loss(self.loss_dev)
         if self.train_embedding:
             if self.exchange is not None or not self.deterministic:
                 self.table_grad.zero_()

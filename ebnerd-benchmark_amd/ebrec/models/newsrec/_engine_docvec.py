@@ -18,8 +18,7 @@ import torch
 from ebrec import _hip
 
 from ._engine import ADAM_EPS, BETA1, BETA2, LOSS_KIND, EncoderBuffers, FlatParams, glorot_uniform_np, require_gpu
-
-SITE_MLP0 = 8
+from ._mlp import MLPStack
 
 
 class DocVecEngine:
@@ -32,17 +31,13 @@ class DocVecEngine:
         self.h, self.d, self.A = int(head_num), int(head_dim), int(attention_hidden_dim)
         self.E = self.h * self.d
         self.p, self.loss, self.l2, self.seed, self.pg = float(dropout), loss, float(l2), seed, process_group
-        if len(self.units) > 4:
-            raise ValueError("at most 4 hidden Dense layers (dropout sites 8..11 of ebn_step_state)")
         E, A = self.E, self.A
-        shapes, prev = {}, self.Din
-        for l, u in enumerate(self.units):
-            shapes.update({f"d{l}_W": (prev, u), f"d{l}_b": (u,), f"bn{l}_g": (u,), f"bn{l}_b": (u,)})
-            prev = u
+        shapes = MLPStack.shapes("", self.Din, self.units)
+        prev = self.units[-1] if self.units else self.Din
         shapes.update({"out_W": (prev, E), "out_b": (E,), "u_Wqkv": (E, 3 * E), "u_W": (E, A), "u_b": (A,), "u_q": (A,)})
         self.params = FlatParams(shapes, self.device)
-        self.bn_mean = [torch.zeros(u, device=self.device) for u in self.units]
-        self.bn_var = [torch.ones(u, device=self.device) for u in self.units]
+        self.mlp = MLPStack(self.params, "", self.Din, self.units, self.device, self.l2)
+        self.bn_mean, self.bn_var = self.mlp.bn_mean, self.mlp.bn_var
         self._init_weights(seed)
         st = _hip.StepState()
         st.step, st.seed, st.lr, st.adam_alpha = 0, (0 if seed is None else int(seed)) & 0xFFFFFFFF, learning_rate, 0.0
@@ -59,12 +54,9 @@ class DocVecEngine:
     def _init_weights(self, seed):
         rng_seed = (lambda k: None) if seed is None else (lambda k: int(seed) * 1000 + k)
         pv = self.params.view
+        self.mlp.init_weights(rng_seed, glorot_uniform_np)
         with torch.no_grad():
-            prev = self.Din
-            for l, u in enumerate(self.units):  # Dense: GlorotUniform kernel, zero bias; BN: gamma 1, beta 0
-                pv(f"d{l}_W").copy_(torch.from_numpy(glorot_uniform_np((prev, u), rng_seed(l))))
-                pv(f"bn{l}_g").fill_(1.0)
-                prev = u
+            prev = self.mlp.out_dim
             pv("out_W").copy_(torch.from_numpy(glorot_uniform_np((prev, self.E), rng_seed(99))))
             s = (lambda: seed) if seed is not None else (lambda: None)
             pv("u_Wqkv").copy_(torch.from_numpy(np.concatenate([glorot_uniform_np((self.E, self.E), s()) for _ in range(3)], 1)))
@@ -72,23 +64,15 @@ class DocVecEngine:
             pv("u_q").copy_(torch.from_numpy(glorot_uniform_np((self.A, 1), s())[:, 0]))
 
     def weight_names(self):
-        names = []
-        for l in range(len(self.units)):
-            names += [f"news.dense{l}.kernel", f"news.dense{l}.bias", f"news.bn{l}.gamma", f"news.bn{l}.beta",
-                      f"news.bn{l}.moving_mean", f"news.bn{l}.moving_variance"]
-        return names + ["news.out.kernel", "news.out.bias", "user.attn.WQ", "user.attn.WK", "user.attn.WV", "user.att.W",
-                        "user.att.b", "user.att.q"]
+        return self.mlp.weight_names("news") + ["news.out.kernel", "news.out.bias", "user.attn.WQ", "user.attn.WK",
+                                                 "user.attn.WV", "user.att.W", "user.att.b", "user.att.q"]
 
     def get_weights(self):
         pv, E = self.params.view, self.E
-        out = []
-        for l in range(len(self.units)):
-            out += [pv(f"d{l}_W").cpu().numpy(), pv(f"d{l}_b").cpu().numpy(), pv(f"bn{l}_g").cpu().numpy(),
-                    pv(f"bn{l}_b").cpu().numpy(), self.bn_mean[l].cpu().numpy(), self.bn_var[l].cpu().numpy()]
         w = pv("u_Wqkv").cpu().numpy()
-        out += [pv("out_W").cpu().numpy(), pv("out_b").cpu().numpy(), w[:, :E].copy(), w[:, E:2 * E].copy(), w[:, 2 * E:].copy(),
-                pv("u_W").cpu().numpy(), pv("u_b").cpu().numpy(), pv("u_q").cpu().numpy().reshape(-1, 1)]
-        return out
+        return self.mlp.get_weights() + [pv("out_W").cpu().numpy(), pv("out_b").cpu().numpy(), w[:, :E].copy(), w[:, E:2 * E].copy(),
+                                         w[:, 2 * E:].copy(), pv("u_W").cpu().numpy(), pv("u_b").cpu().numpy(),
+                                         pv("u_q").cpu().numpy().reshape(-1, 1)]
 
     def set_weights(self, weights):
         n = 6 * len(self.units) + 8
@@ -96,12 +80,9 @@ class DocVecEngine:
             raise ValueError(f"expected {n} weight arrays, got {len(weights)}")
         w = [torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float32))) for a in weights]
         pv = self.params.view
+        self.mlp.set_weights(w)
+        i = 6 * len(self.units)
         with torch.no_grad():
-            i = 0
-            for l in range(len(self.units)):
-                pv(f"d{l}_W").copy_(w[i]); pv(f"d{l}_b").copy_(w[i + 1]); pv(f"bn{l}_g").copy_(w[i + 2]); pv(f"bn{l}_b").copy_(w[i + 3])
-                self.bn_mean[l].copy_(w[i + 4]); self.bn_var[l].copy_(w[i + 5])
-                i += 6
             pv("out_W").copy_(w[i]); pv("out_b").copy_(w[i + 1])
             pv("u_Wqkv").copy_(torch.cat(w[i + 2:i + 5], dim=1))
             pv("u_W").copy_(w[i + 5]); pv("u_b").copy_(w[i + 6].reshape(-1)); pv("u_q").copy_(w[i + 7].reshape(-1))
@@ -128,17 +109,11 @@ class DocVecEngine:
         b = self._bufs.get("mlp")
         if b is None or b["N"] < N:
             f = lambda *s: torch.empty(*s, device=self.device)
-            b = {"N": N, "X0": f(N, self.Din), "R": [f(N, u) for u in self.units], "xhat": [f(N, u) for u in self.units],
-                 "Xn": [f(N, u) for u in self.units], "mean": [[f(u), f(u)] for u in self.units],
-                 "istd": [[f(u), f(u)] for u in self.units], "NE": f(N, self.E), "dNE": f(N, self.E),
-                 "dA": [f(N, u) for u in self.units], "dB": [f(N, u) for u in self.units],
+            b = {"N": N, "X0": f(N, self.Din), "NE": f(N, self.E), "dNE": f(N, self.E), "dXl": f(N, self.mlp.out_dim),
                  "scores": f(N), "probs": f(N), "labels": f(N)}
-            width = max(self.units + [self.E])
-            b["partials"] = f(int(_hip.lib().ebn_colsum_partials_len(N, width)))
-            dims = [self.Din] + self.units
-            ws = max([int(_hip.lib().ebn_gemm_workspace_floats(dims[i], dims[i + 1], N)) for i in range(len(self.units))] +
-                     [int(_hip.lib().ebn_gemm_workspace_floats(dims[-1], self.E, N)), 1])
-            b["ws"] = f(ws)
+            b["partials"] = f(int(_hip.lib().ebn_colsum_partials_len(N, self.E)))
+            b["ws"] = f(max(int(_hip.lib().ebn_gemm_workspace_floats(self.mlp.out_dim, self.E, N)), 1))
+            self.mlp.bufs(N)
             self._bufs["mlp"] = b
         return b
 
@@ -159,57 +134,23 @@ class DocVecEngine:
     def _news_forward(self, mb, n_hist, n_cand, train):
         """MLP over the N = n_hist + n_cand rows already in mb['X0'] -> mb['NE'][:N]."""
         N = n_hist + n_cand
-        S = _hip.stream_handle
         pv = self.params.view
-        st = _hip.ptr(self.state) if train else None
-        x, prev = mb["X0"], self.Din
-        for l, u in enumerate(self.units):
-            R = mb["R"][l]
-            self._gemm(0, 0, N, u, prev, x, prev, pv(f"d{l}_W"), u, 0.0, R, u)
-            _hip.call("ebn_bias_relu_f32", _hip.ptr(R), _hip.ptr(pv(f"d{l}_b")), _hip.ptr(R), N, u, S())
-            for site, (r0, nr) in enumerate(((0, n_hist), (n_hist, n_cand))):  # one BN call per TimeDistributed call site
-                if nr == 0:
-                    continue
-                _hip.call("ebn_batchnorm_fwd_f32", _hip.ptr(R[r0:]), _hip.ptr(pv(f"bn{l}_g")), _hip.ptr(pv(f"bn{l}_b")),
-                          _hip.ptr(self.bn_mean[l]), _hip.ptr(self.bn_var[l]), _hip.ptr(mb["Xn"][l][r0:]),
-                          _hip.ptr(mb["xhat"][l][r0:]), _hip.ptr(mb["mean"][l][site]), _hip.ptr(mb["istd"][l][site]),
-                          _hip.ptr(mb["partials"]), nr, u, 1 if train else 0, st, SITE_MLP0 + l,
-                          ctypes.c_float(self.p if train else 0.0), ctypes.c_int64(r0 * u), S())
-            x, prev = mb["Xn"][l], u
-        self._gemm(0, 0, N, self.E, prev, x, prev, pv("out_W"), self.E, 0.0, mb["NE"], self.E)
-        _hip.call("ebn_bias_relu_f32", _hip.ptr(mb["NE"]), _hip.ptr(pv("out_b")), _hip.ptr(mb["NE"]), N, self.E, S())
+        x = self.mlp.forward(mb["X0"], n_hist, n_cand, train, self.state, self.p)
+        mb["x_last"] = x
+        self._gemm(0, 0, N, self.E, self.mlp.out_dim, x, self.mlp.out_dim, pv("out_W"), self.E, 0.0, mb["NE"], self.E)
+        _hip.call("ebn_bias_relu_f32", _hip.ptr(mb["NE"]), _hip.ptr(pv("out_b")), _hip.ptr(mb["NE"]), N, self.E, _hip.stream_handle())
 
     def _news_backward(self, mb, n_hist, n_cand):
         N = n_hist + n_cand
-        S = _hip.stream_handle
         pv, g = self.params.view, self.params.g
-        st = _hip.ptr(self.state)
-        L = len(self.units)
-        x_last, prev = (mb["Xn"][L - 1], self.units[-1]) if L else (mb["X0"], self.Din)
+        prev, x_last = self.mlp.out_dim, mb["x_last"]
         dpre = mb["dNE"]  # relu backward in place
         _hip.call("ebn_bias_relu_bwd_f32", _hip.ptr(mb["NE"]), _hip.ptr(mb["dNE"]), _hip.ptr(dpre), _hip.ptr(g("out_b")),
-                  _hip.ptr(mb["partials"]), N, self.E, 0, S())
+                  _hip.ptr(mb["partials"]), N, self.E, 0, _hip.stream_handle())
         self._gemm(1, 0, prev, self.E, N, x_last, prev, dpre, self.E, 0.0, g("out_W"), self.E, mb["ws"])
-        if L:
-            self._gemm(0, 1, N, prev, self.E, dpre, self.E, pv("out_W"), self.E, 0.0, mb["dA"][L - 1], prev)
-        for l in reversed(range(L)):
-            u = self.units[l]
-            x_in, din = (mb["Xn"][l - 1], self.units[l - 1]) if l else (mb["X0"], self.Din)
-            dY, dR = mb["dA"][l], mb["dB"][l]
-            for site, (r0, nr) in enumerate(((0, n_hist), (n_hist, n_cand))):
-                if nr == 0:
-                    continue
-                _hip.call("ebn_batchnorm_bwd_f32", _hip.ptr(dY[r0:]), _hip.ptr(mb["xhat"][l][r0:]), _hip.ptr(pv(f"bn{l}_g")),
-                          _hip.ptr(mb["istd"][l][site]), _hip.ptr(dR[r0:]), _hip.ptr(g(f"bn{l}_g")), _hip.ptr(g(f"bn{l}_b")),
-                          _hip.ptr(mb["partials"]), nr, u, 1, 1 if site else 0, st, SITE_MLP0 + l, ctypes.c_float(self.p),
-                          ctypes.c_int64(r0 * u), S())
-            _hip.call("ebn_bias_relu_bwd_f32", _hip.ptr(mb["R"][l]), _hip.ptr(dR), _hip.ptr(dR), _hip.ptr(g(f"d{l}_b")),
-                      _hip.ptr(mb["partials"]), N, u, 0, S())
-            self._gemm(1, 0, din, u, N, x_in, din, dR, u, 0.0, g(f"d{l}_W"), u, mb["ws"])
-            if self.l2 > 0:  # kernel_regularizer=l2(lambda): d/dW of lambda*sum(W^2)
-                _hip.call("ebn_axpy_f32", ctypes.c_float(2.0 * self.l2), _hip.ptr(pv(f"d{l}_W")), _hip.ptr(g(f"d{l}_W")), din * u, S())
-            if l:
-                self._gemm(0, 1, N, din, u, dR, u, pv(f"d{l}_W"), u, 0.0, mb["dA"][l - 1], din)
+        if self.units:
+            self._gemm(0, 1, N, prev, self.E, dpre, self.E, pv("out_W"), self.E, 0.0, mb["dXl"], prev)
+            self.mlp.backward(mb["dXl"], mb["X0"], n_hist, n_cand, self.state, self.p, need_dx0=False)
 
     @staticmethod
     def _fwd_scratch(b):
@@ -318,10 +259,7 @@ class DocVecEngine:
                   _hip.ptr(ub.loss_rows), _hip.ptr(mb["dNE"][n_hist:]), _hip.ptr(ub.duser), B, C, E, LOSS_KIND[self.loss],
                   ctypes.c_float(1.0 / B), S())
         _hip.call("ebn_sum_f32", _hip.ptr(ub.loss_rows), B, ctypes.c_float(1.0), _hip.ptr(self.loss_dev), 0, S())
-        for l in range(len(self.units)):  # + lambda * sum(W^2) per regularised kernel, once (not per call site)
-            if self.l2 > 0:
-                W = self.params.view(f"d{l}_W")
-                _hip.call("ebn_sumsq_f32", _hip.ptr(W), W.numel(), ctypes.c_float(self.l2), _hip.ptr(self.loss_dev), 1, S())
+        self.mlp.add_l2_loss(self.loss_dev)
         g = self.params.g
         grads = _hip.EncoderGrads(g("u_Wqkv").data_ptr(), g("u_W").data_ptr(), g("u_b").data_ptr(), g("u_q").data_ptr())
         scratch = _hip.EncoderScratch(ub.dY.data_ptr(), ub.dQKV.data_ptr(), ub.de.data_ptr(), ub.partials.data_ptr(),

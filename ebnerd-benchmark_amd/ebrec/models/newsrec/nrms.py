@@ -45,10 +45,6 @@ class NRMSModel:
             self.word2vec_embedding = glorot_uniform_np((vocab_size, word_emb_dim), seed)
         else:
             self.word2vec_embedding = word2vec_embedding
-        if getattr(hparams, "newsencoder_units_per_layer", None):
-            raise NotImplementedError(
-                "hparams.newsencoder_units_per_layer (the optional per-token Dense/BN stack of "
-                "nrms.py:142-152) is not built for NRMSModel yet; the reproducibility script sets it to None")
         # validate before touching the device (same errors as nrms.py:56-80)
         self._get_loss(hparams.loss)
         self._get_opt(hparams.optimizer, hparams.learning_rate)
@@ -56,7 +52,9 @@ class NRMSModel:
             np.asarray(self.word2vec_embedding), hparams.title_size, hparams.history_size, hparams.head_num,
             hparams.head_dim, hparams.attention_hidden_dim, hparams.dropout, hparams.learning_rate, hparams.loss,
             seed=seed, train_embedding=train_embedding, device=device, process_group=process_group,
-            shard_table=shard_table, shard_mode=shard_mode, deterministic=deterministic)
+            shard_table=shard_table, shard_mode=shard_mode, deterministic=deterministic,
+            units=getattr(hparams, "newsencoder_units_per_layer", None),
+            l2=getattr(hparams, "newsencoder_l2_regularization", 0.0))
         self.model, self.scorer = self._build_graph()
 
     # -- same helper names as the reference ------------------------------------------
@@ -79,7 +77,7 @@ class NRMSModel:
     def _build_graph(self):
         self.newsencoder = EncoderModel(self._encode_news, "news_encoder")
         self.userencoder = EncoderModel(self._encode_users, "user_encoder")
-        return TrainModel(self, WEIGHT_NAMES), ScorerModel(self)
+        return TrainModel(self, self._engine.weight_names()), ScorerModel(self)
 
     # -- sub-model bodies --------------------------------------------------------------
     def _encode_news(self, ids):

@@ -14,7 +14,7 @@ output.  This file therefore restates the published
 semantics of the Keras ops at the reference's call sites; statements that
 depend on Keras behaviour are tagged [KERAS-SEMANTICS].  The evaluation
 metrics, by contrast, ARE pinned against the reference run in this container
-(see oracle/metrics_numpy.py and tests/golden/make_metrics_golden.py).
+(tests/golden/make_metrics_golden.py -> tests/golden/metrics_golden.json).
 
 Every function cites the reference file:line it follows (paths relative to
 /root/reference/src/ebrec/models/newsrec/).
@@ -260,6 +260,81 @@ def news_encoder_bwd(dout, cache, V, need_emb_grad=True):
     return g
 
 
+def add_mlp_params(P, units, E, A, seed=0, randomize_bn=True):
+    """Parameters of the optional per-token stack of the NRMS news encoder (nrms.py:142-152), prefix "n_";
+    the additive-attention kernel n_W then takes the last layer's width."""
+    rng = np.random.default_rng(seed)
+    prev = E
+    for l, u in enumerate(units):
+        P[f"n_d{l}_W"] = glorot_uniform((prev, u), rng) * 1.5
+        P[f"n_d{l}_b"] = rng.standard_normal(u) * 0.1
+        P[f"n_bn{l}_g"] = 1 + 0.1 * rng.standard_normal(u) * randomize_bn
+        P[f"n_bn{l}_b"] = 0.1 * rng.standard_normal(u) * randomize_bn
+        P[f"n_bn{l}_mean"] = 0.1 * rng.standard_normal(u) * randomize_bn
+        P[f"n_bn{l}_var"] = 1 + 0.2 * rng.random(u) * randomize_bn
+        prev = u
+    P["n_W"] = glorot_uniform((prev, A), rng) * 2
+    P["n_units"] = list(units)
+    return P
+
+
+def nrms_mlp_forward(his, pred, P, h, d, training=False, drop: Drop | None = None):
+    """NRMS with hparams.newsencoder_units_per_layer (nrms.py:142-152): embedding -> Dropout -> SelfAttention ->
+    [Dense-ReLU -> BatchNorm -> Dropout] per token -> AttLayer2; NO dropout straight after the self-attention in
+    this branch.  The two TimeDistributed call sites (history, candidates) have their own batch statistics."""
+    B, H, T = his.shape
+    C = pred.shape[1]
+    units = P["n_units"]
+    outs, caches, stats = [], [], []
+    row_off = 0
+    for ids in (his.reshape(B * H, T), pred.reshape(B * C, T)):
+        N = ids.shape[0]
+        X = embedding_fwd(ids, P["emb"])
+        m0 = None
+        if training and drop is not None and drop.p > 0:
+            keep = dropout_keep_mask(drop.key(SITE_NEWS_IN), X.size, drop.p, start=row_off * T * X.shape[-1]).reshape(X.shape)
+            m0 = keep.astype(X.dtype) / (1.0 - drop.p)
+            X = X * m0
+        O, c_sa = self_attention_fwd(X, P["n_WQ"], P["n_WK"], P["n_WV"], h, d)
+        Z, c_stack, st = dense_bn_stack_fwd(O.reshape(N * T, -1), P, units, "n_", training, drop, row_off * T)
+        out, c_al = att_layer2_fwd(Z.reshape(N, T, -1), P["n_W"], P["n_b"], P["n_q"])
+        outs.append(out)
+        caches.append((ids, m0, c_sa, c_stack, c_al, O.shape))
+        stats.append(st)
+        row_off += N
+    NEh, NEc = outs[0].reshape(B, H, -1), outs[1].reshape(B, C, -1)
+    user, c_user = user_encoder_from_news_fwd(NEh, P, h, d)
+    s = np.einsum("bce,be->bc", NEc, user)
+    return softmax_rows(s), s, (B, H, C, caches, c_user, NEc, user, stats)
+
+
+def nrms_mlp_loss_and_grads(his, pred, y, P, h, d, loss="cross_entropy_loss", l2=0.0, training=True,
+                            drop: Drop | None = None):
+    probs, s, cache = nrms_mlp_forward(his, pred, P, h, d, training, drop)
+    B, H, C, caches, c_user, NEc, user, stats = cache
+    units = P["n_units"]
+    L, ds = loss_fwd_bwd(s, y, loss)
+    dNEc = ds[..., None] * user[:, None, :]
+    duser = np.einsum("bc,bce->be", ds, NEc)
+    dNEh, g = user_encoder_from_news_bwd(duser, c_user)
+    V = P["emb"].shape[0]
+    for dout, (ids, m0, c_sa, c_stack, c_al, oshape) in zip((dNEh.reshape(B * H, -1), dNEc.reshape(B * C, -1)), caches):
+        dZ, dW, db, dq = att_layer2_bwd(dout, c_al)
+        g_stack, dO = dense_bn_stack_bwd(dZ.reshape(-1, dZ.shape[-1]), c_stack, P, units, "n_")
+        dX, dWQ, dWK, dWV = self_attention_bwd(dO.reshape(oshape), c_sa)
+        if m0 is not None:
+            dX = dX * m0
+        site = {"n_WQ": dWQ, "n_WK": dWK, "n_WV": dWV, "n_W": dW, "n_b": db, "n_q": dq, "emb": embedding_bwd(ids, dX, V)}
+        site.update(g_stack)
+        for k, v in site.items():
+            g[k] = g.get(k, 0) + v
+    for l in range(len(units)):  # kernel_regularizer=l2(lambda), once per kernel
+        W = P[f"n_d{l}_W"]
+        L = L + l2 * (W * W).sum()
+        g[f"n_d{l}_W"] = g[f"n_d{l}_W"] + 2 * l2 * W
+    return L, probs, g, stats
+
+
 def user_encoder_from_news_fwd(NEh, P, h, d):
     """nrms.py:108-111 on already-encoded history (B,H,E)."""
     O, c_sa = self_attention_fwd(NEh, P["u_WQ"], P["u_WK"], P["u_WV"], h, d)
@@ -377,61 +452,71 @@ def init_docvec_params(Din, units, h, d, A, seed=0, dtype=np.float64, randomize_
     return P
 
 
-def docvec_news_encoder_fwd(X, P, training=False, drop: Drop | None = None, site_offset=0,
-                            row_offset=0):
-    """nrms_docvec.py:113-135.  X (R, Din) = all rows of ONE call site (batch
-    statistics are per call site [KERAS-SEMANTICS]).  Returns out, cache, and the
-    new moving statistics (list of (mean, var)) when training."""
+def dense_bn_stack_fwd(X, P, units, prefix="", training=False, drop: Drop | None = None, row_offset=0):
+    """[Dense(u, relu, l2) -> BatchNormalization -> Dropout] x len(units) on the rows of ONE call site
+    (nrms_docvec.py:116-124; nrms.py:143-152 applies the same stack per token).  Batch statistics are per call
+    site [KERAS-SEMANTICS]; the dropout stream is indexed by (row_offset + row, column)."""
     caches, new_stats = [], []
     x = X
-    for l, u in enumerate(P["units"]):
-        pre = x @ P[f"d{l}_W"] + P[f"d{l}_b"]
-        r = np.maximum(pre, 0)  # Dense(relu), nrms_docvec.py:116-122
+    for l, u in enumerate(units):
+        pre = x @ P[f"{prefix}d{l}_W"] + P[f"{prefix}d{l}_b"]
+        r = np.maximum(pre, 0)
         if training:
             mu, var = r.mean(0), r.var(0)  # biased batch variance
             new_stats.append((mu, var))
         else:
-            mu, var = P[f"bn{l}_mean"], P[f"bn{l}_var"]
+            mu, var = P[f"{prefix}bn{l}_mean"], P[f"{prefix}bn{l}_var"]
         istd = 1.0 / np.sqrt(var + x.dtype.type(BN_EPS))
         xh = (r - mu) * istd
-        bn = xh * P[f"bn{l}_g"] + P[f"bn{l}_b"]  # nrms_docvec.py:123
+        bn = xh * P[f"{prefix}bn{l}_g"] + P[f"{prefix}bn{l}_b"]
         msk = None
         y = bn
-        if training and drop is not None and drop.p > 0:  # nrms_docvec.py:124
-            keep = dropout_keep_mask(drop.key(SITE_MLP0 + l + site_offset), bn.size, drop.p,
-                                     start=row_offset * u).reshape(bn.shape)
+        if training and drop is not None and drop.p > 0:
+            keep = dropout_keep_mask(drop.key(SITE_MLP0 + l), bn.size, drop.p, start=row_offset * u).reshape(bn.shape)
             msk = keep.astype(bn.dtype) * (1.0 / (1.0 - drop.p))
             y = bn * msk
         caches.append((x, pre, xh, istd, msk))
         x = y
-    pre = x @ P["out_W"] + P["out_b"]
-    out = np.maximum(pre, 0)  # nrms_docvec.py:130
-    return out, (caches, x, pre, training), new_stats
+    return x, (caches, training), new_stats
 
 
-def docvec_news_encoder_bwd(dout, cache, P):
-    caches, xl, pre, training = cache
+def dense_bn_stack_bwd(dx, cache, P, units, prefix=""):
+    caches, training = cache
     g = {}
-    dpre = dout * (pre > 0)
-    g["out_W"] = xl.T @ dpre
-    g["out_b"] = dpre.sum(0)
-    dx = dpre @ P["out_W"].T
-    for l in reversed(range(len(P["units"]))):
+    for l in reversed(range(len(units))):
         x, pre_l, xh, istd, msk = caches[l]
         if msk is not None:
             dx = dx * msk
-        g[f"bn{l}_g"] = (dx * xh).sum(0)
-        g[f"bn{l}_b"] = dx.sum(0)
-        dxh = dx * P[f"bn{l}_g"]
+        g[f"{prefix}bn{l}_g"] = (dx * xh).sum(0)
+        g[f"{prefix}bn{l}_b"] = dx.sum(0)
+        dxh = dx * P[f"{prefix}bn{l}_g"]
         if training:
             R = x.shape[0]
             dr = istd / R * (R * dxh - dxh.sum(0) - xh * (dxh * xh).sum(0))
         else:
             dr = dxh * istd
         dpre_l = dr * (pre_l > 0)
-        g[f"d{l}_W"] = x.T @ dpre_l
-        g[f"d{l}_b"] = dpre_l.sum(0)
-        dx = dpre_l @ P[f"d{l}_W"].T
+        g[f"{prefix}d{l}_W"] = x.T @ dpre_l
+        g[f"{prefix}d{l}_b"] = dpre_l.sum(0)
+        dx = dpre_l @ P[f"{prefix}d{l}_W"].T
+    return g, dx
+
+
+def docvec_news_encoder_fwd(X, P, training=False, drop: Drop | None = None, site_offset=0, row_offset=0):
+    """nrms_docvec.py:113-135.  X (R, Din) = all rows of ONE call site.  Returns out, cache, and the new moving
+    statistics (list of (mean, var)) when training."""
+    x, c_stack, new_stats = dense_bn_stack_fwd(X, P, P["units"], "", training, drop, row_offset)
+    pre = x @ P["out_W"] + P["out_b"]
+    out = np.maximum(pre, 0)  # nrms_docvec.py:130
+    return out, (c_stack, x, pre), new_stats
+
+
+def docvec_news_encoder_bwd(dout, cache, P):
+    c_stack, xl, pre = cache
+    dpre = dout * (pre > 0)
+    g = {"out_W": xl.T @ dpre, "out_b": dpre.sum(0)}
+    g_stack, dx = dense_bn_stack_bwd(dpre @ P["out_W"].T, c_stack, P, P["units"], "")
+    g.update(g_stack)
     return g, dx
 
 
@@ -468,9 +553,9 @@ def docvec_loss_and_grads(his, pred, y, P, h, d, loss="cross_entropy_loss", l2=0
     return L, probs, g, (st_h, st_c)
 
 
-def bn_update_moving(P, stats_seq):
+def bn_update_moving(P, stats_seq, prefix=""):
     """moving = moving*0.99 + batch*0.01, one update per call site, in call order."""
     for stats in stats_seq:
         for l, (mu, var) in enumerate(stats):
-            P[f"bn{l}_mean"] = P[f"bn{l}_mean"] * BN_MOM + mu * (1 - BN_MOM)
-            P[f"bn{l}_var"] = P[f"bn{l}_var"] * BN_MOM + var * (1 - BN_MOM)
+            P[f"{prefix}bn{l}_mean"] = P[f"{prefix}bn{l}_mean"] * BN_MOM + mu * (1 - BN_MOM)
+            P[f"{prefix}bn{l}_var"] = P[f"{prefix}bn{l}_var"] * BN_MOM + var * (1 - BN_MOM)

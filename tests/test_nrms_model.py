@@ -362,3 +362,46 @@ def test_varying_batch_sizes_empty_inputs_and_large_eval_batches(nrms):
     ids = rng.integers(0, V, (9000, 6))
     want, _ = on.news_encoder_fwd(ids, P2, 2, 16)
     assert_close(m.newsencoder.predict(ids), want, rtol=2e-5, atol=2e-5, what="chunked news encoding")
+
+
+# ---------------------------------------------------------------- optional per-token Dense/BN stack (nrms.py:142-152)
+def _mlp_weight_list(P, units):
+    out = [P["emb"], P["n_WQ"], P["n_WK"], P["n_WV"]]
+    for l in range(len(units)):
+        out += [P[f"n_d{l}_W"], P[f"n_d{l}_b"], P[f"n_bn{l}_g"], P[f"n_bn{l}_b"], P[f"n_bn{l}_mean"], P[f"n_bn{l}_var"]]
+    return out + [P[k] for k in ("n_W", "n_b", "n_q", "u_WQ", "u_WK", "u_WV", "u_W", "u_b", "u_q")]
+
+
+@pytest.mark.parametrize("p,l2", [(0.0, 0.0), (0.2, 1e-4)])
+def test_news_encoder_units_per_layer_branch_matches_oracle(nrms, p, l2):
+    units = [48, 32]  # must end with head_num*head_dim
+    hp = make_hp(head_num=4, head_dim=8, attention_hidden_dim=10, history_size=5, title_size=6, dropout=p,
+                 newsencoder_units_per_layer=units, newsencoder_l2_regularization=l2)
+    V, D, seed = 80, 20, 6
+    rng = np.random.default_rng(71)
+    P = on.random_nrms_params(V, D, 4, 8, 10, seed=3)
+    on.add_mlp_params(P, units, 32, 10, seed=4)
+    P = {k: (v.astype(np.float32).astype(np.float64) if isinstance(v, np.ndarray) else v) for k, v in P.items()}
+    m = nrms(hp, word2vec_embedding=P["emb"], seed=seed)
+    assert len(m.model.get_weights()) == 13 + 12 and "news.bn1.moving_variance" in [v.name for v in m.model.variables]
+    m.model.set_weights(_mlp_weight_list(P, units))
+    his, pred, y = batch(rng, 6, 5, 4, 6, V)
+    probs, _, _ = on.nrms_mlp_forward(his, pred, P, 4, 8, training=False)
+    assert_close(m.model.predict((his, pred)), probs, rtol=0, atol=2e-5, what="units branch, inference (moving statistics)")
+    L, _, g, stats = on.nrms_mlp_loss_and_grads(his, pred, y, P, 4, 8, l2=l2, training=True, drop=on.Drop(p, seed, 1) if p > 0 else None)
+    got = float(m.train_step(his, pred, y).item())
+    assert abs(got - L) <= 3e-5 * max(1.0, abs(L)), (got, L)
+    eng = m._engine
+    for k in ("n_d0_W", "n_d0_b", "n_bn0_g", "n_bn1_b", "n_d1_W", "n_W", "n_b", "n_q", "u_W"):
+        want = g[k].reshape(eng.params.shapes[k])
+        assert_close(eng.params.g(k).cpu().numpy(), want, rtol=2e-4, atol=1e-6 + 2e-4 * np.abs(want).max(), what=f"d{k}")
+    want = np.concatenate([g["n_WQ"], g["n_WK"], g["n_WV"]], 1)
+    assert_close(eng.params.g("n_Wqkv").cpu().numpy(), want, rtol=2e-4, atol=1e-6 + 2e-4 * np.abs(want).max(), what="dn_Wqkv")
+    assert_close(eng.table_grad.cpu().numpy(), g["emb"], rtol=2e-4, atol=1e-6 + 2e-4 * np.abs(g["emb"]).max(), what="dEmb")
+    Pn = dict(P)
+    on.bn_update_moving(Pn, stats, prefix="n_")  # history call site, then candidates
+    for l in range(2):
+        assert_close(eng.mlp.bn_mean[l].cpu().numpy(), Pn[f"n_bn{l}_mean"], rtol=1e-5, atol=1e-6, what=f"moving mean {l}")
+        assert_close(eng.mlp.bn_var[l].cpu().numpy(), Pn[f"n_bn{l}_var"], rtol=1e-5, atol=1e-6, what=f"moving var {l}")
+    with pytest.raises(ValueError, match="must end with"):
+        nrms(make_hp(head_num=4, head_dim=8, newsencoder_units_per_layer=[48, 30]), word_emb_dim=8, vocab_size=10)
