@@ -128,11 +128,16 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world == 1:
         raise SystemExit("--gpus N>1 must be launched with python -m torch.distributed.run --nproc-per-node N")
+    local = local % max(torch.cuda.device_count(), 1)  # (only matters when ranks are over-subscribed in a dry run)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)  # RCCL over xGMI
+        backend = os.environ.get("EBN_DIST_BACKEND", "nccl")  # "nccl" = RCCL over xGMI; "gloo" only for dry runs
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     c = dict(CONFIGS[args.config])
     if args.batch:
