@@ -46,6 +46,8 @@ CONFIGS = {
     "c1": dict(V=32000, D=300, H=20, C=5, T=30, h=20, d=20, A=200, train_embedding=True, B=32),
     "c2": dict(V=250002, D=1024, H=20, C=5, T=30, h=20, d=20, A=200, train_embedding=False, B=32),
     "c4": dict(V=32000, D=300, H=50, C=5, T=30, h=20, d=20, A=200, train_embedding=True, B=32),
+    # NRMSDocVec: 125542 EB-NeRD articles x 768-d document vectors resident in HBM, MLP 512-512-512 -> 256
+    "c3": dict(n_articles=125542, doc=768, units=[512, 512, 512], H=20, C=5, h=16, d=16, A=200, B=32),
 }
 
 
@@ -111,6 +113,55 @@ def cpu_baseline(c, seconds=15.0):
                       f"{' frozen' if not c['train_embedding'] else ' trainable'}) in {el:.1f}s, oracle/nrms_torch.py fp32 eager"}
 
 
+def bench_docvec(args, c, world, rank, device, sync):
+    """configs[2]: NRMSDocVec train step on article-row batches gathered on the device."""
+    from ebrec.models.newsrec import NRMSDocVec
+
+    hp = type("hparams_bench_docvec", (HP,), dict(title_size=c["doc"], history_size=c["H"], head_num=c["h"], head_dim=c["d"],
+                                                    attention_hidden_dim=c["A"], newsencoder_units_per_layer=c["units"]))
+    model = NRMSDocVec(hp, seed=42, device=device)
+    eng = model._engine
+    rng = np.random.default_rng(42)
+    matrix = rng.standard_normal((c["n_articles"], c["doc"]), dtype=np.float32)
+    matrix[0] = 0
+    eng.set_article_matrix(matrix)
+    g = torch.Generator(device="cpu").manual_seed(123 + rank)
+    batches = []
+    for _ in range(8):
+        his = torch.randint(0, c["n_articles"], (c["B"], c["H"]), generator=g, dtype=torch.int32).to(device)
+        pred = torch.randint(0, c["n_articles"], (c["B"], c["C"]), generator=g, dtype=torch.int32).to(device)
+        y = torch.zeros(c["B"], c["C"])
+        y[torch.arange(c["B"]), torch.randint(0, c["C"], (c["B"],), generator=g)] = 1.0
+        batches.append((his, pred, y.to(device)))
+    eng.enable_graphs(not args.no_graph)
+    for i in range(args.warmup):
+        eng.train_step(*batches[i % 8], indexed=True)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        eng.train_step(*batches[i % 8], indexed=True)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        n_rows = c["B"] * (c["H"] + c["C"])
+        print(json.dumps({
+            "metric": "training impressions/sec", "value": world * c["B"] * args.steps / dt, "unit": "impressions/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "launch": "eager" if args.no_graph else "hipGraph replay", "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"NRMSDocVec train step, BASELINE.json configs[2] (c3): {c['n_articles']} x {c['doc']} document vectors in HBM, "
+                                   f"MLP {c['units']} -> {c['h'] * c['d']}, history_size={c['H']} npratio={c['C'] - 1}, dropout 0.2, adam lr=1e-4",
+                       "global_batch": world * c["B"], "per_gpu_batch": c["B"], "parallelism": f"dp{world}",
+                       "final_loss": float(eng.loss_dev.item())},
+            "roofline": {"kernel": "whole step (launch/latency-bound: ~0.19 GFLOP and 2.5 MB of gathered vectors per step)", "bound": "hbm",
+                         "achieved": n_rows * (4 + 2 * c["doc"] * 4) * args.steps / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": n_rows * (4 + 2 * c["doc"] * 4) * args.steps / dt / 1e9 / HBM_PEAK_GBS, "traffic": None}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -142,6 +193,18 @@ def main():
     c = dict(CONFIGS[args.config])
     if args.batch:
         c["B"] = args.batch
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    if args.config == "c3":
+        bench_docvec(args, c, world, rank, device, sync)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     from ebrec.models.newsrec import NRMSModel
 
     rng = np.random.default_rng(42)  # identical weights on every rank (data-parallel replicas)
@@ -150,12 +213,6 @@ def main():
                       train_embedding=c["train_embedding"], device=device)
     eng = model._engine
     batches = synthetic_batches(c, 8, 123 + rank, device)
-
-    def sync():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
 
     eng.enable_graphs(not args.no_graph)
     for i in range(args.warmup):

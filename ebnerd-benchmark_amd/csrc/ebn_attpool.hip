@@ -152,8 +152,7 @@ extern "C" int ebn_attpool_bwd_dpre_f32(float* U, const float* q, const float* d
   hipLaunchKernelGGL(attpool_bwd_dpre_kernel, dim3(static_cast<unsigned>(nb)), dim3(POOL_THREADS), 0,
                      ebn_stream(stream), U, q, de, partials, R, A, rpb);
   EBN_CHECK_LAUNCH();
-  hipLaunchKernelGGL(ebn_reduce_partials_kernel, dim3(static_cast<unsigned>(ebn_ceil_div(2 * A, 32))), dim3(256),
-                     0, ebn_stream(stream), partials, static_cast<int>(nb), 2, A, dq, db, accumulate);
+  ebn_reduce_partials(partials, nb, 2, A, 1.0f, dq, db, accumulate, nullptr, nullptr, ebn_stream(stream));
   EBN_CHECK_LAUNCH();
   return EBN_OK;
 }

@@ -21,59 +21,61 @@ __global__ __launch_bounds__(256) void bias_relu_kernel(const float* __restrict_
   }
 }
 
-// dX = dY*(Y>0); partials[b][0][c] = column sums of dX
-__global__ __launch_bounds__(256) void bias_relu_bwd_kernel(const float* __restrict__ Y, const float* __restrict__ dY,
-                                                            float* __restrict__ dX, float* __restrict__ partials,
-                                                            int64_t R, int C, int64_t rpb) {
-  const int64_t r0 = static_cast<int64_t>(blockIdx.x) * rpb;
-  const int64_t r1 = (r0 + rpb < R) ? r0 + rpb : R;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    float s = 0.f;
-    for (int64_t r = r0; r < r1; ++r) {
-      const float g = (Y[r * C + c] > 0.f) ? dY[r * C + c] : 0.f;
-      dX[r * C + c] = g;
-      s += g;
-    }
-    partials[(static_cast<int64_t>(blockIdx.x) * 2 + 0) * C + c] = s;
-    partials[(static_cast<int64_t>(blockIdx.x) * 2 + 1) * C + c] = 0.f;
+// ---- stage-1 functors of the column reductions (ebn_reduce.h) ------------------------------------------------
+struct ReluBwd {  // dX = dY*(Y>0); a0 = column sums of dX
+  const float* Y;
+  const float* dY;
+  float* dX;
+  int C;
+  __device__ void row(int64_t r, int c, float& a0, float&) const {
+    const int64_t i = r * C + c;
+    const float g = (Y[i] > 0.f) ? dY[i] : 0.f;
+    dX[i] = g;
+    a0 += g;
   }
-}
+};
 
-// partials[b][0][c] = sum_r (X[r,c] - (mean ? mean[c] : 0))^P  with P = 1 or 2
 template <int P>
-__global__ __launch_bounds__(256) void col_moment_kernel(const float* __restrict__ X, const float* __restrict__ mean,
-                                                         float* __restrict__ partials, int64_t R, int C,
-                                                         int64_t rpb) {
-  const int64_t r0 = static_cast<int64_t>(blockIdx.x) * rpb;
-  const int64_t r1 = (r0 + rpb < R) ? r0 + rpb : R;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    const float mu = mean ? mean[c] : 0.f;
-    float s = 0.f;
-    for (int64_t r = r0; r < r1; ++r) {
-      const float x = X[r * C + c] - mu;
-      s += (P == 1) ? x : x * x;
-    }
-    partials[(static_cast<int64_t>(blockIdx.x) * 2 + 0) * C + c] = s;
-    partials[(static_cast<int64_t>(blockIdx.x) * 2 + 1) * C + c] = 0.f;
+struct ColMoment {  // a0 = sum (x - mean)^P
+  const float* X;
+  const float* mean;  // may be null (P == 1)
+  int C;
+  __device__ void row(int64_t r, int c, float& a0, float&) const {
+    const float x = X[r * C + c] - (mean ? mean[c] : 0.f);
+    a0 += (P == 1) ? x : x * x;
   }
-}
+};
 
-// v[c] *= scale (turn sums into means)
-__global__ __launch_bounds__(256) void scale_vec_kernel(float* __restrict__ v, int C, float scale) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c < C) v[c] *= scale;
-}
+struct BnBwdStats {  // a0 = sum dY' xhat (dgamma), a1 = sum dY' (dbeta); dY' = dY * dropout multiplier
+  const float* dY;
+  const float* xhat;
+  int C;
+  const uint32_t* key_ptr;
+  uint32_t thresh;
+  float scale;
+  int64_t elem_offset;
+  __device__ void row(int64_t r, int c, float& a0, float& a1) const {
+    const int64_t i = r * C + c;
+    float g = dY[i];
+    if (key_ptr != nullptr) g *= ebn_drop_mult(*key_ptr, static_cast<uint64_t>(i + elem_offset), thresh, scale);
+    a0 = fmaf(g, xhat[i], a0);
+    a1 += g;
+  }
+};
 
-// var[c] (in istd_out) -> istd; update moving stats
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ mean, float* __restrict__ var_istd,
-                                                          float* __restrict__ mmean, float* __restrict__ mvar,
-                                                          int C) {
+// var (sum of squared deviations / R) from the partials -> moving statistics, istd.  One thread per column.
+__global__ __launch_bounds__(256) void bn_var_finalize_kernel(const float* __restrict__ partials, int nblk, int C,
+                                                              float inv_R, const float* __restrict__ mean,
+                                                              float* __restrict__ istd, float* __restrict__ mmean,
+                                                              float* __restrict__ mvar) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
-  const float var = var_istd[c];
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += partials[static_cast<int64_t>(b) * 2 * C + c];
+  const float var = s * inv_R;
   mmean[c] = mmean[c] * BN_MOM + mean[c] * (1.0f - BN_MOM);
   mvar[c] = mvar[c] * BN_MOM + var * (1.0f - BN_MOM);
-  var_istd[c] = 1.0f / sqrtf(var + BN_EPS);
+  istd[c] = 1.0f / sqrtf(var + BN_EPS);
 }
 
 __global__ __launch_bounds__(256) void bn_eval_stats_kernel(const float* __restrict__ mmean,
@@ -104,28 +106,6 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
   }
 }
 
-// partials[b][0][c] = sum dY' xhat (dgamma), [b][1][c] = sum dY' (dbeta); dY' = dY * dropout mult
-__global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* __restrict__ dY, const float* __restrict__ xhat,
-                                                           float* __restrict__ partials, int64_t R, int C,
-                                                           int64_t rpb, const uint32_t* __restrict__ key_ptr,
-                                                           uint32_t thresh, float scale, int64_t elem_offset) {
-  const bool do_drop = key_ptr != nullptr;
-  const uint32_t key = do_drop ? *key_ptr : 0u;
-  const int64_t r0 = static_cast<int64_t>(blockIdx.x) * rpb;
-  const int64_t r1 = (r0 + rpb < R) ? r0 + rpb : R;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    float sg = 0.f, sb = 0.f;
-    for (int64_t r = r0; r < r1; ++r) {
-      float g = dY[r * C + c];
-      if (do_drop) g *= ebn_drop_mult(key, static_cast<uint64_t>(r * C + c + elem_offset), thresh, scale);
-      sg = fmaf(g, xhat[r * C + c], sg);
-      sb += g;
-    }
-    partials[(static_cast<int64_t>(blockIdx.x) * 2 + 0) * C + c] = sg;
-    partials[(static_cast<int64_t>(blockIdx.x) * 2 + 1) * C + c] = sb;
-  }
-}
-
 // training: dX = istd*gamma*(dY' - dbeta_site/R - xhat*dgamma_site/R); eval: dX = dY'*gamma*istd
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dY, const float* __restrict__ xhat,
                                                            const float* __restrict__ gamma,
@@ -148,12 +128,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   }
 }
 
-__global__ __launch_bounds__(256) void add_vec_kernel(float* __restrict__ dst, const float* __restrict__ src, int C,
-                                                      int accumulate) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c < C) dst[c] = accumulate ? dst[c] + src[c] : src[c];
-}
-
 __global__ __launch_bounds__(256) void axpy_kernel(float a, const float* __restrict__ x, float* __restrict__ y,
                                                    int64_t n) {
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n;
@@ -161,7 +135,24 @@ __global__ __launch_bounds__(256) void axpy_kernel(float a, const float* __restr
     y[i] = fmaf(a, x[i], y[i]);
 }
 
-// single-block deterministic sum (n is small: loss rows, or a weight matrix for the L2 term)
+// L2 kernel regulariser in one pass over W: g += 2*lambda*W, partial[block] = sum W^2 of the block's elements
+__global__ __launch_bounds__(256) void l2_reg_kernel(const float* __restrict__ W, float* __restrict__ g, int64_t n,
+                                                     float two_lambda, float* __restrict__ partial) {
+  __shared__ float sw[4];
+  float s = 0.f;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * 256) {
+    const float w = W[i];
+    g[i] = fmaf(two_lambda, w, g[i]);
+    s = fmaf(w, w, s);
+  }
+  s = ebn_wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
+}
+
+// deterministic sum (optionally of squares) of n floats by ONE 1024-thread block (n is small: loss rows, partials)
 template <bool SQ>
 __global__ __launch_bounds__(1024) void sum_kernel(const float* __restrict__ x, int64_t n, float scale,
                                                    float* __restrict__ out, int accumulate) {
@@ -189,11 +180,15 @@ inline unsigned grid_for(int64_t n) {
   return static_cast<unsigned>(g);
 }
 
+constexpr int L2_BLOCKS = 256;
+
 }  // namespace
 
 extern "C" int64_t ebn_colsum_partials_len(int64_t R, int32_t Ccols) {
-  // 2 reduction kinds x blocks x C, plus 2*C floats of per-site scratch (dgamma/dbeta of one call site)
-  return ebn_colred_blocks(R) * 2 * Ccols + 2 * static_cast<int64_t>(Ccols);
+  // 2 reduction kinds x row blocks x C, plus 2*C floats of per-site scratch (dgamma/dbeta of one call site);
+  // never less than the L2_BLOCKS floats ebn_l2_reg_f32 needs
+  const int64_t n = ebn_colred_blocks(R) * 2 * Ccols + 2 * static_cast<int64_t>(Ccols);
+  return n > L2_BLOCKS ? n : L2_BLOCKS;
 }
 
 extern "C" int ebn_bias_relu_f32(const float* X, const float* bias, float* Y, int64_t R, int32_t Ccols,
@@ -213,14 +208,10 @@ extern "C" int ebn_bias_relu_bwd_f32(const float* Y, const float* dY, float* dX,
   EBN_REQUIRE(R >= 0 && Ccols > 0, EBN_ERR_BAD_ARG);
   if (R == 0) return EBN_OK;
   hipStream_t s = ebn_stream(stream);
-  const int64_t nb = ebn_colred_blocks(R);
-  const int64_t rpb = ebn_ceil_div(R, nb);
-  hipLaunchKernelGGL(bias_relu_bwd_kernel, dim3(static_cast<unsigned>(nb)), dim3(256), 0, s, Y, dY, dX, partials, R,
-                     Ccols, rpb);
+  int64_t nb;
+  ebn_colred_stage1(ReluBwd{Y, dY, dX, Ccols}, partials, R, Ccols, s, &nb);
   EBN_CHECK_LAUNCH();
-  hipLaunchKernelGGL(ebn_reduce_partials_kernel, dim3(static_cast<unsigned>(ebn_ceil_div(2 * Ccols, 32))),
-                     dim3(256), 0, s, partials, static_cast<int>(nb), 2, Ccols, dbias,
-                     static_cast<float*>(nullptr), accumulate);
+  ebn_reduce_partials(partials, nb, 1, Ccols, 1.0f, dbias, nullptr, accumulate, nullptr, nullptr, s);
   EBN_CHECK_LAUNCH();
   return EBN_OK;
 }
@@ -237,22 +228,14 @@ extern "C" int ebn_batchnorm_fwd_f32(const float* X, const float* gamma, const f
   hipStream_t s = ebn_stream(stream);
   const int C = Ccols;
   const unsigned cgrid = static_cast<unsigned>(ebn_ceil_div(C, 256));
-  if (training) {
-    const int64_t nb = ebn_colred_blocks(R);
-    const int64_t rpb = ebn_ceil_div(R, nb);
-    const unsigned rgrid = static_cast<unsigned>(ebn_ceil_div(2 * C, 32));
-    hipLaunchKernelGGL((col_moment_kernel<1>), dim3(static_cast<unsigned>(nb)), dim3(256), 0, s, X,
-                       static_cast<const float*>(nullptr), partials, R, C, rpb);
-    hipLaunchKernelGGL(ebn_reduce_partials_kernel, dim3(rgrid), dim3(256), 0, s, partials, static_cast<int>(nb), 2, C,
-                       mean_out, static_cast<float*>(nullptr), 0);
-    hipLaunchKernelGGL(scale_vec_kernel, dim3(cgrid), dim3(256), 0, s, mean_out, C, 1.0f / static_cast<float>(R));
-    hipLaunchKernelGGL((col_moment_kernel<2>), dim3(static_cast<unsigned>(nb)), dim3(256), 0, s, X, mean_out, partials,
-                       R, C, rpb);
-    hipLaunchKernelGGL(ebn_reduce_partials_kernel, dim3(rgrid), dim3(256), 0, s, partials, static_cast<int>(nb), 2, C,
-                       istd_out, static_cast<float*>(nullptr), 0);
-    hipLaunchKernelGGL(scale_vec_kernel, dim3(cgrid), dim3(256), 0, s, istd_out, C, 1.0f / static_cast<float>(R));
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cgrid), dim3(256), 0, s, mean_out, istd_out, moving_mean, moving_var,
-                       C);
+  if (training) {  // two-pass batch statistics of this call site: mean, then biased variance about it
+    const float inv_R = 1.0f / static_cast<float>(R);
+    int64_t nb;
+    ebn_colred_stage1(ColMoment<1>{X, nullptr, C}, partials, R, C, s, &nb);
+    ebn_reduce_partials(partials, nb, 1, C, inv_R, mean_out, nullptr, 0, nullptr, nullptr, s);
+    ebn_colred_stage1(ColMoment<2>{X, mean_out, C}, partials, R, C, s, &nb);
+    hipLaunchKernelGGL(bn_var_finalize_kernel, dim3(cgrid), dim3(256), 0, s, partials, static_cast<int>(nb), C, inv_R,
+                       mean_out, istd_out, moving_mean, moving_var);
   } else {
     hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(cgrid), dim3(256), 0, s, moving_mean, moving_var, mean_out, istd_out,
                        C);
@@ -275,21 +258,15 @@ extern "C" int ebn_batchnorm_bwd_f32(const float* dY, const float* xhat, const f
   hipStream_t s = ebn_stream(stream);
   const int C = Ccols;
   const EbnDrop dr = training ? ebn_make_drop(st, site, drop_p) : ebn_make_drop(nullptr, -1, 0.f);
-  const int64_t nb = ebn_colred_blocks(R);
-  const int64_t rpb = ebn_ceil_div(R, nb);
-  float* site_dg = partials + nb * 2 * C;  // per-call-site sums (the batch-stat terms must not mix sites)
+  int64_t nb;
+  ebn_colred_stage1(BnBwdStats{dY, xhat, C, dr.key_ptr, dr.thresh, dr.scale, elem_offset}, partials, R, C, s, &nb);
+  float* site_dg = partials + nb * 2 * C;  // per-call-site sums (the batch-statistics terms must not mix sites)
   float* site_db = site_dg + C;
-  hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(static_cast<unsigned>(nb)), dim3(256), 0, s, dY, xhat, partials, R, C,
-                     rpb, dr.key_ptr, dr.thresh, dr.scale, elem_offset);
-  hipLaunchKernelGGL(ebn_reduce_partials_kernel, dim3(static_cast<unsigned>(ebn_ceil_div(2 * C, 32))), dim3(256), 0,
-                     s, partials, static_cast<int>(nb), 2, C, site_dg, site_db, 0);
+  ebn_reduce_partials(partials, nb, 2, C, 1.0f, dgamma, dbeta, accumulate, site_dg, site_db, s);
   EBN_CHECK_LAUNCH();
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(R * C)), dim3(256), 0, s, dY, xhat, gamma, istd, site_dg,
                      site_db, dX, R * C, C, 1.0f / static_cast<float>(R), training, dr.key_ptr, dr.thresh, dr.scale,
                      elem_offset);
-  const unsigned cgrid = static_cast<unsigned>(ebn_ceil_div(C, 256));
-  hipLaunchKernelGGL(add_vec_kernel, dim3(cgrid), dim3(256), 0, s, dgamma, site_dg, C, accumulate);
-  hipLaunchKernelGGL(add_vec_kernel, dim3(cgrid), dim3(256), 0, s, dbeta, site_db, C, accumulate);
   EBN_CHECK_LAUNCH();
   return EBN_OK;
 }
@@ -298,6 +275,20 @@ extern "C" int ebn_axpy_f32(float a, const float* x, float* y, int64_t n, ebn_st
   EBN_REQUIRE(x && y && n >= 0, EBN_ERR_BAD_ARG);
   if (n == 0) return EBN_OK;
   hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n)), dim3(256), 0, ebn_stream(stream), a, x, y, n);
+  EBN_CHECK_LAUNCH();
+  return EBN_OK;
+}
+
+extern "C" int ebn_l2_reg_f32(const float* W, float* gW, int64_t n, float lambda, float* partials, float* loss,
+                              ebn_stream_t stream) {
+  EBN_REQUIRE(W && gW && partials && loss && n >= 0, EBN_ERR_BAD_ARG);
+  if (n == 0) return EBN_OK;
+  hipStream_t s = ebn_stream(stream);
+  int64_t grid = ebn_ceil_div(n, 256 * 4);
+  if (grid > L2_BLOCKS) grid = L2_BLOCKS;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(l2_reg_kernel, dim3(static_cast<unsigned>(grid)), dim3(256), 0, s, W, gW, n, 2.0f * lambda, partials);
+  hipLaunchKernelGGL((sum_kernel<false>), dim3(1), dim3(1024), 0, s, partials, grid, lambda, loss, 1);
   EBN_CHECK_LAUNCH();
   return EBN_OK;
 }

@@ -318,7 +318,8 @@ class NRMSEngine:
                   _hip.ptr(b.partials), R, A, 0, S())
         _hip.call("ebn_gemm_f32_ws", 1, 0, E, A, R, one, _hip.ptr(b.Z), E, _hip.ptr(b.U), A, zero, _hip.ptr(g("n_W")), A, ws, wsn, S())
         _hip.call("ebn_gemm_f32_ws", 0, 1, R, E, A, one, _hip.ptr(b.U), A, _hip.ptr(pv("n_W")), A, one, _hip.ptr(b.dY), E, ws, wsn, S())
-        dYattn = self.mlp.backward(b.dY, b.Y, n_first * T, (n_seq - n_first) * T, self.state, self.p, need_dx0=True)
+        dYattn = self.mlp.backward(b.dY, b.Y, n_first * T, (n_seq - n_first) * T, self.state, self.p, need_dx0=True,
+                                   loss_dev=self.loss_dev)
         _hip.call("ebn_attn_bwd_f32", _hip.ptr(b.QKV), 3 * E, _hip.ptr(dYattn), E, _hip.ptr(b.dQKV), 3 * E, n_seq, T, self.h, self.d,
                   None, -1, ctypes.c_float(0.0), S())
         _hip.call("ebn_gemm_f32_ws", 1, 0, b.Din, 3 * E, R, one, _hip.ptr(X), b.Din, _hip.ptr(b.dQKV), 3 * E, zero, _hip.ptr(g("n_Wqkv")),
@@ -609,8 +610,6 @@ class NRMSEngine:
         _hip.call("ebn_sum_f32", _hip.ptr(ub.loss_rows), B, ctypes.c_float(1.0), _hip.ptr(self.loss_dev), 0, S())
         self._encoder_bwd("u", ub, B, nb.out, ub.duser, nb.dNE)  # writes dNE[:B*H]
         self._encoder_bwd("n", nb, N, nb.X, nb.dNE, nb.dX, B * H)
-        if self.mlp is not None:
-            self.mlp.add_l2_loss(self.loss_dev)
         if self.train_embedding:
             if self.exchange is not None or not self.deterministic:
                 self.table_grad.zero_()

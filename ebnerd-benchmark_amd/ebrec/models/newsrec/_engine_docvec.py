@@ -44,6 +44,7 @@ class DocVecEngine:
         self.state = torch.frombuffer(bytearray(bytes(st)), dtype=torch.uint8).to(self.device)
         self._lr = float(learning_rate)
         self._bufs = {}
+        self.use_graph, self._graphs = False, {}
         self.loss_dev = torch.zeros(1, device=self.device)
         self.reg_dev = torch.zeros(1, device=self.device)
         self.world = 1
@@ -150,7 +151,7 @@ class DocVecEngine:
         self._gemm(1, 0, prev, self.E, N, x_last, prev, dpre, self.E, 0.0, g("out_W"), self.E, mb["ws"])
         if self.units:
             self._gemm(0, 1, N, prev, self.E, dpre, self.E, pv("out_W"), self.E, 0.0, mb["dXl"], prev)
-            self.mlp.backward(mb["dXl"], mb["X0"], n_hist, n_cand, self.state, self.p, need_dx0=False)
+            self.mlp.backward(mb["dXl"], mb["X0"], n_hist, n_cand, self.state, self.p, need_dx0=False, loss_dev=self.loss_dev)
 
     @staticmethod
     def _fwd_scratch(b):
@@ -238,16 +239,76 @@ class DocVecEngine:
                   self.E, 1 if sigmoid else 0, _hip.stream_handle())
         return out
 
-    def train_step(self, his, pred, y, return_probs=False):
+    def enable_graphs(self, flag=True):
+        """Capture the per-(B, C) kernel sequence of a train step into a hipGraph (the DocVec step is ~70 small
+        launches: launch-bound without it)."""
+        self.use_graph = bool(flag)
+        if not flag:
+            self._graphs = {}
+        return self
+
+    def set_article_matrix(self, matrix) -> None:
+        """Keep the loader's (n_articles+1, Din) document-vector matrix in HBM (386 MB for the 125 542 EB-NeRD
+        articles x 768); batches can then be article-row numbers, gathered on the device by the embedding-gather
+        kernel (``train_step(..., indexed=True)``)."""
+        m = np.asarray(matrix)
+        if m.ndim != 2 or m.shape[1] != self.Din or not np.issubdtype(m.dtype, np.floating):
+            raise ValueError(f"article matrix must be float (n_articles+1, {self.Din}), got {m.dtype} {m.shape}")
+        self.article_matrix = torch.from_numpy(np.ascontiguousarray(m.astype(np.float32))).to(self.device)
+        self._article_matrix_src = matrix
+        self._oob = torch.zeros(1, dtype=torch.int32, device=self.device)
+
+    def _stage_indexed(self, mb, his_idx, pred_idx):
+        n = his_idx.shape[0] * (self.H + pred_idx.shape[1])
+        if "art_idx" not in mb:
+            mb["art_idx"] = torch.empty(mb["N"], dtype=torch.int32, device=self.device)
+        off = 0
+        for a in (his_idx, pred_idx):
+            t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(a).reshape(-1).astype(np.int32, copy=False)))
+            t = t.reshape(-1)
+            mb["art_idx"][off: off + t.numel()].copy_(t.to(device=self.device, dtype=torch.int32), non_blocking=True)
+            off += t.numel()
+        _hip.call("ebn_gather_rows_f32", _hip.ptr(mb["art_idx"]), _hip.ptr(self.article_matrix), _hip.ptr(mb["X0"]), n, self.Din,
+                  self.article_matrix.shape[0], None, -1, ctypes.c_float(0.0), _hip.ptr(self._oob), _hip.stream_handle())
+
+    def train_step(self, his, pred, y, return_probs=False, indexed=False):
         his = his if isinstance(his, torch.Tensor) else np.asarray(his)
         pred = pred if isinstance(pred, torch.Tensor) else np.asarray(pred)
-        self._check_shapes(his, pred)
-        B, C, E = his.shape[0], pred.shape[1], self.E
-        S = _hip.stream_handle
+        if not indexed:
+            self._check_shapes(his, pred)
+        elif his.ndim != 2 or his.shape[1] != self.H or pred.ndim != 2 or pred.shape[0] != his.shape[0]:
+            raise ValueError(f"indexed batches must be (B, {self.H}) and (B, C), got {tuple(his.shape)} {tuple(pred.shape)}")
+        B, C = his.shape[0], pred.shape[1]
+        n_before = (self._bufs.get("mlp") or {}).get("N"), getattr(self._bufs.get("user"), "n_seq", None)
         mb, ub = self._mlp_bufs(B * (self.H + C)), self._user_bufs(B)
-        n_hist, n_cand = self._upload(mb, his, pred)
+        if n_before != (mb["N"], ub.n_seq):
+            self._graphs = {}  # buffers were (re)allocated: captured graphs hold stale pointers
+        if indexed:
+            self._stage_indexed(mb, his, pred)
+        else:
+            self._upload(mb, his, pred)
         labels = (y if isinstance(y, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(y, dtype=np.float32))))
         mb["labels"][: B * C].copy_(labels.reshape(-1).to(device=self.device, dtype=torch.float32))
+        if getattr(self, "use_graph", False) and self.world == 1:
+            g = self._graphs.get((B, C))
+            if g is None:
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._train_kernels(B, C)
+                self._graphs[(B, C)] = g
+            g.replay()
+        else:
+            self._train_kernels(B, C)
+        if return_probs:
+            return self.loss_dev, mb["probs"][: B * C].view(B, C)
+        return self.loss_dev
+
+    def _train_kernels(self, B, C):
+        E = self.E
+        S = _hip.stream_handle
+        mb, ub = self._mlp_bufs(B * (self.H + C)), self._user_bufs(B)
+        n_hist, n_cand = B * self.H, B * C
         st = _hip.ptr(self.state)
         _hip.call("ebn_step_advance", st, BETA1, BETA2, S())
         self._news_forward(mb, n_hist, n_cand, True)
@@ -259,7 +320,6 @@ class DocVecEngine:
                   _hip.ptr(ub.loss_rows), _hip.ptr(mb["dNE"][n_hist:]), _hip.ptr(ub.duser), B, C, E, LOSS_KIND[self.loss],
                   ctypes.c_float(1.0 / B), S())
         _hip.call("ebn_sum_f32", _hip.ptr(ub.loss_rows), B, ctypes.c_float(1.0), _hip.ptr(self.loss_dev), 0, S())
-        self.mlp.add_l2_loss(self.loss_dev)
         g = self.params.g
         grads = _hip.EncoderGrads(g("u_Wqkv").data_ptr(), g("u_W").data_ptr(), g("u_b").data_ptr(), g("u_q").data_ptr())
         scratch = _hip.EncoderScratch(ub.dY.data_ptr(), ub.dQKV.data_ptr(), ub.de.data_ptr(), ub.partials.data_ptr(),
@@ -272,9 +332,6 @@ class DocVecEngine:
         P = self.params
         _hip.call("ebn_adam_keras_step_f32", _hip.ptr(P.data), _hip.ptr(P.grad), _hip.ptr(P.m), _hip.ptr(P.v), P.numel, st,
                   BETA1, BETA2, ADAM_EPS, ctypes.c_float(1.0 / self.world), S())
-        if return_probs:
-            return self.loss_dev, mb["probs"][: B * C].view(B, C)
-        return self.loss_dev
 
     def extra_state(self):
         return {}

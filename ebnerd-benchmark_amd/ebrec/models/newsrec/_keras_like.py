@@ -157,10 +157,12 @@ class TrainModel:
             n_rows = 0
             auc = StreamingAUC() if want_auc else None
             # loaders of this repo + an engine that can hold the token matrix in HBM: ship article-row numbers only
-            indexed = (hasattr(data, "index_batch") and hasattr(eng, "set_article_matrix") and not getattr(data, "eval_mode", False)
-                       and np.issubdtype(np.asarray(data.lookup_article_matrix).dtype, np.integer))
+            indexed = hasattr(data, "index_batch") and hasattr(eng, "set_article_matrix") and not getattr(data, "eval_mode", False)
             if indexed and getattr(eng, "_article_matrix_src", None) is not data.lookup_article_matrix:
-                eng.set_article_matrix(data.lookup_article_matrix)
+                try:
+                    eng.set_article_matrix(data.lookup_article_matrix)
+                except ValueError:  # not this engine's kind of matrix (token ids vs document vectors): host-gathered batches
+                    indexed = False
             for step, idx in enumerate(order):
                 (his, pred), yb = data.index_batch(int(idx)) if indexed else data[int(idx)]
                 nb = len(his)

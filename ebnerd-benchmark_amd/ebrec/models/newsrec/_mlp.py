@@ -89,9 +89,9 @@ class MLPStack:
             x, prev = b["Xn"][l], u
         return x
 
-    def backward(self, d_last, x0, n0: int, n1: int, state, p: float, need_dx0: bool):
-        """d_last (N, out_dim) is consumed.  Parameter gradients are OVERWRITTEN in the FlatParams grad buffer;
-        returns d(x0) (N, din) when need_dx0."""
+    def backward(self, d_last, x0, n0: int, n1: int, state, p: float, need_dx0: bool, loss_dev=None):
+        """d_last (N, out_dim) is consumed.  Parameter gradients are OVERWRITTEN in the FlatParams grad buffer; the L2
+        penalty lambda*sum(W^2) of every regularised kernel is added to loss_dev[0]; returns d(x0) (N, din) when need_dx0."""
         N, S, b = n0 + n1, _hip.stream_handle, self._b
         st = _hip.ptr(state)
         dY = d_last
@@ -110,22 +110,15 @@ class MLPStack:
             _hip.call("ebn_bias_relu_bwd_f32", _hip.ptr(b["R"][l]), _hip.ptr(dR), _hip.ptr(dR), _hip.ptr(self._g(f"d{l}_b")),
                       _hip.ptr(b["partials"]), N, u, 0, S())
             self.gemm(1, 0, din, u, N, x_in, din, dR, u, 0.0, self._g(f"d{l}_W"), u, b["ws"])
-            if self.l2 > 0:  # kernel_regularizer=l2(lambda): d/dW of lambda*sum(W^2)
-                _hip.call("ebn_axpy_f32", ctypes.c_float(2.0 * self.l2), _hip.ptr(self._pv(f"d{l}_W")), _hip.ptr(self._g(f"d{l}_W")),
-                          din * u, S())
+            if self.l2 > 0:  # kernel_regularizer=l2(lambda): gW += 2*lambda*W and loss += lambda*sum(W^2), one pass over W
+                _hip.call("ebn_l2_reg_f32", _hip.ptr(self._pv(f"d{l}_W")), _hip.ptr(self._g(f"d{l}_W")), din * u,
+                          ctypes.c_float(self.l2), _hip.ptr(b["partials"]), _hip.ptr(loss_dev), S())
             if l:
                 self.gemm(0, 1, N, din, u, dR, u, self._pv(f"d{l}_W"), u, 0.0, b["dA"][l - 1], din, b["ws"])
                 dY = b["dA"][l - 1]
             elif need_dx0:
                 self.gemm(0, 1, N, din, u, dR, u, self._pv(f"d{l}_W"), u, 0.0, b["dX0"], din, b["ws"])
         return b["dX0"] if (need_dx0 and self.units) else (d_last if need_dx0 else None)
-
-    def add_l2_loss(self, loss_dev):
-        """loss += lambda * sum(W^2) per regularised kernel, once (not per call site)."""
-        if self.l2 > 0:
-            for l in range(len(self.units)):
-                W = self._pv(f"d{l}_W")
-                _hip.call("ebn_sumsq_f32", _hip.ptr(W), W.numel(), ctypes.c_float(self.l2), _hip.ptr(loss_dev), 1, _hip.stream_handle())
 
     # ---- weights in Keras creation order per layer: kernel, bias, gamma, beta, moving_mean, moving_variance
     def weight_names(self, base: str):

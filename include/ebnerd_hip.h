@@ -256,6 +256,11 @@ int ebn_batchnorm_bwd_f32(const float* dY, const float* xhat, const float* gamma
 
 /* y = a*x + y over n elements (L2 kernel-regulariser gradient, gradient accumulation). */
 int ebn_axpy_f32(float a, const float* x, float* y, int64_t n, ebn_stream_t stream);
+/* kernel_regularizer=l2(lambda) of one Dense kernel in a single pass (nrms_docvec.py:119-121, nrms.py:146-148):
+ * gW += 2*lambda*W and loss[0] += lambda*sum(W^2); `partials` = scratch of at least 256 floats
+ * (ebn_colsum_partials_len never returns less).                                                            */
+int ebn_l2_reg_f32(const float* W, float* gW, int64_t n, float lambda, float* partials, float* loss,
+                   ebn_stream_t stream);
 /* out[0] (+)= scale * sum(x[0..n)) -- deterministic single-block reduction.            */
 int ebn_sum_f32(const float* x, int64_t n, float scale, float* out, int32_t accumulate,
                 ebn_stream_t stream);

@@ -111,3 +111,24 @@ def test_docvec_fit_surface_and_weights_roundtrip(docvec, tmp_path):
     m2.model.load_weights(str(path))
     assert np.array_equal(m2.model.predict((his, pred)), m.model.predict((his, pred)))
     assert m.model.count_params() == sum(a.size for a in w)
+
+
+def test_docvec_graph_replay_and_indexed_batches_match_eager_host_batches(docvec):
+    hp = make_hp(title_size=32, newsencoder_units_per_layer=[24, 16], head_num=2, head_dim=8, attention_hidden_dim=6, history_size=4,
+                 learning_rate=1e-3)
+    rng = np.random.default_rng(9)
+    matrix = rng.standard_normal((50, 32)).astype(np.float32)
+    matrix[0] = 0
+    ms = [docvec(hp, seed=3) for _ in range(3)]
+    ms[1]._engine.enable_graphs()
+    ms[2]._engine.enable_graphs()
+    ms[2]._engine.set_article_matrix(matrix)
+    for step in range(4):
+        hi, pi = rng.integers(0, 50, (6, 4)), rng.integers(0, 50, (6, 5))
+        y = np.eye(5, dtype=np.float32)[rng.integers(0, 5, 6)]
+        l0 = float(ms[0].train_step(matrix[hi], matrix[pi], y).item())
+        l1 = float(ms[1].train_step(matrix[hi], matrix[pi], y).item())
+        l2 = float(ms[2]._engine.train_step(hi, pi, y, indexed=True).item())
+        assert l0 == l1 == l2, (step, l0, l1, l2)
+    w = [m.model.get_weights() for m in ms]
+    assert all(np.array_equal(a, b) and np.array_equal(a, c) for a, b, c in zip(*w))
