@@ -38,16 +38,23 @@ __host__ __device__ __forceinline__ uint32_t ebn_dropout_key(uint32_t seed, uint
   return ebn_lowbias32(k);
 }
 
+// One 32-bit hash decides TWO consecutive elements (16 bits each): element idx uses the low (even idx) or high
+// (odd idx) half of lowbias32(pair ^ key'), pair = idx >> 1, key' = key ^ (bits 32.. of pair) * 0x27D4EB2F.
+// `thresh` is a 16-bit threshold: keep iff half >= thresh (drop probability = thresh / 65536).
+__host__ __device__ __forceinline__ uint32_t ebn_dropout_pair_hash(uint32_t key, uint64_t pair) {
+  return ebn_lowbias32(static_cast<uint32_t>(pair) ^ key ^ (static_cast<uint32_t>(pair >> 32) * 0x27D4EB2Fu));
+}
+
 __host__ __device__ __forceinline__ bool ebn_dropout_keep(uint32_t key, uint64_t idx, uint32_t thresh) {
-  uint32_t h = ebn_lowbias32(static_cast<uint32_t>(idx) ^ key);
-  h = ebn_lowbias32(h + static_cast<uint32_t>(idx >> 32) * 0x27D4EB2Fu + 0x165667B1u);
-  return h >= thresh;
+  const uint32_t h = ebn_dropout_pair_hash(key, idx >> 1);
+  const uint32_t half = (idx & 1u) ? (h >> 16) : (h & 0xFFFFu);
+  return half >= thresh;
 }
 
 static inline uint32_t ebn_dropout_threshold(float p) {
-  double t = static_cast<double>(p) * 4294967296.0;
+  double t = static_cast<double>(p) * 65536.0;
   if (t < 0) t = 0;
-  if (t > 4294967295.0) t = 4294967295.0;
+  if (t > 65535.0) t = 65535.0;
   return static_cast<uint32_t>(t);
 }
 

@@ -42,11 +42,12 @@ __global__ __launch_bounds__(GATHER_THREADS) void gather_rows_vec4_kernel(
   for (int u = 0; u < GATHER_UNROLL; ++u) {
     if (!ok[u]) continue;
     if (do_drop) {
-      const uint64_t e0 = static_cast<uint64_t>(item[u]) * 4u;
-      v[u].x *= ebn_drop_mult(key, e0 + 0, thresh, scale);
-      v[u].y *= ebn_drop_mult(key, e0 + 1, thresh, scale);
-      v[u].z *= ebn_drop_mult(key, e0 + 2, thresh, scale);
-      v[u].w *= ebn_drop_mult(key, e0 + 3, thresh, scale);
+      const uint64_t pair0 = static_cast<uint64_t>(item[u]) * 2u;  // elements 4*item .. 4*item+3 = pairs 2*item, 2*item+1
+      const uint32_t h0 = ebn_dropout_pair_hash(key, pair0), h1 = ebn_dropout_pair_hash(key, pair0 + 1);
+      v[u].x = ((h0 & 0xFFFFu) >= thresh) ? v[u].x * scale : 0.f;
+      v[u].y = ((h0 >> 16) >= thresh) ? v[u].y * scale : 0.f;
+      v[u].z = ((h1 & 0xFFFFu) >= thresh) ? v[u].z * scale : 0.f;
+      v[u].w = ((h1 >> 16) >= thresh) ? v[u].w * scale : 0.f;
     }
     out[item[u]] = v[u];
   }

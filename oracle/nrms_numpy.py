@@ -60,18 +60,21 @@ def dropout_key(seed: int, step: int, site: int) -> int:
 
 
 def dropout_threshold(p: float) -> int:
-    return int(min(max(int(p * 4294967296.0), 0), 4294967295))
+    """16-bit threshold: an element is dropped iff its 16-bit hash half is < threshold (probability t/65536)."""
+    return int(min(max(int(p * 65536.0), 0), 65535))
 
 
 def dropout_keep_mask(key: int, n_elem: int, p: float, start: int = 0) -> np.ndarray:
-    """keep[i] for flat element index start+i; an element is dropped with prob p."""
+    """keep[i] for flat element index start+i.  One lowbias32 hash decides two consecutive elements: element idx
+    uses the low (even idx) / high (odd idx) 16 bits of lowbias32(pair ^ key ^ pair_hi * 0x27D4EB2F), pair = idx >> 1."""
     idx = np.arange(start, start + n_elem, dtype=np.uint64)
-    lo = (idx & np.uint64(0xFFFFFFFF)).astype(np.uint32)
-    hi = (idx >> np.uint64(32)).astype(np.uint32)
+    pair = idx >> np.uint64(1)
+    lo = (pair & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    hi = (pair >> np.uint64(32)).astype(np.uint32)
     with np.errstate(over="ignore"):
-        h = lowbias32(lo ^ _U32(key))
-        h = lowbias32(h + hi * _U32(0x27D4EB2F) + _U32(0x165667B1))
-    return h >= _U32(dropout_threshold(p))
+        h = lowbias32(lo ^ _U32(key) ^ (hi * _U32(0x27D4EB2F)))
+    half = np.where((idx & np.uint64(1)).astype(bool), h >> _U32(16), h & _U32(0xFFFF))
+    return half >= _U32(dropout_threshold(p))
 
 
 def dropout_apply(x: np.ndarray, key: int, p: float):

@@ -58,12 +58,12 @@ def test_known_hash_values_pin_the_dropout_stream():
     """Fixed points of the counter-based stream shared with csrc/ebn_common.h."""
     assert [int(x) for x in on.lowbias32(np.arange(4, dtype=np.uint32))] == [0, 1753845952, 3507691905, 1408362973]
     assert on.dropout_key(42, 3, 0) == 1591691161 and on.dropout_key(0, 1, 1) == 1901086856
-    assert on.dropout_threshold(0.2) == 858993459 and on.dropout_threshold(0.0) == 0 and on.dropout_threshold(1.0) == 4294967295
+    assert on.dropout_threshold(0.2) == 13107 and on.dropout_threshold(0.0) == 0 and on.dropout_threshold(1.0) == 65535
     k = on.dropout_key(42, 3, 0)
     assert k == on.dropout_key(42, 3, 0) and k != on.dropout_key(42, 3, 1) and k != on.dropout_key(42, 4, 0)
     keep = on.dropout_keep_mask(k, 200000, 0.2)
     assert abs(keep.mean() - 0.8) < 0.005
-    big = on.dropout_keep_mask(k, 8, 0.5, start=2 ** 32 - 4)  # crosses the 32-bit index boundary
+    big = on.dropout_keep_mask(k, 8, 0.5, start=2 ** 33 - 4)  # crosses the 32-bit pair-index boundary
     assert big.shape == (8,)
 
 
