@@ -22,6 +22,7 @@ Extra objects on the JSON line:
 from __future__ import annotations
 
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -205,6 +206,7 @@ def main():
         if world > 1:
             dist.destroy_process_group()
         return
+    from ebrec import _hip
     from ebrec.models.newsrec import NRMSModel
 
     rng = np.random.default_rng(42)  # identical weights on every rank (data-parallel replicas)
@@ -244,6 +246,9 @@ def main():
         n_tok = c["B"] * (c["H"] + c["C"]) * c["T"]
         E = c["h"] * c["d"]
         gemm_flops = 2.0 * n_tok * c["D"] * 3 * E
+        bm, bn, sp = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        _hip.call("ebn_gemm_plan", n_tok, 3 * E, c["D"], 0, ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(sp))
+        gemm_name = f"gemm_f32_kernel<{bm.value}, {bn.value}, {4 if bm.value == 256 else 2}, false, false, true, 1>"
         gather_bytes = n_tok * (4 + 2 * c["D"] * 4)  # id + row read + row write (materialising gather)
         traffic = {}
         tf = ROOT / "profiles" / "traffic.json"
@@ -260,7 +265,7 @@ def main():
                                    f"att_hidden={c['A']} dropout=0.2 adam lr=1e-4 CE loss",
                        "global_batch": world * c["B"], "per_gpu_batch": c["B"], "parallelism": f"dp{world}",
                        "final_loss": loss},
-            "roofline": {"kernel": "gemm_f32_kernel<128, 128, false, false, true, 1> (news-encoder Q|K|V projection, fwd)", "bound": "mfma",
+            "roofline": {"kernel": gemm_name + " (news-encoder Q|K|V projection, fwd)", "bound": "mfma",
                          "achieved": gemm_flops / kt["qkv_gemm"] / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": gemm_flops / kt["qkv_gemm"] / 1e12 / MFMA_F32_PEAK_TFLOPS,
                          "traffic": traffic.get("qkv_gemm"), "avg_launch_us": kt["qkv_gemm"] * 1e6,

@@ -5,12 +5,15 @@
 //
 // MFMA-bound (v_mfma_f32_32x32x2_f32: 64 cycles / 4096 FLOP per SIMD -> 157 TFLOP/s chip
 // peak, bitwise an fp32 fma chain -> keeps the 1e-4 parity budget of north_star).
-// Block tile BM x BN x 16, 4 waves as 2x2, each wave (BM/2)x(BN/2) in 32x32 MFMA tiles.
+// Block tile BM x BN x 16 (128x128 or 64x64 with the 4 waves as 2x2; 256x64 with the waves stacked 4x1), each wave
+// owning its share in 32x32 MFMA tiles.
 // Operands are staged k-major in LDS ([k][m] / [k][n], +4 pad) so that the MFMA operand
 // fetch (lane l: A[i=l&31][k=l>>5]) is a conflict-free ds_read_b32; the next K-slab is
 // prefetched into registers while the current one is multiplied (2 LDS buffers, one
 // barrier per slab).  Skinny outputs (weight gradients: M,N ~ 1e3, K ~ 2e4) use split-K with
 // deterministic slab partials in the caller's workspace -- never atomics.
+#include <stdlib.h>
+
 #include "ebn_common.h"
 
 namespace {
@@ -24,6 +27,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BK = 16;
 constexpr int PAD = 4;
 constexpr int GEMM_THREADS = 256;
+#ifndef EBN_GEMM_TALL_PENALTY
+#define EBN_GEMM_TALL_PENALTY 1.02  // measured on exact-turn shapes: profiles/r01_gemm_tuning.md
+#endif
 
 // One operand tile of R_MN x BK (mn = m or n index). KCONTIG: memory is [mn][k] (k fastest);
 // else memory is [k][mn] (mn fastest).
@@ -98,13 +104,16 @@ struct TileLoader {
 // Cpart + z*M*N (dense ld = N) and a reduce kernel finishes; else writes C directly.
 // SITE only labels the instantiation (0 = generic, 1 = the encoders' Q|K|V projection) so that per-kernel profiler
 // summaries separate the roofline kernel of bench.py from the other GEMM call sites of the same shape class.
-template <int BM, int BN, bool TA, bool TB, bool VEC, int SITE>
+template <int BM, int BN, int WAVES_M, bool TA, bool TB, bool VEC, int SITE>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
     int64_t M, int64_t N, int64_t K, float alpha, const float* __restrict__ A, int64_t lda,
     const float* __restrict__ B, int64_t ldb, float beta, float* __restrict__ C, int64_t ldc,
     int64_t k_per_split, float* __restrict__ Cpart) {
-  constexpr int TM = BM / 64;  // 32x32 tiles per wave along m
-  constexpr int TN = BN / 64;
+  constexpr int WAVES_N = 4 / WAVES_M;    // the 4 waves form a WAVES_M x WAVES_N grid over the block tile
+  constexpr int WTM = BM / WAVES_M;       // rows / columns owned by one wave
+  constexpr int WTN = BN / WAVES_N;
+  constexpr int TM = WTM / 32;            // 32x32 MFMA tiles per wave along m / n
+  constexpr int TN = WTN / 32;
   constexpr int LDA_S = BM + PAD;
   constexpr int LDB_S = BN + PAD;
   using LA = TileLoader<BM, !TA, VEC>;
@@ -116,8 +125,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wm = wave >> 1;
-  const int wn = wave & 1;
+  const int wm = wave / WAVES_N;
+  const int wn = wave % WAVES_N;
   // XCD-aware tile order: hardware deals consecutive workgroups round-robin to the 8 XCDs (private
   // L2s); remap so that each XCD walks a CONTIGUOUS run of tiles (neighbouring tiles share their A
   // row-panel / B column-panel in one L2).  Bijective for any grid size; speed only, never correctness.
@@ -179,8 +188,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + 1 < nk) EBN_LOAD_SLAB(kt + 1);  // next slab into registers while this one is multiplied
-    const float* as = As[cur] + kl * LDA_S + wm * (BM / 2) + il;
-    const float* bs = Bs[cur] + kl * LDB_S + wn * (BN / 2) + il;
+    const float* as = As[cur] + kl * LDA_S + wm * WTM + il;
+    const float* bs = Bs[cur] + kl * LDB_S + wn * WTN + il;
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
       float a[TM], b[TN];
@@ -209,11 +218,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int64_t col = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+      const int64_t col = n0 + wn * WTN + j * 32 + (lane & 31);
       if (col >= N) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int64_t row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int64_t row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (row >= M) continue;
         float v = alpha * acc[i][j][r];
         if (!split && beta != 0.f) v += beta * out[row * ldo + col];
@@ -238,7 +247,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int WAVES_M>
 int launch_gemm(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha, const float* A,
                 int64_t lda, const float* B, int64_t ldb, float beta, float* C, int64_t ldc, int vecA,
                 int vecB, int splits, int64_t k_per_split, float* part, hipStream_t s, int site) {
@@ -248,14 +257,14 @@ int launch_gemm(int transA, int transB, int64_t M, int64_t N, int64_t K, float a
 #define EBN_GEMM_LAUNCH(TA, TB)                                                                            \
   do {                                                                                                    \
     if (vecA && vecB)                                                                                     \
-      hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB, true, 0>), grid, block, 0, s, M, N, K, alpha, A, lda, \
+      hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WAVES_M, TA, TB, true, 0>), grid, block, 0, s, M, N, K, alpha, A, lda, \
                          B, ldb, beta, C, ldc, k_per_split, part);                                        \
     else                                                                                                  \
-      hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB, false, 0>), grid, block, 0, s, M, N, K, alpha, A,  \
+      hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WAVES_M, TA, TB, false, 0>), grid, block, 0, s, M, N, K, alpha, A,  \
                          lda, B, ldb, beta, C, ldc, k_per_split, part);                                   \
   } while (0)
   if (!transA && !transB && site == 1 && vecA && vecB)
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, false, true, 1>), grid, block, 0, s, M, N, K, alpha, A, lda, B,
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WAVES_M, false, false, true, 1>), grid, block, 0, s, M, N, K, alpha, A, lda, B,
                        ldb, beta, C, ldc, k_per_split, part);
   else if (!transA && !transB) EBN_GEMM_LAUNCH(false, false);
   else if (!transA && transB) EBN_GEMM_LAUNCH(false, true);
@@ -268,21 +277,18 @@ int launch_gemm(int transA, int transB, int64_t M, int64_t N, int64_t K, float a
 
 }  // namespace
 
-// Split-K plan shared by the workspace query and the launcher.
-static void gemm_plan(int64_t M, int64_t N, int64_t K, int64_t ws_floats, int* bm, int* splits,
-                      int64_t* k_per_split) {
-  int64_t max_split = K / (4 * BK);  // keep >= 4 slabs per split
-  if (max_split > 64) max_split = 64;
-  const int64_t max_by_ws = (M * N > 0) ? ws_floats / (M * N) : 0;
-  if (max_split > max_by_ws) max_split = max_by_ws;
-  if (max_split < 1) max_split = 1;
-  const int64_t tiles128 = ebn_ceil_div(M, 128) * ebn_ceil_div(N, 128);
-  // 128x128 tiles (2x the arithmetic intensity) whenever they can still fill 256 CUs x 2
-  *bm = (tiles128 * max_split >= 512) ? 128 : 64;
-  const int64_t tiles = ebn_ceil_div(M, *bm) * ebn_ceil_div(N, *bm);
-  // Workgroups are dealt round-robin to 256 CUs and all cost the same, so the launch takes ceil(n_wg/256) "turns":
-  // among the split factors that give the chip 2..8 workgroups per CU pick the one that wastes the least of its
-  // last turn (e.g. 80 tiles: 16 splits = exactly 5 turns, where 13 splits would idle 19 % of a 5th turn).
+// ---- planner ------------------------------------------------------------------------------------------------
+// Workgroups are dealt round-robin to 256 CUs and all cost the same, so a launch takes ceil(n_wg/256) "turns":
+// among the split factors that give the chip 2..8 workgroups per CU pick the one that wastes the least of its last
+// turn (e.g. 80 tiles: 16 splits = exactly 5 turns, where 13 splits would idle 19 % of a 5th turn).
+struct GemmPlan {
+  int bm, bn;
+  int splits;
+  int64_t kps;
+  double cost;  // turns x tile area x K-range x per-shape penalty, in MFMA work units
+};
+
+static void plan_splits(int64_t tiles, int64_t K, int64_t max_split, int* splits, int64_t* k_per_split) {
   int64_t s = 1;
   if (tiles < 512 && max_split > 1) {
     int64_t lo = ebn_ceil_div(512, tiles), hi = ebn_ceil_div(2048, tiles);
@@ -304,11 +310,55 @@ static void gemm_plan(int64_t M, int64_t N, int64_t K, int64_t ws_floats, int* b
   *k_per_split = kps;
 }
 
+// 256x64 tiles (4 waves stacked along m, each still 64x64): same per-wave MFMA loop as 128x128, 25 % more operand
+// traffic per MFMA, but a 64-column grain -- N = 1200 (the fused Q|K|V projection of head_num 20 x head_dim 20) pads to
+// 1216 instead of 1280, and M = 24000 gives 1786 workgroups = 6.98 turns instead of 1880 = 7.34.
+static int tall_tiles_mode() {
+  static const int mode = [] {
+    const char* e = getenv("EBN_GEMM_TALL");  // 0: never, 1: by cost (default), 2: whenever legal -- tuning only
+    return (e && e[0] >= '0' && e[0] <= '2') ? (e[0] - '0') : 1;
+  }();
+  return mode;
+}
+
+static GemmPlan gemm_plan(int64_t M, int64_t N, int64_t K, int64_t ws_floats) {
+  int64_t max_split = K / (4 * BK);  // keep >= 4 slabs per split
+  if (max_split > 64) max_split = 64;
+  const int64_t max_by_ws = (M * N > 0) ? ws_floats / (M * N) : 0;
+  if (max_split > max_by_ws) max_split = max_by_ws;
+  if (max_split < 1) max_split = 1;
+  GemmPlan p;
+  const int64_t tiles128 = ebn_ceil_div(M, 128) * ebn_ceil_div(N, 128);
+  // 128x128 tiles (2x the arithmetic intensity) whenever they can still fill 256 CUs x 2
+  p.bm = p.bn = (tiles128 * max_split >= 512) ? 128 : 64;
+  const int64_t tiles = ebn_ceil_div(M, p.bm) * ebn_ceil_div(N, p.bn);
+  plan_splits(tiles, K, max_split, &p.splits, &p.kps);
+  p.cost = static_cast<double>(ebn_ceil_div(tiles * p.splits, 256)) * p.bm * p.bn * static_cast<double>(p.kps);
+  if (p.bm == 128 && tall_tiles_mode() > 0 && M >= 256) {
+    GemmPlan q;
+    q.bm = 256;
+    q.bn = 64;
+    const int64_t t = ebn_ceil_div(M, 256) * ebn_ceil_div(N, 64);
+    plan_splits(t, K, max_split, &q.splits, &q.kps);
+    q.cost = static_cast<double>(ebn_ceil_div(t * q.splits, 256)) * 256.0 * 64.0 * static_cast<double>(q.kps) * EBN_GEMM_TALL_PENALTY;
+    if (q.cost < p.cost || tall_tiles_mode() == 2) p = q;
+  }
+  return p;
+}
+
 extern "C" int64_t ebn_gemm_workspace_floats(int64_t M, int64_t N, int64_t K) {
-  int bm, s;
-  int64_t kps;
-  gemm_plan(M, N, K, INT64_MAX / 4, &bm, &s, &kps);
-  return (s > 1) ? static_cast<int64_t>(s) * M * N : 0;
+  const GemmPlan p = gemm_plan(M, N, K, INT64_MAX / 4);
+  return (p.splits > 1) ? static_cast<int64_t>(p.splits) * M * N : 0;
+}
+
+extern "C" int ebn_gemm_plan(int64_t M, int64_t N, int64_t K, int64_t workspace_floats, int32_t* bm, int32_t* bn,
+                             int32_t* splits) {
+  EBN_REQUIRE(M >= 0 && N >= 0 && K >= 0 && bm && bn && splits, EBN_ERR_BAD_ARG);
+  const GemmPlan p = gemm_plan(M, N, K, workspace_floats);
+  *bm = p.bm;
+  *bn = p.bn;
+  *splits = p.splits;
+  return EBN_OK;
 }
 
 extern "C" int ebn_gemm_f32_site(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K, float alpha,
@@ -323,16 +373,19 @@ extern "C" int ebn_gemm_f32_site(int32_t transA, int32_t transB, int64_t M, int6
   // contiguous-axis extent must be a multiple of 4 too (K for k-contiguous operands, M/N otherwise)
   const int vecA = ((lda % 4) == 0 && ebn_aligned16(A) && ((transA ? M : K) % 4) == 0) ? 1 : 0;
   const int vecB = ((ldb % 4) == 0 && ebn_aligned16(B) && ((transB ? K : N) % 4) == 0) ? 1 : 0;
-  int bm, splits;
-  int64_t kps;
-  gemm_plan(M, N, K, workspace ? workspace_floats : 0, &bm, &splits, &kps);
+  const GemmPlan plan = gemm_plan(M, N, K, workspace ? workspace_floats : 0);
+  const int splits = plan.splits;
+  const int64_t kps = plan.kps;
   int rc;
-  if (bm == 128)
-    rc = launch_gemm<128, 128>(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, vecA, vecB,
-                               splits, kps, workspace, s, site);
+  if (plan.bm == 256)
+    rc = launch_gemm<256, 64, 4>(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, vecA, vecB, splits, kps,
+                                 workspace, s, site);
+  else if (plan.bm == 128)
+    rc = launch_gemm<128, 128, 2>(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, vecA, vecB, splits, kps,
+                                  workspace, s, site);
   else
-    rc = launch_gemm<64, 64>(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, vecA, vecB,
-                             splits, kps, workspace, s, site);
+    rc = launch_gemm<64, 64, 2>(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, vecA, vecB, splits, kps,
+                                workspace, s, site);
   if (rc != EBN_OK) return rc;
   if (splits > 1) {
     int64_t grid = ebn_ceil_div(M * N, 256);

@@ -101,6 +101,10 @@ int ebn_gemm_f32(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K
  * outputs (weight gradients: M,N ~ 1e3, K = all tokens of the batch).
  * ebn_gemm_workspace_floats() returns the size the planner can use for (M,N,K).        */
 int64_t ebn_gemm_workspace_floats(int64_t M, int64_t N, int64_t K);
+/* The plan the launcher will use for (M,N,K) with `workspace_floats` of scratch: block tile bm x bn (128x128, 64x64 or
+ * the tall 256x64 that removes column padding / last-turn idling, e.g. N = 1200) and the split-K factor.  Diagnostic:
+ * lets bench.py and profiler summaries name the kernel instantiation that runs.                                    */
+int ebn_gemm_plan(int64_t M, int64_t N, int64_t K, int64_t workspace_floats, int32_t* bm, int32_t* bn, int32_t* splits);
 int ebn_gemm_f32_ws(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K, float alpha,
                     const float* A, int64_t lda, const float* B, int64_t ldb, float beta, float* C,
                     int64_t ldc, float* workspace, int64_t workspace_floats, ebn_stream_t stream);

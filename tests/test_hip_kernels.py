@@ -95,7 +95,9 @@ def test_embedding_grad_scatter(hip, p):
 
 # ---------------------------------------------------------------- GEMM
 GEMM_SHAPES = [(1, 1, 1), (5, 7, 3), (64, 64, 16), (130, 70, 33), (257, 129, 300), (750, 1200, 300),
-               (640, 200, 400), (300, 1200, 2000), (96, 100, 4096), (1, 400, 400), (513, 5, 64)]
+               (640, 200, 400), (300, 1200, 2000), (96, 100, 4096), (1, 400, 400), (513, 5, 64),
+               # shapes whose plan picks the 256x64 tile family (ragged M and N, split-K)
+               (6000, 1200, 256), (5000, 300, 128), (1030, 1210, 3000)]
 
 
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
