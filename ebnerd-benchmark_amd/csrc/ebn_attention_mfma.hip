@@ -1,5 +1,10 @@
 // a3 / a6 fast path: the SelfAttention core (layers.py:231-252) for L <= 32, d in {16,20,32},
-// entirely on the matrix cores -- one 64-lane wave per (sequence, head), no LDS, no barriers.
+// entirely on the matrix cores -- one 64-lane wave per (sequence, head), no workgroup barriers.
+//
+// Memory side: the wave copies its L x d slices of Q, K, V (and dO) ONCE, as coalesced 16-byte loads, into a
+// wave-private LDS region (rows >= L zero-filled) and builds every MFMA operand form from there; results go back
+// through the same region and leave as coalesced 16-byte stores.  (Building the operand forms straight from global
+// memory touched every 128-byte line from 5-16 separate load instructions and thrashed the 32 KB vector L1.)
 //
 // Everything is a 32x32 exact-fp32 MFMA tile (v_mfma_f32_32x32x2_f32), zero-padded from L x L / L x d.
 // Two facts about that instruction drive the dataflow:
@@ -12,7 +17,7 @@
 // product contracts over the softmax-row index i, so P is needed with i on registers (S = QK^T:
 // lane j, regs i); the softmax statistics (max_j, sum_j) are cheapest with j on registers
 // (T = KQ^T: lane i, regs j -> in-lane reduction + one cross-half swap).  Both tiles are computed
-// (bitwise-consistent: same products, same order) and the per-row stats move between the two
+// (same products, same order) and the per-row statistic c_i = max_i + log2(Z_i) moves between the two
 // layouts with ds_bpermute (__shfl).  Forward = 10+10+16 MFMAs, backward = 88 MFMAs per problem:
 // ~15 / ~37 us for the 16,000 (title, head) problems of a batch-32 step, vs 216 / 1300 us for the
 // LDS/VALU kernel it replaces (profiles/r01_a_*).
@@ -38,31 +43,95 @@ struct MfmaAttnArgs {
 
 __device__ __forceinline__ int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
-// lane (row = lane&31, hi): x[s] = M[row][hi*KH + s]; zero rows >= L.  8-byte loads.
-template <int KH>
-__device__ __forceinline__ void load_row_form(float (&x)[KH], const float* __restrict__ base, int64_t ld,
-                                              int L, int row, int hi) {
-  if (row < L) {
-    const float2* p = reinterpret_cast<const float2*>(base + static_cast<int64_t>(row) * ld + hi * KH);
+// LDS row stride (floats): a multiple of 4 (16-byte rows) that is not a multiple of 16, so that the 32 rows a
+// row-form fetch touches spread over 8 bank groups.
+template <int D>
+struct Tile {
+  static constexpr int STRIDE = (D % 16 == 0) ? D + 4 : D;
+  static constexpr int FLOATS = 32 * STRIDE;
+  static constexpr int VPR = D / 4;  // float4 per row
+  static constexpr int VECS = 32 * VPR;
+  static constexpr int ROUNDS = (VECS + 63) / 64;
+};
+
+// orders this wave's LDS writes before its later LDS reads (and vice versa); no other wave touches the region
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// global M[L][D] (row stride ld) -> lds[32][STRIDE], rows >= L zero.  DROP: multiply by the dropout mask of
+// element index e0 + r*E + c (the mask the forward pass applied to the matching output element).
+template <int D, bool DROP>
+__device__ __forceinline__ void stage_in(float* __restrict__ lds, const float* __restrict__ base, int64_t ld, int L,
+                                         int lane, uint32_t key, uint64_t e0, int E, uint32_t thresh, float scale) {
+  using T = Tile<D>;
 #pragma unroll
-    for (int s = 0; s < KH / 2; ++s) {
-      const float2 v = p[s];
-      x[2 * s] = v.x;
-      x[2 * s + 1] = v.y;
+  for (int t = 0; t < T::ROUNDS; ++t) {
+    const int v = lane + 64 * t;
+    if (T::VECS % 64 != 0 && v >= T::VECS) break;
+    const int r = v / T::VPR, c4 = v - r * T::VPR;
+    const bool ok = r < L;
+    const float4 x = *reinterpret_cast<const float4*>(ok ? base + static_cast<int64_t>(r) * ld + c4 * 4 : base);
+    float4 y = ok ? x : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (DROP) {
+      const uint64_t e = e0 + static_cast<uint64_t>(r) * E + c4 * 4;  // multiple of 4: two aligned pairs
+      const uint32_t h0 = ebn_dropout_pair_hash(key, e >> 1), h1 = ebn_dropout_pair_hash(key, (e >> 1) + 1);
+      y.x *= ((h0 & 0xFFFFu) >= thresh) ? scale : 0.f;
+      y.y *= ((h0 >> 16) >= thresh) ? scale : 0.f;
+      y.z *= ((h1 & 0xFFFFu) >= thresh) ? scale : 0.f;
+      y.w *= ((h1 >> 16) >= thresh) ? scale : 0.f;
     }
-  } else {
-#pragma unroll
-    for (int s = 0; s < KH; ++s) x[s] = 0.f;
+    *reinterpret_cast<float4*>(lds + r * T::STRIDE + c4 * 4) = y;
   }
 }
 
-// lane (c = lane&31, hi): y[s] = M[crow(s,hi)][c]; zero when the row is >= L or c >= d.
-__device__ __forceinline__ void load_col_form(float (&y)[16], const float* __restrict__ base, int64_t ld,
-                                              int L, int d, int c, int hi) {
+// lds[32][STRIDE] -> global M[L][D], optionally through the dropout mask
+template <int D, bool DROP>
+__device__ __forceinline__ void stage_out(const float* __restrict__ lds, float* __restrict__ base, int64_t ld, int L,
+                                          int lane, uint32_t key, uint64_t e0, int E, uint32_t thresh, float scale) {
+  using T = Tile<D>;
+#pragma unroll
+  for (int t = 0; t < T::ROUNDS; ++t) {
+    const int v = lane + 64 * t;
+    if (T::VECS % 64 != 0 && v >= T::VECS) break;
+    const int r = v / T::VPR, c4 = v - r * T::VPR;
+    if (r >= L) continue;
+    float4 y = *reinterpret_cast<const float4*>(lds + r * T::STRIDE + c4 * 4);
+    if (DROP) {
+      const uint64_t e = e0 + static_cast<uint64_t>(r) * E + c4 * 4;
+      const uint32_t h0 = ebn_dropout_pair_hash(key, e >> 1), h1 = ebn_dropout_pair_hash(key, (e >> 1) + 1);
+      y.x *= ((h0 & 0xFFFFu) >= thresh) ? scale : 0.f;
+      y.y *= ((h0 >> 16) >= thresh) ? scale : 0.f;
+      y.z *= ((h1 & 0xFFFFu) >= thresh) ? scale : 0.f;
+      y.w *= ((h1 >> 16) >= thresh) ? scale : 0.f;
+    }
+    *reinterpret_cast<float4*>(base + static_cast<int64_t>(r) * ld + c4 * 4) = y;
+  }
+}
+
+// lane (row = lane&31, hi): x[s] = M[row][hi*KH + s].  8-byte LDS reads.
+template <int D>
+__device__ __forceinline__ void lds_row_form(float (&x)[D / 2], const float* __restrict__ lds, int row, int hi) {
+  constexpr int KH = D / 2;
+  const float2* p = reinterpret_cast<const float2*>(lds + row * Tile<D>::STRIDE + hi * KH);
+#pragma unroll
+  for (int s = 0; s < KH / 2; ++s) {
+    const float2 v = p[s];
+    x[2 * s] = v.x;
+    x[2 * s + 1] = v.y;
+  }
+}
+
+// lane (c = lane&31, hi): y[s] = M[crow(s,hi)][c]; zero for c >= D.
+template <int D>
+__device__ __forceinline__ void lds_col_form(float (&y)[16], const float* __restrict__ lds, int c, int hi) {
+  const int cc = (c < D) ? c : 0;
 #pragma unroll
   for (int s = 0; s < 16; ++s) {
-    const int row = crow(s, hi);
-    y[s] = (row < L && c < d) ? base[static_cast<int64_t>(row) * ld + c] : 0.f;
+    const float v = lds[crow(s, hi) * Tile<D>::STRIDE + cc];
+    y[s] = (c < D) ? v : 0.f;
   }
 }
 
@@ -86,59 +155,77 @@ __device__ __forceinline__ f32x16 mm_col_tile(const float (&a)[16], const f32x16
   return acc;
 }
 
-// store a result tile whose lane owns row `row` and registers own columns crow(r,hi): float4 groups
+// result tile whose lane owns row `row` and whose registers own columns crow(r,hi) -> lds[row][c], float4 groups
 template <int D>
-__device__ __forceinline__ void store_tile_rows(float* __restrict__ dst, const f32x16& acc, int hi, float mul) {
+__device__ __forceinline__ void tile_rows_to_lds(float* __restrict__ lds, const f32x16& acc, int row, int hi, float mul) {
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const int c0 = 8 * g + 4 * hi;
     if (c0 < D) {
       float4 v = make_float4(acc[4 * g] * mul, acc[4 * g + 1] * mul, acc[4 * g + 2] * mul, acc[4 * g + 3] * mul);
-      *reinterpret_cast<float4*>(dst + c0) = v;
+      *reinterpret_cast<float4*>(lds + row * Tile<D>::STRIDE + c0) = v;
     }
   }
 }
 
-// softmax statistics of row i held by lane i (both halves end with the same values):
-// t[r] = T[j=crow(r,hi)][i] * inv.  Returns m and 1/Z; turns t into P_ij (zero for j >= L).
-__device__ __forceinline__ void softmax_in_lane(f32x16& t, int L, int hi, float inv, float& m, float& invz) {
-  m = -INFINITY;
+// Softmax in the exp2 domain: `inv2` = log2(e)/sqrt(d), so exp(x/sqrt(d) - max) = exp2(x*inv2 - max2) and one
+// v_exp_f32 per element replaces the ~20-instruction expf expansion (the softmax of 2 x 32 x 32 scores was the VALU
+// bottleneck of these kernels).  Arguments are <= 0, flush-to-zero below 2^-126 is the correct limit.
+//
+// Statistics of row i, held by lane i (both halves end with the same values): t[r] = T[j=crow(r,hi)][i].
+// Returns c = max2 + log2(Z), so that P_ij = exp2(t_ij*inv2 - c) in either layout; turns t into P_ij (zero for j >= L).
+__device__ __forceinline__ float softmax_in_lane(f32x16& t, int L, int hi, float inv2) {
+  float m = -INFINITY;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    t[r] *= inv;
+    t[r] *= inv2;
     if (crow(r, hi) < L) m = fmaxf(m, t[r]);
   }
   m = fmaxf(m, __shfl_xor(m, 32, 64));
   float z = 0.f;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const float e = (crow(r, hi) < L) ? expf(t[r] - m) : 0.f;
-    t[r] = e;
-    z += e;
-  }
+  for (int r = 0; r < 16; ++r) z += (crow(r, hi) < L) ? __builtin_amdgcn_exp2f(t[r] - m) : 0.f;
   z += __shfl_xor(z, 32, 64);
-  invz = 1.0f / z;
+  const float c = m + __builtin_amdgcn_logf(z);  // v_log_f32 = log2; z in [1, 32]
 #pragma unroll
-  for (int r = 0; r < 16; ++r) t[r] *= invz;
+  for (int r = 0; r < 16; ++r) t[r] = (crow(r, hi) < L) ? __builtin_amdgcn_exp2f(t[r] - c) : 0.f;
+  return c;
 }
 
-// s[r] = S[i=crow(r,hi)][j] -> P_ji using the stats of row i fetched from lane i
-__device__ __forceinline__ void softmax_from_stats(f32x16& s, int L, int hi, float inv, float m, float invz) {
+// s[r] = S[i=crow(r,hi)][j] -> P_ij using c_i fetched from lane i
+__device__ __forceinline__ void softmax_from_stats(f32x16& s, int L, int hi, float inv2, float c) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int i = crow(r, hi);
-    const float mi = __shfl(m, i, 64);
-    const float zi = __shfl(invz, i, 64);
-    s[r] = (i < L) ? expf(s[r] * inv - mi) * zi : 0.f;
+    const float ci = __shfl(c, i, 64);
+    s[r] = (i < L) ? __builtin_amdgcn_exp2f(s[r] * inv2 - ci) : 0.f;
   }
+}
+
+// forward only needs the statistics from the T layout
+__device__ __forceinline__ float softmax_stats_only(const f32x16& t, int L, int hi, float inv2) {
+  float m = -INFINITY;
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    if (crow(r, hi) < L) m = fmaxf(m, t[r] * inv2);
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  float z = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) z += (crow(r, hi) < L) ? __builtin_amdgcn_exp2f(t[r] * inv2 - m) : 0.f;
+  z += __shfl_xor(z, 32, 64);
+  return m + __builtin_amdgcn_logf(z);
 }
 
 template <int D>
 __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(MfmaAttnArgs a) {
-  constexpr int KH = D / 2;
+  using T = Tile<D>;
+  __shared__ __attribute__((aligned(16))) float smem[4][3 * T::FLOATS];
   const int lane = threadIdx.x & 63;
   const int64_t prob = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
-  if (prob >= a.n_prob) return;  // wave-uniform; no barriers in this kernel
+  if (prob >= a.n_prob) return;  // wave-uniform; no workgroup barriers in this kernel
+  float* sq = smem[threadIdx.x >> 6];
+  float* sk = sq + T::FLOATS;
+  float* sv = sk + T::FLOATS;
   const int row = lane & 31, hi = lane >> 5;
   const int L = a.L, E = a.h * D;
   const int64_t seq = prob / a.h;
@@ -147,40 +234,44 @@ __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(MfmaAttnArgs a) {
   const float* qb = a.qkv + row0 * a.ld_qkv + head * D;
   const float inv = 1.0f / sqrtf(static_cast<float>(D));
 
-  float qr[KH], kr[KH];
-  load_row_form<KH>(qr, qb, a.ld_qkv, L, row, hi);
-  load_row_form<KH>(kr, qb + E, a.ld_qkv, L, row, hi);
-  float vc[16];
-  load_col_form(vc, qb + 2 * E, a.ld_qkv, L, D, row, hi);
+  stage_in<D, false>(sq, qb, a.ld_qkv, L, lane, 0u, 0u, 0, 0u, 0.f);
+  stage_in<D, false>(sk, qb + E, a.ld_qkv, L, lane, 0u, 0u, 0, 0u, 0.f);
+  stage_in<D, false>(sv, qb + 2 * E, a.ld_qkv, L, lane, 0u, 0u, 0, 0u, 0.f);
+  wave_lds_sync();
 
-  f32x16 T = mm_rows<KH>(kr, qr);  // T[j][i]: lane i, regs j
-  f32x16 S = mm_rows<KH>(qr, kr);  // S[i][j]: lane j, regs i
-  float m, invz;
-  softmax_in_lane(T, L, hi, inv, m, invz);
-  softmax_from_stats(S, L, hi, inv, m, invz);  // P[i][j]: lane j, regs i
+  float qr[D / 2], kr[D / 2];
+  lds_row_form<D>(qr, sq, row, hi);
+  lds_row_form<D>(kr, sk, row, hi);
+  float vc[16];
+  lds_col_form<D>(vc, sv, row, hi);
+
+  f32x16 Tt = mm_rows<D / 2>(kr, qr);  // T[j][i]: lane i, regs j
+  f32x16 S = mm_rows<D / 2>(qr, kr);   // S[i][j]: lane j, regs i
+  const float c = softmax_stats_only(Tt, L, hi, inv * 1.44269504088896341f);
+  softmax_from_stats(S, L, hi, inv * 1.44269504088896341f, c);  // P[i][j]: lane j, regs i
   const f32x16 O = mm_col_tile(vc, S);         // O^T[c][j]: lane j, regs c
 
-  if (row < L) {
-    f32x16 o = O;
-    if (a.key_ptr != nullptr) {
-      const uint32_t key = *a.key_ptr;
-      const uint64_t e0 = static_cast<uint64_t>(row0 + row) * E + head * D;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int c = crow(r, hi);
-        if (c < D) o[r] *= ebn_drop_mult(key, e0 + c, a.thresh, a.scale);
-      }
-    }
-    store_tile_rows<D>(a.out + (row0 + row) * a.ld_out + head * D, o, hi, 1.0f);
-  }
+  wave_lds_sync();  // every operand read of sq is done: reuse it for the output rows
+  tile_rows_to_lds<D>(sq, O, row, hi, 1.0f);
+  wave_lds_sync();
+  float* ob = a.out + row0 * a.ld_out + head * D;
+  const uint64_t e0 = static_cast<uint64_t>(row0) * E + head * D;
+  if (a.key_ptr != nullptr) stage_out<D, true>(sq, ob, a.ld_out, L, lane, *a.key_ptr, e0, E, a.thresh, a.scale);
+  else stage_out<D, false>(sq, ob, a.ld_out, L, lane, 0u, 0u, 0, 0u, 0.f);
 }
 
 template <int D>
 __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(MfmaAttnArgs a) {
+  using T = Tile<D>;
   constexpr int KH = D / 2;
+  __shared__ __attribute__((aligned(16))) float smem[4][4 * T::FLOATS];
   const int lane = threadIdx.x & 63;
   const int64_t prob = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
   if (prob >= a.n_prob) return;
+  float* sq = smem[threadIdx.x >> 6];
+  float* sk = sq + T::FLOATS;
+  float* sv = sk + T::FLOATS;  // V, then the staging buffer of the three result tiles
+  float* sg = sv + T::FLOATS;  // dO with the forward dropout mask applied
   const int row = lane & 31, hi = lane >> 5;
   const int L = a.L, E = a.h * D;
   const int64_t seq = prob / a.h;
@@ -189,48 +280,50 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(MfmaAttnArgs a) {
   const float* qb = a.qkv + row0 * a.ld_qkv + head * D;
   const float* gb = a.dout + row0 * a.ld_dout + head * D;
   const float inv = 1.0f / sqrtf(static_cast<float>(D));
-  const bool do_drop = a.key_ptr != nullptr;
-  const uint32_t key = do_drop ? *a.key_ptr : 0u;
 
-  float qr[KH], kr[KH], vr[KH], gr[KH];
-  load_row_form<KH>(qr, qb, a.ld_qkv, L, row, hi);
-  load_row_form<KH>(kr, qb + E, a.ld_qkv, L, row, hi);
-  load_row_form<KH>(vr, qb + 2 * E, a.ld_qkv, L, row, hi);
-  load_row_form<KH>(gr, gb, a.ld_dout, L, row, hi);
-  if (do_drop && row < L) {
-    const uint64_t e0 = static_cast<uint64_t>(row0 + row) * E + head * D + hi * KH;
-#pragma unroll
-    for (int s = 0; s < KH; ++s) gr[s] *= ebn_drop_mult(key, e0 + s, a.thresh, a.scale);
+  stage_in<D, false>(sq, qb, a.ld_qkv, L, lane, 0u, 0u, 0, 0u, 0.f);
+  stage_in<D, false>(sk, qb + E, a.ld_qkv, L, lane, 0u, 0u, 0, 0u, 0.f);
+  stage_in<D, false>(sv, qb + 2 * E, a.ld_qkv, L, lane, 0u, 0u, 0, 0u, 0.f);
+  if (a.key_ptr != nullptr)
+    stage_in<D, true>(sg, gb, a.ld_dout, L, lane, *a.key_ptr, static_cast<uint64_t>(row0) * E + head * D, E, a.thresh, a.scale);
+  else
+    stage_in<D, false>(sg, gb, a.ld_dout, L, lane, 0u, 0u, 0, 0u, 0.f);
+  wave_lds_sync();
+
+  f32x16 Pij, Pji;
+  {
+    float qr[KH], kr[KH];
+    lds_row_form<D>(qr, sq, row, hi);
+    lds_row_form<D>(kr, sk, row, hi);
+    Pij = mm_rows<KH>(kr, qr);  // T[j][i]: lane i, regs j
+    Pji = mm_rows<KH>(qr, kr);  // S[i][j]: lane j, regs i
   }
+  const float c = softmax_in_lane(Pij, L, hi, inv * 1.44269504088896341f);
+  softmax_from_stats(Pji, L, hi, inv * 1.44269504088896341f, c);
 
-  f32x16 Pij = mm_rows<KH>(kr, qr);  // T[j][i]: lane i, regs j
-  f32x16 Pji = mm_rows<KH>(qr, kr);  // S[i][j]: lane j, regs i
-  float m, invz;
-  softmax_in_lane(Pij, L, hi, inv, m, invz);
-  softmax_from_stats(Pji, L, hi, inv, m, invz);
-
-  f32x16 dPij = mm_rows<KH>(gr, vr);  // dP[i][j] = V[i].dO[j]: lane i, regs j
-  f32x16 dPji = mm_rows<KH>(vr, gr);  // lane j, regs i
+  f32x16 dPij, dPji;
+  {
+    float vr[KH], gr[KH];
+    lds_row_form<D>(vr, sv, row, hi);
+    lds_row_form<D>(gr, sg, row, hi);
+    dPij = mm_rows<KH>(gr, vr);  // dP[i][j] = V[i].dO[j]: lane i, regs j
+    dPji = mm_rows<KH>(vr, gr);  // lane j, regs i
+  }
   float rowdot = 0.f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) rowdot = fmaf(Pij[r], dPij[r], rowdot);
   rowdot += __shfl_xor(rowdot, 32, 64);  // sum_j P[i][j] dP[i][j] for i = lane&31
 
-  // dV^T[c][i] = sum_j dO[j][c] P[i][j]
-  float col[16];
-  load_col_form(col, gb, a.ld_dout, L, D, row, hi);
-  if (do_drop) {
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      const int j = crow(s, hi);
-      if (j < L && row < D)
-        col[s] *= ebn_drop_mult(key, static_cast<uint64_t>(row0 + j) * E + head * D + row, a.thresh, a.scale);
-    }
-  }
   float* ob = a.out + row0 * a.ld_out + head * D;
+  float col[16];
+  // dV^T[c][i] = sum_j dO[j][c] P[i][j]
+  lds_col_form<D>(col, sg, row, hi);
   {
     const f32x16 dV = mm_col_tile(col, Pij);
-    if (row < L) store_tile_rows<D>(ob + static_cast<int64_t>(row) * a.ld_out + 2 * E, dV, hi, 1.0f);
+    wave_lds_sync();  // the row-form reads of sv are done
+    tile_rows_to_lds<D>(sv, dV, row, hi, 1.0f);
+    wave_lds_sync();
+    stage_out<D, false>(sv, ob + 2 * E, a.ld_out, L, lane, 0u, 0u, 0, 0u, 0.f);
   }
   // dS in both layouts
 #pragma unroll
@@ -240,16 +333,22 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(MfmaAttnArgs a) {
     Pji[r] = Pji[r] * (dPji[r] - rd);  // dS[i][j]: lane j, regs i
   }
   // dQ^T[c][i] = inv * sum_j K[j][c] dS[i][j]
-  load_col_form(col, qb + E, a.ld_qkv, L, D, row, hi);
+  lds_col_form<D>(col, sk, row, hi);
   {
     const f32x16 dQ = mm_col_tile(col, Pij);
-    if (row < L) store_tile_rows<D>(ob + static_cast<int64_t>(row) * a.ld_out, dQ, hi, inv);
+    wave_lds_sync();
+    tile_rows_to_lds<D>(sv, dQ, row, hi, inv);
+    wave_lds_sync();
+    stage_out<D, false>(sv, ob, a.ld_out, L, lane, 0u, 0u, 0, 0u, 0.f);
   }
   // dK^T[c][j] = inv * sum_i Q[i][c] dS[i][j]
-  load_col_form(col, qb, a.ld_qkv, L, D, row, hi);
+  lds_col_form<D>(col, sq, row, hi);
   {
     const f32x16 dK = mm_col_tile(col, Pji);
-    if (row < L) store_tile_rows<D>(ob + static_cast<int64_t>(row) * a.ld_out + E, dK, hi, inv);
+    wave_lds_sync();
+    tile_rows_to_lds<D>(sv, dK, row, hi, inv);
+    wave_lds_sync();
+    stage_out<D, false>(sv, ob + E, a.ld_out, L, lane, 0u, 0u, 0, 0u, 0.f);
   }
 }
 
