@@ -6,16 +6,16 @@
 
 namespace {
 
-// one wave per impression b
-__global__ __launch_bounds__(64) void score_fwd_kernel(const float* __restrict__ cand,
+// one 4-wave workgroup per impression b: the waves take candidates round-robin, wave 0 finishes the activation
+__global__ __launch_bounds__(256) void score_fwd_kernel(const float* __restrict__ cand,
                                                        const float* __restrict__ user,
                                                        float* __restrict__ scores, float* __restrict__ probs,
                                                        int C, int E, int mode) {
   extern __shared__ float sm[];  // C scores
   const int64_t b = blockIdx.x;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float* u = user + b * E;
-  for (int c = 0; c < C; ++c) {
+  for (int c = wave; c < C; c += 4) {
     const float* x = cand + (b * C + c) * E;
     float part = 0.f;
     for (int e = lane; e < E; e += 64) part = fmaf(x[e], u[e], part);
@@ -23,6 +23,7 @@ __global__ __launch_bounds__(64) void score_fwd_kernel(const float* __restrict__
     if (lane == 0) sm[c] = part;
   }
   __syncthreads();
+  if (wave != 0) return;
   if (mode == 1) {  // sigmoid (scorer model, nrms.py:205)
     for (int c = lane; c < C; c += 64) {
       const float s = sm[c];
@@ -214,7 +215,7 @@ extern "C" int ebn_score_fwd_f32(const float* cand, const float* user, float* sc
   EBN_REQUIRE(B >= 0 && C > 0 && E > 0, EBN_ERR_BAD_ARG);
   EBN_REQUIRE(C <= 8192, EBN_ERR_UNSUPPORTED);
   if (B == 0) return EBN_OK;
-  hipLaunchKernelGGL(score_fwd_kernel, dim3(static_cast<unsigned>(B)), dim3(64), C * sizeof(float),
+  hipLaunchKernelGGL(score_fwd_kernel, dim3(static_cast<unsigned>(B)), dim3(256), C * sizeof(float),
                      ebn_stream(stream), cand, user, scores, probs, C, E, mode);
   EBN_CHECK_LAUNCH();
   return EBN_OK;
