@@ -80,6 +80,7 @@ __global__ __launch_bounds__(POOL_THREADS) void attpool_bwd_pool_kernel(const fl
     s = ebn_wave_sum(s);
     for (int l = lane; l < L; l += 64) de[n * L + l] = w[n * L + l] * (sm[l] - s);
   }
+  if (dX == nullptr) return;
   for (int l = 0; l < L; ++l) {
     const float wl = w[n * L + l];
     float* dr = dX + (n * L + l) * E;
@@ -303,14 +304,14 @@ extern "C" int ebn_attpool_fwd_f32(float* U, const float* b, const float* q, con
 extern "C" int ebn_attpool_bwd_pool_f32(const float* X, const float* w, const float* dout, float* dX,
                                         float* de, int64_t n_seq, int32_t L, int32_t E,
                                         ebn_stream_t stream) {
-  EBN_REQUIRE(X && w && dout && dX && de, EBN_ERR_BAD_ARG);
+  EBN_REQUIRE(X && w && dout && de, EBN_ERR_BAD_ARG);
   EBN_REQUIRE(n_seq >= 0 && L > 0 && E > 0, EBN_ERR_BAD_ARG);
   EBN_REQUIRE(L <= 8192, EBN_ERR_UNSUPPORTED);
   if (n_seq == 0) return EBN_OK;
-  const bool vec = (E % 4 == 0) && E <= 1024 && ebn_aligned16(X) && ebn_aligned16(dout) && ebn_aligned16(dX);
+  const bool vec = (E % 4 == 0) && E <= 1024 && ebn_aligned16(X) && ebn_aligned16(dout) && ebn_aligned16(dX);  // NULL is aligned
   if (vec)
     hipLaunchKernelGGL(attpool_bwd_pool_vec_kernel, dim3(static_cast<unsigned>(n_seq)), dim3(POOL_THREADS),
-                       L * sizeof(float), ebn_stream(stream), X, w, dout, dX, de, L, E, 1);
+                       L * sizeof(float), ebn_stream(stream), X, w, dout, dX, de, L, E, dX != nullptr ? 1 : 0);
   else
     hipLaunchKernelGGL(attpool_bwd_pool_kernel, dim3(static_cast<unsigned>(n_seq)), dim3(POOL_THREADS),
                        L * sizeof(float), ebn_stream(stream), X, w, dout, dX, de, L, E);

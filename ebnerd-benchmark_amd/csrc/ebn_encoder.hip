@@ -54,12 +54,13 @@ extern "C" int ebn_encoder_bwd_f32(const ebn_encoder_dims* dims, const ebn_encod
   const int A = dims->A;
   if (R == 0) return EBN_OK;
   const float beta = accumulate ? 1.0f : 0.0f;
-  // AttLayer2 backward: dY = w*dout, de; then dq, db and U <- d(pre-tanh)
-  EBN_TRY(ebn_attpool_bwd_pool_f32(a->Y, a->w, dout, s->dY, s->de, dims->n_seq, dims->L, E, stream));
+  // AttLayer2 backward: de; then dq, db and U <- d(pre-tanh)
+  EBN_TRY(ebn_attpool_bwd_pool_f32(a->Y, a->w, dout, nullptr, s->de, dims->n_seq, dims->L, E, stream));
   EBN_TRY(ebn_attpool_bwd_dpre_f32(a->U, p->q, s->de, g->dq, g->db, s->partials, R, A, accumulate, stream));
-  // dW = Y^T . dpre ; dY += dpre . W^T
+  // dW = Y^T . dpre ; dY = dpre . W^T + w (x) dout
   EBN_TRY(ebn_gemm_f32_ws(1, 0, E, A, R, 1.0f, a->Y, E, a->U, A, beta, g->dW, A, s->gemm_ws, s->gemm_ws_floats, stream));
-  EBN_TRY(ebn_gemm_f32_ws(0, 1, R, E, A, 1.0f, a->U, A, p->W, A, 1.0f, s->dY, E, s->gemm_ws, s->gemm_ws_floats, stream));
+  EBN_TRY(ebn_gemm_f32_rank1(R, E, A, 1.0f, a->U, A, p->W, A, s->dY, E, a->w, dout, E, dims->L, s->gemm_ws,
+                             s->gemm_ws_floats, stream));
   // self-attention core backward (re-derives the dropout mask of Y)
   EBN_TRY(ebn_attn_bwd_f32(a->QKV, 3 * E, s->dY, E, s->dQKV, 3 * E, dims->n_seq, dims->L, dims->h, dims->d, st,
                            dims->drop_site, dims->drop_p, stream));

@@ -99,16 +99,26 @@ struct TileLoader {
   }
 };
 
+// Optional rank-1-per-sequence term of the epilogue: C[row][col] += rs[row] * cv[row / L][col]  (EPI = 1).
+// It is the d(x) of the AttLayer2 pooling, w[n,l] * dout[n,:] (layers.py:79-81 backward), folded into the GEMM that
+// produces the other half of d(x), so that neither kernel has to write and re-read the [R,E] gradient.
+struct GemmEpi {
+  const float* rs;
+  const float* cv;
+  int64_t ldcv;
+  int32_t L;
+};
+
 // TA: A stored [K,M]; TB: B stored [N,K].
 // gridDim.z = split-K factor; when > 1 each z-slice writes alpha*partial to
 // Cpart + z*M*N (dense ld = N) and a reduce kernel finishes; else writes C directly.
 // SITE only labels the instantiation (0 = generic, 1 = the encoders' Q|K|V projection) so that per-kernel profiler
 // summaries separate the roofline kernel of bench.py from the other GEMM call sites of the same shape class.
-template <int BM, int BN, int WAVES_M, bool TA, bool TB, bool VEC, int SITE>
+template <int BM, int BN, int WAVES_M, bool TA, bool TB, bool VEC, int SITE, int EPI = 0>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
     int64_t M, int64_t N, int64_t K, float alpha, const float* __restrict__ A, int64_t lda,
     const float* __restrict__ B, int64_t ldb, float beta, float* __restrict__ C, int64_t ldc,
-    int64_t k_per_split, float* __restrict__ Cpart) {
+    int64_t k_per_split, float* __restrict__ Cpart, GemmEpi epi) {
   constexpr int WAVES_N = 4 / WAVES_M;    // the 4 waves form a WAVES_M x WAVES_N grid over the block tile
   constexpr int WTM = BM / WAVES_M;       // rows / columns owned by one wave
   constexpr int WTN = BN / WAVES_N;
@@ -226,6 +236,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
         if (row >= M) continue;
         float v = alpha * acc[i][j][r];
         if (!split && beta != 0.f) v += beta * out[row * ldo + col];
+        if (EPI == 1 && !split) v = fmaf(epi.rs[row], epi.cv[(row / epi.L) * epi.ldcv + col], v);
         out[row * ldo + col] = v;
       }
     }
@@ -234,7 +245,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int splits,
                                                             int64_t M, int64_t N, float beta,
-                                                            float* __restrict__ C, int64_t ldc) {
+                                                            float* __restrict__ C, int64_t ldc, GemmEpi epi) {
   const int64_t total = M * N;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < total;
        i += static_cast<int64_t>(gridDim.x) * 256) {
@@ -243,6 +254,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     const int64_t row = i / N;
     const int64_t col = i - row * N;
     float* c = C + row * ldc + col;
+    if (epi.rs != nullptr) s = fmaf(epi.rs[row], epi.cv[(row / epi.L) * epi.ldcv + col], s);
     *c = (beta != 0.f) ? (s + beta * *c) : s;
   }
 }
@@ -250,7 +262,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 template <int BM, int BN, int WAVES_M>
 int launch_gemm(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha, const float* A,
                 int64_t lda, const float* B, int64_t ldb, float beta, float* C, int64_t ldc, int vecA,
-                int vecB, int splits, int64_t k_per_split, float* part, hipStream_t s, int site) {
+                int vecB, int splits, int64_t k_per_split, float* part, hipStream_t s, int site, GemmEpi epi) {
   dim3 grid(static_cast<unsigned>(ebn_ceil_div(N, BN)), static_cast<unsigned>(ebn_ceil_div(M, BM)),
             static_cast<unsigned>(splits));
   dim3 block(GEMM_THREADS);
@@ -258,14 +270,17 @@ int launch_gemm(int transA, int transB, int64_t M, int64_t N, int64_t K, float a
   do {                                                                                                    \
     if (vecA && vecB)                                                                                     \
       hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WAVES_M, TA, TB, true, 0>), grid, block, 0, s, M, N, K, alpha, A, lda, \
-                         B, ldb, beta, C, ldc, k_per_split, part);                                        \
+                         B, ldb, beta, C, ldc, k_per_split, part, epi);                                   \
     else                                                                                                  \
       hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WAVES_M, TA, TB, false, 0>), grid, block, 0, s, M, N, K, alpha, A,  \
-                         lda, B, ldb, beta, C, ldc, k_per_split, part);                                   \
+                         lda, B, ldb, beta, C, ldc, k_per_split, part, epi);                              \
   } while (0)
-  if (!transA && !transB && site == 1 && vecA && vecB)
+  if (epi.rs != nullptr)  // caller guarantees !transA && transB && vecA && vecB
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WAVES_M, false, true, true, 0, 1>), grid, block, 0, s, M, N, K, alpha, A, lda,
+                       B, ldb, beta, C, ldc, k_per_split, part, epi);
+  else if (!transA && !transB && site == 1 && vecA && vecB)
     hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WAVES_M, false, false, true, 1>), grid, block, 0, s, M, N, K, alpha, A, lda, B,
-                       ldb, beta, C, ldc, k_per_split, part);
+                       ldb, beta, C, ldc, k_per_split, part, epi);
   else if (!transA && !transB) EBN_GEMM_LAUNCH(false, false);
   else if (!transA && transB) EBN_GEMM_LAUNCH(false, true);
   else if (transA && !transB) EBN_GEMM_LAUNCH(true, false);
@@ -361,15 +376,9 @@ extern "C" int ebn_gemm_plan(int64_t M, int64_t N, int64_t K, int64_t workspace_
   return EBN_OK;
 }
 
-extern "C" int ebn_gemm_f32_site(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K, float alpha,
-                                 const float* A, int64_t lda, const float* B, int64_t ldb, float beta, float* C,
-                                 int64_t ldc, float* workspace, int64_t workspace_floats, int32_t site,
-                                 ebn_stream_t stream) {
-  EBN_REQUIRE(M >= 0 && N >= 0 && K >= 0, EBN_ERR_BAD_ARG);
-  if (M == 0 || N == 0) return EBN_OK;
-  EBN_REQUIRE(A && B && C, EBN_ERR_BAD_ARG);
-  EBN_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, EBN_ERR_BAD_ARG);
-  hipStream_t s = ebn_stream(stream);
+static int gemm_dispatch(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K, float alpha, const float* A,
+                         int64_t lda, const float* B, int64_t ldb, float beta, float* C, int64_t ldc, float* workspace,
+                         int64_t workspace_floats, int32_t site, GemmEpi epi, hipStream_t s) {
   // contiguous-axis extent must be a multiple of 4 too (K for k-contiguous operands, M/N otherwise)
   const int vecA = ((lda % 4) == 0 && ebn_aligned16(A) && ((transA ? M : K) % 4) == 0) ? 1 : 0;
   const int vecB = ((ldb % 4) == 0 && ebn_aligned16(B) && ((transB ? K : N) % 4) == 0) ? 1 : 0;
@@ -379,22 +388,67 @@ extern "C" int ebn_gemm_f32_site(int32_t transA, int32_t transB, int64_t M, int6
   int rc;
   if (plan.bm == 256)
     rc = launch_gemm<256, 64, 4>(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, vecA, vecB, splits, kps,
-                                 workspace, s, site);
+                                 workspace, s, site, epi);
   else if (plan.bm == 128)
     rc = launch_gemm<128, 128, 2>(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, vecA, vecB, splits, kps,
-                                  workspace, s, site);
+                                  workspace, s, site, epi);
   else
     rc = launch_gemm<64, 64, 2>(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, vecA, vecB, splits, kps,
-                                workspace, s, site);
+                                workspace, s, site, epi);
   if (rc != EBN_OK) return rc;
   if (splits > 1) {
     int64_t grid = ebn_ceil_div(M * N, 256);
     if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(static_cast<unsigned>(grid)), dim3(256), 0, s, workspace,
-                       splits, M, N, beta, C, ldc);
+                       splits, M, N, beta, C, ldc, epi);
     EBN_CHECK_LAUNCH();
   }
   return EBN_OK;
+}
+
+extern "C" int ebn_gemm_f32_site(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K, float alpha,
+                                 const float* A, int64_t lda, const float* B, int64_t ldb, float beta, float* C,
+                                 int64_t ldc, float* workspace, int64_t workspace_floats, int32_t site,
+                                 ebn_stream_t stream) {
+  EBN_REQUIRE(M >= 0 && N >= 0 && K >= 0, EBN_ERR_BAD_ARG);
+  if (M == 0 || N == 0) return EBN_OK;
+  EBN_REQUIRE(A && B && C, EBN_ERR_BAD_ARG);
+  EBN_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, EBN_ERR_BAD_ARG);
+  return gemm_dispatch(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, workspace, workspace_floats, site,
+                       GemmEpi{nullptr, nullptr, 0, 1}, ebn_stream(stream));
+}
+
+namespace {
+__global__ __launch_bounds__(256) void rank1_fill_kernel(float* __restrict__ C, int64_t ldc, int64_t M, int64_t N,
+                                                         GemmEpi epi) {
+  const int64_t total = M * N;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < total; i += static_cast<int64_t>(gridDim.x) * 256) {
+    const int64_t row = i / N, col = i - row * N;
+    C[row * ldc + col] = epi.rs[row] * epi.cv[(row / epi.L) * epi.ldcv + col];
+  }
+}
+}  // namespace
+
+extern "C" int ebn_gemm_f32_rank1(int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda,
+                                  const float* B, int64_t ldb, float* C, int64_t ldc, const float* row_scale,
+                                  const float* seq_rows, int64_t ld_seq, int32_t L, float* workspace,
+                                  int64_t workspace_floats, ebn_stream_t stream) {
+  EBN_REQUIRE(M >= 0 && N >= 0 && K >= 0 && L > 0, EBN_ERR_BAD_ARG);
+  if (M == 0 || N == 0) return EBN_OK;
+  EBN_REQUIRE(A && B && C && row_scale && seq_rows, EBN_ERR_BAD_ARG);
+  EBN_REQUIRE(lda >= K && ldb >= K && ldc >= N && ld_seq >= N, EBN_ERR_BAD_ARG);
+  const GemmEpi epi{row_scale, seq_rows, ld_seq, L};
+  hipStream_t s = ebn_stream(stream);
+  const bool vec = (lda % 4) == 0 && ebn_aligned16(A) && (ldb % 4) == 0 && ebn_aligned16(B) && (K % 4) == 0;
+  if (vec)
+    return gemm_dispatch(0, 1, M, N, K, alpha, A, lda, B, ldb, 0.0f, C, ldc, workspace, workspace_floats, 0, epi, s);
+  // unaligned operands: write the rank-1 term, then accumulate the product onto it with the scalar-load kernels
+  int64_t grid = ebn_ceil_div(M * N, 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(rank1_fill_kernel, dim3(static_cast<unsigned>(grid)), dim3(256), 0, s, C, ldc, M, N, epi);
+  EBN_CHECK_LAUNCH();
+  return gemm_dispatch(0, 1, M, N, K, alpha, A, lda, B, ldb, 1.0f, C, ldc, workspace, workspace_floats, 0,
+                       GemmEpi{nullptr, nullptr, 0, 1}, s);
 }
 
 extern "C" int ebn_gemm_f32_ws(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K, float alpha,

@@ -128,13 +128,22 @@ int ebn_attn_bwd_f32(const float* qkv, int64_t ld_qkv, const float* dout, int64_
                      float* dqkv, int64_t ld_dqkv, int64_t n_seq, int32_t L, int32_t h, int32_t d,
                      const ebn_step_state* st, int32_t site, float drop_p, ebn_stream_t stream);
 
+/* C[M,N] = alpha * A[M,K] * B[N,K]^T + row_scale[m] * seq_rows[m / L, n]   (C overwritten; A row-major, B stored [N,K]).
+ * The d(x) of AttLayer2 in one pass: dpre.W^T (backward of K.dot(x, W), layers.py:65) plus w[n,l]*dout[n,:] (backward of
+ * the weighted sum, layers.py:79-81) -- the rank-1 term is added in the GEMM epilogue instead of being written by
+ * ebn_attpool_bwd_pool_f32 and read back through beta = 1.  workspace as for ebn_gemm_f32_ws(0, 1, M, N, K).       */
+int ebn_gemm_f32_rank1(int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda, const float* B,
+                       int64_t ldb, float* C, int64_t ldc, const float* row_scale, const float* seq_rows,
+                       int64_t ld_seq, int32_t L, float* workspace, int64_t workspace_floats, ebn_stream_t stream);
+
 /* ---- a4/a7  AttLayer2 (layers.py:55-81) after the x.W matmul ----------------------
  * fwd: U <- tanh(U + b) in place ([R,A], R = n_seq*L); e = U.q; a = exp(e);
  *      w = a/(sum_l a + 1e-7); out[n,:] = sum_l w[n,l] X[n,l,:].                    */
 int ebn_attpool_fwd_f32(float* U, const float* b, const float* q, const float* X, float* out,
                         float* w, int64_t n_seq, int32_t L, int32_t E, int32_t A,
                         ebn_stream_t stream);
-/* bwd step 1: dX[n,l,:] = w[n,l]*dout[n,:]; de[n,l] = w (dw - sum w dw), dw = dout.X */
+/* bwd step 1: dX[n,l,:] = w[n,l]*dout[n,:]; de[n,l] = w (dw - sum w dw), dw = dout.X.
+ * dX may be NULL: only de is produced (the caller adds the dX term with ebn_gemm_f32_rank1). */
 int ebn_attpool_bwd_pool_f32(const float* X, const float* w, const float* dout, float* dX,
                              float* de, int64_t n_seq, int32_t L, int32_t E,
                              ebn_stream_t stream);

@@ -252,6 +252,16 @@ def test_attpool_forward_and_backward(hip, n_seq, L, E, A):
     gemm(0, 1, R, E, A, 1.0, U, A, Wd, A, 1.0, dXd, E)
     assert_close(host(dWd), dW, rtol=3e-5, atol=3e-5, what="dW")
     assert_close(host(dXd).reshape(n_seq, L, E), dX, rtol=3e-5, atol=1e-5, what="dX")
+    # the fused form the encoder stage uses: pool backward without its dX write + the rank-1 term in the GEMM epilogue
+    de2 = torch.empty(R, device="cuda")
+    hip.call("ebn_attpool_bwd_pool_f32", P(Xd), P(w), P(dev(dout)), None, P(de2), n_seq, L, E, S())
+    assert np.array_equal(host(de2), host(de)), "de must not depend on whether dX is written"
+    for use_ws in (False, True):
+        ws = torch.empty(max(int(hip.lib().ebn_gemm_workspace_floats(R, E, A)), 1), device="cuda") if use_ws else None
+        dX2 = torch.full((R, E), 7.0, device="cuda")
+        hip.call("ebn_gemm_f32_rank1", R, E, A, ctypes.c_float(1.0), P(U), A, P(Wd), A, P(dX2), E, P(w), P(dev(dout)), E, L,
+                 P(ws), 0 if ws is None else ws.numel(), S())
+        assert_close(host(dX2).reshape(n_seq, L, E), dX, rtol=3e-5, atol=1e-5, what=f"dX via rank-1 epilogue ws={use_ws}")
     # accumulate flag adds on top
     hip.call("ebn_attpool_bwd_dpre_f32", P(U), P(dev(q)), P(dev(np.zeros(R))), P(dqd), P(dbd), P(part), R, A, 1, S())
     assert_close(host(dqd), dq[:, 0], rtol=3e-5, atol=2e-5, what="dq accumulate(0)")
