@@ -27,9 +27,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BK = 16;
 constexpr int PAD = 4;
 constexpr int GEMM_THREADS = 256;
-#ifndef EBN_GEMM_TALL_PENALTY
-#define EBN_GEMM_TALL_PENALTY 1.02  // measured on exact-turn shapes: profiles/r01_gemm_tuning.md
-#endif
 
 // One operand tile of R_MN x BK (mn = m or n index). KCONTIG: memory is [mn][k] (k fastest);
 // else memory is [k][mn] (mn fastest).
@@ -293,45 +290,27 @@ int launch_gemm(int transA, int transB, int64_t M, int64_t N, int64_t K, float a
 }  // namespace
 
 // ---- planner ------------------------------------------------------------------------------------------------
-// Workgroups are dealt round-robin to 256 CUs and all cost the same, so a launch takes ceil(n_wg/256) "turns":
-// among the split factors that give the chip 2..8 workgroups per CU pick the one that wastes the least of its last
-// turn (e.g. 80 tiles: 16 splits = exactly 5 turns, where 13 splits would idle 19 % of a 5th turn).
+// Picks the block tile and the split-K factor that minimise a small time model (microseconds):
+//     t = slabs_per_wg * max(W * ts_full, ceil(W / R) * ts_lone) + t0   [+ t_reduce when splits > 1]
+// * workgroups are dealt round-robin to 256 CUs and all cost the same: the busiest CU gets W = ceil(n_wg / 256) of
+//   them (padding of M / N to the tile and the idle part of the last "turn" are what the tile choice trades);
+// * ts_full = time of one 16-deep K slab of one tile on a CU at the kernel's steady-state MFMA rate (128x128:
+//   590 us / (8 x 64 slabs) on the 24000x1200x1024 projection; 256x64: 514 us / (7 x 64); 64x64 tiles reach ~3/4 of
+//   that rate); ts_lone = the same slab when the workgroup has the CU to itself and nothing hides its latencies;
+//   R = workgroups a CU holds at once;
+// * a split-K reduce costs a launch (~4.5 us) plus (splits + 1) passes over the output at ~2.5 TB/s.
+// Calibrated against tools/gemm_probe.py on the 14 GEMM shapes of a c2 training step (profiles/r01_gemm_tuning.md).
 struct GemmPlan {
   int bm, bn;
   int splits;
   int64_t kps;
-  double cost;  // turns x tile area x K-range x per-shape penalty, in MFMA work units
+  double cost;
 };
 
-static void plan_splits(int64_t tiles, int64_t K, int64_t max_split, int* splits, int64_t* k_per_split) {
-  int64_t s = 1;
-  if (tiles < 512 && max_split > 1) {
-    int64_t lo = ebn_ceil_div(512, tiles), hi = ebn_ceil_div(2048, tiles);
-    if (lo > max_split) lo = max_split;
-    if (hi > max_split) hi = max_split;
-    double best = -1.0;
-    for (int64_t c = lo; c <= hi; ++c) {
-      const double turns = static_cast<double>(tiles * c) / 256.0;
-      const double eff = turns / static_cast<double>(ebn_ceil_div(tiles * c, 256));
-      if (eff > best + 1e-9) {
-        best = eff;
-        s = c;
-      }
-    }
-  }
-  int64_t kps = ebn_ceil_div(ebn_ceil_div(K > 0 ? K : 1, s), BK) * BK;
-  s = ebn_ceil_div(K > 0 ? K : 1, kps);
-  *splits = static_cast<int>(s < 1 ? 1 : s);
-  *k_per_split = kps;
-}
-
-// 256x64 tiles (4 waves stacked along m, each still 64x64): same per-wave MFMA loop as 128x128, 25 % more operand
-// traffic per MFMA, but a 64-column grain -- N = 1200 (the fused Q|K|V projection of head_num 20 x head_dim 20) pads to
-// 1216 instead of 1280, and M = 24000 gives 1786 workgroups = 6.98 turns instead of 1880 = 7.34.
 static int tall_tiles_mode() {
   static const int mode = [] {
-    const char* e = getenv("EBN_GEMM_TALL");  // 0: never, 1: by cost (default), 2: whenever legal -- tuning only
-    return (e && e[0] >= '0' && e[0] <= '2') ? (e[0] - '0') : 1;
+    const char* e = getenv("EBN_GEMM_TALL");  // 0: never, 1: by cost (default) -- tuning only
+    return (e && e[0] >= '0' && e[0] <= '1') ? (e[0] - '0') : 1;
   }();
   return mode;
 }
@@ -342,23 +321,31 @@ static GemmPlan gemm_plan(int64_t M, int64_t N, int64_t K, int64_t ws_floats) {
   const int64_t max_by_ws = (M * N > 0) ? ws_floats / (M * N) : 0;
   if (max_split > max_by_ws) max_split = max_by_ws;
   if (max_split < 1) max_split = 1;
-  GemmPlan p;
-  const int64_t tiles128 = ebn_ceil_div(M, 128) * ebn_ceil_div(N, 128);
-  // 128x128 tiles (2x the arithmetic intensity) whenever they can still fill 256 CUs x 2
-  p.bm = p.bn = (tiles128 * max_split >= 512) ? 128 : 64;
-  const int64_t tiles = ebn_ceil_div(M, p.bm) * ebn_ceil_div(N, p.bn);
-  plan_splits(tiles, K, max_split, &p.splits, &p.kps);
-  p.cost = static_cast<double>(ebn_ceil_div(tiles * p.splits, 256)) * p.bm * p.bn * static_cast<double>(p.kps);
-  if (p.bm == 128 && tall_tiles_mode() > 0 && M >= 256) {
-    GemmPlan q;
-    q.bm = 256;
-    q.bn = 64;
-    const int64_t t = ebn_ceil_div(M, 256) * ebn_ceil_div(N, 64);
-    plan_splits(t, K, max_split, &q.splits, &q.kps);
-    q.cost = static_cast<double>(ebn_ceil_div(t * q.splits, 256)) * 256.0 * 64.0 * static_cast<double>(q.kps) * EBN_GEMM_TALL_PENALTY;
-    if (q.cost < p.cost || tall_tiles_mode() == 2) p = q;
+  static const struct {
+    int bm, bn;
+    double ts_full, ts_lone;
+    int resident;
+  } kTiles[3] = {{128, 128, 1.15, 1.5, 3}, {256, 64, 1.17, 1.5, 3}, {64, 64, 0.35, 0.48, 4}};
+  const double out_mb = static_cast<double>(M) * static_cast<double>(N) * 4e-6;
+  GemmPlan best{128, 128, 1, ebn_ceil_div(K > 0 ? K : 1, BK) * BK, 1e300};
+  for (int t = 0; t < 3; ++t) {
+    if (kTiles[t].bm == 256 && (tall_tiles_mode() == 0 || M < 256)) continue;
+    const int64_t tiles = ebn_ceil_div(M, kTiles[t].bm) * ebn_ceil_div(N, kTiles[t].bn);
+    int64_t prev_s = 0;
+    for (int64_t c = 1; c <= max_split; ++c) {
+      const int64_t kps = ebn_ceil_div(ebn_ceil_div(K > 0 ? K : 1, c), BK) * BK;
+      const int64_t sp = ebn_ceil_div(K > 0 ? K : 1, kps);  // effective split count for this K range
+      if (sp == prev_s) continue;
+      prev_s = sp;
+      const int64_t W = ebn_ceil_div(tiles * sp, 256);
+      const double full = static_cast<double>(W) * kTiles[t].ts_full;
+      const double lone = static_cast<double>(ebn_ceil_div(W, kTiles[t].resident)) * kTiles[t].ts_lone;
+      double cost = static_cast<double>(kps / BK) * (full > lone ? full : lone) + 3.0;
+      if (sp > 1) cost += 4.5 + static_cast<double>(sp + 1) * out_mb / 2.5;
+      if (cost < best.cost) best = GemmPlan{kTiles[t].bm, kTiles[t].bn, static_cast<int>(sp), kps, cost};
+    }
   }
-  return p;
+  return best;
 }
 
 extern "C" int64_t ebn_gemm_workspace_floats(int64_t M, int64_t N, int64_t K) {

@@ -1,4 +1,5 @@
-"""Runs one GEMM shape repeatedly (for rocprofv3 --pmc passes). usage: gemm_probe.py tA tB M N K [iters]"""
+"""Runs one GEMM shape repeatedly (for rocprofv3 --pmc passes). usage: gemm_probe.py tA tB M N K [iters] [nows]
+(nows: no split-K workspace -> the planner cannot split)"""
 import ctypes, sys
 from pathlib import Path
 import torch
@@ -13,13 +14,14 @@ B = torch.randn((N, K) if tB else (K, N), device="cuda", generator=g)
 C = torch.empty(M, N, device="cuda")
 n = int(_hip.lib().ebn_gemm_workspace_floats(M, N, K))
 ws = torch.empty(max(n, 1), device="cuda")
+nows = len(sys.argv) > 7 and sys.argv[7] == "nows"
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 for i in range(iters + 2):
     if i == 2:
         e0.record()
     _hip.call("ebn_gemm_f32_ws", tA, tB, M, N, K, ctypes.c_float(1.0), _hip.ptr(A), A.shape[1], _hip.ptr(B), B.shape[1],
-              ctypes.c_float(0.0), _hip.ptr(C), N, _hip.ptr(ws), ws.numel(), _hip.stream_handle())
+              ctypes.c_float(0.0), _hip.ptr(C), N, None if nows else _hip.ptr(ws), 0 if nows else ws.numel(), _hip.stream_handle())
 e1.record()
 torch.cuda.synchronize()
 t = e0.elapsed_time(e1) / iters * 1e-3
-print(f"gemm tA={tA} tB={tB} {M}x{N}x{K}: {t*1e6:.1f} us, {2.0*M*N*K/t/1e12:.1f} TFLOP/s")
+print(f"gemm tA={tA} tB={tB} {M}x{N}x{K}{' nows' if nows else ''}: {t*1e6:.1f} us, {2.0*M*N*K/t/1e12:.1f} TFLOP/s")
