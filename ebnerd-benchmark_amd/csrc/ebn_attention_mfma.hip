@@ -61,7 +61,7 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// global M[L][D] (row stride ld) -> lds[32][STRIDE], rows >= L zero.  DROP: multiply by the dropout mask of
+// global M[L][D] (row stride ld) -> lds[L][STRIDE].  DROP: multiply by the dropout mask of
 // element index e0 + r*E + c (the mask the forward pass applied to the matching output element).
 template <int D, bool DROP>
 __device__ __forceinline__ void stage_in(float* __restrict__ lds, const float* __restrict__ base, int64_t ld, int L,
@@ -72,9 +72,8 @@ __device__ __forceinline__ void stage_in(float* __restrict__ lds, const float* _
     const int v = lane + 64 * t;
     if (T::VECS % 64 != 0 && v >= T::VECS) break;
     const int r = v / T::VPR, c4 = v - r * T::VPR;
-    const bool ok = r < L;
-    const float4 x = *reinterpret_cast<const float4*>(ok ? base + static_cast<int64_t>(r) * ld + c4 * 4 : base);
-    float4 y = ok ? x : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r >= L) continue;
+    float4 y = *reinterpret_cast<const float4*>(base + static_cast<int64_t>(r) * ld + c4 * 4);
     if (DROP) {
       const uint64_t e = e0 + static_cast<uint64_t>(r) * E + c4 * 4;  // multiple of 4: two aligned pairs
       const uint32_t h0 = ebn_dropout_pair_hash(key, e >> 1), h1 = ebn_dropout_pair_hash(key, (e >> 1) + 1);
@@ -111,27 +110,31 @@ __device__ __forceinline__ void stage_out(const float* __restrict__ lds, float* 
   }
 }
 
+// The LDS regions hold L rows (not 32): rows >= L are predicated to zero on the way into the registers.
 // lane (row = lane&31, hi): x[s] = M[row][hi*KH + s].  8-byte LDS reads.
 template <int D>
-__device__ __forceinline__ void lds_row_form(float (&x)[D / 2], const float* __restrict__ lds, int row, int hi) {
+__device__ __forceinline__ void lds_row_form(float (&x)[D / 2], const float* __restrict__ lds, int L, int row, int hi) {
   constexpr int KH = D / 2;
-  const float2* p = reinterpret_cast<const float2*>(lds + row * Tile<D>::STRIDE + hi * KH);
+  const bool ok = row < L;
+  const float2* p = reinterpret_cast<const float2*>(lds + (ok ? row : 0) * Tile<D>::STRIDE + hi * KH);
 #pragma unroll
   for (int s = 0; s < KH / 2; ++s) {
     const float2 v = p[s];
-    x[2 * s] = v.x;
-    x[2 * s + 1] = v.y;
+    x[2 * s] = ok ? v.x : 0.f;
+    x[2 * s + 1] = ok ? v.y : 0.f;
   }
 }
 
-// lane (c = lane&31, hi): y[s] = M[crow(s,hi)][c]; zero for c >= D.
+// lane (c = lane&31, hi): y[s] = M[crow(s,hi)][c]; zero for c >= D or a row >= L.
 template <int D>
-__device__ __forceinline__ void lds_col_form(float (&y)[16], const float* __restrict__ lds, int c, int hi) {
+__device__ __forceinline__ void lds_col_form(float (&y)[16], const float* __restrict__ lds, int L, int c, int hi) {
   const int cc = (c < D) ? c : 0;
 #pragma unroll
   for (int s = 0; s < 16; ++s) {
-    const float v = lds[crow(s, hi) * Tile<D>::STRIDE + cc];
-    y[s] = (c < D) ? v : 0.f;
+    const int r = crow(s, hi);
+    const bool ok = (c < D) && (r < L);
+    const float v = lds[(r < L ? r : 0) * Tile<D>::STRIDE + cc];
+    y[s] = ok ? v : 0.f;
   }
 }
 
@@ -157,7 +160,9 @@ __device__ __forceinline__ f32x16 mm_col_tile(const float (&a)[16], const f32x16
 
 // result tile whose lane owns row `row` and whose registers own columns crow(r,hi) -> lds[row][c], float4 groups
 template <int D>
-__device__ __forceinline__ void tile_rows_to_lds(float* __restrict__ lds, const f32x16& acc, int row, int hi, float mul) {
+__device__ __forceinline__ void tile_rows_to_lds(float* __restrict__ lds, const f32x16& acc, int L, int row, int hi,
+                                                 float mul) {
+  if (row >= L) return;
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const int c0 = 8 * g + 4 * hi;
@@ -219,20 +224,21 @@ __device__ __forceinline__ float softmax_stats_only(const f32x16& t, int L, int 
 template <int D>
 __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(MfmaAttnArgs a) {
   using T = Tile<D>;
-  __shared__ __attribute__((aligned(16))) float smem[4][3 * T::FLOATS];
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // 4 waves x 3 regions x L x STRIDE
   const int lane = threadIdx.x & 63;
   const int64_t prob = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
   if (prob >= a.n_prob) return;  // wave-uniform; no workgroup barriers in this kernel
-  float* sq = smem[threadIdx.x >> 6];
-  float* sk = sq + T::FLOATS;
-  float* sv = sk + T::FLOATS;
-  const int row = lane & 31, hi = lane >> 5;
   const int L = a.L, E = a.h * D;
+  const int region = L * T::STRIDE;
+  float* sq = smem + (threadIdx.x >> 6) * 3 * region;
+  float* sk = sq + region;
+  float* sv = sk + region;
+  const int row = lane & 31, hi = lane >> 5;
   const int64_t seq = prob / a.h;
   const int head = static_cast<int>(prob - seq * a.h);
   const int64_t row0 = seq * L;
   const float* qb = a.qkv + row0 * a.ld_qkv + head * D;
-  const float inv = 1.0f / sqrtf(static_cast<float>(D));
+  const float inv2 = 1.44269504088896341f / sqrtf(static_cast<float>(D));
 
   stage_in<D, false>(sq, qb, a.ld_qkv, L, lane, 0u, 0u, 0, 0u, 0.f);
   stage_in<D, false>(sk, qb + E, a.ld_qkv, L, lane, 0u, 0u, 0, 0u, 0.f);
@@ -240,19 +246,19 @@ __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(MfmaAttnArgs a) {
   wave_lds_sync();
 
   float qr[D / 2], kr[D / 2];
-  lds_row_form<D>(qr, sq, row, hi);
-  lds_row_form<D>(kr, sk, row, hi);
+  lds_row_form<D>(qr, sq, L, row, hi);
+  lds_row_form<D>(kr, sk, L, row, hi);
   float vc[16];
-  lds_col_form<D>(vc, sv, row, hi);
+  lds_col_form<D>(vc, sv, L, row, hi);
 
   f32x16 Tt = mm_rows<D / 2>(kr, qr);  // T[j][i]: lane i, regs j
   f32x16 S = mm_rows<D / 2>(qr, kr);   // S[i][j]: lane j, regs i
-  const float c = softmax_stats_only(Tt, L, hi, inv * 1.44269504088896341f);
-  softmax_from_stats(S, L, hi, inv * 1.44269504088896341f, c);  // P[i][j]: lane j, regs i
-  const f32x16 O = mm_col_tile(vc, S);         // O^T[c][j]: lane j, regs c
+  const float c = softmax_stats_only(Tt, L, hi, inv2);
+  softmax_from_stats(S, L, hi, inv2, c);  // P[i][j]: lane j, regs i
+  const f32x16 O = mm_col_tile(vc, S);    // O^T[c][j]: lane j, regs c
 
   wave_lds_sync();  // every operand read of sq is done: reuse it for the output rows
-  tile_rows_to_lds<D>(sq, O, row, hi, 1.0f);
+  tile_rows_to_lds<D>(sq, O, L, row, hi, 1.0f);
   wave_lds_sync();
   float* ob = a.out + row0 * a.ld_out + head * D;
   const uint64_t e0 = static_cast<uint64_t>(row0) * E + head * D;
@@ -260,26 +266,30 @@ __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(MfmaAttnArgs a) {
   else stage_out<D, false>(sq, ob, a.ld_out, L, lane, 0u, 0u, 0, 0u, 0.f);
 }
 
+// Backward.  The "lane i" tiles (P, dP -> dV, dQ) are finished before the "lane j" tiles (-> dK) are started, so
+// that at most two 32x32 tiles are live at a time: the kernel fits 128 registers = 4 waves per SIMD.
 template <int D>
 __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(MfmaAttnArgs a) {
   using T = Tile<D>;
   constexpr int KH = D / 2;
-  __shared__ __attribute__((aligned(16))) float smem[4][4 * T::FLOATS];
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // 4 waves x 4 regions x L x STRIDE
   const int lane = threadIdx.x & 63;
   const int64_t prob = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
   if (prob >= a.n_prob) return;
-  float* sq = smem[threadIdx.x >> 6];
-  float* sk = sq + T::FLOATS;
-  float* sv = sk + T::FLOATS;  // V, then the staging buffer of the three result tiles
-  float* sg = sv + T::FLOATS;  // dO with the forward dropout mask applied
-  const int row = lane & 31, hi = lane >> 5;
   const int L = a.L, E = a.h * D;
+  const int region = L * T::STRIDE;
+  float* sq = smem + (threadIdx.x >> 6) * 4 * region;
+  float* sk = sq + region;
+  float* sv = sk + region;  // V, then the staging buffer of the three result tiles
+  float* sg = sv + region;  // dO with the forward dropout mask applied
+  const int row = lane & 31, hi = lane >> 5;
   const int64_t seq = prob / a.h;
   const int head = static_cast<int>(prob - seq * a.h);
   const int64_t row0 = seq * L;
   const float* qb = a.qkv + row0 * a.ld_qkv + head * D;
   const float* gb = a.dout + row0 * a.ld_dout + head * D;
   const float inv = 1.0f / sqrtf(static_cast<float>(D));
+  const float inv2 = inv * 1.44269504088896341f;
 
   stage_in<D, false>(sq, qb, a.ld_qkv, L, lane, 0u, 0u, 0, 0u, 0.f);
   stage_in<D, false>(sk, qb + E, a.ld_qkv, L, lane, 0u, 0u, 0, 0u, 0.f);
@@ -290,65 +300,94 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(MfmaAttnArgs a) {
     stage_in<D, false>(sg, gb, a.ld_dout, L, lane, 0u, 0u, 0, 0u, 0.f);
   wave_lds_sync();
 
-  f32x16 Pij, Pji;
-  {
-    float qr[KH], kr[KH];
-    lds_row_form<D>(qr, sq, row, hi);
-    lds_row_form<D>(kr, sk, row, hi);
-    Pij = mm_rows<KH>(kr, qr);  // T[j][i]: lane i, regs j
-    Pji = mm_rows<KH>(qr, kr);  // S[i][j]: lane j, regs i
-  }
-  const float c = softmax_in_lane(Pij, L, hi, inv * 1.44269504088896341f);
-  softmax_from_stats(Pji, L, hi, inv * 1.44269504088896341f, c);
-
-  f32x16 dPij, dPji;
-  {
-    float vr[KH], gr[KH];
-    lds_row_form<D>(vr, sv, row, hi);
-    lds_row_form<D>(gr, sg, row, hi);
-    dPij = mm_rows<KH>(gr, vr);  // dP[i][j] = V[i].dO[j]: lane i, regs j
-    dPji = mm_rows<KH>(vr, gr);  // lane j, regs i
-  }
-  float rowdot = 0.f;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) rowdot = fmaf(Pij[r], dPij[r], rowdot);
-  rowdot += __shfl_xor(rowdot, 32, 64);  // sum_j P[i][j] dP[i][j] for i = lane&31
-
   float* ob = a.out + row0 * a.ld_out + head * D;
-  float col[16];
-  // dV^T[c][i] = sum_j dO[j][c] P[i][j]
-  lds_col_form<D>(col, sg, row, hi);
+  float c, rowdot;
+  // ---- lane-i layout: P[i][j] and dP[i][j] with i on lanes -> dV, dQ
   {
-    const f32x16 dV = mm_col_tile(col, Pij);
-    wave_lds_sync();  // the row-form reads of sv are done
-    tile_rows_to_lds<D>(sv, dV, row, hi, 1.0f);
-    wave_lds_sync();
-    stage_out<D, false>(sv, ob + 2 * E, a.ld_out, L, lane, 0u, 0u, 0, 0u, 0.f);
-  }
-  // dS in both layouts
+    f32x16 P, dP;
+    {
+      float qr[KH], kr[KH];
+      lds_row_form<D>(qr, sq, L, row, hi);
+      lds_row_form<D>(kr, sk, L, row, hi);
+      P = mm_rows<KH>(kr, qr);  // T[j][i]: lane i, regs j
+    }
+    c = softmax_in_lane(P, L, hi, inv2);
+    {
+      float vr[KH], gr[KH];
+      lds_row_form<D>(vr, sv, L, row, hi);
+      lds_row_form<D>(gr, sg, L, row, hi);
+      dP = mm_rows<KH>(gr, vr);  // dP[i][j] = V[i].dO[j]: lane i, regs j
+    }
+    rowdot = 0.f;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    Pij[r] = Pij[r] * (dPij[r] - rowdot);  // dS[i][j]: lane i, regs j
-    const float rd = __shfl(rowdot, crow(r, hi), 64);
-    Pji[r] = Pji[r] * (dPji[r] - rd);  // dS[i][j]: lane j, regs i
+    for (int r = 0; r < 16; ++r) rowdot = fmaf(P[r], dP[r], rowdot);
+    rowdot += __shfl_xor(rowdot, 32, 64);  // sum_j P[i][j] dP[i][j] for i = lane&31
+
+    float col[16];
+    // dV^T[c][i] = sum_j dO[j][c] P[i][j]
+    lds_col_form<D>(col, sg, L, row, hi);
+    {
+      const f32x16 dV = mm_col_tile(col, P);
+      wave_lds_sync();  // the row-form reads of sv are done
+      tile_rows_to_lds<D>(sv, dV, L, row, hi, 1.0f);
+      wave_lds_sync();
+      stage_out<D, false>(sv, ob + 2 * E, a.ld_out, L, lane, 0u, 0u, 0, 0u, 0.f);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) P[r] = P[r] * (dP[r] - rowdot);  // dS[i][j]: lane i, regs j
+    // dQ^T[c][i] = inv * sum_j K[j][c] dS[i][j]
+    lds_col_form<D>(col, sk, L, row, hi);
+    {
+      const f32x16 dQ = mm_col_tile(col, P);
+      wave_lds_sync();
+      tile_rows_to_lds<D>(sv, dQ, L, row, hi, inv);
+      wave_lds_sync();
+      stage_out<D, false>(sv, ob, a.ld_out, L, lane, 0u, 0u, 0, 0u, 0.f);
+    }
   }
-  // dQ^T[c][i] = inv * sum_j K[j][c] dS[i][j]
-  lds_col_form<D>(col, sk, row, hi);
+  // ---- lane-j layout: the same two tiles with j on lanes -> dK
   {
-    const f32x16 dQ = mm_col_tile(col, Pij);
-    wave_lds_sync();
-    tile_rows_to_lds<D>(sv, dQ, row, hi, inv);
-    wave_lds_sync();
-    stage_out<D, false>(sv, ob, a.ld_out, L, lane, 0u, 0u, 0, 0u, 0.f);
-  }
-  // dK^T[c][j] = inv * sum_i Q[i][c] dS[i][j]
-  lds_col_form<D>(col, sq, row, hi);
-  {
-    const f32x16 dK = mm_col_tile(col, Pji);
-    wave_lds_sync();
-    tile_rows_to_lds<D>(sv, dK, row, hi, inv);
-    wave_lds_sync();
-    stage_out<D, false>(sv, ob + E, a.ld_out, L, lane, 0u, 0u, 0, 0u, 0.f);
+    f32x16 P, dP;
+    {
+      float qr[KH], kr[KH];
+      lds_row_form<D>(qr, sq, L, row, hi);
+      lds_row_form<D>(kr, sk, L, row, hi);
+      P = mm_rows<KH>(qr, kr);  // S[i][j]: lane j, regs i
+    }
+    softmax_from_stats(P, L, hi, inv2, c);
+    {
+      float vr[KH], gr[KH];
+      lds_row_form<D>(gr, sg, L, row, hi);
+      // V was overwritten by the staged results: its row form comes from global memory again (L1/L2-resident)
+      if (row < L) {
+        const float2* pv = reinterpret_cast<const float2*>(qb + 2 * E + static_cast<int64_t>(row) * a.ld_qkv + hi * KH);
+#pragma unroll
+        for (int s2 = 0; s2 < KH / 2; ++s2) {
+          const float2 v = pv[s2];
+          vr[2 * s2] = v.x;
+          vr[2 * s2 + 1] = v.y;
+        }
+      } else {
+#pragma unroll
+        for (int s2 = 0; s2 < KH; ++s2) vr[s2] = 0.f;
+      }
+      dP = mm_rows<KH>(vr, gr);  // lane j, regs i
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float rd = __shfl(rowdot, crow(r, hi), 64);
+      P[r] = P[r] * (dP[r] - rd);  // dS[i][j]: lane j, regs i
+    }
+    // dK^T[c][j] = inv * sum_i Q[i][c] dS[i][j]
+    float col[16];
+    lds_col_form<D>(col, sq, L, row, hi);
+    {
+      const f32x16 dK = mm_col_tile(col, P);
+      wave_lds_sync();
+      tile_rows_to_lds<D>(sv, dK, L, row, hi, inv);
+      wave_lds_sync();
+      stage_out<D, false>(sv, ob + E, a.ld_out, L, lane, 0u, 0u, 0, 0u, 0.f);
+    }
   }
 }
 
@@ -368,9 +407,10 @@ int ebn_attn_mfma_fwd(const float* qkv, int64_t ld_qkv, float* out, int64_t ld_o
   if (!*handled) return EBN_OK;
   MfmaAttnArgs a{qkv, ld_qkv, nullptr, 0, out, ld_out, n_seq * h, L, h, dr.key_ptr, dr.thresh, dr.scale};
   const dim3 grid(static_cast<unsigned>(ebn_ceil_div(a.n_prob, 4))), block(256);
-  if (d == 16) hipLaunchKernelGGL(attn_mfma_fwd_kernel<16>, grid, block, 0, s, a);
-  else if (d == 20) hipLaunchKernelGGL(attn_mfma_fwd_kernel<20>, grid, block, 0, s, a);
-  else hipLaunchKernelGGL(attn_mfma_fwd_kernel<32>, grid, block, 0, s, a);
+  const size_t lds = static_cast<size_t>(4) * 3 * L * sizeof(float);  // x STRIDE below
+  if (d == 16) hipLaunchKernelGGL(attn_mfma_fwd_kernel<16>, grid, block, lds * Tile<16>::STRIDE, s, a);
+  else if (d == 20) hipLaunchKernelGGL(attn_mfma_fwd_kernel<20>, grid, block, lds * Tile<20>::STRIDE, s, a);
+  else hipLaunchKernelGGL(attn_mfma_fwd_kernel<32>, grid, block, lds * Tile<32>::STRIDE, s, a);
   EBN_CHECK_LAUNCH();
   return EBN_OK;
 }
@@ -382,9 +422,10 @@ int ebn_attn_mfma_bwd(const float* qkv, int64_t ld_qkv, const float* dout, int64
   if (!*handled) return EBN_OK;
   MfmaAttnArgs a{qkv, ld_qkv, dout, ld_dout, dqkv, ld_dqkv, n_seq * h, L, h, dr.key_ptr, dr.thresh, dr.scale};
   const dim3 grid(static_cast<unsigned>(ebn_ceil_div(a.n_prob, 4))), block(256);
-  if (d == 16) hipLaunchKernelGGL(attn_mfma_bwd_kernel<16>, grid, block, 0, s, a);
-  else if (d == 20) hipLaunchKernelGGL(attn_mfma_bwd_kernel<20>, grid, block, 0, s, a);
-  else hipLaunchKernelGGL(attn_mfma_bwd_kernel<32>, grid, block, 0, s, a);
+  const size_t lds = static_cast<size_t>(4) * 4 * L * sizeof(float);  // x STRIDE below
+  if (d == 16) hipLaunchKernelGGL(attn_mfma_bwd_kernel<16>, grid, block, lds * Tile<16>::STRIDE, s, a);
+  else if (d == 20) hipLaunchKernelGGL(attn_mfma_bwd_kernel<20>, grid, block, lds * Tile<20>::STRIDE, s, a);
+  else hipLaunchKernelGGL(attn_mfma_bwd_kernel<32>, grid, block, lds * Tile<32>::STRIDE, s, a);
   EBN_CHECK_LAUNCH();
   return EBN_OK;
 }
