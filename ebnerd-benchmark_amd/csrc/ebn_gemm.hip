@@ -315,6 +315,14 @@ static int tall_tiles_mode() {
   return mode;
 }
 
+static int forced_tile_bm() {  // EBN_GEMM_FORCE_TILE = 64 | 128 | 256: restrict the planner to one family -- tuning only
+  static const int bm = [] {
+    const char* e = getenv("EBN_GEMM_FORCE_TILE");
+    return e ? atoi(e) : 0;
+  }();
+  return bm;
+}
+
 static GemmPlan gemm_plan(int64_t M, int64_t N, int64_t K, int64_t ws_floats) {
   int64_t max_split = K / (4 * BK);  // keep >= 4 slabs per split
   if (max_split > 64) max_split = 64;
@@ -325,11 +333,12 @@ static GemmPlan gemm_plan(int64_t M, int64_t N, int64_t K, int64_t ws_floats) {
     int bm, bn;
     double ts_full, ts_lone;
     int resident;
-  } kTiles[3] = {{128, 128, 1.15, 1.5, 3}, {256, 64, 1.17, 1.5, 3}, {64, 64, 0.35, 0.48, 4}};
+  } kTiles[3] = {{128, 128, 1.15, 1.5, 3}, {256, 64, 1.17, 1.5, 3}, {64, 64, 0.32, 0.48, 4}};
   const double out_mb = static_cast<double>(M) * static_cast<double>(N) * 4e-6;
   GemmPlan best{128, 128, 1, ebn_ceil_div(K > 0 ? K : 1, BK) * BK, 1e300};
   for (int t = 0; t < 3; ++t) {
     if (kTiles[t].bm == 256 && (tall_tiles_mode() == 0 || M < 256)) continue;
+    if (forced_tile_bm() != 0 && forced_tile_bm() != kTiles[t].bm && !(kTiles[t].bm == 64 && M < 256 && forced_tile_bm() == 256)) continue;
     const int64_t tiles = ebn_ceil_div(M, kTiles[t].bm) * ebn_ceil_div(N, kTiles[t].bn);
     int64_t prev_s = 0;
     for (int64_t c = 1; c <= max_split; ++c) {
