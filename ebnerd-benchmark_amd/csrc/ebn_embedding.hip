@@ -12,24 +12,28 @@ namespace {
 constexpr int GATHER_THREADS = 256;
 constexpr int GATHER_UNROLL = 4;
 
+// IT: index type of a work item (uint32_t whenever n_items < 2^32: a 64-bit division by the runtime row length costs
+// ~100 VALU instructions per item and was a third of this kernel's time); SHIFT >= 0: vpr == 1 << SHIFT (D = 1024
+// -> 8), the row/column split is a shift and a mask.
+template <typename IT, int SHIFT>
 __global__ __launch_bounds__(GATHER_THREADS) void gather_rows_vec4_kernel(
     const int32_t* __restrict__ ids, const float4* __restrict__ table, float4* __restrict__ out,
     int64_t n_items, int32_t vpr, int64_t V, const uint32_t* __restrict__ key_ptr, uint32_t thresh,
     float scale, int32_t* __restrict__ oob_flag) {
-  const int64_t base = (static_cast<int64_t>(blockIdx.x) * GATHER_UNROLL) * GATHER_THREADS + threadIdx.x;
+  const IT base = (static_cast<IT>(blockIdx.x) * GATHER_UNROLL) * GATHER_THREADS + threadIdx.x;
   const bool do_drop = key_ptr != nullptr;
   const uint32_t key = do_drop ? *key_ptr : 0u;
   float4 v[GATHER_UNROLL];
-  int64_t item[GATHER_UNROLL];
+  IT item[GATHER_UNROLL];
   bool ok[GATHER_UNROLL];
 #pragma unroll
   for (int u = 0; u < GATHER_UNROLL; ++u) {
-    item[u] = base + static_cast<int64_t>(u) * GATHER_THREADS;
-    ok[u] = item[u] < n_items;
+    item[u] = base + static_cast<IT>(u) * GATHER_THREADS;
+    ok[u] = static_cast<int64_t>(item[u]) < n_items;
     v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (ok[u]) {
-      const int64_t row = item[u] / vpr;
-      const int32_t col = static_cast<int32_t>(item[u] - row * vpr);
+      const IT row = (SHIFT >= 0) ? (item[u] >> (SHIFT >= 0 ? SHIFT : 0)) : item[u] / static_cast<IT>(vpr);
+      const int32_t col = static_cast<int32_t>(item[u] - row * static_cast<IT>(vpr));
       const int64_t id = ids[row];
       if (id >= 0 && id < V) {
         v[u] = table[id * vpr + col];
@@ -78,16 +82,17 @@ __global__ __launch_bounds__(GATHER_THREADS) void gather_rows_scalar_kernel(
 
 // Backward: dense dTable[ids[r],:] += dX[r,:]*mult. Hardware fp32 atomics (global_atomic_add_f32);
 // hot rows (token 0 of padded history) serialise in L2, not in HBM.
+template <typename IT>
 __global__ __launch_bounds__(GATHER_THREADS) void scatter_add_rows_kernel(
     const int32_t* __restrict__ ids, const float* __restrict__ dX, float* __restrict__ dTable,
     int64_t n_items, int32_t D, int64_t V, const uint32_t* __restrict__ key_ptr, uint32_t thresh,
     float scale) {
   const bool do_drop = key_ptr != nullptr;
   const uint32_t key = do_drop ? *key_ptr : 0u;
-  for (int64_t it = static_cast<int64_t>(blockIdx.x) * GATHER_THREADS + threadIdx.x; it < n_items;
-       it += static_cast<int64_t>(gridDim.x) * GATHER_THREADS) {
-    const int64_t row = it / D;
-    const int32_t col = static_cast<int32_t>(it - row * D);
+  for (IT it = static_cast<IT>(blockIdx.x) * GATHER_THREADS + threadIdx.x; static_cast<int64_t>(it) < n_items;
+       it += static_cast<IT>(gridDim.x) * GATHER_THREADS) {
+    const IT row = it / static_cast<IT>(D);  // 32-bit when the item count allows: see gather_rows_vec4_kernel
+    const int32_t col = static_cast<int32_t>(it - row * static_cast<IT>(D));
     const int64_t id = ids[row];
     if (id < 0 || id >= V) continue;
     float g = dX[it];
@@ -99,15 +104,16 @@ __global__ __launch_bounds__(GATHER_THREADS) void scatter_add_rows_kernel(
 constexpr double FIXED_SCALE = 1099511627776.0;  // 2^40
 
 // Deterministic backward: 64-bit integer atomics on a fixed-point accumulator (order-independent sums).
+template <typename IT>
 __global__ __launch_bounds__(GATHER_THREADS) void scatter_add_rows_fixed_kernel(
     const int32_t* __restrict__ ids, const float* __restrict__ dX, long long* __restrict__ acc, int64_t n_items,
     int32_t D, int64_t V, const uint32_t* __restrict__ key_ptr, uint32_t thresh, float scale) {
   const bool do_drop = key_ptr != nullptr;
   const uint32_t key = do_drop ? *key_ptr : 0u;
-  for (int64_t it = static_cast<int64_t>(blockIdx.x) * GATHER_THREADS + threadIdx.x; it < n_items;
-       it += static_cast<int64_t>(gridDim.x) * GATHER_THREADS) {
-    const int64_t row = it / D;
-    const int32_t col = static_cast<int32_t>(it - row * D);
+  for (IT it = static_cast<IT>(blockIdx.x) * GATHER_THREADS + threadIdx.x; static_cast<int64_t>(it) < n_items;
+       it += static_cast<IT>(gridDim.x) * GATHER_THREADS) {
+    const IT row = it / static_cast<IT>(D);  // 32-bit when the item count allows: see gather_rows_vec4_kernel
+    const int32_t col = static_cast<int32_t>(it - row * static_cast<IT>(D));
     const int64_t id = ids[row];
     if (id < 0 || id >= V) continue;
     float g = dX[it];
@@ -161,9 +167,14 @@ extern "C" int ebn_embedding_grad_scatter_fixed(const int32_t* ids, const float*
   const int64_t n_items = n_tok * D;
   int64_t grid = ebn_ceil_div(n_items, GATHER_THREADS);
   if (grid > 256 * 32) grid = 256 * 32;
-  hipLaunchKernelGGL(scatter_add_rows_fixed_kernel, dim3(static_cast<unsigned>(grid)), dim3(GATHER_THREADS), 0,
-                     ebn_stream(stream), ids, dX, reinterpret_cast<long long*>(acc), n_items, D, V, dr.key_ptr,
-                     dr.thresh, dr.scale);
+  if (n_items + grid * GATHER_THREADS < (static_cast<int64_t>(1) << 32))
+    hipLaunchKernelGGL(scatter_add_rows_fixed_kernel<uint32_t>, dim3(static_cast<unsigned>(grid)), dim3(GATHER_THREADS), 0,
+                       ebn_stream(stream), ids, dX, reinterpret_cast<long long*>(acc), n_items, D, V, dr.key_ptr,
+                       dr.thresh, dr.scale);
+  else
+    hipLaunchKernelGGL(scatter_add_rows_fixed_kernel<int64_t>, dim3(static_cast<unsigned>(grid)), dim3(GATHER_THREADS), 0,
+                       ebn_stream(stream), ids, dX, reinterpret_cast<long long*>(acc), n_items, D, V, dr.key_ptr,
+                       dr.thresh, dr.scale);
   EBN_CHECK_LAUNCH();
   return EBN_OK;
 }
@@ -207,10 +218,16 @@ extern "C" int ebn_gather_rows_f32(const int32_t* ids, const float* table, float
     const int64_t per_block = static_cast<int64_t>(GATHER_THREADS) * GATHER_UNROLL;
     const int64_t grid = ebn_ceil_div(n_items, per_block);
     EBN_REQUIRE(grid <= 0x7FFFFFFF, EBN_ERR_UNSUPPORTED);
-    hipLaunchKernelGGL(gather_rows_vec4_kernel, dim3(static_cast<unsigned>(grid)), dim3(GATHER_THREADS),
-                       0, ebn_stream(stream), ids, reinterpret_cast<const float4*>(table),
-                       reinterpret_cast<float4*>(out), n_items, vpr, V, dr.key_ptr, dr.thresh, dr.scale,
-                       oob_flag);
+    const bool small = n_items + per_block < (static_cast<int64_t>(1) << 32);  // every item index fits 32 bits
+#define EBN_GATHER_LAUNCH(IT, SH)                                                                                     \
+  hipLaunchKernelGGL((gather_rows_vec4_kernel<IT, SH>), dim3(static_cast<unsigned>(grid)), dim3(GATHER_THREADS), 0,   \
+                     ebn_stream(stream), ids, reinterpret_cast<const float4*>(table), reinterpret_cast<float4*>(out), \
+                     n_items, vpr, V, dr.key_ptr, dr.thresh, dr.scale, oob_flag)
+    if (small && vpr == 256) EBN_GATHER_LAUNCH(uint32_t, 8);
+    else if (small && vpr == 64) EBN_GATHER_LAUNCH(uint32_t, 6);
+    else if (small) EBN_GATHER_LAUNCH(uint32_t, -1);
+    else EBN_GATHER_LAUNCH(int64_t, -1);
+#undef EBN_GATHER_LAUNCH
   } else {
     const int64_t n_items = n_tok * D;
     int64_t grid = ebn_ceil_div(n_items, GATHER_THREADS);
@@ -234,8 +251,12 @@ extern "C" int ebn_embedding_grad_scatter_f32(const int32_t* ids, const float* d
   const int64_t n_items = n_tok * D;
   int64_t grid = ebn_ceil_div(n_items, GATHER_THREADS);
   if (grid > 256 * 32) grid = 256 * 32;
-  hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(static_cast<unsigned>(grid)), dim3(GATHER_THREADS), 0,
-                     ebn_stream(stream), ids, dX, dTable, n_items, D, V, dr.key_ptr, dr.thresh, dr.scale);
+  if (n_items + grid * GATHER_THREADS < (static_cast<int64_t>(1) << 32))
+    hipLaunchKernelGGL(scatter_add_rows_kernel<uint32_t>, dim3(static_cast<unsigned>(grid)), dim3(GATHER_THREADS), 0,
+                       ebn_stream(stream), ids, dX, dTable, n_items, D, V, dr.key_ptr, dr.thresh, dr.scale);
+  else
+    hipLaunchKernelGGL(scatter_add_rows_kernel<int64_t>, dim3(static_cast<unsigned>(grid)), dim3(GATHER_THREADS), 0,
+                       ebn_stream(stream), ids, dX, dTable, n_items, D, V, dr.key_ptr, dr.thresh, dr.scale);
   EBN_CHECK_LAUNCH();
   return EBN_OK;
 }

@@ -283,7 +283,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
         if (row >= M) continue;
         float v = alpha * acc[i][j][r];
         if (!split && beta != 0.f) v += beta * out[row * ldo + col];
-        if (EPI == 1 && !split) v = fmaf(epi.rs[row], epi.cv[(row / epi.L) * epi.ldcv + col], v);
+        if (EPI == 1 && !split)  // 32-bit division: M < 2^31 rows
+          v = fmaf(epi.rs[row], epi.cv[static_cast<int64_t>(static_cast<uint32_t>(row) / static_cast<uint32_t>(epi.L)) * epi.ldcv + col], v);
         out[row * ldo + col] = v;
       }
     }
@@ -293,15 +294,26 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int splits,
                                                             int64_t M, int64_t N, float beta,
                                                             float* __restrict__ C, int64_t ldc, GemmEpi epi) {
-  const int64_t total = M * N;
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < total;
-       i += static_cast<int64_t>(gridDim.x) * 256) {
+  // M * N < 2^31 (checked by the launcher): 32-bit index arithmetic -- a 64-bit division per element costs more than
+  // the sum itself
+  const uint32_t total = static_cast<uint32_t>(M * N);
+  const uint32_t n32 = static_cast<uint32_t>(N);
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
     float s = 0.f;
-    for (int z = 0; z < splits; ++z) s += part[static_cast<int64_t>(z) * total + i];
-    const int64_t row = i / N;
-    const int64_t col = i - row * N;
-    float* c = C + row * ldc + col;
-    if (epi.rs != nullptr) s = fmaf(epi.rs[row], epi.cv[(row / epi.L) * epi.ldcv + col], s);
+    int z = 0;
+    for (; z + 4 <= splits; z += 4) {  // 4 independent loads in flight
+      const float v0 = part[static_cast<int64_t>(z) * total + i], v1 = part[static_cast<int64_t>(z + 1) * total + i];
+      const float v2 = part[static_cast<int64_t>(z + 2) * total + i], v3 = part[static_cast<int64_t>(z + 3) * total + i];
+      s += v0;
+      s += v1;
+      s += v2;
+      s += v3;
+    }
+    for (; z < splits; ++z) s += part[static_cast<int64_t>(z) * total + i];
+    const uint32_t row = i / n32;
+    const uint32_t col = i - row * n32;
+    float* c = C + static_cast<int64_t>(row) * ldc + col;
+    if (epi.rs != nullptr) s = fmaf(epi.rs[row], epi.cv[static_cast<int64_t>(row / static_cast<uint32_t>(epi.L)) * epi.ldcv + col], s);
     *c = (beta != 0.f) ? (s + beta * *c) : s;
   }
 }
@@ -378,7 +390,7 @@ static GemmPlan gemm_plan(int64_t M, int64_t N, int64_t K, int64_t ws_floats) {
   if (max_split > 64) max_split = 64;
   const int64_t max_by_ws = (M * N > 0) ? ws_floats / (M * N) : 0;
   if (max_split > max_by_ws) max_split = max_by_ws;
-  if (max_split < 1) max_split = 1;
+  if (max_split < 1 || M * N >= (static_cast<int64_t>(1) << 31)) max_split = 1;  // the reduce kernel indexes in 32 bits
   static const struct {
     int bm, bn;
     double ts_full, ts_lone;
@@ -480,6 +492,7 @@ extern "C" int ebn_gemm_f32_rank1(int64_t M, int64_t N, int64_t K, float alpha, 
                                   const float* seq_rows, int64_t ld_seq, int32_t L, float* workspace,
                                   int64_t workspace_floats, ebn_stream_t stream) {
   EBN_REQUIRE(M >= 0 && N >= 0 && K >= 0 && L > 0, EBN_ERR_BAD_ARG);
+  EBN_REQUIRE(M < (static_cast<int64_t>(1) << 31), EBN_ERR_UNSUPPORTED);
   if (M == 0 || N == 0) return EBN_OK;
   EBN_REQUIRE(A && B && C && row_scale && seq_rows, EBN_ERR_BAD_ARG);
   EBN_REQUIRE(lda >= K && ldb >= K && ldc >= N && ld_seq >= N, EBN_ERR_BAD_ARG);
