@@ -401,6 +401,12 @@ static bool mfma_path_ok(int32_t L, int32_t d, int64_t lda, int64_t ldb, int64_t
   return ebn_aligned16(p0) && ebn_aligned16(p1) && ebn_aligned16(p2);
 }
 
+// more than 64 KB of dynamic LDS per workgroup (d = 32, L = 32 backward: 72 KB) has to be granted per kernel
+template <class K>
+static void allow_lds(K kernel, size_t bytes) {
+  if (bytes > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+}
+
 int ebn_attn_mfma_fwd(const float* qkv, int64_t ld_qkv, float* out, int64_t ld_out, int64_t n_seq, int32_t L,
                       int32_t h, int32_t d, const EbnDrop& dr, hipStream_t s, bool* handled) {
   *handled = mfma_path_ok(L, d, ld_qkv, ld_out, ld_out, qkv, out, out);
@@ -410,7 +416,10 @@ int ebn_attn_mfma_fwd(const float* qkv, int64_t ld_qkv, float* out, int64_t ld_o
   const size_t lds = static_cast<size_t>(4) * 3 * L * sizeof(float);  // x STRIDE below
   if (d == 16) hipLaunchKernelGGL(attn_mfma_fwd_kernel<16>, grid, block, lds * Tile<16>::STRIDE, s, a);
   else if (d == 20) hipLaunchKernelGGL(attn_mfma_fwd_kernel<20>, grid, block, lds * Tile<20>::STRIDE, s, a);
-  else hipLaunchKernelGGL(attn_mfma_fwd_kernel<32>, grid, block, lds * Tile<32>::STRIDE, s, a);
+  else {
+    allow_lds(attn_mfma_fwd_kernel<32>, lds * Tile<32>::STRIDE);
+    hipLaunchKernelGGL(attn_mfma_fwd_kernel<32>, grid, block, lds * Tile<32>::STRIDE, s, a);
+  }
   EBN_CHECK_LAUNCH();
   return EBN_OK;
 }
@@ -425,7 +434,10 @@ int ebn_attn_mfma_bwd(const float* qkv, int64_t ld_qkv, const float* dout, int64
   const size_t lds = static_cast<size_t>(4) * 4 * L * sizeof(float);  // x STRIDE below
   if (d == 16) hipLaunchKernelGGL(attn_mfma_bwd_kernel<16>, grid, block, lds * Tile<16>::STRIDE, s, a);
   else if (d == 20) hipLaunchKernelGGL(attn_mfma_bwd_kernel<20>, grid, block, lds * Tile<20>::STRIDE, s, a);
-  else hipLaunchKernelGGL(attn_mfma_bwd_kernel<32>, grid, block, lds * Tile<32>::STRIDE, s, a);
+  else {
+    allow_lds(attn_mfma_bwd_kernel<32>, lds * Tile<32>::STRIDE);
+    hipLaunchKernelGGL(attn_mfma_bwd_kernel<32>, grid, block, lds * Tile<32>::STRIDE, s, a);
+  }
   EBN_CHECK_LAUNCH();
   return EBN_OK;
 }

@@ -148,7 +148,9 @@ def test_gemm_unaligned_pointers_take_the_scalar_path(hip):
 
 # ---------------------------------------------------------------- a3/a6 attention core
 ATTN_CASES = [(4, 30, 20, 20), (3, 20, 20, 20), (2, 50, 16, 16), (5, 1, 2, 4), (2, 33, 3, 32), (3, 32, 2, 5),
-              (1, 64, 2, 8)]
+              (1, 64, 2, 8),
+              # the other instantiations of the MFMA path (L <= 32, d in {16, 20, 32}), incl. its largest LDS footprint
+              (2, 32, 4, 32), (3, 17, 2, 16), (2, 32, 2, 16), (1, 5, 3, 32), (9, 1, 1, 20)]
 
 
 def _qkv_case(n_seq, L, h, d, seed):
