@@ -23,6 +23,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef EBN_GEMM_XCD
 #define EBN_GEMM_XCD 1
 #endif
+#ifndef EBN_GEMM_GLDS
+#define EBN_GEMM_GLDS 1  // direct global->LDS tile fetch when both operands are stored [K][mn] (the weight-gradient GEMMs)
+#endif
 
 constexpr int BK = 16;
 constexpr int PAD = 4;
@@ -30,7 +33,7 @@ constexpr int GEMM_THREADS = 256;
 
 // One operand tile of R_MN x BK (mn = m or n index). KCONTIG: memory is [mn][k] (k fastest);
 // else memory is [k][mn] (mn fastest).
-template <int BMN, bool KCONTIG, bool VEC>
+template <int BMN, bool KCONTIG, bool VEC, int PADX = PAD>
 struct TileLoader {
   static constexpr int VECS = BMN * BK / 4;            // float4 per tile
   static constexpr int PER_THREAD = VECS / GEMM_THREADS;  // 2 (BMN=128) or 1 (BMN=64)
@@ -80,7 +83,7 @@ struct TileLoader {
 
   // LDS image: S[k][mn], row stride BMN+PAD
   __device__ static __forceinline__ void store(float* __restrict__ S, int v, float4 r) {
-    constexpr int LD = BMN + PAD;
+    constexpr int LD = BMN + PADX;
     if (KCONTIG) {
       const int mn = v / (BK / 4);
       const int kq = v % (BK / 4);
@@ -121,13 +124,23 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
   constexpr int WTN = BN / WAVES_N;
   constexpr int TM = WTM / 32;            // 32x32 MFMA tiles per wave along m / n
   constexpr int TN = WTN / 32;
-  constexpr int LDA_S = BM + PAD;
-  constexpr int LDB_S = BN + PAD;
-  using LA = TileLoader<BM, !TA, VEC>;
-  using LB = TileLoader<BN, TB, VEC>;
+  // GLDS: both operands are stored [K][mn] -> a 16-deep slab is 16 contiguous row pieces per operand, which
+  // global_load_lds_dwordx4 (wave-uniform LDS base + lane x 16 B) can drop straight into an UNPADDED [k][mn] image:
+  // no staging registers, no ds_write pass.  (The pad only ever served the scalar stores of k-contiguous operands;
+  // the operand fetch reads 32 consecutive floats of one k row either way.)
+  constexpr bool GLDS = (EBN_GEMM_GLDS != 0) && TA && !TB && VEC;
+  constexpr int PADX = GLDS ? 0 : PAD;
+  constexpr int LDA_S = BM + PADX;
+  constexpr int LDB_S = BN + PADX;
+  using LA = TileLoader<BM, !TA, VEC, PADX>;
+  using LB = TileLoader<BN, TB, VEC, PADX>;
 
-  __shared__ __attribute__((aligned(16))) float As[2][BK * LDA_S];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB_S];
+  // ONE __shared__ object: with two, hipcc cannot tell the glds destination from the buffer being read and waits
+  // vmcnt(0) before the first ds_read of every slab (cdna_hip_programming.md, glds trap (a))
+  constexpr int A_FLOATS = BK * LDA_S, B_FLOATS = BK * LDB_S;
+  __shared__ __attribute__((aligned(16))) float smem[2 * (A_FLOATS + B_FLOATS)];
+#define EBN_AS(b) (smem + (b) * A_FLOATS)
+#define EBN_BS(b) (smem + 2 * A_FLOATS + (b) * B_FLOATS)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -205,6 +218,45 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
     }
   }
 
+  // ---- direct-to-LDS fetch (GLDS kernels): wave w issues IPW instructions per operand and slab; instruction q
+  // covers RPI consecutive k rows (64 lanes x 16 B = RPI rows of BMN floats)
+  constexpr int A_LPR = BM / 4, A_RPI = 64 / (A_LPR < 64 ? A_LPR : 64), A_IPW = (BK / A_RPI) / 4;
+  constexpr int B_LPR = BN / 4, B_RPI = 64 / (B_LPR < 64 ? B_LPR : 64), B_IPW = (BK / B_RPI) / 4;
+  static_assert(!GLDS || (BM <= 256 && BN <= 256 && A_IPW >= 1 && B_IPW >= 1), "glds tiling");
+  const float* ga[GLDS ? A_IPW : 1];
+  const float* gb[GLDS ? B_IPW : 1];
+  if (GLDS) {
+#pragma unroll
+    for (int q = 0; q < A_IPW; ++q) {
+      const int krow = (wave * A_IPW + q) * A_RPI + lane / A_LPR;
+      int64_t col = m0 + (lane % A_LPR) * 4;
+      col = col < M ? col : M - 4;
+      ga[q] = A + (kbeg + krow) * lda + col;
+    }
+#pragma unroll
+    for (int q = 0; q < B_IPW; ++q) {
+      const int krow = (wave * B_IPW + q) * B_RPI + lane / B_LPR;
+      int64_t col = n0 + (lane % B_LPR) * 4;
+      col = col < N ? col : N - 4;
+      gb[q] = B + (kbeg + krow) * ldb + col;
+    }
+  }
+#define EBN_GLDS_SLAB(BUF)                                                                                          \
+  do {                                                                                                              \
+    _Pragma("unroll") for (int q = 0; q < A_IPW; ++q) {                                                             \
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ga[q],                        \
+                                       (__attribute__((address_space(3))) void*)(EBN_AS(BUF) + (wave * A_IPW + q) * A_RPI * BM), \
+                                       16, 0, 0);                                                                   \
+      ga[q] += BK * lda;                                                                                            \
+    }                                                                                                               \
+    _Pragma("unroll") for (int q = 0; q < B_IPW; ++q) {                                                             \
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gb[q],                        \
+                                       (__attribute__((address_space(3))) void*)(EBN_BS(BUF) + (wave * B_IPW + q) * B_RPI * BN), \
+                                       16, 0, 0);                                                                   \
+      gb[q] += BK * ldb;                                                                                            \
+    }                                                                                                               \
+  } while (0)
+
 #define EBN_LOAD_SLAB(KT)                                                                \
   do {                                                                                   \
   if (VEC && (KT) < nk_full) {                                                           \
@@ -226,8 +278,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
   } while (0)
 #define EBN_STORE_SLAB(BUF)                                                                              \
   {                                                                                                      \
-    _Pragma("unroll") for (int i = 0; i < LA::PER_THREAD; ++i) LA::store(As[BUF], tid + i * GEMM_THREADS, ra[i]); \
-    _Pragma("unroll") for (int i = 0; i < LB::PER_THREAD; ++i) LB::store(Bs[BUF], tid + i * GEMM_THREADS, rb[i]); \
+    _Pragma("unroll") for (int i = 0; i < LA::PER_THREAD; ++i) LA::store(EBN_AS(BUF), tid + i * GEMM_THREADS, ra[i]); \
+    _Pragma("unroll") for (int i = 0; i < LB::PER_THREAD; ++i) LB::store(EBN_BS(BUF), tid + i * GEMM_THREADS, rb[i]); \
   }
 
   // Pipeline: LDS buffer `cur` holds slab kt; slab kt+1 is fetched into registers while slab kt is multiplied
@@ -235,8 +287,12 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
   // (profiles/r01_gemm_tuning.md): two-slab-deep prefetch, BK=32, k-contiguous LDS image with burst b128
   // operand reads, s_setprio around the MFMA cluster / per-workgroup static priority -- all within +-3 %.
   if (nk > 0) {
-    EBN_LOAD_SLAB(0);
-    EBN_STORE_SLAB(0);
+    if (GLDS && nk_full > 0) {
+      EBN_GLDS_SLAB(0);
+    } else {
+      EBN_LOAD_SLAB(0);
+      EBN_STORE_SLAB(0);
+    }
   }
   __syncthreads();
 
@@ -244,9 +300,13 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
   const int il = lane & 31;
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) EBN_LOAD_SLAB(kt + 1);  // next slab into registers while this one is multiplied
-    const float* as = As[cur] + kl * LDA_S + wm * WTM + il;
-    const float* bs = Bs[cur] + kl * LDB_S + wn * WTN + il;
+    // next slab: straight into the other LDS buffer (GLDS; its readers passed the barrier of the previous
+    // iteration), or into registers while this one is multiplied
+    const bool via_lds = GLDS && (kt + 1 < nk_full);
+    if (via_lds) EBN_GLDS_SLAB(cur ^ 1);
+    else if (kt + 1 < nk) EBN_LOAD_SLAB(kt + 1);
+    const float* as = EBN_AS(cur) + kl * LDA_S + wm * WTM + il;
+    const float* bs = EBN_BS(cur) + kl * LDB_S + wn * WTN + il;
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
       float a[TM], b[TN];
@@ -260,11 +320,14 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nk) EBN_STORE_SLAB(cur ^ 1);
-    __syncthreads();
+    if (!via_lds && kt + 1 < nk) EBN_STORE_SLAB(cur ^ 1);
+    __syncthreads();  // also drains the glds queue (vmcnt) -- the slab must have landed before anyone reads it
     cur ^= 1;
   }
 #undef EBN_LOAD_SLAB
+#undef EBN_GLDS_SLAB
+#undef EBN_AS
+#undef EBN_BS
 #undef EBN_STORE_SLAB
 
   // epilogue. C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
