@@ -271,6 +271,45 @@ extern "C" int ebn_batchnorm_bwd_f32(const float* dY, const float* xhat, const f
   return EBN_OK;
 }
 
+namespace {
+struct Copy3 {
+  const uint32_t* s[3];
+  uint32_t* d[3];
+  int64_t n[3];  // dwords
+};
+__global__ __launch_bounds__(256) void copy3_kernel(Copy3 c) {
+  const int which = blockIdx.y;
+  const uint32_t* __restrict__ s = c.s[which];
+  uint32_t* __restrict__ d = c.d[which];
+  const int64_t n = c.n[which];
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * 256) d[i] = s[i];
+}
+}  // namespace
+
+extern "C" int ebn_copy3(const void* s0, void* d0, int64_t n0, const void* s1, void* d1, int64_t n1, const void* s2,
+                         void* d2, int64_t n2, ebn_stream_t stream) {
+  const void* ss[3] = {s0, s1, s2};
+  void* dd[3] = {d0, d1, d2};
+  int64_t nn[3] = {n0, n1, n2};
+  Copy3 c;
+  int64_t most = 0;
+  for (int i = 0; i < 3; ++i) {
+    EBN_REQUIRE(nn[i] >= 0 && (nn[i] % 4) == 0, EBN_ERR_BAD_ARG);
+    if (ss[i] == nullptr || nn[i] == 0) nn[i] = 0;
+    else EBN_REQUIRE(dd[i] != nullptr, EBN_ERR_BAD_ARG);
+    c.s[i] = static_cast<const uint32_t*>(ss[i]);
+    c.d[i] = static_cast<uint32_t*>(dd[i]);
+    c.n[i] = nn[i] / 4;
+    if (c.n[i] > most) most = c.n[i];
+  }
+  if (most == 0) return EBN_OK;
+  int64_t gx = ebn_ceil_div(most, 256);
+  if (gx > 1024) gx = 1024;
+  hipLaunchKernelGGL(copy3_kernel, dim3(static_cast<unsigned>(gx), 3), dim3(256), 0, ebn_stream(stream), c);
+  EBN_CHECK_LAUNCH();
+  return EBN_OK;
+}
+
 extern "C" int ebn_axpy_f32(float a, const float* x, float* y, int64_t n, ebn_stream_t stream) {
   EBN_REQUIRE(x && y && n >= 0, EBN_ERR_BAD_ARG);
   if (n == 0) return EBN_OK;

@@ -365,6 +365,11 @@ class NRMSEngine:
                   ctypes.byref(grads), ctypes.byref(scratch), _hip.ptr(dX), 0, _hip.ptr(self.state),
                   _hip.stream_handle())
 
+    def _device_batch(self, his, pred, y) -> bool:
+        same_dev = lambda t: t.is_cuda and (self.device.index is None or t.device.index == self.device.index)
+        ok = lambda t, dt: isinstance(t, torch.Tensor) and same_dev(t) and t.dtype == dt and t.is_contiguous()
+        return ok(his, torch.int32) and ok(pred, torch.int32) and ok(y, torch.float32)
+
     def _upload_ids(self, dst, *arrays):
         """Token ids -> int32 device buffer; ids outside [0,V) raise like TF-CPU's Embedding does."""
         off = 0
@@ -547,9 +552,16 @@ class NRMSEngine:
         else:
             self._check_shapes(his, pred)
             nb, ub = self._train_bufs(B, C)
-            self._upload_ids(nb.ids, his, pred)
-        labels = (y if isinstance(y, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(y, dtype=np.float32))))
-        nb.labels[: B * C].copy_(labels.reshape(-1).to(device=self.device, dtype=torch.float32), non_blocking=True)
+            if self._device_batch(his, pred, y):  # batch already in HBM in the step's dtypes: one copy launch, not three
+                nh = his.numel()
+                _hip.call("ebn_copy3", _hip.ptr(his), _hip.ptr(nb.ids), nh * 4, _hip.ptr(pred), _hip.ptr(nb.ids[nh:]),
+                          pred.numel() * 4, _hip.ptr(y), _hip.ptr(nb.labels), y.numel() * 4, _hip.stream_handle())
+                y = None
+            else:
+                self._upload_ids(nb.ids, his, pred)
+        if y is not None:
+            labels = (y if isinstance(y, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(y, dtype=np.float32))))
+            nb.labels[: B * C].copy_(labels.reshape(-1).to(device=self.device, dtype=torch.float32), non_blocking=True)
         if self.use_graph and self.kernel_events is None and self.exchange is None:  # sharded lookups have data-dependent sizes
             graphs = self._graphs.get((B, C))
             if graphs is None:

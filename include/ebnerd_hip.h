@@ -267,6 +267,12 @@ int ebn_batchnorm_bwd_f32(const float* dY, const float* xhat, const float* gamma
                           int32_t accumulate, const ebn_step_state* st, int32_t site,
                           float drop_p, int64_t elem_offset, ebn_stream_t stream);
 
+/* Step prologue: copy up to three device buffers (history ids, candidate ids, labels of a batch handed over as device
+ * tensors -- the inputs of nrms.py:170-176) into the step's static buffers with ONE launch; n_i in bytes, multiples
+ * of 4; a NULL source or n_i = 0 skips that pair.                                                                   */
+int ebn_copy3(const void* s0, void* d0, int64_t n0, const void* s1, void* d1, int64_t n1, const void* s2, void* d2,
+              int64_t n2, ebn_stream_t stream);
+
 /* y = a*x + y over n elements (L2 kernel-regulariser gradient, gradient accumulation). */
 int ebn_axpy_f32(float a, const float* x, float* y, int64_t n, ebn_stream_t stream);
 /* kernel_regularizer=l2(lambda) of one Dense kernel in a single pass (nrms_docvec.py:119-121, nrms.py:146-148):

@@ -269,6 +269,24 @@ def test_row_sharded_table_path_on_one_gpu_equals_replicated(nrms, train_embeddi
         assert np.allclose(wa, wb, rtol=1e-4, atol=1e-6)
 
 
+def test_device_resident_batches_equal_host_batches(nrms):
+    """Batches handed over as device tensors in the step's dtypes go through the one-launch prologue copy (ebn_copy3);
+    the step is the same as with numpy batches, bit for bit (graph replay and kernel-by-kernel)."""
+    hp = make_hp(dropout=0.2, learning_rate=1e-3)
+    rng = np.random.default_rng(77)
+    for use_graph in (True, False):
+        a = nrms(hp, word_emb_dim=16, vocab_size=90, seed=5)
+        b = nrms(hp, word_emb_dim=16, vocab_size=90, seed=5)
+        a._engine.use_graph = b._engine.use_graph = use_graph
+        for _ in range(3):
+            his, pred, y = batch(rng, 4, hp.history_size, 5, hp.title_size, 90)
+            la = float(a.train_step(his, pred, y).item())
+            dev = lambda x, dt: torch.as_tensor(np.ascontiguousarray(x)).to(device="cuda", dtype=dt)
+            lb = float(b.train_step(dev(his, torch.int32), dev(pred, torch.int32), dev(y, torch.float32)).item())
+            assert la == lb
+        assert all(np.array_equal(x, z) for x, z in zip(a.model.get_weights(), b.model.get_weights()))
+
+
 def test_indexed_batches_equal_token_batches(nrms):
     """Device-side batch assembly: article-row numbers + the loader's token matrix in HBM give the same step as the
     host-gathered token batches (dataloader.py:169-179), bit for bit with a frozen table."""
