@@ -432,14 +432,6 @@ struct GemmPlan {
   double cost;
 };
 
-static int tall_tiles_mode() {
-  static const int mode = [] {
-    const char* e = getenv("EBN_GEMM_TALL");  // 0: never, 1: by cost (default) -- tuning only
-    return (e && e[0] >= '0' && e[0] <= '1') ? (e[0] - '0') : 1;
-  }();
-  return mode;
-}
-
 static int forced_tile_bm() {  // EBN_GEMM_FORCE_TILE = 64 | 128 | 256: restrict the planner to one family -- tuning only
   static const int bm = [] {
     const char* e = getenv("EBN_GEMM_FORCE_TILE");
@@ -462,7 +454,7 @@ static GemmPlan gemm_plan(int64_t M, int64_t N, int64_t K, int64_t ws_floats) {
   const double out_mb = static_cast<double>(M) * static_cast<double>(N) * 4e-6;
   GemmPlan best{128, 128, 1, ebn_ceil_div(K > 0 ? K : 1, BK) * BK, 1e300};
   for (int t = 0; t < 3; ++t) {
-    if (kTiles[t].bm == 256 && (tall_tiles_mode() == 0 || M < 256)) continue;
+    if (kTiles[t].bm == 256 && M < 256) continue;
     if (forced_tile_bm() != 0 && forced_tile_bm() != kTiles[t].bm && !(kTiles[t].bm == 64 && M < 256 && forced_tile_bm() == 256)) continue;
     const int64_t tiles = ebn_ceil_div(M, kTiles[t].bm) * ebn_ceil_div(N, kTiles[t].bn);
     int64_t prev_s = 0;
