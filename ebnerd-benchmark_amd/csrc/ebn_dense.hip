@@ -173,6 +173,157 @@ __global__ __launch_bounds__(1024) void sum_kernel(const float* __restrict__ x, 
   }
 }
 
+// ---- single-launch "column strip" variants for a call site of at most STRIP_ROWS rows -------------------------------
+// A TimeDistributed call site of the DocVec encoder has B*H = 640 or B*C = 160 rows: the two-stage reductions above
+// cost 3-5 launches of ~4.5 us each for a few hundred KB of data.  Here one 1024-thread workgroup owns 16 columns:
+// thread (c = t & 15, lane = t >> 4) keeps its <= 16 rows (lane, lane + 64, ...) in registers, column sums go through
+// LDS in a fixed order (deterministic), and statistics, finalisation and the element-wise pass share one launch.
+constexpr int STRIP_COLS = 16;
+constexpr int STRIP_LANES = 64;
+constexpr int STRIP_PER = 16;
+constexpr int STRIP_ROWS = STRIP_LANES * STRIP_PER;  // 1024
+
+// sum over the 64 row lanes of each column; every thread gets the total of its column
+__device__ __forceinline__ float strip_colsum(float v, float (*sm)[STRIP_COLS + 1], int c, int lane) {
+  __syncthreads();  // sm may still be read from a previous call
+  sm[lane][c] = v;
+  __syncthreads();
+  if (lane < 8) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += sm[lane * 8 + k][c];
+    sm[STRIP_LANES + lane][c] = t;
+  }
+  __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) tot += sm[STRIP_LANES + k][c];
+  return tot;
+}
+
+__global__ __launch_bounds__(1024) void bn_fwd_strip_kernel(const float* __restrict__ X, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ mmean,
+                                                            float* __restrict__ mvar, float* __restrict__ Y,
+                                                            float* __restrict__ xhat, float* __restrict__ mean_out,
+                                                            float* __restrict__ istd_out, int R, int C,
+                                                            const uint32_t* __restrict__ key_ptr, uint32_t thresh,
+                                                            float scale, int64_t elem_offset) {
+  __shared__ float sm[STRIP_LANES + 8][STRIP_COLS + 1];
+  const int cl = threadIdx.x & (STRIP_COLS - 1), lane = threadIdx.x >> 4;
+  const int c = blockIdx.x * STRIP_COLS + cl;
+  const bool cok = c < C;
+  const float inv_R = 1.0f / static_cast<float>(R);
+  float x[STRIP_PER];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < STRIP_PER; ++j) {
+    const int r = lane + STRIP_LANES * j;
+    x[j] = (cok && r < R) ? X[static_cast<int64_t>(r) * C + c] : 0.f;
+    s += x[j];
+  }
+  const float mean = strip_colsum(s, sm, cl, lane) * inv_R;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < STRIP_PER; ++j) {
+    const int r = lane + STRIP_LANES * j;
+    const float d = (r < R) ? x[j] - mean : 0.f;
+    q = fmaf(d, d, q);
+  }
+  const float var = strip_colsum(q, sm, cl, lane) * inv_R;  // biased, two-pass
+  const float istd = 1.0f / sqrtf(var + BN_EPS);
+  if (!cok) return;
+  if (lane == 0) {
+    mmean[c] = mmean[c] * BN_MOM + mean * (1.0f - BN_MOM);
+    mvar[c] = mvar[c] * BN_MOM + var * (1.0f - BN_MOM);
+    mean_out[c] = mean;
+    istd_out[c] = istd;
+  }
+  const bool do_drop = key_ptr != nullptr;
+  const uint32_t key = do_drop ? *key_ptr : 0u;
+  const float g = gamma[c], b = beta[c];
+#pragma unroll
+  for (int j = 0; j < STRIP_PER; ++j) {
+    const int r = lane + STRIP_LANES * j;
+    if (r >= R) break;
+    const int64_t i = static_cast<int64_t>(r) * C + c;
+    const float xh = (x[j] - mean) * istd;
+    xhat[i] = xh;
+    float y = xh * g + b;
+    if (do_drop) y *= ebn_drop_mult(key, static_cast<uint64_t>(i + elem_offset), thresh, scale);
+    Y[i] = y;
+  }
+}
+
+__global__ __launch_bounds__(1024) void bn_bwd_strip_kernel(const float* __restrict__ dY, const float* __restrict__ xhat,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ istd, float* __restrict__ dX,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int R,
+                                                            int C, int training, int accumulate,
+                                                            const uint32_t* __restrict__ key_ptr, uint32_t thresh,
+                                                            float scale, int64_t elem_offset) {
+  __shared__ float sm[STRIP_LANES + 8][STRIP_COLS + 1];
+  const int cl = threadIdx.x & (STRIP_COLS - 1), lane = threadIdx.x >> 4;
+  const int c = blockIdx.x * STRIP_COLS + cl;
+  const bool cok = c < C;
+  const bool do_drop = key_ptr != nullptr;
+  const uint32_t key = do_drop ? *key_ptr : 0u;
+  float g[STRIP_PER], xh[STRIP_PER];
+  float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+  for (int j = 0; j < STRIP_PER; ++j) {
+    const int r = lane + STRIP_LANES * j;
+    g[j] = 0.f;
+    xh[j] = 0.f;
+    if (cok && r < R) {
+      const int64_t i = static_cast<int64_t>(r) * C + c;
+      g[j] = dY[i];
+      if (do_drop) g[j] *= ebn_drop_mult(key, static_cast<uint64_t>(i + elem_offset), thresh, scale);
+      xh[j] = xhat[i];
+    }
+    a0 = fmaf(g[j], xh[j], a0);
+    a1 += g[j];
+  }
+  const float dg = strip_colsum(a0, sm, cl, lane);
+  const float db = strip_colsum(a1, sm, cl, lane);
+  if (!cok) return;
+  if (lane == 0) {
+    dgamma[c] = accumulate ? dgamma[c] + dg : dg;
+    dbeta[c] = accumulate ? dbeta[c] + db : db;
+  }
+  const float inv_R = 1.0f / static_cast<float>(R);
+  const float k = gamma[c] * istd[c];
+#pragma unroll
+  for (int j = 0; j < STRIP_PER; ++j) {
+    const int r = lane + STRIP_LANES * j;
+    if (r >= R) break;
+    float v = g[j];
+    if (training) v = g[j] - db * inv_R - xh[j] * dg * inv_R;
+    dX[static_cast<int64_t>(r) * C + c] = v * k;
+  }
+}
+
+__global__ __launch_bounds__(1024) void relu_bwd_strip_kernel(const float* __restrict__ Y, const float* __restrict__ dY,
+                                                              float* __restrict__ dX, float* __restrict__ dbias, int R,
+                                                              int C, int accumulate) {
+  __shared__ float sm[STRIP_LANES + 8][STRIP_COLS + 1];
+  const int cl = threadIdx.x & (STRIP_COLS - 1), lane = threadIdx.x >> 4;
+  const int c = blockIdx.x * STRIP_COLS + cl;
+  const bool cok = c < C;
+  float a0 = 0.f;
+#pragma unroll
+  for (int j = 0; j < STRIP_PER; ++j) {
+    const int r = lane + STRIP_LANES * j;
+    if (cok && r < R) {
+      const int64_t i = static_cast<int64_t>(r) * C + c;
+      const float g = (Y[i] > 0.f) ? dY[i] : 0.f;
+      dX[i] = g;
+      a0 += g;
+    }
+  }
+  const float tot = strip_colsum(a0, sm, cl, lane);
+  if (cok && lane == 0) dbias[c] = accumulate ? dbias[c] + tot : tot;
+}
+
 inline unsigned grid_for(int64_t n) {
   int64_t g = ebn_ceil_div(n, 256);
   if (g > 256 * 16) g = 256 * 16;
@@ -208,6 +359,12 @@ extern "C" int ebn_bias_relu_bwd_f32(const float* Y, const float* dY, float* dX,
   EBN_REQUIRE(R >= 0 && Ccols > 0, EBN_ERR_BAD_ARG);
   if (R == 0) return EBN_OK;
   hipStream_t s = ebn_stream(stream);
+  if (R <= STRIP_ROWS) {
+    hipLaunchKernelGGL(relu_bwd_strip_kernel, dim3(static_cast<unsigned>(ebn_ceil_div(Ccols, STRIP_COLS))), dim3(1024), 0, s,
+                       Y, dY, dX, dbias, static_cast<int>(R), Ccols, accumulate);
+    EBN_CHECK_LAUNCH();
+    return EBN_OK;
+  }
   int64_t nb;
   ebn_colred_stage1(ReluBwd{Y, dY, dX, Ccols}, partials, R, Ccols, s, &nb);
   EBN_CHECK_LAUNCH();
@@ -228,6 +385,14 @@ extern "C" int ebn_batchnorm_fwd_f32(const float* X, const float* gamma, const f
   hipStream_t s = ebn_stream(stream);
   const int C = Ccols;
   const unsigned cgrid = static_cast<unsigned>(ebn_ceil_div(C, 256));
+  if (training && R <= STRIP_ROWS) {
+    const EbnDrop dr = ebn_make_drop(st, site, drop_p);
+    hipLaunchKernelGGL(bn_fwd_strip_kernel, dim3(static_cast<unsigned>(ebn_ceil_div(C, STRIP_COLS))), dim3(1024), 0, s, X,
+                       gamma, beta, moving_mean, moving_var, Y, xhat, mean_out, istd_out, static_cast<int>(R), C,
+                       dr.key_ptr, dr.thresh, dr.scale, elem_offset);
+    EBN_CHECK_LAUNCH();
+    return EBN_OK;
+  }
   if (training) {  // two-pass batch statistics of this call site: mean, then biased variance about it
     const float inv_R = 1.0f / static_cast<float>(R);
     int64_t nb;
@@ -258,6 +423,13 @@ extern "C" int ebn_batchnorm_bwd_f32(const float* dY, const float* xhat, const f
   hipStream_t s = ebn_stream(stream);
   const int C = Ccols;
   const EbnDrop dr = training ? ebn_make_drop(st, site, drop_p) : ebn_make_drop(nullptr, -1, 0.f);
+  if (R <= STRIP_ROWS) {
+    hipLaunchKernelGGL(bn_bwd_strip_kernel, dim3(static_cast<unsigned>(ebn_ceil_div(C, STRIP_COLS))), dim3(1024), 0, s, dY,
+                       xhat, gamma, istd, dX, dgamma, dbeta, static_cast<int>(R), C, training, accumulate, dr.key_ptr,
+                       dr.thresh, dr.scale, elem_offset);
+    EBN_CHECK_LAUNCH();
+    return EBN_OK;
+  }
   int64_t nb;
   ebn_colred_stage1(BnBwdStats{dY, xhat, C, dr.key_ptr, dr.thresh, dr.scale, elem_offset}, partials, R, C, s, &nb);
   float* site_dg = partials + nb * 2 * C;  // per-call-site sums (the batch-statistics terms must not mix sites)

@@ -429,9 +429,9 @@ def test_adam_keras_multi_step(hip, n):
 
 
 # ---------------------------------------------------------------- DocVec dense helpers
-def test_bias_relu_forward_backward(hip):
+@pytest.mark.parametrize("R,C", [(160, 512), (1025, 70), (3, 5)])  # both sides of the single-launch strip limit
+def test_bias_relu_forward_backward(hip, R, C):
     rng = np.random.default_rng(61)
-    R, C = 160, 512
     X = rng.standard_normal((R, C))
     b = rng.standard_normal(C) * 0.2
     Y = torch.empty(R, C, device="cuda")
@@ -448,10 +448,10 @@ def test_bias_relu_forward_backward(hip):
     assert_close(host(dbias), wdx.sum(0), rtol=2e-5, atol=2e-5, what="dbias")
 
 
+@pytest.mark.parametrize("R,C", [(640, 96), (37, 21), (1024, 512), (1500, 40)])  # <= 1024 rows: single-launch strip kernels
 @pytest.mark.parametrize("training,p", [(1, 0.0), (1, 0.2), (0, 0.0)])
-def test_batchnorm_forward_backward(hip, training, p):
+def test_batchnorm_forward_backward(hip, training, p, R, C):
     rng = np.random.default_rng(67)
-    R, C = 640, 96
     X = np.maximum(rng.standard_normal((R, C)) + 0.3, 0)
     gamma = 1 + 0.1 * rng.standard_normal(C)
     beta = 0.1 * rng.standard_normal(C)
