@@ -152,6 +152,31 @@ __global__ __launch_bounds__(256) void l2_reg_kernel(const float* __restrict__ W
   if (threadIdx.x == 0) partial[blockIdx.x] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
 }
 
+struct L2Seg4 {
+  const float* W[4];
+  float* g[4];
+  int64_t n[4];
+};
+// blockIdx.y = segment; partial[seg * gridDim.x + block]
+__global__ __launch_bounds__(256) void l2_reg4_kernel(L2Seg4 sg, float two_lambda, float* __restrict__ partial) {
+  __shared__ float sw[4];
+  const int seg = blockIdx.y;
+  const float* __restrict__ W = sg.W[seg];
+  float* __restrict__ g = sg.g[seg];
+  const int64_t n = sg.n[seg];
+  float s = 0.f;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * 256) {
+    const float w = W[i];
+    g[i] = fmaf(two_lambda, w, g[i]);
+    s = fmaf(w, w, s);
+  }
+  s = ebn_wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[seg * gridDim.x + blockIdx.x] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
+}
+
 // deterministic sum (optionally of squares) of n floats by ONE 1024-thread block (n is small: loss rows, partials)
 template <bool SQ>
 __global__ __launch_bounds__(1024) void sum_kernel(const float* __restrict__ x, int64_t n, float scale,
@@ -218,7 +243,9 @@ __global__ __launch_bounds__(1024) void bn_fwd_strip_kernel(const float* __restr
 #pragma unroll
   for (int j = 0; j < STRIP_PER; ++j) {
     const int r = lane + STRIP_LANES * j;
-    x[j] = (cok && r < R) ? X[static_cast<int64_t>(r) * C + c] : 0.f;
+    const bool ok = cok && r < R;
+    const float v = X[ok ? static_cast<int64_t>(r) * C + c : 0];  // unconditional, clamped address
+    x[j] = ok ? v : 0.f;
     s += x[j];
   }
   const float mean = strip_colsum(s, sm, cl, lane) * inv_R;
@@ -272,14 +299,13 @@ __global__ __launch_bounds__(1024) void bn_bwd_strip_kernel(const float* __restr
 #pragma unroll
   for (int j = 0; j < STRIP_PER; ++j) {
     const int r = lane + STRIP_LANES * j;
-    g[j] = 0.f;
-    xh[j] = 0.f;
-    if (cok && r < R) {
-      const int64_t i = static_cast<int64_t>(r) * C + c;
-      g[j] = dY[i];
-      if (do_drop) g[j] *= ebn_drop_mult(key, static_cast<uint64_t>(i + elem_offset), thresh, scale);
-      xh[j] = xhat[i];
-    }
+    const bool ok = cok && r < R;
+    const int64_t i = ok ? static_cast<int64_t>(r) * C + c : 0;  // unconditional, clamped address
+    float gv = dY[i];
+    const float xv = xhat[i];
+    if (do_drop) gv *= ebn_drop_mult(key, static_cast<uint64_t>(i + elem_offset), thresh, scale);
+    g[j] = ok ? gv : 0.f;
+    xh[j] = ok ? xv : 0.f;
     a0 = fmaf(g[j], xh[j], a0);
     a1 += g[j];
   }
@@ -309,15 +335,25 @@ __global__ __launch_bounds__(1024) void relu_bwd_strip_kernel(const float* __res
   const int cl = threadIdx.x & (STRIP_COLS - 1), lane = threadIdx.x >> 4;
   const int c = blockIdx.x * STRIP_COLS + cl;
   const bool cok = c < C;
+  // all loads first, unconditionally addressed (clamped): a load that depends on a loaded value or sits under a
+  // per-element branch is serialised by the compiler (vmcnt(0) per element)
+  float y[STRIP_PER], g[STRIP_PER];
+#pragma unroll
+  for (int j = 0; j < STRIP_PER; ++j) {
+    const int r = lane + STRIP_LANES * j;
+    const bool ok = cok && r < R;
+    const int64_t i = ok ? static_cast<int64_t>(r) * C + c : 0;
+    y[j] = Y[i];
+    g[j] = dY[i];
+  }
   float a0 = 0.f;
 #pragma unroll
   for (int j = 0; j < STRIP_PER; ++j) {
     const int r = lane + STRIP_LANES * j;
     if (cok && r < R) {
-      const int64_t i = static_cast<int64_t>(r) * C + c;
-      const float g = (Y[i] > 0.f) ? dY[i] : 0.f;
-      dX[i] = g;
-      a0 += g;
+      const float v = (y[j] > 0.f) ? g[j] : 0.f;
+      dX[static_cast<int64_t>(r) * C + c] = v;
+      a0 += v;
     }
   }
   const float tot = strip_colsum(a0, sm, cl, lane);
@@ -486,6 +522,43 @@ extern "C" int ebn_axpy_f32(float a, const float* x, float* y, int64_t n, ebn_st
   EBN_REQUIRE(x && y && n >= 0, EBN_ERR_BAD_ARG);
   if (n == 0) return EBN_OK;
   hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n)), dim3(256), 0, ebn_stream(stream), a, x, y, n);
+  EBN_CHECK_LAUNCH();
+  return EBN_OK;
+}
+
+extern "C" int ebn_l2_reg4_f32(const float* W0, float* g0, int64_t n0, const float* W1, float* g1, int64_t n1,
+                               const float* W2, float* g2, int64_t n2, const float* W3, float* g3, int64_t n3,
+                               float lambda, float* partials, float* loss, ebn_stream_t stream) {
+  EBN_REQUIRE(partials && loss, EBN_ERR_BAD_ARG);
+  const float* Ws[4] = {W0, W1, W2, W3};
+  float* gs[4] = {g0, g1, g2, g3};
+  const int64_t ns[4] = {n0, n1, n2, n3};
+  L2Seg4 sg;
+  int nseg = 0;
+  int64_t most = 0;
+  for (int i = 0; i < 4; ++i) {
+    EBN_REQUIRE(ns[i] >= 0, EBN_ERR_BAD_ARG);
+    if (Ws[i] == nullptr || ns[i] == 0) continue;
+    EBN_REQUIRE(gs[i] != nullptr, EBN_ERR_BAD_ARG);
+    sg.W[nseg] = Ws[i];
+    sg.g[nseg] = gs[i];
+    sg.n[nseg] = ns[i];
+    if (ns[i] > most) most = ns[i];
+    ++nseg;
+  }
+  if (nseg == 0) return EBN_OK;
+  for (int i = nseg; i < 4; ++i) {
+    sg.W[i] = nullptr;
+    sg.g[i] = nullptr;
+    sg.n[i] = 0;
+  }
+  hipStream_t s = ebn_stream(stream);
+  int64_t grid = ebn_ceil_div(most, 256 * 4);
+  if (grid > L2_BLOCKS) grid = L2_BLOCKS;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(l2_reg4_kernel, dim3(static_cast<unsigned>(grid), static_cast<unsigned>(nseg)), dim3(256), 0, s, sg,
+                     2.0f * lambda, partials);
+  hipLaunchKernelGGL((sum_kernel<false>), dim3(1), dim3(1024), 0, s, partials, grid * nseg, lambda, loss, 1);
   EBN_CHECK_LAUNCH();
   return EBN_OK;
 }

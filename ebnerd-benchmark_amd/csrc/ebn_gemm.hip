@@ -107,6 +107,7 @@ struct GemmEpi {
   const float* cv;
   int64_t ldcv;
   int32_t L;
+  const float* bias;  // EPI = 2: C = max(acc + bias[col], 0) -- Dense(units, activation="relu") forward
 };
 
 // TA: A stored [K,M]; TB: B stored [N,K].
@@ -348,6 +349,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
         if (!split && beta != 0.f) v += beta * out[row * ldo + col];
         if (EPI == 1 && !split)  // 32-bit division: M < 2^31 rows
           v = fmaf(epi.rs[row], epi.cv[static_cast<int64_t>(static_cast<uint32_t>(row) / static_cast<uint32_t>(epi.L)) * epi.ldcv + col], v);
+        if (EPI == 2 && !split) v = fmaxf(v + epi.bias[col], 0.f);
         out[row * ldo + col] = v;
       }
     }
@@ -377,6 +379,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     const uint32_t col = i - row * n32;
     float* c = C + static_cast<int64_t>(row) * ldc + col;
     if (epi.rs != nullptr) s = fmaf(epi.rs[row], epi.cv[static_cast<int64_t>(row / static_cast<uint32_t>(epi.L)) * epi.ldcv + col], s);
+    if (epi.bias != nullptr) s = fmaxf(s + epi.bias[col], 0.f);
     *c = (beta != 0.f) ? (s + beta * *c) : s;
   }
 }
@@ -397,7 +400,10 @@ int launch_gemm(int transA, int transB, int64_t M, int64_t N, int64_t K, float a
       hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WAVES_M, TA, TB, false, 0>), grid, block, 0, s, M, N, K, alpha, A,  \
                          lda, B, ldb, beta, C, ldc, k_per_split, part, epi);                              \
   } while (0)
-  if (epi.rs != nullptr)  // caller guarantees !transA && transB && vecA && vecB
+  if (epi.bias != nullptr)  // caller guarantees !transA && !transB && vecA && vecB
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WAVES_M, false, false, true, 0, 2>), grid, block, 0, s, M, N, K, alpha, A, lda,
+                       B, ldb, beta, C, ldc, k_per_split, part, epi);
+  else if (epi.rs != nullptr)  // caller guarantees !transA && transB && vecA && vecB
     hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WAVES_M, false, true, true, 0, 1>), grid, block, 0, s, M, N, K, alpha, A, lda,
                        B, ldb, beta, C, ldc, k_per_split, part, epi);
   else if (!transA && !transB && site == 1 && vecA && vecB)
@@ -528,7 +534,7 @@ extern "C" int ebn_gemm_f32_site(int32_t transA, int32_t transB, int64_t M, int6
   EBN_REQUIRE(A && B && C, EBN_ERR_BAD_ARG);
   EBN_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, EBN_ERR_BAD_ARG);
   return gemm_dispatch(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, workspace, workspace_floats, site,
-                       GemmEpi{nullptr, nullptr, 0, 1}, ebn_stream(stream));
+                       GemmEpi{nullptr, nullptr, 0, 1, nullptr}, ebn_stream(stream));
 }
 
 namespace {
@@ -551,7 +557,7 @@ extern "C" int ebn_gemm_f32_rank1(int64_t M, int64_t N, int64_t K, float alpha, 
   if (M == 0 || N == 0) return EBN_OK;
   EBN_REQUIRE(A && B && C && row_scale && seq_rows, EBN_ERR_BAD_ARG);
   EBN_REQUIRE(lda >= K && ldb >= K && ldc >= N && ld_seq >= N, EBN_ERR_BAD_ARG);
-  const GemmEpi epi{row_scale, seq_rows, ld_seq, L};
+  const GemmEpi epi{row_scale, seq_rows, ld_seq, L, nullptr};
   hipStream_t s = ebn_stream(stream);
   const bool vec = (lda % 4) == 0 && ebn_aligned16(A) && (ldb % 4) == 0 && ebn_aligned16(B) && (K % 4) == 0;
   if (vec)
@@ -562,7 +568,30 @@ extern "C" int ebn_gemm_f32_rank1(int64_t M, int64_t N, int64_t K, float alpha, 
   hipLaunchKernelGGL(rank1_fill_kernel, dim3(static_cast<unsigned>(grid)), dim3(256), 0, s, C, ldc, M, N, epi);
   EBN_CHECK_LAUNCH();
   return gemm_dispatch(0, 1, M, N, K, alpha, A, lda, B, ldb, 1.0f, C, ldc, workspace, workspace_floats, 0,
-                       GemmEpi{nullptr, nullptr, 0, 1}, s);
+                       GemmEpi{nullptr, nullptr, 0, 1, nullptr}, s);
+}
+
+extern "C" int ebn_dense_relu_fwd_f32(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
+                                      int64_t ldb, const float* bias, float* C, int64_t ldc, float* workspace,
+                                      int64_t workspace_floats, ebn_stream_t stream) {
+  EBN_REQUIRE(M >= 0 && N >= 0 && K >= 0, EBN_ERR_BAD_ARG);
+  if (M == 0 || N == 0) return EBN_OK;
+  EBN_REQUIRE(A && B && C && bias, EBN_ERR_BAD_ARG);
+  EBN_REQUIRE(lda >= K && ldb >= N && ldc >= N, EBN_ERR_BAD_ARG);
+  hipStream_t s = ebn_stream(stream);
+  const bool vec = (lda % 4) == 0 && ebn_aligned16(A) && (K % 4) == 0 && (ldb % 4) == 0 && ebn_aligned16(B) && (N % 4) == 0;
+  if (vec)
+    return gemm_dispatch(0, 0, M, N, K, 1.0f, A, lda, B, ldb, 0.0f, C, ldc, workspace, workspace_floats, 0,
+                         GemmEpi{nullptr, nullptr, 0, 1, bias}, s);
+  // unaligned operands: plain product with the scalar-load kernels, then bias + ReLU in place
+  const int rc = gemm_dispatch(0, 0, M, N, K, 1.0f, A, lda, B, ldb, 0.0f, C, ldc, workspace, workspace_floats, 0,
+                               GemmEpi{nullptr, nullptr, 0, 1, nullptr}, s);
+  if (rc != EBN_OK) return rc;
+  for (int64_t r = 0; ldc != N && r < M; ++r) {  // strided C: row by row (rare)
+    const int rr = ebn_bias_relu_f32(C + r * ldc, bias, C + r * ldc, 1, static_cast<int32_t>(N), stream);
+    if (rr != EBN_OK) return rr;
+  }
+  return (ldc == N) ? ebn_bias_relu_f32(C, bias, C, M, static_cast<int32_t>(N), stream) : EBN_OK;
 }
 
 extern "C" int ebn_gemm_f32_ws(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K, float alpha,

@@ -113,7 +113,8 @@ class DocVecEngine:
             b = {"N": N, "X0": f(N, self.Din), "NE": f(N, self.E), "dNE": f(N, self.E), "dXl": f(N, self.mlp.out_dim),
                  "scores": f(N), "probs": f(N), "labels": f(N)}
             b["partials"] = f(int(_hip.lib().ebn_colsum_partials_len(N, self.E)))
-            b["ws"] = f(max(int(_hip.lib().ebn_gemm_workspace_floats(self.mlp.out_dim, self.E, N)), 1))
+            wsf = _hip.lib().ebn_gemm_workspace_floats
+            b["ws"] = f(max(int(wsf(self.mlp.out_dim, self.E, N)), int(wsf(N, self.E, self.mlp.out_dim)), 1))
             self.mlp.bufs(N)
             self._bufs["mlp"] = b
         return b
@@ -138,8 +139,9 @@ class DocVecEngine:
         pv = self.params.view
         x = self.mlp.forward(mb["X0"], n_hist, n_cand, train, self.state, self.p)
         mb["x_last"] = x
-        self._gemm(0, 0, N, self.E, self.mlp.out_dim, x, self.mlp.out_dim, pv("out_W"), self.E, 0.0, mb["NE"], self.E)
-        _hip.call("ebn_bias_relu_f32", _hip.ptr(mb["NE"]), _hip.ptr(pv("out_b")), _hip.ptr(mb["NE"]), N, self.E, _hip.stream_handle())
+        ws = mb.get("ws")  # Dense(E, relu): bias and ReLU ride in the GEMM epilogue
+        _hip.call("ebn_dense_relu_fwd_f32", N, self.E, self.mlp.out_dim, _hip.ptr(x), self.mlp.out_dim, _hip.ptr(pv("out_W")), self.E,
+                  _hip.ptr(pv("out_b")), _hip.ptr(mb["NE"]), self.E, _hip.ptr(ws), 0 if ws is None else ws.numel(), _hip.stream_handle())
 
     def _news_backward(self, mb, n_hist, n_cand):
         N = n_hist + n_cand
@@ -258,18 +260,29 @@ class DocVecEngine:
         self._article_matrix_src = matrix
         self._oob = torch.zeros(1, dtype=torch.int32, device=self.device)
 
-    def _stage_indexed(self, mb, his_idx, pred_idx):
+    def _stage_indexed(self, mb, his_idx, pred_idx, y=None):
+        """Article-row numbers -> mb["art_idx"], then the document vectors are gathered on the device.  Returns y, or None
+        when the labels were copied along (device-resident batch in the step's dtypes: one copy launch for all three)."""
         n = his_idx.shape[0] * (self.H + pred_idx.shape[1])
         if "art_idx" not in mb:
             mb["art_idx"] = torch.empty(mb["N"], dtype=torch.int32, device=self.device)
-        off = 0
-        for a in (his_idx, pred_idx):
-            t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(a).reshape(-1).astype(np.int32, copy=False)))
-            t = t.reshape(-1)
-            mb["art_idx"][off: off + t.numel()].copy_(t.to(device=self.device, dtype=torch.int32), non_blocking=True)
-            off += t.numel()
+        same_dev = lambda t: t.is_cuda and (self.device.index is None or t.device.index == self.device.index)
+        ok = lambda t, dt: isinstance(t, torch.Tensor) and same_dev(t) and t.dtype == dt and t.is_contiguous()
+        if ok(his_idx, torch.int32) and ok(pred_idx, torch.int32) and ok(y, torch.float32):
+            nh = his_idx.numel()
+            _hip.call("ebn_copy3", _hip.ptr(his_idx), _hip.ptr(mb["art_idx"]), nh * 4, _hip.ptr(pred_idx), _hip.ptr(mb["art_idx"][nh:]),
+                      pred_idx.numel() * 4, _hip.ptr(y), _hip.ptr(mb["labels"]), y.numel() * 4, _hip.stream_handle())
+            y = None
+        else:
+            off = 0
+            for a in (his_idx, pred_idx):
+                t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(a).reshape(-1).astype(np.int32, copy=False)))
+                t = t.reshape(-1)
+                mb["art_idx"][off: off + t.numel()].copy_(t.to(device=self.device, dtype=torch.int32), non_blocking=True)
+                off += t.numel()
         _hip.call("ebn_gather_rows_f32", _hip.ptr(mb["art_idx"]), _hip.ptr(self.article_matrix), _hip.ptr(mb["X0"]), n, self.Din,
                   self.article_matrix.shape[0], None, -1, ctypes.c_float(0.0), _hip.ptr(self._oob), _hip.stream_handle())
+        return y
 
     def train_step(self, his, pred, y, return_probs=False, indexed=False):
         his = his if isinstance(his, torch.Tensor) else np.asarray(his)
@@ -284,11 +297,12 @@ class DocVecEngine:
         if n_before != (mb["N"], ub.n_seq):
             self._graphs = {}  # buffers were (re)allocated: captured graphs hold stale pointers
         if indexed:
-            self._stage_indexed(mb, his, pred)
+            y = self._stage_indexed(mb, his, pred, y)
         else:
             self._upload(mb, his, pred)
-        labels = (y if isinstance(y, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(y, dtype=np.float32))))
-        mb["labels"][: B * C].copy_(labels.reshape(-1).to(device=self.device, dtype=torch.float32))
+        if y is not None:
+            labels = (y if isinstance(y, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(y, dtype=np.float32))))
+            mb["labels"][: B * C].copy_(labels.reshape(-1).to(device=self.device, dtype=torch.float32))
         if getattr(self, "use_graph", False) and self.world == 1:
             g = self._graphs.get((B, C))
             if g is None:

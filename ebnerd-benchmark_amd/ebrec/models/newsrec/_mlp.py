@@ -76,8 +76,8 @@ class MLPStack:
         prev = self.din
         for l, u in enumerate(self.units):
             R = b["R"][l]
-            self.gemm(0, 0, N, u, prev, x, prev, self._pv(f"d{l}_W"), u, 0.0, R, u, b["ws"])
-            _hip.call("ebn_bias_relu_f32", _hip.ptr(R), _hip.ptr(self._pv(f"d{l}_b")), _hip.ptr(R), N, u, S())
+            _hip.call("ebn_dense_relu_fwd_f32", N, u, prev, _hip.ptr(x), prev, _hip.ptr(self._pv(f"d{l}_W")), u,
+                      _hip.ptr(self._pv(f"d{l}_b")), _hip.ptr(R), u, _hip.ptr(b["ws"]), b["ws"].numel(), S())
             for site, (r0, nr) in enumerate(((0, n0), (n0, n1))):
                 if nr == 0:
                     continue
@@ -110,14 +110,19 @@ class MLPStack:
             _hip.call("ebn_bias_relu_bwd_f32", _hip.ptr(b["R"][l]), _hip.ptr(dR), _hip.ptr(dR), _hip.ptr(self._g(f"d{l}_b")),
                       _hip.ptr(b["partials"]), N, u, 0, S())
             self.gemm(1, 0, din, u, N, x_in, din, dR, u, 0.0, self._g(f"d{l}_W"), u, b["ws"])
-            if self.l2 > 0:  # kernel_regularizer=l2(lambda): gW += 2*lambda*W and loss += lambda*sum(W^2), one pass over W
-                _hip.call("ebn_l2_reg_f32", _hip.ptr(self._pv(f"d{l}_W")), _hip.ptr(self._g(f"d{l}_W")), din * u,
-                          ctypes.c_float(self.l2), _hip.ptr(b["partials"]), _hip.ptr(loss_dev), S())
             if l:
                 self.gemm(0, 1, N, din, u, dR, u, self._pv(f"d{l}_W"), u, 0.0, b["dA"][l - 1], din, b["ws"])
                 dY = b["dA"][l - 1]
             elif need_dx0:
                 self.gemm(0, 1, N, din, u, dR, u, self._pv(f"d{l}_W"), u, 0.0, b["dX0"], din, b["ws"])
+        if self.l2 > 0 and self.units:
+            # kernel_regularizer=l2(lambda) of every Dense kernel of the stack, after all dW are written: gW += 2*lambda*W
+            # and loss += lambda*sum(W^2) -- one pass over the weights, two launches for the whole stack
+            seg, dims = [], [self.din] + self.units
+            for l in range(len(self.units)):
+                seg += [_hip.ptr(self._pv(f"d{l}_W")), _hip.ptr(self._g(f"d{l}_W")), dims[l] * dims[l + 1]]
+            seg += [None, None, 0] * (4 - len(self.units))
+            _hip.call("ebn_l2_reg4_f32", *seg, ctypes.c_float(self.l2), _hip.ptr(b["partials"]), _hip.ptr(loss_dev), S())
         return b["dX0"] if (need_dx0 and self.units) else (d_last if need_dx0 else None)
 
     # ---- weights in Keras creation order per layer: kernel, bias, gamma, beta, moving_mean, moving_variance

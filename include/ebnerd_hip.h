@@ -136,6 +136,13 @@ int ebn_gemm_f32_rank1(int64_t M, int64_t N, int64_t K, float alpha, const float
                        int64_t ldb, float* C, int64_t ldc, const float* row_scale, const float* seq_rows,
                        int64_t ld_seq, int32_t L, float* workspace, int64_t workspace_floats, ebn_stream_t stream);
 
+/* C[M,N] = max(A[M,K] * B[K,N] + bias[n], 0): tf.keras.layers.Dense(units, activation="relu") forward
+ * (nrms_docvec.py:116-119,130; nrms.py:143-146) in one pass -- bias and ReLU ride in the GEMM epilogue (or in its
+ * split-K reduce) instead of a separate element-wise launch.  workspace as for ebn_gemm_f32_ws(0, 0, M, N, K).    */
+int ebn_dense_relu_fwd_f32(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                           const float* bias, float* C, int64_t ldc, float* workspace, int64_t workspace_floats,
+                           ebn_stream_t stream);
+
 /* ---- a4/a7  AttLayer2 (layers.py:55-81) after the x.W matmul ----------------------
  * fwd: U <- tanh(U + b) in place ([R,A], R = n_seq*L); e = U.q; a = exp(e);
  *      w = a/(sum_l a + 1e-7); out[n,:] = sum_l w[n,l] X[n,l,:].                    */
@@ -280,6 +287,11 @@ int ebn_axpy_f32(float a, const float* x, float* y, int64_t n, ebn_stream_t stre
  * (ebn_colsum_partials_len never returns less).                                                            */
 int ebn_l2_reg_f32(const float* W, float* gW, int64_t n, float lambda, float* partials, float* loss,
                    ebn_stream_t stream);
+/* The same for up to four Dense kernels with two launches in total (NULL W_i / n_i = 0 skips a slot): gW_i += 2*lambda*W_i,
+ * loss[0] += lambda * sum_i sum(W_i^2); `partials` = scratch of at least 1024 floats.                                 */
+int ebn_l2_reg4_f32(const float* W0, float* g0, int64_t n0, const float* W1, float* g1, int64_t n1, const float* W2,
+                    float* g2, int64_t n2, const float* W3, float* g3, int64_t n3, float lambda, float* partials,
+                    float* loss, ebn_stream_t stream);
 /* out[0] (+)= scale * sum(x[0..n)) -- deterministic single-block reduction.            */
 int ebn_sum_f32(const float* x, int64_t n, float scale, float* out, int32_t accumulate,
                 ebn_stream_t stream);

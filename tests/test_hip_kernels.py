@@ -551,3 +551,34 @@ def test_fixed_point_scatter_is_order_independent_and_accurate(hip):
         outs.append(g.cpu().numpy())
     assert np.array_equal(outs[0], outs[1])  # bitwise, whatever the order
     assert_close(outs[0], want, rtol=2e-7, atol=1e-9, what="fixed-point dTable")
+
+
+@pytest.mark.parametrize("M,N,K", [(800, 512, 768), (160, 256, 512), (37, 20, 12), (1300, 64, 40), (5, 7, 3)])
+def test_dense_relu_forward_is_gemm_bias_relu(hip, M, N, K):
+    """Dense(units, activation="relu") forward in one pass: epilogue of the GEMM or of its split-K reduce."""
+    rng = np.random.default_rng(M + N + K)
+    A, B, b = rng.standard_normal((M, K)), rng.standard_normal((K, N)) / np.sqrt(K), rng.standard_normal(N) * 0.3
+    want = np.maximum(A.astype(np.float32).astype(np.float64) @ B.astype(np.float32).astype(np.float64) + b.astype(np.float32), 0)
+    for use_ws in (False, True):
+        ws = torch.empty(max(int(hip.lib().ebn_gemm_workspace_floats(M, N, K)), 1), device="cuda") if use_ws else None
+        C = torch.full((M, N), -3.0, device="cuda")
+        hip.call("ebn_dense_relu_fwd_f32", M, N, K, P(dev(A)), K, P(dev(B)), N, P(dev(b)), P(C), N, P(ws),
+                 0 if ws is None else ws.numel(), S())
+        assert_close(host(C), want, rtol=2e-6, atol=1e-5 + 3e-7 * K, what=f"dense relu {M}x{N}x{K} ws={use_ws}")
+        assert (host(C) >= 0).all()
+
+
+def test_l2_regulariser_of_a_stack_in_two_launches(hip):
+    rng = np.random.default_rng(5)
+    Ws = [rng.standard_normal(n).astype(np.float32) for n in (768 * 512, 1000, 7)]
+    gs = [rng.standard_normal(w.size).astype(np.float32) for w in Ws]
+    lam = 1e-3
+    loss = torch.full((1,), 2.5, device="cuda")
+    part = torch.empty(1024, device="cuda")
+    dW, dg = [dev(w) for w in Ws], [dev(g) for g in gs]
+    hip.call("ebn_l2_reg4_f32", P(dW[0]), P(dg[0]), Ws[0].size, P(dW[1]), P(dg[1]), Ws[1].size, None, None, 0, P(dW[2]), P(dg[2]),
+             Ws[2].size, ctypes.c_float(lam), P(part), P(loss), S())
+    for w, g, d in zip(Ws, gs, dg):
+        assert_close(host(d), g.astype(np.float64) + 2 * lam * w.astype(np.float64), rtol=1e-6, atol=1e-7, what="gW += 2 lambda W")
+    want = 2.5 + lam * sum(float((w.astype(np.float64) ** 2).sum()) for w in Ws)
+    assert abs(float(loss.item()) - want) <= 1e-5 * want
