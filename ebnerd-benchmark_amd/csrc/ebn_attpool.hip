@@ -265,13 +265,24 @@ __global__ __launch_bounds__(POOL_THREADS) void attpool_bwd_dpre_kernel(float* _
   for (int k = threadIdx.x; k < A; k += POOL_THREADS) {
     const float qk = q[k];
     float dq = 0.f, db = 0.f;
-    for (int64_t r = r0; r < r1; ++r) {
-      const float u = U[r * A + k];
-      const float der = de[r];
-      dq = fmaf(der, u, dq);
-      const float dp = der * qk * (1.0f - u * u);
-      U[r * A + k] = dp;
-      db += dp;
+    // 8 rows at a time: all loads of a batch are issued before the first store to U (a store into the array being read
+    // keeps the compiler from hoisting the next row's load: one dependent round trip per row otherwise)
+    for (int64_t rb = r0; rb < r1; rb += 8) {
+      float u[8], der[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int64_t r = (rb + j < r1) ? rb + j : r1 - 1;  // clamped, unconditional
+        u[j] = U[r * A + k];
+        der[j] = de[r];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (rb + j >= r1) break;
+        dq = fmaf(der[j], u[j], dq);
+        const float dp = der[j] * qk * (1.0f - u[j] * u[j]);
+        U[(rb + j) * A + k] = dp;
+        db += dp;
+      }
     }
     partials[(static_cast<int64_t>(blockIdx.x) * 2 + 0) * A + k] = dq;
     partials[(static_cast<int64_t>(blockIdx.x) * 2 + 1) * A + k] = db;
