@@ -63,9 +63,30 @@ __device__ __forceinline__ void wave_lds_sync() {
 
 // global M[L][D] (row stride ld) -> lds[L][STRIDE].  DROP: multiply by the dropout mask of
 // element index e0 + r*E + c (the mask the forward pass applied to the matching output element).
+// Staging is split into "issue every load" and "write to LDS": loads that sit under a per-element guard, or behind
+// the LDS store of the previous piece, are serialised by the compiler (one global round trip after the other -- with
+// 9-12 pieces per wave that was most of a wave's lifetime).  The loads are unconditional with a clamped row.
+template <int D>
+struct Staged {
+  float4 v[Tile<D>::ROUNDS];
+};
+
+template <int D>
+__device__ __forceinline__ void stage_load(Staged<D>& st, const float* __restrict__ base, int64_t ld, int L, int lane) {
+  using T = Tile<D>;
+#pragma unroll
+  for (int t = 0; t < T::ROUNDS; ++t) {
+    int v = lane + 64 * t;
+    if (T::VECS % 64 != 0 && v >= T::VECS) v = 0;
+    const int r = v / T::VPR, c4 = v - r * T::VPR;
+    const int rc = r < L ? r : 0;
+    st.v[t] = *reinterpret_cast<const float4*>(base + static_cast<int64_t>(rc) * ld + c4 * 4);
+  }
+}
+
 template <int D, bool DROP>
-__device__ __forceinline__ void stage_in(float* __restrict__ lds, const float* __restrict__ base, int64_t ld, int L,
-                                         int lane, uint32_t key, uint64_t e0, int E, uint32_t thresh, float scale) {
+__device__ __forceinline__ void stage_store(float* __restrict__ lds, const Staged<D>& st, int L, int lane, uint32_t key,
+                                            uint64_t e0, int E, uint32_t thresh, float scale) {
   using T = Tile<D>;
 #pragma unroll
   for (int t = 0; t < T::ROUNDS; ++t) {
@@ -73,7 +94,7 @@ __device__ __forceinline__ void stage_in(float* __restrict__ lds, const float* _
     if (T::VECS % 64 != 0 && v >= T::VECS) break;
     const int r = v / T::VPR, c4 = v - r * T::VPR;
     if (r >= L) continue;
-    float4 y = *reinterpret_cast<const float4*>(base + static_cast<int64_t>(r) * ld + c4 * 4);
+    float4 y = st.v[t];
     if (DROP) {
       const uint64_t e = e0 + static_cast<uint64_t>(r) * E + c4 * 4;  // multiple of 4: two aligned pairs
       const uint32_t h0 = ebn_dropout_pair_hash(key, e >> 1), h1 = ebn_dropout_pair_hash(key, (e >> 1) + 1);
@@ -240,9 +261,15 @@ __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(MfmaAttnArgs a) {
   const float* qb = a.qkv + row0 * a.ld_qkv + head * D;
   const float inv2 = 1.44269504088896341f / sqrtf(static_cast<float>(D));
 
-  stage_in<D, false>(sq, qb, a.ld_qkv, L, lane, 0u, 0u, 0, 0u, 0.f);
-  stage_in<D, false>(sk, qb + E, a.ld_qkv, L, lane, 0u, 0u, 0, 0u, 0.f);
-  stage_in<D, false>(sv, qb + 2 * E, a.ld_qkv, L, lane, 0u, 0u, 0, 0u, 0.f);
+  {
+    Staged<D> tq, tk, tv;
+    stage_load<D>(tq, qb, a.ld_qkv, L, lane);
+    stage_load<D>(tk, qb + E, a.ld_qkv, L, lane);
+    stage_load<D>(tv, qb + 2 * E, a.ld_qkv, L, lane);
+    stage_store<D, false>(sq, tq, L, lane, 0u, 0u, 0, 0u, 0.f);
+    stage_store<D, false>(sk, tk, L, lane, 0u, 0u, 0, 0u, 0.f);
+    stage_store<D, false>(sv, tv, L, lane, 0u, 0u, 0, 0u, 0.f);
+  }
   wave_lds_sync();
 
   float qr[D / 2], kr[D / 2];
@@ -291,13 +318,20 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(MfmaAttnArgs a) {
   const float inv = 1.0f / sqrtf(static_cast<float>(D));
   const float inv2 = inv * 1.44269504088896341f;
 
-  stage_in<D, false>(sq, qb, a.ld_qkv, L, lane, 0u, 0u, 0, 0u, 0.f);
-  stage_in<D, false>(sk, qb + E, a.ld_qkv, L, lane, 0u, 0u, 0, 0u, 0.f);
-  stage_in<D, false>(sv, qb + 2 * E, a.ld_qkv, L, lane, 0u, 0u, 0, 0u, 0.f);
-  if (a.key_ptr != nullptr)
-    stage_in<D, true>(sg, gb, a.ld_dout, L, lane, *a.key_ptr, static_cast<uint64_t>(row0) * E + head * D, E, a.thresh, a.scale);
-  else
-    stage_in<D, false>(sg, gb, a.ld_dout, L, lane, 0u, 0u, 0, 0u, 0.f);
+  {
+    Staged<D> tq, tk, tv, tg;
+    stage_load<D>(tq, qb, a.ld_qkv, L, lane);
+    stage_load<D>(tk, qb + E, a.ld_qkv, L, lane);
+    stage_load<D>(tv, qb + 2 * E, a.ld_qkv, L, lane);
+    stage_load<D>(tg, gb, a.ld_dout, L, lane);
+    stage_store<D, false>(sq, tq, L, lane, 0u, 0u, 0, 0u, 0.f);
+    stage_store<D, false>(sk, tk, L, lane, 0u, 0u, 0, 0u, 0.f);
+    stage_store<D, false>(sv, tv, L, lane, 0u, 0u, 0, 0u, 0.f);
+    if (a.key_ptr != nullptr)
+      stage_store<D, true>(sg, tg, L, lane, *a.key_ptr, static_cast<uint64_t>(row0) * E + head * D, E, a.thresh, a.scale);
+    else
+      stage_store<D, false>(sg, tg, L, lane, 0u, 0u, 0, 0u, 0.f);
+  }
   wave_lds_sync();
 
   float* ob = a.out + row0 * a.ld_out + head * D;
