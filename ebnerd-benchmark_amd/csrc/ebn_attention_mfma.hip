@@ -336,6 +336,7 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(MfmaAttnArgs a) {
 
   float* ob = a.out + row0 * a.ld_out + head * D;
   float c, rowdot;
+  float vr[KH];  // row form of V (lane = row): identical in both passes
   // ---- lane-i layout: P[i][j] and dP[i][j] with i on lanes -> dV, dQ
   {
     f32x16 P, dP;
@@ -347,8 +348,8 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(MfmaAttnArgs a) {
     }
     c = softmax_in_lane(P, L, hi, inv2);
     {
-      float vr[KH], gr[KH];
-      lds_row_form<D>(vr, sv, L, row, hi);
+      float gr[KH];
+      lds_row_form<D>(vr, sv, L, row, hi);  // kept for the lane-j pass: sv is about to be reused for the results
       lds_row_form<D>(gr, sg, L, row, hi);
       dP = mm_rows<KH>(gr, vr);  // dP[i][j] = V[i].dO[j]: lane i, regs j
     }
@@ -390,21 +391,8 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(MfmaAttnArgs a) {
     }
     softmax_from_stats(P, L, hi, inv2, c);
     {
-      float vr[KH], gr[KH];
+      float gr[KH];
       lds_row_form<D>(gr, sg, L, row, hi);
-      // V was overwritten by the staged results: its row form comes from global memory again (L1/L2-resident)
-      if (row < L) {
-        const float2* pv = reinterpret_cast<const float2*>(qb + 2 * E + static_cast<int64_t>(row) * a.ld_qkv + hi * KH);
-#pragma unroll
-        for (int s2 = 0; s2 < KH / 2; ++s2) {
-          const float2 v = pv[s2];
-          vr[2 * s2] = v.x;
-          vr[2 * s2 + 1] = v.y;
-        }
-      } else {
-#pragma unroll
-        for (int s2 = 0; s2 < KH; ++s2) vr[s2] = 0.f;
-      }
       dP = mm_rows<KH>(vr, gr);  // lane j, regs i
     }
 #pragma unroll
