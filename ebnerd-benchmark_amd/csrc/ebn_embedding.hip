@@ -26,22 +26,28 @@ __global__ __launch_bounds__(GATHER_THREADS) void gather_rows_vec4_kernel(
   float4 v[GATHER_UNROLL];
   IT item[GATHER_UNROLL];
   bool ok[GATHER_UNROLL];
+  int32_t col[GATHER_UNROLL];
+  int64_t id[GATHER_UNROLL];
+  // ids first, then the rows: every load is unconditional with a clamped address (a load under a per-item guard is
+  // serialised behind the previous item's), validity is applied with selects afterwards
 #pragma unroll
   for (int u = 0; u < GATHER_UNROLL; ++u) {
     item[u] = base + static_cast<IT>(u) * GATHER_THREADS;
     ok[u] = static_cast<int64_t>(item[u]) < n_items;
-    v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (ok[u]) {
-      const IT row = (SHIFT >= 0) ? (item[u] >> (SHIFT >= 0 ? SHIFT : 0)) : item[u] / static_cast<IT>(vpr);
-      const int32_t col = static_cast<int32_t>(item[u] - row * static_cast<IT>(vpr));
-      const int64_t id = ids[row];
-      if (id >= 0 && id < V) {
-        v[u] = table[id * vpr + col];
-      } else if (oob_flag != nullptr) {
-        *oob_flag = 1;
-      }
-    }
+    const IT it = ok[u] ? item[u] : 0;
+    const IT row = (SHIFT >= 0) ? (it >> (SHIFT >= 0 ? SHIFT : 0)) : it / static_cast<IT>(vpr);
+    col[u] = static_cast<int32_t>(it - row * static_cast<IT>(vpr));
+    id[u] = ids[row];
   }
+  bool bad = false;
+#pragma unroll
+  for (int u = 0; u < GATHER_UNROLL; ++u) {
+    const bool in_range = id[u] >= 0 && id[u] < V;
+    bad |= ok[u] && !in_range;
+    const float4 t = table[(in_range ? id[u] : 0) * vpr + col[u]];
+    v[u] = (ok[u] && in_range) ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (bad && oob_flag != nullptr) *oob_flag = 1;
 #pragma unroll
   for (int u = 0; u < GATHER_UNROLL; ++u) {
     if (!ok[u]) continue;
