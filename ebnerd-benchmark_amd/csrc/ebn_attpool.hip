@@ -94,9 +94,20 @@ __global__ __launch_bounds__(POOL_THREADS) void attpool_bwd_pool_kernel(const fl
 // the math -- the scalar kernels walk their rows one dependent load at a time and sit at ~1/3 of the HBM rate.
 constexpr int POOL_RB = 8;  // rows per wave per batch
 
+// Loads are unconditional with a CLAMPED OFFSET (a select between two pointers, or a select on the loaded value right
+// next to the load, is turned into a branch around the load by hipcc, and every such load then waits vmcnt(0) on its
+// own).  ld4_clamped returns garbage-but-finite data for !ok; ld4_or_zero adds the zeroing select.
+__device__ __forceinline__ float4 ld4_clamped(const float* __restrict__ base, int64_t off, bool ok) {
+  return *reinterpret_cast<const float4*>(base + (ok ? off : 0));
+}
 __device__ __forceinline__ float4 ld4_or_zero(const float* __restrict__ base, int64_t off, bool ok) {
-  const float4 v = *reinterpret_cast<const float4*>(ok ? base + off : base);
-  return ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 v = ld4_clamped(base, off, ok);
+  float4 r;
+  r.x = ok ? v.x : 0.f;
+  r.y = ok ? v.y : 0.f;
+  r.z = ok ? v.z : 0.f;
+  r.w = ok ? v.w : 0.f;
+  return r;
 }
 
 __global__ __launch_bounds__(POOL_THREADS) void attpool_fwd_vec_kernel(float* __restrict__ U,
@@ -118,7 +129,7 @@ __global__ __launch_bounds__(POOL_THREADS) void attpool_fwd_vec_kernel(float* __
 #pragma unroll
       for (int j = 0; j < POOL_RB; ++j) {
         const int l = l0 + POOL_WAVES * j;
-        u[j] = ld4_or_zero(U, (n * L + l) * A + lane * 4, kok && l < L);
+        u[j] = ld4_clamped(U, (n * L + l) * A + lane * 4, kok && l < L);  // rows >= L are never used; lanes >= A4 are masked below
       }
 #pragma unroll
       for (int j = 0; j < POOL_RB; ++j) {
@@ -132,7 +143,7 @@ __global__ __launch_bounds__(POOL_THREADS) void attpool_fwd_vec_kernel(float* __
         if (kok) *reinterpret_cast<float4*>(U + (n * L + l) * A + lane * 4) = t;
         // same order as the scalar kernel would give for 4 consecutive k of one lane is not required: the
         // oracle comparison is tolerance-based; the order here is fixed (deterministic)
-        float part = fmaf(t.w, qq.w, fmaf(t.z, qq.z, fmaf(t.y, qq.y, t.x * qq.x)));
+        float part = kok ? fmaf(t.w, qq.w, fmaf(t.z, qq.z, fmaf(t.y, qq.y, t.x * qq.x))) : 0.f;
         part = ebn_wave_sum(part);
         if (lane == 0) sm[l] = part;
       }
@@ -166,7 +177,7 @@ __global__ __launch_bounds__(POOL_THREADS) void attpool_fwd_vec_kernel(float* __
 #pragma unroll
       for (int j = 0; j < POOL_RB; ++j) {
         const int l = l0 + NP * j;
-        x[j] = ld4_or_zero(X, (n * L + l) * E + c4 * 4, ok && l < L);
+        x[j] = ld4_clamped(X, (n * L + l) * E + c4 * 4, ok && l < L);  // weight 0 for l >= L, result unused for !ok
       }
 #pragma unroll
       for (int j = 0; j < POOL_RB; ++j) {
@@ -224,7 +235,7 @@ __global__ __launch_bounds__(POOL_THREADS) void attpool_bwd_pool_vec_kernel(cons
 #pragma unroll
       for (int j = 0; j < POOL_RB; ++j) {
         const int l = l0 + POOL_WAVES * j;
-        x[j] = ld4_or_zero(X, (n * L + l) * E + (lane + 64 * v) * 4, l < L && lane + 64 * v < E4);
+        x[j] = ld4_clamped(X, (n * L + l) * E + (lane + 64 * v) * 4, l < L && lane + 64 * v < E4);  // gg = 0 / row unused
       }
 #pragma unroll
       for (int j = 0; j < POOL_RB; ++j)
