@@ -56,9 +56,16 @@ struct TileLoader {
     }
     const int64_t off = KCONTIG ? (gmn * ld + gk) : (gk * ld + gmn);
     if (VEC) {
+      // clamp the OFFSET (not the pointer) and zero per component: a pointer select next to a whole-value select is
+      // turned back into a branch around the load, and each such load then waits vmcnt(0) on its own
       const bool valid = (gmn < MN) && (gk < Kdim);
-      const float4 r = *reinterpret_cast<const float4*>(valid ? (P + off) : P);
-      return valid ? r : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 r = *reinterpret_cast<const float4*>(P + (valid ? off : 0));
+      float4 z;
+      z.x = valid ? r.x : 0.f;
+      z.y = valid ? r.y : 0.f;
+      z.z = valid ? r.z : 0.f;
+      z.w = valid ? r.w : 0.f;
+      return z;
     }
     float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
     if (KCONTIG) {
