@@ -339,27 +339,80 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
 #undef EBN_STORE_SLAB
 
   // epilogue. C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-  const bool split = gridDim.z > 1;
-  float* out = split ? (Cpart + zsplit * M * N) : C;
-  const int64_t ldo = split ? N : ldc;
+  if constexpr (EPI != 0) {
+    // Epilogues that READ (the rank-1 operands, the bias): all reads of the 16 elements of a 32x32 tile are issued first,
+    // unconditionally and with clamped indices; validity only guards the stores.  Reads placed next to the per-element
+    // guards are serialised -- one global round trip per element, 128 per lane for the rank-1 form.  (The plain
+    // epilogue below is kept as it was: restructuring it costs the big projections 2 % through register allocation.)
+    const bool split = gridDim.z > 1;
+    float* out = split ? (Cpart + zsplit * M * N) : C;
+    const int64_t ldo = split ? N : ldc;
+    const bool read_c = !split && beta != 0.f;
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int64_t col = n0 + wn * WTN + j * 32 + (lane & 31);
-      if (col >= N) continue;
+      for (int j = 0; j < TN; ++j) {
+        const int64_t col = n0 + wn * WTN + j * 32 + (lane & 31);
+        const bool col_ok = col < N;
+        const int64_t colc = col_ok ? col : N - 1;
+        const int64_t row_base = m0 + wm * WTM + i * 32 + 4 * (lane >> 5);
+        float add[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row >= M) continue;
-        float v = alpha * acc[i][j][r];
-        if (!split && beta != 0.f) v += beta * out[row * ldo + col];
-        if (EPI == 1 && !split)  // 32-bit division: M < 2^31 rows
-          v = fmaf(epi.rs[row], epi.cv[static_cast<int64_t>(static_cast<uint32_t>(row) / static_cast<uint32_t>(epi.L)) * epi.ldcv + col], v);
-        if (EPI == 2 && !split) v = fmaxf(v + epi.bias[col], 0.f);
-        out[row * ldo + col] = v;
+        for (int r = 0; r < 16; ++r) add[r] = 0.f;
+        if (EPI == 1 && !split) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int64_t row = row_base + (r & 3) + 8 * (r >> 2);
+            const uint32_t rowc = static_cast<uint32_t>(row < M ? row : M - 1);  // M < 2^31 rows: 32-bit division
+            add[r] = epi.rs[rowc] * epi.cv[static_cast<int64_t>(rowc / static_cast<uint32_t>(epi.L)) * epi.ldcv + colc];
+          }
+        }
+        if (EPI == 2 && !split) {
+          const float bv = epi.bias[colc];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) add[r] = bv;
+        }
+        if (read_c) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int64_t row = row_base + (r & 3) + 8 * (r >> 2);
+            add[r] = fmaf(beta, out[(row < M ? row : M - 1) * ldo + colc], add[r]);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = row_base + (r & 3) + 8 * (r >> 2);
+          float v = fmaf(alpha, acc[i][j][r], add[r]);
+          if (EPI == 2 && !split) v = fmaxf(v, 0.f);
+          if (col_ok && row < M) out[row * ldo + col] = v;
+        }
       }
     }
+
+  } else {
+    const bool split = gridDim.z > 1;
+    float* out = split ? (Cpart + zsplit * M * N) : C;
+    const int64_t ldo = split ? N : ldc;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int64_t col = n0 + wn * WTN + j * 32 + (lane & 31);
+        if (col >= N) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (row >= M) continue;
+          float v = alpha * acc[i][j][r];
+          if (!split && beta != 0.f) v += beta * out[row * ldo + col];
+          if (EPI == 1 && !split)  // 32-bit division: M < 2^31 rows
+            v = fmaf(epi.rs[row], epi.cv[static_cast<int64_t>(static_cast<uint32_t>(row) / static_cast<uint32_t>(epi.L)) * epi.ldcv + col], v);
+          if (EPI == 2 && !split) v = fmaxf(v + epi.bias[col], 0.f);
+          out[row * ldo + col] = v;
+        }
+      }
+    }
+
   }
 }
 
