@@ -233,6 +233,8 @@ class ScorerModel:
     (dataloader.py:99-103); identical history rows of a batch are encoded ONCE here and the
     scores come from a ragged pair-dot kernel -- same outputs, ~C_i x fewer user encodings."""
 
+    cache_articles = True  # encode the loader's article matrix once per predict() (set False to force per-batch encoding)
+
     def __init__(self, owner):
         self._owner = owner
 
@@ -241,6 +243,15 @@ class ScorerModel:
         data = x if _is_loader(x) else _ArrayBatches(x, None, batch_size)
         outs = []
         compact = getattr(data, "compact_eval_batch", None) if getattr(data, "eval_mode", False) else None
+        indexed = getattr(data, "index_eval_batch", None) if compact is not None else None
+        if indexed is not None and self.cache_articles and hasattr(self._owner, "_score_indexed"):
+            # every article of the loader's matrix is encoded ONCE (the weights do not change during predict); a batch
+            # then costs one user-encoder pass over gathered news vectors and a ragged pair-dot
+            news_all = self._owner._encode_article_matrix(data.lookup_article_matrix)
+            for i in range(len(data)):
+                his_idx, cand_idx, rows, _y = indexed(i)
+                outs.append(self._owner._score_indexed(news_all, his_idx, cand_idx, rows).cpu().numpy().reshape(-1, 1))
+            return np.concatenate(outs, axis=0) if outs else np.zeros((0, 1), np.float32)
         for i in range(len(data)):
             if compact is not None:  # this repo's loaders: history rows are NOT materialised per candidate
                 his, cand, rows, _y = compact(i)

@@ -130,6 +130,16 @@ class NRMSDataLoader(NewsrecDataLoader):
         sl = slice(self._inv_off[lo], self._inv_off[hi])
         return (self._history_rows(lo, hi), self._inv_flat[sl].reshape(hi - lo, C)), self._y_flat[sl].reshape(hi - lo, C)
 
+    def index_eval_batch(self, idx):
+        """Eval batch as article-row numbers of ``lookup_article_matrix``: (his (b,H) int32, cand (sum C_i,) int32,
+        impression_of_row (sum C_i,) int32, y (sum C_i, 1)) -- what a scorer that has encoded every article of the
+        matrix ONCE needs per batch."""
+        lo, hi = self._rows(idx)
+        sl = slice(self._inv_off[lo], self._inv_off[hi])
+        repeats = np.diff(self._inv_off[lo: hi + 1])
+        rows = np.repeat(np.arange(hi - lo, dtype=np.int32), repeats)
+        return self._history_rows(lo, hi), self._inv_flat[sl], rows, self._y_flat[sl].reshape(-1, 1)
+
     def compact_eval_batch(self, idx):
         """Eval batch WITHOUT the per-candidate repetition of the history: (his (b,H,T), pred (sum C_i, T),
         impression_of_row (sum C_i,), y (sum C_i, 1)).  Scores are identical to the repeated layout."""

@@ -17,8 +17,12 @@ Differences from the reference that are deliberate and visible:
 """
 from __future__ import annotations
 
+import ctypes
+
 import numpy as np
 import torch
+
+from ebrec import _hip
 
 from ._engine import NRMSEngine, glorot_uniform_np
 from ._keras_like import EncoderModel, ScorerModel, TrainModel, dedup_rows
@@ -113,6 +117,23 @@ class NRMSModel:
         ui = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.int32)).to(eng.device)
         ci = torch.from_numpy(c_inv).to(eng.device)
         return eng.pair_scores(user, news, ui, ci, sigmoid=True)
+
+    def _encode_article_matrix(self, matrix) -> torch.Tensor:
+        """news vectors (n_articles+1, E) of every row of a loader's token matrix, on the device."""
+        return self._engine.encode_news(np.asarray(matrix))
+
+    def _score_indexed(self, news_all: torch.Tensor, his_idx, cand_idx, rows) -> torch.Tensor:
+        """Scores of one eval batch from cached news vectors: his_idx (b,H) / cand_idx (n,) are rows of news_all,
+        rows[i] = impression of candidate i."""
+        eng = self._engine
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(eng.device)
+        hi = dev(np.asarray(his_idx).reshape(-1))
+        b = len(his_idx)
+        NEh = torch.empty(b * eng.H, eng.E, device=eng.device)
+        _hip.call("ebn_gather_rows_f32", _hip.ptr(hi), _hip.ptr(news_all), _hip.ptr(NEh), b * eng.H, eng.E, news_all.shape[0],
+                  None, -1, ctypes.c_float(0.0), None, _hip.stream_handle())
+        user = eng.encode_users_from_news(NEh.view(b, eng.H, eng.E))
+        return eng.pair_scores(user, news_all, dev(rows), dev(cand_idx), sigmoid=True)
 
     # -- interchange ------------------------------------------------------------------
     def from_keras_weight_list(self, weights):

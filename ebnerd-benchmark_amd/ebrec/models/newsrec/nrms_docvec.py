@@ -10,8 +10,12 @@ article ``[Dense(u, relu, l2) -> BatchNormalization -> Dropout] x units -> Dense
 """
 from __future__ import annotations
 
+import ctypes
+
 import numpy as np
 import torch
+
+from ebrec import _hip
 
 from ._engine_docvec import DocVecEngine
 from ._keras_like import EncoderModel, ScorerModel, TrainModel, dedup_rows
@@ -72,6 +76,21 @@ class NRMSDocVec:
         news = eng.encode_news(cand_u)
         return eng.pair_scores(user, news, torch.from_numpy(np.ascontiguousarray(rows, dtype=np.int32)).to(eng.device),
                                torch.from_numpy(c_inv).to(eng.device), sigmoid=True)
+
+    def _encode_article_matrix(self, matrix) -> torch.Tensor:
+        """news vectors (n_articles+1, E) of every document vector of a loader's matrix, on the device."""
+        return self._engine.encode_news(np.asarray(matrix, dtype=np.float32))
+
+    def _score_indexed(self, news_all: torch.Tensor, his_idx, cand_idx, rows) -> torch.Tensor:
+        eng = self._engine
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(eng.device)
+        hi = dev(np.asarray(his_idx).reshape(-1))
+        b = len(his_idx)
+        NEh = torch.empty(b * eng.H, eng.E, device=eng.device)
+        _hip.call("ebn_gather_rows_f32", _hip.ptr(hi), _hip.ptr(news_all), _hip.ptr(NEh), b * eng.H, eng.E, news_all.shape[0],
+                  None, -1, ctypes.c_float(0.0), None, _hip.stream_handle())
+        user = eng.encode_users_from_news(NEh.view(b, eng.H, eng.E))
+        return eng.pair_scores(user, news_all, dev(rows), dev(cand_idx), sigmoid=True)
 
     def train_step(self, his, pred, y):
         return self._engine.train_step(his, pred, y)

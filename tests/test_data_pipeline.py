@@ -186,6 +186,12 @@ def test_nrms_loader_eval_mode_like_reference_test(frames):
     np.testing.assert_array_equal(yc, y)
     total = sum(len(loader[i][1]) for i in range(len(loader)))
     assert total == int(beh["n"].sum())
+    # the same batch as article-row numbers of the lookup matrix (what the article-caching scorer consumes)
+    hi, ci, rows_i, yi = loader.index_eval_batch(0)
+    np.testing.assert_array_equal(loader.lookup_article_matrix[hi], hc)
+    np.testing.assert_array_equal(loader.lookup_article_matrix[ci], pc)
+    np.testing.assert_array_equal(rows_i, rows)
+    np.testing.assert_array_equal(yi, yc)
 
 
 def test_loader_errors_and_unknown_mean(frames):

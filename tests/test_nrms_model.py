@@ -269,6 +269,34 @@ def test_row_sharded_table_path_on_one_gpu_equals_replicated(nrms, train_embeddi
         assert np.allclose(wa, wb, rtol=1e-4, atol=1e-6)
 
 
+def test_scorer_with_article_cache_equals_per_batch_encoding(nrms):
+    """scorer.predict(eval loader): encoding the loader's article matrix once and scoring batches from the cached news
+    vectors gives the scores of the per-batch path (and of the reference layout with repeated histories)."""
+    import pandas as pd
+
+    from ebrec.models.newsrec.dataloader import NRMSDataLoader
+
+    hp = make_hp(history_size=6, title_size=8)
+    rng = np.random.default_rng(43)
+    V, n_art, n = 150, 40, 50
+    art_ids = np.arange(500, 500 + n_art)
+    mapping = {int(a): rng.integers(1, V, 8).tolist() for a in art_ids}
+    df = pd.DataFrame({"user_id": rng.integers(0, 9, n), "article_id_fixed": [rng.choice(np.append(art_ids, 0), 6).tolist() for _ in range(n)],
+                       "article_ids_inview": [rng.choice(np.append(art_ids, 7), int(rng.integers(1, 9))).tolist() for _ in range(n)],
+                       "labels": [[0] for _ in range(n)]})
+    df["labels"] = [[0] * len(v) for v in df["article_ids_inview"]]
+    loader = NRMSDataLoader(behaviors=df, article_dict=mapping, history_column="article_id_fixed", unknown_representation="zeros",
+                            eval_mode=True, batch_size=16)
+    m = nrms(hp, word2vec_embedding=rng.standard_normal((V, 32)).astype(np.float32), seed=3)
+    cached = m.scorer.predict(loader)
+    m.scorer.cache_articles = False
+    per_batch = m.scorer.predict(loader)
+    repeated = np.concatenate([m.scorer.predict(loader[i][0]) for i in range(len(loader))])
+    assert cached.shape == per_batch.shape == (sum(len(v) for v in df["article_ids_inview"]), 1)
+    assert_close(cached, per_batch, rtol=0, atol=2e-6, what="article cache vs per-batch")
+    assert_close(cached, repeated, rtol=0, atol=2e-6, what="article cache vs repeated-history layout")
+
+
 def test_device_resident_batches_equal_host_batches(nrms):
     """Batches handed over as device tensors in the step's dtypes go through the one-launch prologue copy (ebn_copy3);
     the step is the same as with numpy batches, bit for bit (graph replay and kernel-by-kernel)."""
