@@ -38,6 +38,32 @@ def require_gpu() -> torch.device:
     return torch.device("cuda", torch.cuda.current_device())
 
 
+def eval_loss_from_news(eng, news_all: torch.Tensor, his_idx, pred_idx, y):
+    """Validation loss of one batch from CACHED news vectors (both engines): his_idx (B,H) / pred_idx (B,C) are rows of
+    news_all (n_articles+1, E).  Same kernels as eval_loss after the news encoder: user encoder, scorer, compiled loss.
+    Returns (loss[1], probs (B,C)) device tensors."""
+    his_idx, pred_idx = np.asarray(his_idx), np.asarray(pred_idx)
+    B, C = his_idx.shape[0], pred_idx.shape[1]
+    H, E = eng.H, eng.E
+    idx = torch.from_numpy(np.ascontiguousarray(np.concatenate([his_idx.reshape(-1), pred_idx.reshape(-1)]), dtype=np.int32)).to(eng.device)
+    NE = torch.empty(B * (H + C), E, device=eng.device)
+    S = _hip.stream_handle
+    _hip.call("ebn_gather_rows_f32", _hip.ptr(idx), _hip.ptr(news_all), _hip.ptr(NE), B * (H + C), E, news_all.shape[0], None, -1,
+              ctypes.c_float(0.0), None, S())
+    user = eng.encode_users_from_news(NE[: B * H].view(B, H, E))
+    cand = NE[B * H:]
+    scores, probs = torch.empty(B, C, device=eng.device), torch.empty(B, C, device=eng.device)
+    _hip.call("ebn_score_fwd_f32", _hip.ptr(cand), _hip.ptr(user), _hip.ptr(scores), _hip.ptr(probs), B, C, E, 0, S())
+    labels = (y if isinstance(y, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(y, dtype=np.float32))))
+    labels = labels.to(device=eng.device, dtype=torch.float32).reshape(B, C).contiguous()
+    rows, junk_c, junk_u = torch.empty(B, device=eng.device), torch.empty(B * C, E, device=eng.device), torch.empty(B, E, device=eng.device)
+    loss = torch.empty(1, device=eng.device)
+    _hip.call("ebn_score_loss_bwd_f32", _hip.ptr(cand), _hip.ptr(user), _hip.ptr(scores), _hip.ptr(labels), _hip.ptr(rows),
+              _hip.ptr(junk_c), _hip.ptr(junk_u), B, C, E, LOSS_KIND[eng.loss], ctypes.c_float(1.0 / B), S())
+    _hip.call("ebn_sum_f32", _hip.ptr(rows), B, ctypes.c_float(1.0), _hip.ptr(loss), 0, S())
+    return loss, probs
+
+
 def glorot_uniform_np(shape, seed):
     """[KERAS-SEMANTICS] GlorotUniform(seed): the same (seed, shape) gives the same draw, which is
     why WQ, WK and WV of one layer start identical in the reference (layers.py:155-172)."""

@@ -13,6 +13,7 @@ from types import SimpleNamespace
 import numpy as np
 import torch
 
+from ._engine import eval_loss_from_news
 from .callbacks import Callback, History, StreamingAUC
 
 
@@ -62,6 +63,8 @@ class _Variable(SimpleNamespace):
 
 class TrainModel:
     """``NRMSModel.model``: inputs [his (B,H,T), pred (B,C,T)] -> softmax probabilities (B,C)."""
+
+    cache_articles = True  # evaluate(): encode the loader's article matrix once (set False to force per-batch encoding)
 
     def __init__(self, owner, names):
         self._owner = owner
@@ -200,15 +203,24 @@ class TrainModel:
         data = x if _is_loader(x) else _ArrayBatches(x, y, batch_size)
         eng = self._engine
         auc = StreamingAUC() if "auc" in self.metrics_names else None
-        loss_sum, n_rows = 0.0, 0
+        loss_sum, n_rows = torch.zeros(1, device=eng.device), 0
+        # loaders of this repo: encode every article of the lookup matrix ONCE (the weights are fixed during evaluate) and
+        # run each batch from the cached news vectors -- the validation pass of fit() costs user encoders only
+        cached = (self.cache_articles and hasattr(data, "index_batch") and hasattr(self._owner, "_encode_article_matrix")
+                  and not getattr(data, "eval_mode", False))
+        news_all = self._owner._encode_article_matrix(data.lookup_article_matrix) if cached else None
         for i in range(len(data)):
-            (his, pred), yb = data[i]
-            loss, probs = eng.eval_loss(his, pred, yb)
-            loss_sum += float(loss.item()) * len(his)
+            if cached:
+                (his, pred), yb = data.index_batch(i)
+                loss, probs = eval_loss_from_news(eng, news_all, his, pred, yb)
+            else:
+                (his, pred), yb = data[i]
+                loss, probs = eng.eval_loss(his, pred, yb)
+            loss_sum += loss * len(his)  # stays on the device: one host sync per evaluate(), not per batch
             n_rows += len(his)
             if auc is not None:
                 auc.update_device(torch.as_tensor(np.asarray(yb)).to(eng.device), probs)
-        out = {"loss": loss_sum / max(n_rows, 1)}
+        out = {"loss": float(loss_sum.item()) / max(n_rows, 1)}
         if auc is not None:
             out["auc"] = auc.result()
         return out if return_dict else ([out["loss"]] + ([out["auc"]] if auc is not None else []))

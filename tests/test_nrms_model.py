@@ -297,6 +297,30 @@ def test_scorer_with_article_cache_equals_per_batch_encoding(nrms):
     assert_close(cached, repeated, rtol=0, atol=2e-6, what="article cache vs repeated-history layout")
 
 
+def test_evaluate_with_article_cache_equals_per_batch_encoding(nrms):
+    """model.evaluate(train-layout loader): loss / AUC from cached news vectors == the per-batch forward."""
+    import pandas as pd
+
+    from ebrec.models.newsrec.dataloader import NRMSDataLoader
+
+    hp = make_hp(history_size=6, title_size=8)
+    rng = np.random.default_rng(47)
+    V, n_art, n = 150, 40, 70
+    art_ids = np.arange(500, 500 + n_art)
+    mapping = {int(a): rng.integers(1, V, 8).tolist() for a in art_ids}
+    df = pd.DataFrame({"user_id": rng.integers(0, 9, n), "article_id_fixed": [rng.choice(np.append(art_ids, 0), 6).tolist() for _ in range(n)],
+                       "article_ids_inview": [rng.choice(art_ids, 5).tolist() for _ in range(n)],
+                       "labels": [np.eye(5, dtype=int)[rng.integers(0, 5)].tolist() for _ in range(n)]})
+    loader = NRMSDataLoader(behaviors=df, article_dict=mapping, history_column="article_id_fixed", unknown_representation="zeros", batch_size=16)
+    for loss in ("cross_entropy_loss", "log_loss"):
+        m = nrms(make_hp(history_size=6, title_size=8, loss=loss), word2vec_embedding=rng.standard_normal((V, 32)).astype(np.float32), seed=3)
+        m.model.compile(optimizer="adam", loss=m.model.loss, metrics=["AUC"])
+        a = m.model.evaluate(loader, return_dict=True)
+        m.model.cache_articles = False
+        b = m.model.evaluate(loader, return_dict=True)
+        assert abs(a["loss"] - b["loss"]) <= 2e-6 * max(1.0, abs(b["loss"])) and abs(a["auc"] - b["auc"]) <= 1e-6, (a, b)
+
+
 def test_device_resident_batches_equal_host_batches(nrms):
     """Batches handed over as device tensors in the step's dtypes go through the one-launch prologue copy (ebn_copy3);
     the step is the same as with numpy batches, bit for bit (graph replay and kernel-by-kernel)."""
