@@ -60,3 +60,13 @@ def test_gemm_planner_is_a_pure_host_query_with_sane_plans():
     assert _plan(1024, 1200, 24000)[:2] == (256, 64) and _plan(1024, 1200, 24000)[2] > 1  # its weight gradient: split-K
     assert _plan(640, 1200, 400) == (64, 64, 1)  # user-encoder projection: a reduce launch would cost more than it saves
     assert _hip.lib().ebn_gemm_plan(-1, 1, 1, 0, None, None, None) == -1
+
+
+def test_integration_doc_lists_exactly_the_exported_entry_points():
+    """INTEGRATION.md's table of entry points by reference symbol stays in sync with the header."""
+    import re
+    from pathlib import Path
+
+    text = (Path(__file__).resolve().parents[1] / "INTEGRATION.md").read_text()
+    mentioned = set(re.findall(r"`(ebn_[a-z0-9_]+)`", text))
+    assert mentioned == set(_hip.declared_functions()), mentioned ^ set(_hip.declared_functions())
