@@ -97,7 +97,9 @@ def test_embedding_grad_scatter(hip, p):
 GEMM_SHAPES = [(1, 1, 1), (5, 7, 3), (64, 64, 16), (130, 70, 33), (257, 129, 300), (750, 1200, 300),
                (640, 200, 400), (300, 1200, 2000), (96, 100, 4096), (1, 400, 400), (513, 5, 64),
                # shapes whose plan picks the 256x64 tile family (ragged M and N, split-K)
-               (6000, 1200, 256), (5000, 300, 128), (1030, 1210, 3000)]
+               (6000, 1200, 256), (5000, 300, 128), (1030, 1210, 3000),
+               # split-K whose last K range ends in a partial slab (direct-to-LDS fetch for the full slabs, guarded loader for the tail)
+               (256, 256, 2004), (512, 64, 8200)]
 
 
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
