@@ -186,6 +186,27 @@ def test_attention_forward_is_transposed_softmax_times_v(hip, n_seq, L, h, d, p)
         assert np.abs(host(out).reshape(n_seq, L, E) - wrong).max() > 1e-3  # the quirk is observable
 
 
+@pytest.mark.parametrize("n_seq,L,h,d", [(3, 30, 20, 20), (2, 50, 4, 16)])  # MFMA path and the fallback
+def test_attention_forward_with_saturated_softmax(hip, n_seq, L, h, d):
+    """Logits of magnitude ~1e2 (one-hot attention rows): the exp2-domain softmax must neither overflow nor lose the
+    winner; finite everywhere and equal to the float64 oracle."""
+    E = h * d
+    rng = np.random.default_rng(3)
+    qkv = (rng.standard_normal((n_seq, L, 3 * E))).astype(np.float32)
+    qkv[..., :2 * E] *= 7.0  # |q.k|/sqrt(d) up to a few hundred
+    Qh = qkv[..., :E].reshape(n_seq, L, h, d).transpose(0, 2, 1, 3).astype(np.float64)
+    Kh = qkv[..., E:2 * E].reshape(n_seq, L, h, d).transpose(0, 2, 1, 3).astype(np.float64)
+    Vh = qkv[..., 2 * E:].reshape(n_seq, L, h, d).transpose(0, 2, 1, 3).astype(np.float64)
+    Pm = on.softmax_rows(Qh @ Kh.transpose(0, 1, 3, 2) / np.sqrt(d))
+    O = (Pm.transpose(0, 1, 3, 2) @ Vh).transpose(0, 2, 1, 3).reshape(n_seq, L, E)
+    out = torch.empty(n_seq * L, E, device="cuda")
+    hip.call("ebn_attn_fwd_f32", P(dev(qkv.reshape(n_seq * L, 3 * E))), 3 * E, P(out), E, n_seq, L, h, d, None, -1,
+             ctypes.c_float(0.0), S())
+    got = host(out).reshape(n_seq, L, E)
+    assert np.isfinite(got).all()
+    assert_close(got, O, rtol=2e-4, atol=2e-4, what="saturated attn fwd")  # logits ~3e2: fp32 resolution of the exponent
+
+
 @pytest.mark.parametrize("n_seq,L,h,d", ATTN_CASES)
 @pytest.mark.parametrize("p", [0.0, 0.2])
 def test_attention_backward(hip, n_seq, L, h, d, p):
