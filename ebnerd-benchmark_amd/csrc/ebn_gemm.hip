@@ -92,12 +92,12 @@ struct TileLoader {
   __device__ static __forceinline__ void store(float* __restrict__ S, int v, float4 r) {
     constexpr int LD = BMN + PADX;
     if (KCONTIG) {
+      // k-contiguous operand: image S4[mn][kq ^ ((mn >> 2) & 3)] of float4 (4 consecutive k): ONE ds_write_b128 per
+      // float4 (8 lanes of a store group cover 128 contiguous bytes), read back with ds_read_b128 -- the XOR spreads
+      // the 16 rows of a read group over all 64 banks
       const int mn = v / (BK / 4);
       const int kq = v % (BK / 4);
-      S[(kq * 4 + 0) * LD + mn] = r.x;
-      S[(kq * 4 + 1) * LD + mn] = r.y;
-      S[(kq * 4 + 2) * LD + mn] = r.z;
-      S[(kq * 4 + 3) * LD + mn] = r.w;
+      *reinterpret_cast<float4*>(&S[(mn * 4 + (kq ^ ((mn >> 2) & 3))) * 4]) = r;
     } else {
       const int k = v / (BMN / 4);
       const int mq = v % (BMN / 4);
@@ -145,7 +145,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
 
   // ONE __shared__ object: with two, hipcc cannot tell the glds destination from the buffer being read and waits
   // vmcnt(0) before the first ds_read of every slab (cdna_hip_programming.md, glds trap (a))
-  constexpr int A_FLOATS = BK * LDA_S, B_FLOATS = BK * LDB_S;
+  constexpr bool A_KC = !TA, B_KC = TB;  // k-contiguous operands use the float4 image
+  constexpr int A_FLOATS = A_KC ? BM * BK : BK * LDA_S, B_FLOATS = B_KC ? BN * BK : BK * LDB_S;
   __shared__ __attribute__((aligned(16))) float smem[2 * (A_FLOATS + B_FLOATS)];
 #define EBN_AS(b) (smem + (b) * A_FLOATS)
 #define EBN_BS(b) (smem + 2 * A_FLOATS + (b) * B_FLOATS)
@@ -313,20 +314,42 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
     const bool via_lds = GLDS && (kt + 1 < nk_full);
     if (via_lds) EBN_GLDS_SLAB(cur ^ 1);
     else if (kt + 1 < nk) EBN_LOAD_SLAB(kt + 1);
-    const float* as = EBN_AS(cur) + kl * LDA_S + wm * WTM + il;
-    const float* bs = EBN_BS(cur) + kl * LDB_S + wn * WTN + il;
+    // MFMA contraction index = (instruction, lane half); the slab's 16 k are assigned as
+    //   step 4j + w of half kl  <->  k = 8j + 4kl + w      (A and B agree, so any assignment is valid)
+    // which makes the four values a lane feeds to steps 4j..4j+3 one float4 of a k-contiguous operand.
+    const float* as = A_KC ? EBN_AS(cur) + (wm * WTM + il) * 16 : EBN_AS(cur) + (4 * kl) * LDA_S + wm * WTM + il;
+    const float* bs = B_KC ? EBN_BS(cur) + (wn * WTN + il) * 16 : EBN_BS(cur) + (4 * kl) * LDB_S + wn * WTN + il;
+    const int sw = (il >> 2) & 3;
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      float a[TM], b[TN];
+    for (int j8 = 0; j8 < BK / 8; ++j8) {
+      float a[TM][4], b[TN][4];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = as[kk * LDA_S + i * 32];
+      for (int i = 0; i < TM; ++i) {
+        if (A_KC) {
+          const float4 t = *reinterpret_cast<const float4*>(as + i * 32 * 16 + (((2 * j8 + kl) ^ sw) * 4));
+          a[i][0] = t.x; a[i][1] = t.y; a[i][2] = t.z; a[i][3] = t.w;
+        } else {
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = bs[kk * LDB_S + j * 32];
+          for (int w = 0; w < 4; ++w) a[i][w] = as[(8 * j8 + w) * LDA_S + i * 32];
+        }
+      }
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int j = 0; j < TN; ++j) {
+        if (B_KC) {
+          const float4 t = *reinterpret_cast<const float4*>(bs + j * 32 * 16 + (((2 * j8 + kl) ^ sw) * 4));
+          b[j][0] = t.x; b[j][1] = t.y; b[j][2] = t.z; b[j][3] = t.w;
+        } else {
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+          for (int w = 0; w < 4; ++w) b[j][w] = bs[(8 * j8 + w) * LDB_S + j * 32];
+        }
+      }
+#pragma unroll
+      for (int w = 0; w < 4; ++w)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][w], b[j][w], acc[i][j], 0, 0, 0);
     }
     if (!via_lds && kt + 1 < nk) EBN_STORE_SLAB(cur ^ 1);
     __syncthreads();  // also drains the glds queue (vmcnt) -- the slab must have landed before anyone reads it
