@@ -303,22 +303,29 @@ class DocVecEngine:
         if y is not None:
             labels = (y if isinstance(y, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(y, dtype=np.float32))))
             mb["labels"][: B * C].copy_(labels.reshape(-1).to(device=self.device, dtype=torch.float32))
-        if getattr(self, "use_graph", False) and self.world == 1:
+        if getattr(self, "use_graph", False):
+            # graph(forward + backward) -> gradient all-reduce over RCCL (eager, data-parallel only) -> graph(Adam)
             g = self._graphs.get((B, C))
             if g is None:
                 torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    self._train_kernels(B, C)
-                self._graphs[(B, C)] = g
-            g.replay()
+                g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g1):
+                    self._fwd_bwd_kernels(B, C)
+                with torch.cuda.graph(g2, pool=g1.pool()):
+                    self._optimizer_kernels()
+                g = self._graphs[(B, C)] = (g1, g2)
+            g[0].replay()
+            self._allreduce_grads()
+            g[1].replay()
         else:
-            self._train_kernels(B, C)
+            self._fwd_bwd_kernels(B, C)
+            self._allreduce_grads()
+            self._optimizer_kernels()
         if return_probs:
             return self.loss_dev, mb["probs"][: B * C].view(B, C)
         return self.loss_dev
 
-    def _train_kernels(self, B, C):
+    def _fwd_bwd_kernels(self, B, C):
         E = self.E
         S = _hip.stream_handle
         mb, ub = self._mlp_bufs(B * (self.H + C)), self._user_bufs(B)
@@ -341,8 +348,14 @@ class DocVecEngine:
         _hip.call("ebn_encoder_bwd_f32", ctypes.byref(dims), ctypes.byref(params), ctypes.byref(acts), _hip.ptr(ub.duser),
                   ctypes.byref(grads), ctypes.byref(scratch), _hip.ptr(mb["dNE"]), 0, st, S())
         self._news_backward(mb, n_hist, n_cand)
+
+    def _allreduce_grads(self):
         if self.world > 1:
             torch.distributed.all_reduce(self.params.grad, group=self.pg)
+
+    def _optimizer_kernels(self):
+        S = _hip.stream_handle
+        st = _hip.ptr(self.state)
         P = self.params
         _hip.call("ebn_adam_keras_step_f32", _hip.ptr(P.data), _hip.ptr(P.grad), _hip.ptr(P.m), _hip.ptr(P.v), P.numel, st,
                   BETA1, BETA2, ADAM_EPS, ctypes.c_float(1.0 / self.world), S())
