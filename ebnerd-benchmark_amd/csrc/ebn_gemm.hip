@@ -7,11 +7,16 @@
 // peak, bitwise an fp32 fma chain -> keeps the 1e-4 parity budget of north_star).
 // Block tile BM x BN x 16 (128x128 or 64x64 with the 4 waves as 2x2; 256x64 with the waves stacked 4x1), each wave
 // owning its share in 32x32 MFMA tiles.
-// Operands are staged k-major in LDS ([k][m] / [k][n], +4 pad) so that the MFMA operand
-// fetch (lane l: A[i=l&31][k=l>>5]) is a conflict-free ds_read_b32; the next K-slab is
-// prefetched into registers while the current one is multiplied (2 LDS buffers, one
-// barrier per slab).  Skinny outputs (weight gradients: M,N ~ 1e3, K ~ 2e4) use split-K with
-// deterministic slab partials in the caller's workspace -- never atomics.
+// LDS images of a 16-deep K slab, chosen per operand by how it is stored in memory:
+//   mn-contiguous ([K][mn]):  S[k][mn] -- one ds_write_b128 per fetched float4 (or, when BOTH operands are stored this
+//     way, global_load_lds_dwordx4 straight into an unpadded image: the weight-gradient GEMMs); operand fetch is a
+//     conflict-free ds_read_b32 of 32 consecutive floats of one k row;
+//   k-contiguous ([mn][K]):   S4[mn][kq ^ ((mn>>2)&3)] of float4 -- one ds_write_b128 per fetched float4 and one
+//     conflict-free ds_read_b128 per four MFMA steps.
+// The slab's 16 k are assigned to the MFMA's (step, lane half) as k = 8j + 4*half + w for step 4j + w, identically
+// for A and B, which is what makes a k-contiguous float4 feed four consecutive steps.  The next slab is prefetched
+// while the current one is multiplied (2 LDS buffers, one barrier per slab).  Skinny outputs (weight gradients:
+// M,N ~ 1e3, K ~ 2e4) use split-K with deterministic slab partials in the caller's workspace -- never atomics.
 #include <stdlib.h>
 
 #include "ebn_common.h"
@@ -293,8 +298,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
 
   // Pipeline: LDS buffer `cur` holds slab kt; slab kt+1 is fetched into registers while slab kt is multiplied
   // and written to LDS[cur^1] afterwards; one barrier per slab.  Variants measured and rejected on MI355X
-  // (profiles/r01_gemm_tuning.md): two-slab-deep prefetch, BK=32, k-contiguous LDS image with burst b128
-  // operand reads, s_setprio around the MFMA cluster / per-workgroup static priority -- all within +-3 %.
+  // (profiles/r01_gemm_tuning.md): two-slab-deep prefetch, BK=32, S[k/4][mn][4] image with ds_read_b64, glds-filled
+  // float4 image, in-kernel split-K fix-up, s_setprio around the MFMA cluster / per-workgroup static priority.
   if (nk > 0) {
     if (GLDS && nk_full > 0) {
       EBN_GLDS_SLAB(0);
