@@ -3,14 +3,14 @@
 //
 // HBM-bound: per token the kernel reads 4 B of id + D*4 B of table row and writes D*4 B.
 // Work items are 16-byte vectors; consecutive lanes take consecutive vectors of a row so a
-// wave covers whole 128-B lines of the (V x D) table; each thread keeps UNROLL independent
+// wave covers whole 128-B lines of the (V x D) table; each thread keeps GATHER_UNROLL independent
 // row loads in flight before the first store (random rows -> latency-bound otherwise).
 #include "ebn_common.h"
 
 namespace {
 
 constexpr int GATHER_THREADS = 256;
-constexpr int GATHER_UNROLL = 4;
+constexpr int GATHER_UNROLL = 2;  // measured 1..8 on MI355X: 2 is best with the fused dropout (0.70 of the HBM peak at c2; 4 -> 0.66, 8 -> 0.65)
 
 // IT: index type of a work item (uint32_t whenever n_items < 2^32: a 64-bit division by the runtime row length costs
 // ~100 VALU instructions per item and was a third of this kernel's time); SHIFT >= 0: vpr == 1 << SHIFT (D = 1024
