@@ -27,6 +27,11 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifndef EBN_ATTN_WAVES
+#define EBN_ATTN_WAVES 4  // independent (sequence, head) problems per workgroup, one wave each
+#endif
+constexpr int ATT_WAVES = EBN_ATTN_WAVES;
+
 struct MfmaAttnArgs {
   const float* qkv;
   int64_t ld_qkv;
@@ -243,11 +248,11 @@ __device__ __forceinline__ float softmax_stats_only(const f32x16& t, int L, int 
 }
 
 template <int D>
-__global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(MfmaAttnArgs a) {
+__global__ __launch_bounds__(64 * ATT_WAVES) void attn_mfma_fwd_kernel(MfmaAttnArgs a) {
   using T = Tile<D>;
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // 4 waves x 3 regions x L x STRIDE
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // ATT_WAVES x 3 regions x L x STRIDE
   const int lane = threadIdx.x & 63;
-  const int64_t prob = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  const int64_t prob = static_cast<int64_t>(blockIdx.x) * ATT_WAVES + (threadIdx.x >> 6);
   if (prob >= a.n_prob) return;  // wave-uniform; no workgroup barriers in this kernel
   const int L = a.L, E = a.h * D;
   const int region = L * T::STRIDE;
@@ -296,12 +301,12 @@ __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(MfmaAttnArgs a) {
 // Backward.  The "lane i" tiles (P, dP -> dV, dQ) are finished before the "lane j" tiles (-> dK) are started, so
 // that at most two 32x32 tiles are live at a time: the kernel fits 128 registers = 4 waves per SIMD.
 template <int D>
-__global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(MfmaAttnArgs a) {
+__global__ __launch_bounds__(64 * ATT_WAVES) void attn_mfma_bwd_kernel(MfmaAttnArgs a) {
   using T = Tile<D>;
   constexpr int KH = D / 2;
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // 4 waves x 4 regions x L x STRIDE
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // ATT_WAVES x 4 regions x L x STRIDE
   const int lane = threadIdx.x & 63;
-  const int64_t prob = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  const int64_t prob = static_cast<int64_t>(blockIdx.x) * ATT_WAVES + (threadIdx.x >> 6);
   if (prob >= a.n_prob) return;
   const int L = a.L, E = a.h * D;
   const int region = L * T::STRIDE;
@@ -434,8 +439,8 @@ int ebn_attn_mfma_fwd(const float* qkv, int64_t ld_qkv, float* out, int64_t ld_o
   *handled = mfma_path_ok(L, d, ld_qkv, ld_out, ld_out, qkv, out, out);
   if (!*handled) return EBN_OK;
   MfmaAttnArgs a{qkv, ld_qkv, nullptr, 0, out, ld_out, n_seq * h, L, h, dr.key_ptr, dr.thresh, dr.scale};
-  const dim3 grid(static_cast<unsigned>(ebn_ceil_div(a.n_prob, 4))), block(256);
-  const size_t lds = static_cast<size_t>(4) * 3 * L * sizeof(float);  // x STRIDE below
+  const dim3 grid(static_cast<unsigned>(ebn_ceil_div(a.n_prob, ATT_WAVES))), block(64 * ATT_WAVES);
+  const size_t lds = static_cast<size_t>(ATT_WAVES) * 3 * L * sizeof(float);  // x STRIDE below
   if (d == 16) hipLaunchKernelGGL(attn_mfma_fwd_kernel<16>, grid, block, lds * Tile<16>::STRIDE, s, a);
   else if (d == 20) hipLaunchKernelGGL(attn_mfma_fwd_kernel<20>, grid, block, lds * Tile<20>::STRIDE, s, a);
   else {
@@ -452,8 +457,8 @@ int ebn_attn_mfma_bwd(const float* qkv, int64_t ld_qkv, const float* dout, int64
   *handled = mfma_path_ok(L, d, ld_qkv, ld_dout, ld_dqkv, qkv, dout, dqkv);
   if (!*handled) return EBN_OK;
   MfmaAttnArgs a{qkv, ld_qkv, dout, ld_dout, dqkv, ld_dqkv, n_seq * h, L, h, dr.key_ptr, dr.thresh, dr.scale};
-  const dim3 grid(static_cast<unsigned>(ebn_ceil_div(a.n_prob, 4))), block(256);
-  const size_t lds = static_cast<size_t>(4) * 4 * L * sizeof(float);  // x STRIDE below
+  const dim3 grid(static_cast<unsigned>(ebn_ceil_div(a.n_prob, ATT_WAVES))), block(64 * ATT_WAVES);
+  const size_t lds = static_cast<size_t>(ATT_WAVES) * 4 * L * sizeof(float);  // x STRIDE below
   if (d == 16) hipLaunchKernelGGL(attn_mfma_bwd_kernel<16>, grid, block, lds * Tile<16>::STRIDE, s, a);
   else if (d == 20) hipLaunchKernelGGL(attn_mfma_bwd_kernel<20>, grid, block, lds * Tile<20>::STRIDE, s, a);
   else {
