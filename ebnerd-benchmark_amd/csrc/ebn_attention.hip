@@ -242,10 +242,197 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(AttnArgs a) {
   }
 }
 
+// ---- long sequences: 64 < L <= 256 (a history_size beyond the EB-NeRD defaults) ------------------------------------
+// One 256-thread workgroup per (sequence, head); thread t owns row t (softmax statistics, dV, dQ) and later column t
+// (O, dK).  No L x L matrix is kept: scores are recomputed from the Q/K tiles in LDS (L*d FMAs per thread and pass,
+// trivial next to the projections), only the per-row statistics max / 1/Z / rowdot live in LDS.
+constexpr int LONG_THREADS = 256;
+constexpr int LONG_LMAX = 256;
+
+__device__ __forceinline__ void long_load_tile(float* __restrict__ tile, const float* __restrict__ src, int64_t ld,
+                                               int64_t row0, int col0, int L, int d) {
+  for (int e = threadIdx.x; e < L * d; e += LONG_THREADS) {
+    const int l = e / d, c = e - l * d;
+    tile[e] = src[(row0 + l) * ld + col0 + c];
+  }
+}
+
+__device__ __forceinline__ float long_dot(const float (&x)[DMAX], const float* __restrict__ y, int d) {
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < DMAX; ++c)
+    if (c < d) s = fmaf(x[c], y[c], s);
+  return s;
+}
+
+// row statistics of thread i = threadIdx.x: sM[i] = max_j s_ij, sZ[i] = 1 / sum_j exp(s_ij - max)
+__device__ __forceinline__ void long_row_stats(const float* __restrict__ sQ, const float* __restrict__ sK,
+                                               float* __restrict__ sM, float* __restrict__ sZ, int L, int d, float inv) {
+  const int i = threadIdx.x;
+  if (i < L) {
+    float q[DMAX];
+#pragma unroll
+    for (int c = 0; c < DMAX; ++c) q[c] = (c < d) ? sQ[i * d + c] : 0.f;
+    float mx = -INFINITY;
+    for (int j = 0; j < L; ++j) mx = fmaxf(mx, long_dot(q, sK + j * d, d) * inv);
+    float sum = 0.f;
+    for (int j = 0; j < L; ++j) sum += expf(long_dot(q, sK + j * d, d) * inv - mx);
+    sM[i] = mx;
+    sZ[i] = 1.0f / sum;
+  }
+}
+
+__global__ __launch_bounds__(LONG_THREADS) void attn_long_fwd_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int L = a.L, d = a.d, tile = L * d;
+  float* sQ = smem;
+  float* sK = sQ + tile;
+  float* sV = sK + tile;
+  float* sM = sV + tile;
+  float* sZ = sM + L;
+  const int64_t prob = blockIdx.x;
+  const int64_t seq = prob / a.h;
+  const int head = static_cast<int>(prob - seq * a.h);
+  const int E = a.h * d;
+  const int64_t row0 = seq * L;
+  const float inv = 1.0f / sqrtf(static_cast<float>(d));
+  long_load_tile(sQ, a.qkv, a.ld_qkv, row0, head * d, L, d);
+  long_load_tile(sK, a.qkv, a.ld_qkv, row0, E + head * d, L, d);
+  long_load_tile(sV, a.qkv, a.ld_qkv, row0, 2 * E + head * d, L, d);
+  __syncthreads();
+  long_row_stats(sQ, sK, sM, sZ, L, d, inv);
+  __syncthreads();
+  const int j = threadIdx.x;
+  if (j >= L) return;
+  float k[DMAX], o[DMAX];
+#pragma unroll
+  for (int c = 0; c < DMAX; ++c) {
+    k[c] = (c < d) ? sK[j * d + c] : 0.f;
+    o[c] = 0.f;
+  }
+  for (int i = 0; i < L; ++i) {  // O[j,:] = sum_i P[i,j] V[i,:]   (the TRANSPOSED attention matrix, layers.py:249)
+    const float p = expf(long_dot(k, sQ + i * d, d) * inv - sM[i]) * sZ[i];
+#pragma unroll
+    for (int c = 0; c < DMAX; ++c)
+      if (c < d) o[c] = fmaf(p, sV[i * d + c], o[c]);
+  }
+  const bool do_drop = a.key_ptr != nullptr;
+  const uint32_t key = do_drop ? *a.key_ptr : 0u;
+  float* dst = a.out + (row0 + j) * a.ld_out + head * d;
+  const uint64_t e0 = static_cast<uint64_t>(row0 + j) * E + head * d;
+#pragma unroll
+  for (int c = 0; c < DMAX; ++c) {
+    if (c < d) {
+      float v = o[c];
+      if (do_drop) v *= ebn_drop_mult(key, e0 + c, a.thresh, a.scale);
+      dst[c] = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(LONG_THREADS) void attn_long_bwd_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int L = a.L, d = a.d, tile = L * d;
+  float* sQ = smem;
+  float* sK = sQ + tile;
+  float* sV = sK + tile;
+  float* sG = sV + tile;  // dO with the forward dropout mask applied
+  float* sM = sG + tile;
+  float* sZ = sM + L;
+  float* sR = sZ + L;  // rowdot_i = sum_j P_ij dP_ij
+  const int64_t prob = blockIdx.x;
+  const int64_t seq = prob / a.h;
+  const int head = static_cast<int>(prob - seq * a.h);
+  const int E = a.h * d;
+  const int64_t row0 = seq * L;
+  const float inv = 1.0f / sqrtf(static_cast<float>(d));
+  long_load_tile(sQ, a.qkv, a.ld_qkv, row0, head * d, L, d);
+  long_load_tile(sK, a.qkv, a.ld_qkv, row0, E + head * d, L, d);
+  long_load_tile(sV, a.qkv, a.ld_qkv, row0, 2 * E + head * d, L, d);
+  {
+    const bool do_drop = a.key_ptr != nullptr;
+    const uint32_t key = do_drop ? *a.key_ptr : 0u;
+    for (int e = threadIdx.x; e < tile; e += LONG_THREADS) {
+      const int l = e / d, c = e - l * d;
+      float v = a.dout[(row0 + l) * a.ld_dout + head * d + c];
+      if (do_drop) v *= ebn_drop_mult(key, static_cast<uint64_t>(row0 + l) * E + head * d + c, a.thresh, a.scale);
+      sG[e] = v;
+    }
+  }
+  __syncthreads();
+  long_row_stats(sQ, sK, sM, sZ, L, d, inv);
+  const int t = threadIdx.x;
+  if (t < L) {  // row pass 1: dV[i,:] = sum_j P[i,j] dO[j,:], rowdot_i
+    const int i = t;
+    float q[DMAX], v[DMAX], acc[DMAX];
+#pragma unroll
+    for (int c = 0; c < DMAX; ++c) {
+      q[c] = (c < d) ? sQ[i * d + c] : 0.f;
+      v[c] = (c < d) ? sV[i * d + c] : 0.f;
+      acc[c] = 0.f;
+    }
+    const float mi = sM[i], zi = sZ[i];
+    float rowdot = 0.f;
+    for (int j = 0; j < L; ++j) {
+      const float p = expf(long_dot(q, sK + j * d, d) * inv - mi) * zi;
+      rowdot = fmaf(p, long_dot(v, sG + j * d, d), rowdot);
+#pragma unroll
+      for (int c = 0; c < DMAX; ++c)
+        if (c < d) acc[c] = fmaf(p, sG[j * d + c], acc[c]);
+    }
+    sR[i] = rowdot;
+    float* dv = a.out + (row0 + i) * a.ld_out + 2 * E + head * d;
+#pragma unroll
+    for (int c = 0; c < DMAX; ++c)
+      if (c < d) dv[c] = acc[c];
+    // row pass 2: dQ[i,:] = inv * sum_j dS[i,j] K[j,:],  dS = P (dP - rowdot)
+#pragma unroll
+    for (int c = 0; c < DMAX; ++c) acc[c] = 0.f;
+    for (int j = 0; j < L; ++j) {
+      const float p = expf(long_dot(q, sK + j * d, d) * inv - mi) * zi;
+      const float ds = p * (long_dot(v, sG + j * d, d) - rowdot);
+#pragma unroll
+      for (int c = 0; c < DMAX; ++c)
+        if (c < d) acc[c] = fmaf(ds, sK[j * d + c], acc[c]);
+    }
+    float* dq = a.out + (row0 + i) * a.ld_out + head * d;
+#pragma unroll
+    for (int c = 0; c < DMAX; ++c)
+      if (c < d) dq[c] = acc[c] * inv;
+  }
+  __syncthreads();
+  if (t < L) {  // column pass: dK[j,:] = inv * sum_i dS[i,j] Q[i,:]
+    const int j = t;
+    float k[DMAX], g[DMAX], acc[DMAX];
+#pragma unroll
+    for (int c = 0; c < DMAX; ++c) {
+      k[c] = (c < d) ? sK[j * d + c] : 0.f;
+      g[c] = (c < d) ? sG[j * d + c] : 0.f;
+      acc[c] = 0.f;
+    }
+    for (int i = 0; i < L; ++i) {
+      const float p = expf(long_dot(k, sQ + i * d, d) * inv - sM[i]) * sZ[i];
+      const float ds = p * (long_dot(g, sV + i * d, d) - sR[i]);
+#pragma unroll
+      for (int c = 0; c < DMAX; ++c)
+        if (c < d) acc[c] = fmaf(ds, sQ[i * d + c], acc[c]);
+    }
+    float* dk = a.out + (row0 + j) * a.ld_out + E + head * d;
+#pragma unroll
+    for (int c = 0; c < DMAX; ++c)
+      if (c < d) dk[c] = acc[c] * inv;
+  }
+}
+
+template <class K>
+void allow_big_lds(K kernel, size_t bytes) {
+  if (bytes > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+}
+
 int check_attn_args(const void* qkv, const void* out, int64_t n_seq, int32_t L, int32_t h, int32_t d) {
   EBN_REQUIRE(qkv && out, EBN_ERR_BAD_ARG);
   EBN_REQUIRE(n_seq >= 0 && L > 0 && h > 0 && d > 0, EBN_ERR_BAD_ARG);
-  EBN_REQUIRE(L <= 64 && d <= DMAX, EBN_ERR_UNSUPPORTED);
+  EBN_REQUIRE(L <= LONG_LMAX && d <= DMAX, EBN_ERR_UNSUPPORTED);
   return EBN_OK;
 }
 
@@ -263,6 +450,14 @@ extern "C" int ebn_attn_fwd_f32(const float* qkv, int64_t ld_qkv, float* out, in
   rc = ebn_attn_mfma_fwd(qkv, ld_qkv, out, ld_out, n_seq, L, h, d, dr, ebn_stream(stream), &handled);
   if (rc != EBN_OK || handled) return rc;
   AttnArgs a{qkv, ld_qkv, nullptr, 0, out, ld_out, n_seq * h, L, h, d, dr.key_ptr, dr.thresh, dr.scale};
+  if (L > 64) {
+    const size_t lds = static_cast<size_t>(3 * L * d + 2 * L) * sizeof(float);
+    EBN_REQUIRE(lds <= 160 * 1024 && a.n_prob <= 0x7FFFFFFF, EBN_ERR_UNSUPPORTED);
+    allow_big_lds(attn_long_fwd_kernel, lds);
+    hipLaunchKernelGGL(attn_long_fwd_kernel, dim3(static_cast<unsigned>(a.n_prob)), dim3(LONG_THREADS), lds, ebn_stream(stream), a);
+    EBN_CHECK_LAUNCH();
+    return EBN_OK;
+  }
   const int LP = (L & 1) ? L + 2 : L + 1;
   const int per_group = 3 * L * d + L * LP;
   EBN_REQUIRE(static_cast<size_t>((L <= 32 ? 2 : 1) * per_group) * sizeof(float) <= 65536, EBN_ERR_UNSUPPORTED);
@@ -291,6 +486,14 @@ extern "C" int ebn_attn_bwd_f32(const float* qkv, int64_t ld_qkv, const float* d
   rc = ebn_attn_mfma_bwd(qkv, ld_qkv, dout, ld_dout, dqkv, ld_dqkv, n_seq, L, h, d, dr, ebn_stream(stream), &handled);
   if (rc != EBN_OK || handled) return rc;
   AttnArgs a{qkv, ld_qkv, dout, ld_dout, dqkv, ld_dqkv, n_seq * h, L, h, d, dr.key_ptr, dr.thresh, dr.scale};
+  if (L > 64) {
+    const size_t lds = static_cast<size_t>(4 * L * d + 3 * L) * sizeof(float);
+    EBN_REQUIRE(lds <= 160 * 1024 && a.n_prob <= 0x7FFFFFFF, EBN_ERR_UNSUPPORTED);
+    allow_big_lds(attn_long_bwd_kernel, lds);
+    hipLaunchKernelGGL(attn_long_bwd_kernel, dim3(static_cast<unsigned>(a.n_prob)), dim3(LONG_THREADS), lds, ebn_stream(stream), a);
+    EBN_CHECK_LAUNCH();
+    return EBN_OK;
+  }
   const int LP = (L & 1) ? L + 2 : L + 1;
   const int per_group = 4 * L * d + 2 * L * LP;
   EBN_REQUIRE(static_cast<size_t>((L <= 32 ? 2 : 1) * per_group) * sizeof(float) <= 65536, EBN_ERR_UNSUPPORTED);

@@ -119,7 +119,9 @@ int ebn_gemm_f32_site(int32_t transA, int32_t transB, int64_t M, int64_t N, int6
 /* ---- a3/a6  SelfAttention core (layers.py:231-252) -------------------------------
  * qkv [n_seq*L, ld_qkv] holds Q | K | V in column blocks [0,E) [E,2E) [2E,3E), E=h*d.
  * out[n,j,a*d+c] = sum_i softmax_j'(Q_i.K_j'/sqrt(d))[i,j] * V[i,c]   (P^T V, line 249)
- * times the dropout multiplier of nrms.py:154 when drop_p > 0.                      */
+ * times the dropout multiplier of nrms.py:154 when drop_p > 0.
+ * Supported: L <= 256, d <= 32 (MFMA kernels for L <= 32 and d in {16, 20, 32}; VALU/LDS kernels otherwise);
+ * EBN_ERR_UNSUPPORTED beyond.                                                        */
 int ebn_attn_fwd_f32(const float* qkv, int64_t ld_qkv, float* out, int64_t ld_out, int64_t n_seq,
                      int32_t L, int32_t h, int32_t d, const ebn_step_state* st, int32_t site,
                      float drop_p, ebn_stream_t stream);

@@ -152,7 +152,9 @@ def test_gemm_unaligned_pointers_take_the_scalar_path(hip):
 ATTN_CASES = [(4, 30, 20, 20), (3, 20, 20, 20), (2, 50, 16, 16), (5, 1, 2, 4), (2, 33, 3, 32), (3, 32, 2, 5),
               (1, 64, 2, 8),
               # the other instantiations of the MFMA path (L <= 32, d in {16, 20, 32}), incl. its largest LDS footprint
-              (2, 32, 4, 32), (3, 17, 2, 16), (2, 32, 2, 16), (1, 5, 3, 32), (9, 1, 1, 20)]
+              (2, 32, 4, 32), (3, 17, 2, 16), (2, 32, 2, 16), (1, 5, 3, 32), (9, 1, 1, 20),
+              # long sequences (64 < L <= 256): recompute-based kernels
+              (2, 100, 2, 20), (1, 256, 1, 32), (3, 65, 3, 16)]
 
 
 def _qkv_case(n_seq, L, h, d, seed):
@@ -236,7 +238,7 @@ def test_attention_backward(hip, n_seq, L, h, d, p):
 def test_attention_rejects_unsupported_shapes(hip):
     x = torch.zeros(10, device="cuda")
     with pytest.raises(hip.HipError):
-        hip.call("ebn_attn_fwd_f32", P(x), 300, P(x), 100, 1, 65, 2, 8, None, -1, ctypes.c_float(0), S())
+        hip.call("ebn_attn_fwd_f32", P(x), 300, P(x), 100, 1, 257, 2, 8, None, -1, ctypes.c_float(0), S())
     with pytest.raises(hip.HipError):
         hip.call("ebn_attn_fwd_f32", P(x), 300, P(x), 100, 1, 10, 2, 33, None, -1, ctypes.c_float(0), S())
 

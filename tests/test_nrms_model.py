@@ -56,7 +56,8 @@ def nrms(hip):
 
 
 @pytest.mark.parametrize("cfg", [dict(), dict(history_size=50, title_size=30), dict(head_num=16, head_dim=16),
-                                 dict(title_size=12, history_size=5, head_num=3, head_dim=8, attention_hidden_dim=17)])
+                                 dict(title_size=12, history_size=5, head_num=3, head_dim=8, attention_hidden_dim=17),
+                                 dict(history_size=100, title_size=70, head_num=4, head_dim=20)])  # long-sequence attention kernels
 def test_forward_matches_oracle_on_identical_weights(nrms, cfg):
     hp = make_hp(**cfg)
     V, D = 500, 300 if not cfg.get("head_dim") == 8 else 36
