@@ -1,7 +1,11 @@
 #!/usr/bin/env python
 """Headline benchmark of the MI355X-native NRMS training path.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W [--config c1|c2|c3|c4|c5|c5h50]
+
+N > 1: either launched by ``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`` (one rank per
+GPU over RCCL), or started directly, in which case it re-launches itself that way.  With fewer visible GPUs than ranks
+(a 1-GPU box) the ranks share the GPU over gloo: a functional dry run of the multi-rank path, flagged in the JSON line.
 
 Metric (BASELINE.json): training impressions/sec, plus the embedding-gather HBM GB/s.
 A "step" is one optimizer step -- forward, loss, backward, (RCCL gradient all-reduce), Keras-form
@@ -25,6 +29,8 @@ import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -47,6 +53,9 @@ CONFIGS = {
     "c1": dict(V=32000, D=300, H=20, C=5, T=30, h=20, d=20, A=200, train_embedding=True, B=32),
     "c2": dict(V=250002, D=1024, H=20, C=5, T=30, h=20, d=20, A=200, train_embedding=False, B=32),
     "c4": dict(V=32000, D=300, H=50, C=5, T=30, h=20, d=20, A=200, train_embedding=True, B=32),
+    # configs[4]: the c2 table row-sharded over the ranks, global batch 512 on 8 GPUs = 64 per GPU (H=20, and H=50 as on ebnerd_large)
+    "c5": dict(V=250002, D=1024, H=20, C=5, T=30, h=20, d=20, A=200, train_embedding=False, B=64, shard_table=True),
+    "c5h50": dict(V=250002, D=1024, H=50, C=5, T=30, h=20, d=20, A=200, train_embedding=False, B=64, shard_table=True),
     # NRMSDocVec: 125542 EB-NeRD articles x 768-d document vectors resident in HBM, MLP 512-512-512 -> 256
     "c3": dict(n_articles=125542, doc=768, units=[512, 512, 512], H=20, C=5, h=16, d=16, A=200, B=32),
 }
@@ -101,20 +110,68 @@ def cpu_baseline(c, seconds=15.0):
         y = np.zeros((c["B"], c["C"]), np.float32)
         y[np.arange(c["B"]), rng.integers(0, c["C"], c["B"])] = 1
         return his, pred, y
-    tr.step(*batch())  # warm-up (thread pool, allocator)
-    n, t0 = 0, time.perf_counter()
+    torch.set_num_threads(os.cpu_count() or 1)  # all host cores; the count is reported as "cores"
+    for _ in range(2):
+        tr.step(*batch())  # warm-up (thread pool, allocator, first-touch of the table)
+    times = []
+    t0 = time.perf_counter()
     while True:
+        t1 = time.perf_counter()
         tr.step(*batch())
-        n += 1
+        times.append(time.perf_counter() - t1)
         el = time.perf_counter() - t0
-        if (el >= seconds and n >= 2) or n >= 200:
+        if (el >= seconds and len(times) >= 3) or len(times) >= 200:
             break
-    return {"value": n * c["B"] / el, "unit": "impressions/s", "cores": int(torch.get_num_threads()), "kind": "port",
-            "sample": f"{n} train steps of batch {c['B']} ({c['H']}+{c['C']} titles x {c['T']} tokens, table {c['V']}x{c['D']}"
-                      f"{' frozen' if not c['train_embedding'] else ' trainable'}) in {el:.1f}s, oracle/nrms_torch.py fp32 eager"}
+    n, med = len(times), float(np.median(times))
+    return {"value": c["B"] / med, "unit": "impressions/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": f"median of {n} train steps of batch {c['B']} ({c['H']}+{c['C']} titles x {c['T']} tokens, table {c['V']}x{c['D']}"
+                      f"{' frozen' if not c['train_embedding'] else ' trainable'}) after 2 warm-up steps, {el:.1f}s of CPU work "
+                      f"(bounded to ~{seconds:.0f}s by the bench contract, hence fewer than 20 steps when a step takes >{seconds / 20:.2f}s; "
+                      f"step min/max {min(times) * 1e3:.0f}/{max(times) * 1e3:.0f} ms), oracle/nrms_torch.py fp32 eager, "
+                      f"torch.set_num_threads({os.cpu_count()})"}
 
 
-def bench_docvec(args, c, world, rank, device, sync):
+def timed_repeats(step_fn, args, sync, world, device):
+    """W untimed warm-up steps, then R repeats of EXACTLY K steps, each bracketed by barrier + synchronize on both sides;
+    per repeat the MAX over ranks.  Returns the R wall times (seconds)."""
+    k = 0
+    for _ in range(args.warmup):
+        step_fn(k)
+        k += 1
+    times = []
+    for _ in range(args.repeats):
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step_fn(k)
+            k += 1
+        sync()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        times.append(dt)
+    return times
+
+
+def timing_fields(times, args, world, per_gpu_batch):
+    """value / ms_per_step from the MEDIAN repeat; spread alongside."""
+    ms = sorted(t / args.steps * 1e3 for t in times)
+    med = float(np.median(ms))
+    return {"value": world * per_gpu_batch / (med * 1e-3), "ms_per_step": med, "ms_per_step_min": ms[0], "ms_per_step_max": ms[-1],
+            "repeats": len(ms), "timing": f"median of {len(ms)} repeats of {args.steps} steps each (barrier + synchronize around every repeat, max over ranks)"}
+
+
+def dist_fields(world, backend, n_dev):
+    if world == 1:
+        return {}
+    note = "RCCL over xGMI, one rank per GPU" if backend == "nccl" else \
+        f"{backend}: {world} ranks share {n_dev} GPU(s) -- functional dry run of the multi-rank path, NOT a scaling number"
+    return {"ranks": world, "backend": backend, "dist_note": note}
+
+
+def bench_docvec(args, c, world, rank, device, sync, dfields):
     """configs[2]: NRMSDocVec train step on article-row batches gathered on the device."""
     from ebrec.models.newsrec import NRMSDocVec
 
@@ -135,32 +192,43 @@ def bench_docvec(args, c, world, rank, device, sync):
         y[torch.arange(c["B"]), torch.randint(0, c["C"], (c["B"],), generator=g)] = 1.0
         batches.append((his, pred, y.to(device)))
     eng.enable_graphs(not args.no_graph)
-    for i in range(args.warmup):
-        eng.train_step(*batches[i % 8], indexed=True)
+    times = timed_repeats(lambda k: eng.train_step(*batches[k % 8], indexed=True), args, sync, world, device)
+    # kernel-level roofline: the widest Dense GEMM of the MLP (rows x 768 -> 512), HIP-event timed kernel by kernel
+    eng.kernel_events = {}
+    for k in range(args.steps):
+        eng.train_step(*batches[k % 8], indexed=True)
     sync()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        eng.train_step(*batches[i % 8], indexed=True)
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    events, eng.kernel_events = eng.kernel_events, None
     if rank == 0:
         n_rows = c["B"] * (c["H"] + c["C"])
-        print(json.dumps({
-            "metric": "training impressions/sec", "value": world * c["B"] * args.steps / dt, "unit": "impressions/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "launch": "eager" if args.no_graph else "hipGraph replay", "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"NRMSDocVec train step, BASELINE.json configs[2] (c3): {c['n_articles']} x {c['doc']} document vectors in HBM, "
-                                   f"MLP {c['units']} -> {c['h'] * c['d']}, history_size={c['H']} npratio={c['C'] - 1}, dropout 0.2, adam lr=1e-4",
-                       "global_batch": world * c["B"], "per_gpu_batch": c["B"], "parallelism": f"dp{world}",
-                       "final_loss": float(eng.loss_dev.item())},
-            "roofline": {"kernel": "whole step (launch/latency-bound: ~0.19 GFLOP and 2.5 MB of gathered vectors per step)", "bound": "hbm",
-                         "achieved": n_rows * (4 + 2 * c["doc"] * 4) * args.steps / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": n_rows * (4 + 2 * c["doc"] * 4) * args.steps / dt / 1e9 / HBM_PEAK_GBS, "traffic": None}}), flush=True)
+        kt = {k: float(np.median([a.elapsed_time(b) for a, b in v])) * 1e-3 for k, v in events.items()}
+        line = {"metric": "training impressions/sec", **timing_fields(times, args, world, c["B"]), "unit": "impressions/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup,
+                "launch": "eager" if args.no_graph else "hipGraph replay", "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"NRMSDocVec train step, BASELINE.json configs[2] (c3): {c['n_articles']} x {c['doc']} document vectors in HBM, "
+                                       f"MLP {c['units']} -> {c['h'] * c['d']}, history_size={c['H']} npratio={c['C'] - 1}, dropout 0.2, adam lr=1e-4",
+                           "global_batch": world * c["B"], "per_gpu_batch": c["B"], "parallelism": f"dp{world}",
+                           "final_loss": float(eng.loss_dev.item())}, **dfields}
+        gather_bytes = n_rows * (4 + 2 * c["doc"] * 4)
+        if "gather" in kt:
+            line["roofline"] = {"kernel": "gather_rows_vec4_kernel (document-vector gather, the step's only HBM-sized read; the step itself is "
+                                          "launch/latency-bound: ~0.19 GFLOP and 2.5 MB per step)", "bound": "hbm",
+                                "achieved": gather_bytes / kt["gather"] / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": gather_bytes / kt["gather"] / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                "avg_launch_us": kt["gather"] * 1e6, "algorithmic_bytes_per_launch": gather_bytes}
+        print(json.dumps(line), flush=True)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a torchrun parent: become one (one rank per GPU; over-subscribed on gloo when the
+    box has fewer GPUs than ranks)."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd))
 
 
 def main():
@@ -168,28 +236,33 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--repeats", type=int, default=5, help="the timed loop of --steps steps is run this many times; the median is reported")
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
-    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the config's, 32)")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch kernel by kernel instead of hipGraph replay")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("--gpus N>1 must be launched with python -m torch.distributed.run --nproc-per-node N")
-    local = local % max(torch.cuda.device_count(), 1)  # (only matters when ranks are over-subscribed in a dry run)
+    n_dev = max(torch.cuda.device_count(), 1)
+    local = local % n_dev  # ranks share GPUs only in the over-subscribed dry run
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("EBN_DIST_BACKEND", "nccl")  # "nccl" = RCCL over xGMI; "gloo" only for dry runs
+        # "nccl" = RCCL over xGMI; RCCL refuses two ranks on one GPU, so a box with fewer GPUs than ranks falls back to gloo
+        backend = os.environ.get("EBN_DIST_BACKEND", "nccl" if torch.cuda.device_count() >= world else "gloo")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    dfields = dist_fields(world, backend, n_dev)
 
     c = dict(CONFIGS[args.config])
     if args.batch:
@@ -202,29 +275,24 @@ def main():
             torch.cuda.synchronize()
 
     if args.config == "c3":
-        bench_docvec(args, c, world, rank, device, sync)
+        bench_docvec(args, c, world, rank, device, sync, dfields)
         if world > 1:
             dist.destroy_process_group()
         return
     from ebrec import _hip
     from ebrec.models.newsrec import NRMSModel
 
+    sharded = bool(c.get("shard_table"))
     rng = np.random.default_rng(42)  # identical weights on every rank (data-parallel replicas)
     table = (rng.standard_normal((c["V"], c["D"]), dtype=np.float32) * 0.02) if not c["train_embedding"] else None
     model = NRMSModel(make_hparams(c), word2vec_embedding=table, word_emb_dim=c["D"], vocab_size=c["V"], seed=42,
-                      train_embedding=c["train_embedding"], device=device)
+                      train_embedding=c["train_embedding"], device=device, shard_table=sharded)
+    del table
     eng = model._engine
     batches = synthetic_batches(c, 8, 123 + rank, device)
 
     eng.enable_graphs(not args.no_graph)
-    for i in range(args.warmup):
-        eng.train_step(*batches[i % len(batches)])
-    sync()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        eng.train_step(*batches[i % len(batches)])
-    sync()
-    dt = time.perf_counter() - t0
+    times = timed_repeats(lambda k: eng.train_step(*batches[k % len(batches)]), args, sync, world, device)
     # Kernel-level rooflines: the same K steps once more, launched kernel by kernel (identical kernels and
     # arguments; a captured graph cannot carry per-kernel events) with HIP events on the launch stream
     # around the gather and the Q|K|V projection GEMM.
@@ -235,10 +303,6 @@ def main():
     sync()
     dt_eager = time.perf_counter() - t1
     events, eng.kernel_events = eng.kernel_events, None
-    if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
     loss = float(eng.loss_dev.item())
 
     if rank == 0:
@@ -248,19 +312,24 @@ def main():
         gemm_flops = 2.0 * n_tok * c["D"] * 3 * E
         bm, bn, sp = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
         _hip.call("ebn_gemm_plan", n_tok, 3 * E, c["D"], 0, ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(sp))
-        gemm_name = f"gemm_f32_kernel<{bm.value}, {bn.value}, {4 if bm.value == 256 else 2}, false, false, true, 1, 0>"
+        gemm_name = f"gemm_f32_kernel<{bm.value}, {bn.value}, ...> (ebn_gemm_plan: tile {bm.value}x{bn.value}, split-K {sp.value})"
         gather_bytes = n_tok * (4 + 2 * c["D"] * 4)  # id + row read + row write (materialising gather)
         traffic = {}
         tf = ROOT / "profiles" / "traffic.json"
         if tf.exists():
             traffic = json.loads(tf.read_text()).get(args.config, {})
+        cfg_idx = {"c1": 0, "c2": 1, "c4": 3, "c5": 4, "c5h50": 4}[args.config]
+        table_kind = "trainable" if c["train_embedding"] else "frozen lookup"
+        if sharded:
+            table_kind += f", row-sharded over {world} rank(s) (routed all-to-all of the distinct rows)"
         line = {
-            "metric": "training impressions/sec", "value": world * c["B"] * args.steps / dt, "unit": "impressions/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "ms_per_step_kernel_by_kernel": dt_eager / args.steps * 1e3, "launch": "eager" if args.no_graph else "hipGraph replay",
+            "metric": "training impressions/sec", **timing_fields(times, args, world, c["B"]), "unit": "impressions/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step_kernel_by_kernel": dt_eager / args.steps * 1e3,
+            "launch": "eager" if (args.no_graph or not eng.graph_capable) else "hipGraph replay",
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"NRMS train step, BASELINE.json configs[{ {'c1': 0, 'c2': 1, 'c4': 3}[args.config] }] "
-                                   f"({args.config}): table {c['V']}x{c['D']} {'trainable' if c['train_embedding'] else 'frozen lookup'}, "
+            "config": {"workload": f"NRMS train step, BASELINE.json configs[{cfg_idx}] "
+                                   f"({args.config}): table {c['V']}x{c['D']} {table_kind}, "
                                    f"history_size={c['H']} npratio={c['C'] - 1} title_len={c['T']} head={c['h']}x{c['d']} "
                                    f"att_hidden={c['A']} dropout=0.2 adam lr=1e-4 CE loss",
                        "global_batch": world * c["B"], "per_gpu_batch": c["B"], "parallelism": f"dp{world}",
@@ -275,7 +344,12 @@ def main():
                                 "frac": gather_bytes / kt["gather"] / 1e9 / HBM_PEAK_GBS,
                                 "traffic": traffic.get("gather"), "avg_launch_us": kt["gather"] * 1e6,
                                 "algorithmic_bytes_per_launch": gather_bytes},
+            **dfields,
         }
+        if sharded:
+            line["exchange"] = eng.exchange.stats()
+        if world > 1:
+            line["allreduce_bytes_per_step"] = eng.allreduce_bytes()
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(c, args.cpu_seconds)
         print(json.dumps(line), flush=True)

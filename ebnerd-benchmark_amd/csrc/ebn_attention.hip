@@ -450,7 +450,10 @@ extern "C" int ebn_attn_fwd_f32(const float* qkv, int64_t ld_qkv, float* out, in
   rc = ebn_attn_mfma_fwd(qkv, ld_qkv, out, ld_out, n_seq, L, h, d, dr, ebn_stream(stream), &handled);
   if (rc != EBN_OK || handled) return rc;
   AttnArgs a{qkv, ld_qkv, nullptr, 0, out, ld_out, n_seq * h, L, h, d, dr.key_ptr, dr.thresh, dr.scale};
-  if (L > 64) {
+  // one-wave kernels for L <= 64 while their LDS image fits 64 KB; anything longer or fatter takes the recompute kernels
+  const int LPs = (L & 1) ? L + 2 : L + 1;
+  const bool short_ok = L <= 64 && static_cast<size_t>((L <= 32 ? 2 : 1) * (3 * L * d + L * LPs)) * sizeof(float) <= 65536;
+  if (!short_ok) {
     const size_t lds = static_cast<size_t>(3 * L * d + 2 * L) * sizeof(float);
     EBN_REQUIRE(lds <= 160 * 1024 && a.n_prob <= 0x7FFFFFFF, EBN_ERR_UNSUPPORTED);
     allow_big_lds(attn_long_fwd_kernel, lds);
@@ -486,7 +489,9 @@ extern "C" int ebn_attn_bwd_f32(const float* qkv, int64_t ld_qkv, const float* d
   rc = ebn_attn_mfma_bwd(qkv, ld_qkv, dout, ld_dout, dqkv, ld_dqkv, n_seq, L, h, d, dr, ebn_stream(stream), &handled);
   if (rc != EBN_OK || handled) return rc;
   AttnArgs a{qkv, ld_qkv, dout, ld_dout, dqkv, ld_dqkv, n_seq * h, L, h, d, dr.key_ptr, dr.thresh, dr.scale};
-  if (L > 64) {
+  const int LPs = (L & 1) ? L + 2 : L + 1;
+  const bool short_ok = L <= 64 && static_cast<size_t>((L <= 32 ? 2 : 1) * (4 * L * d + 2 * L * LPs)) * sizeof(float) <= 65536;
+  if (!short_ok) {  // e.g. L = 64, d = 32: the forward image fits the one-wave kernel, the backward one does not
     const size_t lds = static_cast<size_t>(4 * L * d + 3 * L) * sizeof(float);
     EBN_REQUIRE(lds <= 160 * 1024 && a.n_prob <= 0x7FFFFFFF, EBN_ERR_UNSUPPORTED);
     allow_big_lds(attn_long_bwd_kernel, lds);

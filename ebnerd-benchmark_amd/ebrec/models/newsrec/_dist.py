@@ -4,15 +4,24 @@
 Two things shard:
   * impressions (data parallel): replicas all-reduce their flat gradient buckets once per step;
   * optionally the word-embedding table by ROWS (BASELINE.json config 5): rank r owns the contiguous
-    block [r*ceil(V/W), (r+1)*ceil(V/W)).  A lookup is then
-        dedup local token ids -> route each unique id to its owner (all-to-all of ids)
+    block [r*ceil(V/W), (r+1)*ceil(V/W)) (``partition="block"``) or the ids = r mod W (``"cyclic"``: tokenizer
+    ids are roughly frequency-ordered, a block split would make rank 0 the owner of most of a batch).
+    A lookup is then
+        dedup local token ids -> route each distinct id to its owner (all-to-all of row numbers)
         -> owners gather their rows (the HIP gather kernel on the local shard)
         -> all-to-all of the rows back -> expand to token order (HIP gather again, dropout fused).
-    Only the rows a rank actually needs cross xGMI (n_unique x D x 4 B, 7/8 of it remote), instead of
-    the W-fold volume of all-gathering every rank's looked-up rows; the all-gather form is kept as
-    ``mode="allgather"`` because it is the form BASELINE.json names and it validates the routed one.
-    Backward runs the same routes in reverse and scatter-adds into the owner's shard, so table
-    gradients are never all-reduced.
+    Only the rows a rank actually needs cross xGMI (n_distinct x D x 4 B, 7/8 of it remote), instead of
+    the W-fold volume of all-gathering every rank's looked-up rows.  Backward runs the same routes in
+    reverse and scatter-adds into the owner's shard, so table gradients are never all-reduced.
+
+    ``mode="alltoall"`` (default) plans the lookup ON THE DEVICE (csrc/ebn_shard.hip) into fixed-capacity
+    per-owner request lists: both exchanges are equal-split all-to-alls whose sizes the host knows from the
+    batch shape alone -- no host sync, nothing data-dependent on the host, the kernels between the collectives
+    are hipGraph-capturable.  Capacity per (requester, owner) pair = ``capacity_factor`` x n_tok / W distinct
+    rows (never less than min(n_tok, 1024)); an overflow drops ids, sets a device flag and raises at the next
+    ``check()``.  ``mode="alltoall_exact"`` is the variable-size form planned with torch.unique on the host
+    (three host syncs per lookup, eager only) and ``mode="allgather"`` the all-gather form BASELINE.json names;
+    both are kept because they validate the planned one.
 
 Nothing here computes on rows: the local gather / scatter-add are callables supplied by the engine
 (HIP kernels); the CPU tests pass torch stand-ins to exercise the routing under gloo.
@@ -58,16 +67,137 @@ class LookupPlan:
     recv_local: torch.Tensor   # (sum recv,) int32 LOCAL row numbers (global id - my first row) to serve
 
 
+class PlannedBuffers:
+    """Device buffers of the fixed-capacity lookup for up to `n_tok` tokens (allocated once per shape: captured graphs
+    and the collectives work on the same memory every step)."""
+
+    def __init__(self, ex: "ShardedTableExchange", n_tok: int, device, need_grad: bool, ws_ints: int):
+        W, D, cap = ex.world, ex.D, ex.capacity(n_tok)
+        i32 = lambda n: torch.empty(n, dtype=torch.int32, device=device)
+        f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=device)
+        self.n_tok, self.cap = n_tok, cap
+        self.ws, self.slot_rows, self.inv, self.counts = i32(max(ws_ints, 1)), i32(W * cap), i32(n_tok), torch.zeros(W + 2, dtype=torch.int32, device=device)
+        self.served = f32(W * cap, D)
+        # one rank: "exchanging" with yourself is the identity, the receive buffers alias the send buffers
+        self.recv_rows = i32(W * cap) if W > 1 else self.slot_rows
+        self.rows = f32(W * cap, D) if W > 1 else self.served
+        self.d_slot = f32(W * cap, D) if need_grad else None
+        self.d_recv = (f32(W * cap, D) if W > 1 else self.d_slot) if need_grad else None
+
+
 class ShardedTableExchange:
-    def __init__(self, V: int, D: int, group=None, mode: str = "alltoall"):
-        if mode not in ("alltoall", "allgather"):
+    def __init__(self, V: int, D: int, group=None, mode: str = "alltoall", partition: str = "block", capacity_factor: float = 1.25):
+        if mode not in ("alltoall", "alltoall_exact", "allgather"):
             raise ValueError(f"unknown exchange mode {mode}")
-        self.V, self.D, self.group, self.mode = int(V), int(D), group, mode
+        if partition not in ("block", "cyclic"):
+            raise ValueError(f"unknown table partition {partition}")
+        if partition == "cyclic" and mode != "alltoall":
+            raise ValueError("the cyclic partition is implemented by the device-planned exchange (mode='alltoall') only")
+        self.V, self.D, self.group, self.mode, self.partition = int(V), int(D), group, mode, partition
+        self.capacity_factor = float(capacity_factor)
         self.rank, self.world = world_info(group)
         self.per = rows_per_rank(self.V, self.world)
         self.lo, self.hi = row_shard_range(self.V, self.world, self.rank)
+        self.bytes_sent = {"ids": 0, "rows": 0, "grads": 0}   # per lookup of the last shape, this rank, remote part only
+        self.lookups = 0
 
-    # ------------------------------------------------------------------ routing
+    # ------------------------------------------------------------------ geometry
+    @property
+    def cyclic(self) -> bool:
+        return self.partition == "cyclic"
+
+    @property
+    def n_local(self) -> int:
+        """rows this rank owns"""
+        if self.cyclic:
+            return len(range(self.rank, self.V, self.world))
+        return self.hi - self.lo
+
+    def shard_of(self, table):
+        """this rank's rows of a full (V, ...) array, in owner-local order"""
+        return table[self.rank:: self.world] if self.cyclic else table[self.lo: self.hi]
+
+    def unshard(self, parts):
+        """inverse of shard_of over the list of every rank's shard, each padded to `per` rows: the full (V, ...) tensor"""
+        if not self.cyclic:
+            return torch.cat(parts)[: self.V]
+        full = torch.stack(parts, dim=1)  # (per, W, ...): local row l of rank r is global row l*W + r
+        return full.reshape(self.per * self.world, *parts[0].shape[1:])[: self.V]
+
+    def capacity(self, n_tok: int) -> int:
+        """distinct rows one rank may request from one owner in a lookup of n_tok tokens (a host-side function of the
+        SHAPE only: every rank computes the same number without talking)"""
+        if self.world == 1:
+            return max(min(n_tok, self.V), 1)
+        cap = max(int(-(-self.capacity_factor * n_tok // self.world)), min(n_tok, 1024))
+        cap = min(cap, n_tok, self.per)
+        return max(-(-cap // 64) * 64 if cap >= 64 else cap, 1)
+
+    def _a2a(self, out, inp):
+        if self.world > 1:
+            dist.all_to_all_single(out, inp, group=self.group)  # equal splits: sizes are a function of the shape only
+
+    # ------------------------------------------------------------------ device-planned fixed-capacity lookup
+    def lookup_segments(self, ids: torch.Tensor, n_tok: int, b: PlannedBuffers, plan_fn, gather_fn) -> list:
+        """The lookup as an ordered list of ("k" = kernels only | "c" = collective, fn): the engine captures the "k" runs
+        into hipGraphs and launches the "c" entries eagerly between the replays.  ids (>= n_tok,) int32 on the device.
+        After the last segment b.rows[(W*cap), D] holds the distinct rows this rank asked for and b.inv[:n_tok] maps
+        tokens to them.
+          plan_fn(ids, n_tok, cap, ws, slot_rows, inv, counts)   -- ebn_shard_plan_i32
+          gather_fn(local_rows (m,) int32, out (m, D))           -- out[i] = shard[local_rows[i]], zero row for -1"""
+        W, cap = self.world, self.capacity(n_tok)
+        n = W * cap
+
+        def note():
+            self.lookups += 1
+            self.bytes_sent.update(ids=(W - 1) * cap * 4, rows=(W - 1) * cap * self.D * 4)
+
+        segs = [("k", lambda: plan_fn(ids, n_tok, cap, b.ws, b.slot_rows, b.inv, b.counts))]
+        if W > 1:
+            segs.append(("c", lambda: (self._a2a(b.recv_rows[:n], b.slot_rows[:n]), note())))
+        segs.append(("k", lambda: gather_fn(b.recv_rows[:n], b.served[:n])))
+        if W > 1:
+            segs.append(("c", lambda: self._a2a(b.rows[:n], b.served[:n])))
+        return segs
+
+    def grad_segments(self, n_tok: int, b: PlannedBuffers, reduce_fn, scatter_fn) -> list:
+        """Backward of the lookup, same segment form.
+          reduce_fn(inv (n_tok,), d_slot (W*cap, D))             -- d_slot = 0; d_slot[inv[t]] += d(token t)
+          scatter_fn(local_rows (m,) int32, grads (m, D))        -- shard_grad = 0; shard_grad[local_rows[i]] += grads[i], -1 skipped"""
+        W, cap = self.world, self.capacity(n_tok)
+        n = W * cap
+        segs = [("k", lambda: reduce_fn(b.inv[:n_tok], b.d_slot[:n]))]
+        if W > 1:
+            segs.append(("c", lambda: (self._a2a(b.d_recv[:n], b.d_slot[:n]), self.bytes_sent.update(grads=(W - 1) * cap * self.D * 4))))
+        segs.append(("k", lambda: scatter_fn(b.recv_rows[:n], b.d_recv[:n])))
+        return segs
+
+    def planned_lookup(self, ids, n_tok, b, plan_fn, gather_fn) -> None:
+        for _kind, fn in self.lookup_segments(ids, n_tok, b, plan_fn, gather_fn):
+            fn()
+
+    def planned_scatter_grads(self, n_tok, b, reduce_fn, scatter_fn) -> None:
+        for _kind, fn in self.grad_segments(n_tok, b, reduce_fn, scatter_fn):
+            fn()
+
+    def check(self, b: PlannedBuffers, what="embedding table") -> None:
+        """One host read of the plan's flags (the engine calls this once per epoch, not per step)."""
+        c = b.counts.cpu().tolist()
+        b.counts[self.world:].zero_()
+        if c[self.world + 1]:
+            raise IndexError(f"token id out of range [0, {self.V}) for the {what}")
+        if c[self.world]:
+            raise RuntimeError(f"row-sharded lookup overflowed its exchange capacity ({b.cap} distinct rows per owner, wanted up to "
+                               f"{max(c[: self.world])}): rows were dropped.  Raise capacity_factor (now {self.capacity_factor}; "
+                               f"{self.world} can never overflow) or use partition='cyclic' for frequency-ordered vocabularies")
+
+    def stats(self) -> dict:
+        return {"mode": self.mode, "partition": self.partition, "world": self.world, "capacity_factor": self.capacity_factor,
+                "bytes_sent_per_lookup_remote": dict(self.bytes_sent),
+                "note": "per rank and per step: row numbers out, rows back (and row gradients out when the table trains); "
+                        "equal-split all-to-alls of fixed capacity, (world-1)/world of each buffer leaves the GPU"}
+
+    # ------------------------------------------------------------------ host-planned exact routing (validation forms)
     def plan(self, ids: torch.Tensor) -> LookupPlan:
         ids = ids.reshape(-1).to(torch.int64)
         if ids.numel() and (int(ids.min()) < 0 or int(ids.max()) >= self.V):

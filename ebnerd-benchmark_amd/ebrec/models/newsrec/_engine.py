@@ -121,7 +121,8 @@ class NRMSEngine:
     def __init__(self, table: np.ndarray, title_size: int, history_size: int, head_num: int, head_dim: int,
                  attention_hidden_dim: int, dropout: float, learning_rate: float, loss: str, seed=None,
                  train_embedding: bool = True, device=None, process_group=None, shard_table: bool = False,
-                 shard_mode: str = "alltoall", deterministic: bool = True, units=None, l2: float = 0.0):
+                 shard_mode: str = "alltoall", deterministic: bool = True, units=None, l2: float = 0.0,
+                 shard_partition: str = "block", shard_capacity_factor: float = 1.25):
         self.device = require_gpu() if device is None else torch.device(device)
         if loss not in LOSS_KIND:
             raise ValueError(f"this loss not defined {loss}")
@@ -140,8 +141,9 @@ class NRMSEngine:
             # BASELINE config 5: each rank keeps only its contiguous block of rows in HBM
             from ._dist import ShardedTableExchange
 
-            self.exchange = ShardedTableExchange(self.V, self.D, group=process_group, mode=shard_mode)
-            table = table[self.exchange.lo: self.exchange.hi]
+            self.exchange = ShardedTableExchange(self.V, self.D, group=process_group, mode=shard_mode, partition=shard_partition,
+                                                 capacity_factor=shard_capacity_factor)
+            table = self.exchange.shard_of(table)
         self.table = torch.from_numpy(np.ascontiguousarray(table)).to(self.device)
         D, E, A = self.D, self.E, self.A
         # optional per-token [Dense-ReLU -> BatchNorm -> Dropout] stack between self-attention and AttLayer2 (nrms.py:142-152)
@@ -156,7 +158,8 @@ class NRMSEngine:
             shapes.update(MLPStack.shapes("n_", E, self.units))
         shapes.update({"n_W": (E, A), "n_b": (A,), "n_q": (A,), "u_Wqkv": (E, 3 * E), "u_W": (E, A), "u_b": (A,), "u_q": (A,)})
         self.params = FlatParams(shapes, self.device)
-        self.mlp = MLPStack(self.params, "n_", E, self.units, self.device, l2) if self.units else None
+        self._graphs = {}
+        self.mlp = MLPStack(self.params, "n_", E, self.units, self.device, l2, on_realloc=lambda: self._graphs.clear()) if self.units else None
         self._init_weights(seed)
         self.deterministic = bool(deterministic)
         if self.train_embedding:
@@ -173,7 +176,6 @@ class NRMSEngine:
         self.oob_flag = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.loss_dev = torch.zeros(1, device=self.device)
         self.use_graph = False  # capture the per-shape kernel sequence into hipGraphs (enable_graphs())
-        self._graphs = {}
         self.kernel_events = None  # dict name -> [(start, stop)] when bench.py asks for kernel timings
         self.world = 1
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
@@ -227,7 +229,7 @@ class NRMSEngine:
         if w[0].shape != (self.V, self.D):
             raise ValueError(f"embedding shape {w[0].shape} != {(self.V, self.D)}")
         with torch.no_grad():
-            t0 = w[0] if self.exchange is None else w[0][self.exchange.lo: self.exchange.hi]
+            t0 = w[0] if self.exchange is None else self.exchange.shard_of(w[0])
             self.table.copy_(torch.from_numpy(np.ascontiguousarray(t0)))
             i = 1
             for pre in ("n", "u"):
@@ -246,10 +248,26 @@ class NRMSEngine:
         mine[: self.table.shape[0]] = self.table
         parts = [torch.empty_like(mine) for _ in range(self.exchange.world)]
         torch.distributed.all_gather(parts, mine, group=self.pg)
-        return torch.cat(parts)[: self.V]
+        return self.exchange.unshard(parts)
 
     def count_params(self):
         return self.V * self.D + sum(int(np.prod(s)) for s in self.params.shapes.values()) + 2 * sum(self.units)
+
+    @property
+    def _planned(self) -> bool:
+        """row-sharded table with the device-planned fixed-capacity exchange (the graph-capturable form)"""
+        return self.exchange is not None and self.exchange.mode == "alltoall"
+
+    @property
+    def graph_capable(self) -> bool:
+        return self.exchange is None or self._planned
+
+    def allreduce_bytes(self) -> int:
+        """bytes each rank contributes to the per-step gradient all-reduce(s)"""
+        n = self.params.numel * 4
+        if self.train_embedding and self.exchange is None:
+            n += self.table_grad.numel() * 4
+        return n
 
     def enable_graphs(self, flag=True):
         self.use_graph = bool(flag)
@@ -280,6 +298,11 @@ class NRMSEngine:
             b = EncoderBuffers(N, self.T, self.D, self.E, self.A, self.device, own_input=True,
                                need_dx=train and self.train_embedding)
             b.ids = torch.empty(N * self.T, dtype=torch.int32, device=self.device)
+            if self._planned:
+                from ._dist import PlannedBuffers
+
+                ws = int(_hip.lib().ebn_shard_plan_workspace_ints(self.V, self.exchange.world))
+                b.xb = PlannedBuffers(self.exchange, N * self.T, self.device, need_grad=train and self.train_embedding, ws_ints=ws)
             self._bufs[key] = b
             self._graphs.clear()  # captured graphs hold raw pointers into the old buffers
         return b
@@ -411,28 +434,77 @@ class NRMSEngine:
             off += t.numel()
         return off
 
-    def _news_forward(self, b, N, train, n_first=None):
+    def _news_forward(self, b, N, train, n_first=None, looked_up=False):
         """a1..a4 for N titles whose ids are already in b.ids -> b.out[:N].  n_first = titles of the first
-        TimeDistributed call site (history); only the BatchNorm of the optional Dense stack cares."""
+        TimeDistributed call site (history); only the BatchNorm of the optional Dense stack cares.
+        looked_up: the row-sharded lookup of these ids already ran (the train step interleaves it with collectives)."""
         site, p = (0, self.p) if (train and self.p > 0) else (-1, 0.0)
         st = _hip.ptr(self.state) if train else None
+        n_tok = N * self.T
+        if self._planned:
+            # row-sharded table: the device plans the routes, two equal-split all-to-alls fetch the distinct rows, then
+            # the same gather kernel expands them to token order (ids = slots of the received buffer), dropout fused
+            if not looked_up:
+                for _kind, fn in self._lookup_segments(b, N):
+                    fn()
+            xb = b.xb
+            ev = self._timed("gather") if (self.kernel_events is not None and train) else None
+            if ev:
+                ev[0].record()
+            _hip.call("ebn_gather_rows_f32", _hip.ptr(xb.inv), _hip.ptr(xb.rows), _hip.ptr(b.X), n_tok, self.D,
+                      self.exchange.world * self.exchange.capacity(n_tok), st, site, ctypes.c_float(p), _hip.ptr(self.oob_flag),
+                      _hip.stream_handle())
+            if ev:
+                ev[1].record()
+            return self._encoder_fwd("n", b, N, b.X, train, n_first)
         if self.exchange is not None:
-            # row-sharded table: route the distinct ids to their owners, fetch the rows over RCCL, then the same
-            # gather kernel expands them to token order (ids = positions in the unique list) with dropout fused
-            b.plan = self.exchange.plan(b.ids[: N * self.T])
+            # validation forms (host-planned, eager only): route the distinct ids to their owners, fetch the rows over
+            # RCCL, then expand them to token order (ids = positions in the unique list) with dropout fused
+            b.plan = self.exchange.plan(b.ids[: n_tok])
             b.rows_uniq = self.exchange.lookup(b.plan, self._local_gather)
-            _hip.call("ebn_gather_rows_f32", _hip.ptr(b.plan.inv), _hip.ptr(b.rows_uniq), _hip.ptr(b.X), N * self.T,
+            _hip.call("ebn_gather_rows_f32", _hip.ptr(b.plan.inv), _hip.ptr(b.rows_uniq), _hip.ptr(b.X), n_tok,
                       self.D, b.rows_uniq.shape[0], st, site, ctypes.c_float(p), _hip.ptr(self.oob_flag),
                       _hip.stream_handle())
             return self._encoder_fwd("n", b, N, b.X, train, n_first)
         ev = self._timed("gather") if self.kernel_events is not None else None
         if ev:
             ev[0].record()
-        _hip.call("ebn_gather_rows_f32", _hip.ptr(b.ids), _hip.ptr(self.table), _hip.ptr(b.X), N * self.T, self.D,
+        _hip.call("ebn_gather_rows_f32", _hip.ptr(b.ids), _hip.ptr(self.table), _hip.ptr(b.X), n_tok, self.D,
                   self.V, st, site, ctypes.c_float(p), _hip.ptr(self.oob_flag), _hip.stream_handle())
         if ev:
             ev[1].record()
         self._encoder_fwd("n", b, N, b.X, train, n_first)
+
+    # ---- device-planned row-sharded lookup, as ("k" kernels | "c" collective, fn) segments -------------------------
+    def _lookup_segments(self, b, N):
+        ex, n_tok = self.exchange, N * self.T
+
+        def plan(ids, n, cap, ws, slot_rows, inv, counts):
+            _hip.call("ebn_shard_plan_i32", _hip.ptr(ids), n, self.V, ex.world, 1 if ex.cyclic else 0, cap, _hip.ptr(ws),
+                      _hip.ptr(slot_rows), _hip.ptr(inv), _hip.ptr(counts), _hip.stream_handle())
+
+        def serve(local_rows, out):  # rows other ranks (and this one) asked of my shard; -1 padding gathers a zero row, no flag
+            _hip.call("ebn_gather_rows_f32", _hip.ptr(local_rows), _hip.ptr(self.table), _hip.ptr(out), local_rows.numel(), self.D,
+                      self.table.shape[0], None, -1, ctypes.c_float(0.0), None, _hip.stream_handle())
+
+        return ex.lookup_segments(b.ids, n_tok, b.xb, plan, serve)
+
+    def _table_grad_segments(self, b, N):
+        """d(rows): one gradient row per requested slot locally, each slab sent to its owner, owners accumulate."""
+        ex, n_tok = self.exchange, N * self.T
+        site, p = (0, self.p) if self.p > 0 else (-1, 0.0)
+
+        def reduce_local(inv, d_slot):
+            d_slot.zero_()
+            _hip.call("ebn_embedding_grad_scatter_f32", _hip.ptr(inv), _hip.ptr(b.dX), _hip.ptr(d_slot), n_tok, self.D,
+                      d_slot.shape[0], _hip.ptr(self.state), site, ctypes.c_float(p), _hip.stream_handle())
+
+        def accumulate(local_rows, grads):
+            self.table_grad.zero_()
+            _hip.call("ebn_embedding_grad_scatter_f32", _hip.ptr(local_rows), _hip.ptr(grads), _hip.ptr(self.table_grad),
+                      local_rows.numel(), self.D, self.table.shape[0], None, -1, ctypes.c_float(0.0), _hip.stream_handle())
+
+        return ex.grad_segments(n_tok, b.xb, reduce_local, accumulate)
 
     def _local_gather(self, local_rows: torch.Tensor) -> torch.Tensor:
         m = local_rows.numel()
@@ -530,9 +602,23 @@ class NRMSEngine:
             raise ValueError(f"pred_input_title must be (B, C, {self.T}), got {tuple(pred.shape)}")
 
     def _check_oob(self):
+        if self._planned:  # the plan's own flags first: an overflowed exchange also shows up as zero rows in the gather
+            for b in self._bufs.values():
+                if hasattr(b, "xb"):
+                    try:
+                        self.exchange.check(b.xb)
+                    except Exception:
+                        self.oob_flag.zero_()
+                        raise
         if int(self.oob_flag.item()) != 0:
             self.oob_flag.zero_()
             raise IndexError(f"token id out of range [0, {self.V}) for the embedding table")
+
+    check_oob = _check_oob  # fit()/evaluate() call this once per epoch (device-resident batches are not range-checked on the host)
+
+    def l2_penalty(self) -> float:
+        """lambda * sum(W^2) over the regularised Dense kernels (0 without the optional per-token stack)."""
+        return self.mlp.l2_penalty() if self.mlp is not None else 0.0
 
     # ------------------------------------------------------------------ training
     # ------------------------------------------------------------------ device-side batch assembly (a13)
@@ -588,17 +674,15 @@ class NRMSEngine:
         if y is not None:
             labels = (y if isinstance(y, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(y, dtype=np.float32))))
             nb.labels[: B * C].copy_(labels.reshape(-1).to(device=self.device, dtype=torch.float32), non_blocking=True)
-        if self.use_graph and self.kernel_events is None and self.exchange is None:  # sharded lookups have data-dependent sizes
-            graphs = self._graphs.get((B, C))
-            if graphs is None:
-                graphs = self._capture(B, C)
-            graphs[0].replay()
-            self._allreduce_grads()
-            graphs[1].replay()
+        if self.use_graph and self.kernel_events is None and self.graph_capable:
+            run = self._graphs.get((B, C))
+            if run is None:
+                run = self._capture(B, C)
+            for fn in run:
+                fn()
         else:
-            self._fwd_bwd_kernels(B, C)
-            self._allreduce_grads()
-            self._optimizer_kernels()
+            for _kind, fn in self._segments(B, C):
+                fn()
         if return_probs:
             return self.loss_dev, nb.probs[: B * C].view(B, C)
         return self.loss_dev
@@ -618,14 +702,43 @@ class NRMSEngine:
         return nb, ub
 
     def _capture(self, B, C):
+        """Runs of kernel-only segments become hipGraphs; collectives stay eager launches between the replays."""
         torch.cuda.synchronize()
-        g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g1):
-            self._fwd_bwd_kernels(B, C)
-        with torch.cuda.graph(g2, pool=g1.pool()):
-            self._optimizer_kernels()
-        self._graphs[(B, C)] = (g1, g2)
-        return g1, g2
+        segs, run, pool, i = self._segments(B, C), [], None, 0
+        while i < len(segs):
+            if segs[i][0] == "c":
+                run.append(segs[i][1])
+                i += 1
+                continue
+            j = i
+            while j < len(segs) and segs[j][0] == "k":
+                j += 1
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                for _kind, fn in segs[i:j]:
+                    fn()
+            pool = pool or g.pool()
+            run.append(g.replay)
+            self._graph_objs = getattr(self, "_graph_objs", []) + [g]
+            i = j
+        self._graphs[(B, C)] = run
+        return run
+
+    def _segments(self, B, C):
+        """One training step as an ordered list of ("k" = kernels only | "c" = collective, fn)."""
+        N = B * (self.H + C)
+        nb, _ub = self._train_bufs(B, C)
+        multi = self.world > 1
+        segs = [("k", lambda: _hip.call("ebn_step_advance", _hip.ptr(self.state), BETA1, BETA2, _hip.stream_handle()))]
+        if self._planned:
+            segs += self._lookup_segments(nb, N)
+        segs.append(("k", lambda: self._fwd_bwd_kernels(B, C)))
+        if self._planned and self.train_embedding:
+            segs += self._table_grad_segments(nb, N)
+        if multi:
+            segs.append(("c", self._allreduce_grads))
+        segs.append(("k", self._optimizer_kernels))
+        return segs
 
     def _fwd_bwd_kernels(self, B, C):
         H, E = self.H, self.E
@@ -633,9 +746,8 @@ class NRMSEngine:
         S = _hip.stream_handle
         nb, ub = self._train_bufs(B, C)
         st = _hip.ptr(self.state)
-        _hip.call("ebn_step_advance", st, BETA1, BETA2, S())
         # ---- forward
-        self._news_forward(nb, N, True, B * H)
+        self._news_forward(nb, N, True, B * H, looked_up=True)
         self._encoder_fwd("u", ub, B, nb.out, True)  # history encodings are the first B*H rows
         cand = nb.out[B * H:]
         _hip.call("ebn_score_fwd_f32", _hip.ptr(cand), _hip.ptr(ub.out), _hip.ptr(nb.scores), _hip.ptr(nb.probs), B, C,
@@ -648,12 +760,12 @@ class NRMSEngine:
         _hip.call("ebn_sum_f32", _hip.ptr(ub.loss_rows), B, ctypes.c_float(1.0), _hip.ptr(self.loss_dev), 0, S())
         self._encoder_bwd("u", ub, B, nb.out, ub.duser, nb.dNE)  # writes dNE[:B*H]
         self._encoder_bwd("n", nb, N, nb.X, nb.dNE, nb.dX, B * H)
-        if self.train_embedding:
+        if self.train_embedding and not self._planned:
             if self.exchange is not None or not self.deterministic:
                 self.table_grad.zero_()
             site, p = (0, self.p) if self.p > 0 else (-1, 0.0)
             if self.exchange is not None:
-                # reduce to one gradient row per distinct id locally, send each to its owner, owners accumulate
+                # validation forms: one gradient row per distinct id locally, sent to its owner, owners accumulate
                 d_uniq = torch.zeros_like(nb.rows_uniq)
                 _hip.call("ebn_embedding_grad_scatter_f32", _hip.ptr(nb.plan.inv), _hip.ptr(nb.dX), _hip.ptr(d_uniq),
                           N * self.T, self.D, d_uniq.shape[0], st, site, ctypes.c_float(p), S())

@@ -36,7 +36,8 @@ class DocVecEngine:
         prev = self.units[-1] if self.units else self.Din
         shapes.update({"out_W": (prev, E), "out_b": (E,), "u_Wqkv": (E, 3 * E), "u_W": (E, A), "u_b": (A,), "u_q": (A,)})
         self.params = FlatParams(shapes, self.device)
-        self.mlp = MLPStack(self.params, "", self.Din, self.units, self.device, self.l2)
+        self.use_graph, self._graphs = False, {}
+        self.mlp = MLPStack(self.params, "", self.Din, self.units, self.device, self.l2, on_realloc=lambda: self._graphs.clear())
         self.bn_mean, self.bn_var = self.mlp.bn_mean, self.mlp.bn_var
         self._init_weights(seed)
         st = _hip.StepState()
@@ -44,7 +45,6 @@ class DocVecEngine:
         self.state = torch.frombuffer(bytearray(bytes(st)), dtype=torch.uint8).to(self.device)
         self._lr = float(learning_rate)
         self._bufs = {}
-        self.use_graph, self._graphs = False, {}
         self.loss_dev = torch.zeros(1, device=self.device)
         self.reg_dev = torch.zeros(1, device=self.device)
         self.world = 1
@@ -117,6 +117,7 @@ class DocVecEngine:
             b["ws"] = f(max(int(wsf(self.mlp.out_dim, self.E, N)), int(wsf(N, self.E, self.mlp.out_dim)), 1))
             self.mlp.bufs(N)
             self._bufs["mlp"] = b
+            self._graphs.clear()  # captured graphs hold raw pointers into the old buffers (an eval pass may grow them)
         return b
 
     def _user_bufs(self, B):
@@ -126,6 +127,7 @@ class DocVecEngine:
             b.duser = torch.empty(B, self.E, device=self.device)
             b.loss_rows = torch.empty(B, device=self.device)
             self._bufs["user"] = b
+            self._graphs.clear()
         return b
 
     # ------------------------------------------------------------------ kernels
@@ -292,10 +294,7 @@ class DocVecEngine:
         elif his.ndim != 2 or his.shape[1] != self.H or pred.ndim != 2 or pred.shape[0] != his.shape[0]:
             raise ValueError(f"indexed batches must be (B, {self.H}) and (B, C), got {tuple(his.shape)} {tuple(pred.shape)}")
         B, C = his.shape[0], pred.shape[1]
-        n_before = (self._bufs.get("mlp") or {}).get("N"), getattr(self._bufs.get("user"), "n_seq", None)
-        mb, ub = self._mlp_bufs(B * (self.H + C)), self._user_bufs(B)
-        if n_before != (mb["N"], ub.n_seq):
-            self._graphs = {}  # buffers were (re)allocated: captured graphs hold stale pointers
+        mb, ub = self._mlp_bufs(B * (self.H + C)), self._user_bufs(B)  # (re)allocation clears the captured graphs
         if indexed:
             y = self._stage_indexed(mb, his, pred, y)
         else:
@@ -359,6 +358,17 @@ class DocVecEngine:
         P = self.params
         _hip.call("ebn_adam_keras_step_f32", _hip.ptr(P.data), _hip.ptr(P.grad), _hip.ptr(P.m), _hip.ptr(P.v), P.numel, st,
                   BETA1, BETA2, ADAM_EPS, ctypes.c_float(1.0 / self.world), S())
+
+    def check_oob(self):
+        """Article-row numbers outside the document-vector matrix raise (device-resident batches are checked here,
+        once per epoch, not per step)."""
+        oob = getattr(self, "_oob", None)
+        if oob is not None and int(oob.item()) != 0:
+            oob.zero_()
+            raise IndexError(f"article row out of range [0, {self.article_matrix.shape[0]}) for the document-vector matrix")
+
+    def l2_penalty(self) -> float:
+        return self.mlp.l2_penalty()
 
     def extra_state(self):
         return {}

@@ -17,6 +17,26 @@ from ._engine import eval_loss_from_news
 from .callbacks import Callback, History, StreamingAUC
 
 
+def _dist_of(eng):
+    """(rank, world, group) of the engine's data-parallel group; (0, 1, None) for a single process."""
+    world = int(getattr(eng, "world", 1))
+    if world <= 1:
+        return 0, 1, None
+    group = getattr(eng, "pg", None)
+    return torch.distributed.get_rank(group), world, group
+
+
+def _allreduce_host(values, eng, op="sum"):
+    """All-reduce a small list of host floats over the engine's group (device round trip: RCCL needs device buffers).
+    Every rank gets the same result, so callbacks driven by the reduced logs take the same decisions everywhere."""
+    _, world, group = _dist_of(eng)
+    if world == 1:
+        return [float(v) for v in values]
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=eng.device)
+    torch.distributed.all_reduce(t, op={"sum": torch.distributed.ReduceOp.SUM, "min": torch.distributed.ReduceOp.MIN}[op], group=group)
+    return t.cpu().tolist()
+
+
 def _is_loader(x):
     return hasattr(x, "__len__") and hasattr(x, "__getitem__") and not isinstance(x, (tuple, list, np.ndarray))
 
@@ -122,12 +142,17 @@ class TrainModel:
 
     def save_weights(self, filepath, **_):
         """Named tensors (SURVEY.md A.6 order) in a torch file at exactly `filepath`."""
+        rank, world, group = _dist_of(self._engine)
+        # get_weights() is a collective when the table is row-sharded: every rank calls it, rank 0 writes the file
         state = {n: torch.from_numpy(np.ascontiguousarray(w)) for n, w in zip(self._names, self._engine.get_weights())}
         extra = getattr(self._engine, "extra_state", lambda: {})()
-        torch.save({"format": "ebnerd-mi355x-weights-v1", "weights": state, "extra": extra}, str(filepath))
+        if rank == 0:
+            torch.save({"format": "ebnerd-mi355x-weights-v1", "weights": state, "extra": extra}, str(filepath))
+        if world > 1:
+            torch.distributed.barrier(group=group)  # the file exists on return, on every rank
 
     def load_weights(self, filepath, **_):
-        blob = torch.load(str(filepath), map_location="cpu", weights_only=False)
+        blob = torch.load(str(filepath), map_location="cpu", weights_only=True)
         if not isinstance(blob, dict) or blob.get("format") != "ebnerd-mi355x-weights-v1":
             raise ValueError(f"{filepath} is not an ebnerd-mi355x weight file")
         self._engine.set_weights([blob["weights"][n].numpy() for n in self._names])
@@ -149,6 +174,10 @@ class TrainModel:
         want_auc = "auc" in self.metrics_names
         eng = self._engine
         rng = np.random.default_rng(self._owner.seed)
+        rank, world, _group = _dist_of(eng)
+        # data parallel: every step ends in a gradient all-reduce, so every rank must run the SAME number of steps per
+        # epoch -- the shortest shard decides (the surplus batches of longer shards rotate in through the shuffle)
+        n_steps = int(_allreduce_host([len(data)], eng, "min")[0]) if world > 1 else len(data)
         for cb in cbs:
             cb.on_train_begin()
         for epoch in range(initial_epoch, epochs):
@@ -156,6 +185,7 @@ class TrainModel:
                 cb.on_epoch_begin(epoch)
             t0 = time.time()
             order = rng.permutation(len(data)) if shuffle else np.arange(len(data))  # Keras shuffles batch ORDER only
+            order = order[:n_steps]
             loss_sum = torch.zeros(1, device=eng.device)
             n_rows = 0
             auc = StreamingAUC() if want_auc else None
@@ -178,9 +208,12 @@ class TrainModel:
                 n_rows += nb
                 for cb in cbs:
                     cb.on_train_batch_end(step)
-            logs = {"loss": float(loss_sum.item()) / max(n_rows, 1)}
+            ls, nr = _allreduce_host([float(loss_sum.item()), n_rows], eng)  # epoch logs are GLOBAL: identical on every rank
+            logs = {"loss": ls / max(nr, 1)}
+            if hasattr(eng, "check_oob"):
+                eng.check_oob()  # ids outside the table raise (as TF-CPU's Embedding does) at the epoch's one host sync
             if want_auc:
-                logs["auc"] = auc.result()
+                logs["auc"] = auc.result(eng)
             if val is not None:
                 vl = self.evaluate(val, verbose=0, return_dict=True)
                 logs.update({f"val_{k}": v for k, v in vl.items()})
@@ -189,7 +222,8 @@ class TrainModel:
             if verbose:
                 dt = time.time() - t0
                 msg = " - ".join(f"{k}: {v:.4f}" for k, v in logs.items())
-                print(f"Epoch {epoch + 1}/{epochs} - {len(order)} steps - {dt:.1f}s - {n_rows / max(dt, 1e-9):.0f} impressions/s - {msg}")
+                if rank == 0:
+                    print(f"Epoch {epoch + 1}/{epochs} - {len(order)} steps - {dt:.1f}s - {nr / max(dt, 1e-9):.0f} impressions/s - {msg}")
             for cb in cbs:
                 cb.on_epoch_end(epoch, logs)
             if self.stop_training:
@@ -220,9 +254,14 @@ class TrainModel:
             n_rows += len(his)
             if auc is not None:
                 auc.update_device(torch.as_tensor(np.asarray(yb)).to(eng.device), probs)
-        out = {"loss": float(loss_sum.item()) / max(n_rows, 1)}
+        ls, nr = _allreduce_host([float(loss_sum.item()), n_rows], eng)  # every rank evaluates its shard; the result is global
+        out = {"loss": ls / max(nr, 1)}
+        if hasattr(eng, "check_oob"):
+            eng.check_oob()
+        if hasattr(eng, "l2_penalty"):
+            out["loss"] += eng.l2_penalty()  # Keras adds the kernel_regularizer terms to the evaluated loss too
         if auc is not None:
-            out["auc"] = auc.result()
+            out["auc"] = auc.result(eng)
         return out if return_dict else ([out["loss"]] + ([out["auc"]] if auc is not None else []))
 
     def predict(self, x, batch_size=None, verbose=0, **_):

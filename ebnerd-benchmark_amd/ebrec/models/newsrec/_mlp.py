@@ -19,7 +19,8 @@ SITE_MLP0 = 8
 
 
 class MLPStack:
-    def __init__(self, params, prefix: str, din: int, units, device, l2: float):
+    def __init__(self, params, prefix: str, din: int, units, device, l2: float, on_realloc=None):
+        self.on_realloc = on_realloc  # engines drop their captured hipGraphs when the activation buffers move
         self.params, self.prefix, self.din, self.units, self.device, self.l2 = params, prefix, int(din), [int(u) for u in units], device, float(l2)
         if len(self.units) > 4:
             raise ValueError("at most 4 hidden Dense layers (dropout sites 8..11 of ebn_step_state)")
@@ -62,6 +63,8 @@ class MLPStack:
                      [int(wsf(N, dims[i], dims[i + 1])) for i in range(len(self.units))] + [1])
             b["ws"] = f(ws)
             self._b = b
+            if self.on_realloc is not None:
+                self.on_realloc()
         return b
 
     @staticmethod
@@ -124,6 +127,16 @@ class MLPStack:
             seg += [None, None, 0] * (4 - len(self.units))
             _hip.call("ebn_l2_reg4_f32", *seg, ctypes.c_float(self.l2), _hip.ptr(b["partials"]), _hip.ptr(loss_dev), S())
         return b["dX0"] if (need_dx0 and self.units) else (d_last if need_dx0 else None)
+
+    def l2_penalty(self) -> float:
+        """lambda * sum(W^2) of every regularised kernel (host readback; evaluate() only)."""
+        if self.l2 <= 0:
+            return 0.0
+        acc = torch.zeros(1, device=self.device)
+        for l in range(len(self.units)):
+            w = self._pv(f"d{l}_W")
+            _hip.call("ebn_sumsq_f32", _hip.ptr(w), w.numel(), ctypes.c_float(self.l2), _hip.ptr(acc), 1, _hip.stream_handle())
+        return float(acc.item())
 
     # ---- weights in Keras creation order per layer: kernel, bias, gamma, beta, moving_mean, moving_variance
     def weight_names(self, base: str):

@@ -148,7 +148,16 @@ class TensorBoard(Callback):
         self.log_dir, self.histogram_freq = str(log_dir), histogram_freq
         self._writer = None
 
+    @staticmethod
+    def _rank0():
+        import torch.distributed as dist
+
+        return not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
+
     def on_train_begin(self, logs=None):
+        self._jsonl = None
+        if not self._rank0():  # data parallel: the logs are global (all-reduced), one writer is enough
+            return
         Path(self.log_dir).mkdir(parents=True, exist_ok=True)
         try:
             from torch.utils.tensorboard import SummaryWriter
@@ -159,6 +168,8 @@ class TensorBoard(Callback):
         self._jsonl = open(os.path.join(self.log_dir, "scalars.jsonl"), "a")
 
     def on_epoch_end(self, epoch, logs=None):
+        if self._jsonl is None:
+            return
         logs = {k: float(v) for k, v in (logs or {}).items()}
         self._jsonl.write(json.dumps({"epoch": epoch, "time": time.time(), **logs}) + "\n")
         self._jsonl.flush()
@@ -169,7 +180,8 @@ class TensorBoard(Callback):
     def on_train_end(self, logs=None):
         if self._writer is not None:
             self._writer.close()
-        self._jsonl.close()
+        if self._jsonl is not None:
+            self._jsonl.close()
 
 
 class StreamingAUC:
@@ -213,11 +225,20 @@ class StreamingAUC:
         ph.index_add_(0, k, pos)
         nh.index_add_(0, k, 1.0 - pos)
 
-    def result(self) -> float:
+    def result(self, engine=None) -> float:
+        """AUC of everything accumulated; with a data-parallel `engine` (world > 1) the histograms of all ranks are summed
+        first, so every rank reports the same global value (callbacks then act identically on every rank)."""
         pos, neg = self.pos_hist.copy(), self.neg_hist.copy()
         if self._dev is not None:
             pos += self._dev[1].cpu().numpy()
             neg += self._dev[2].cpu().numpy()
+        if engine is not None and int(getattr(engine, "world", 1)) > 1:
+            import torch
+
+            t = torch.from_numpy(np.concatenate([pos, neg])).to(engine.device)
+            torch.distributed.all_reduce(t, group=getattr(engine, "pg", None))
+            both = t.cpu().numpy()
+            pos, neg = both[: pos.size], both[pos.size:]
         # prediction > threshold[i]  <=>  bucket index k > i
         tp = pos.sum() - np.cumsum(pos)[:-1]
         fp = neg.sum() - np.cumsum(neg)[:-1]

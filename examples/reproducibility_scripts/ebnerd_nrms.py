@@ -113,16 +113,24 @@ def run(args, hparams, build_model, article_mapping, MODEL_NAME):
 
     DUMP_DIR = Path(args.dump_dir)
     MODEL_OUTPUT_NAME = f"{MODEL_NAME}-{dt.datetime.now():%Y%m%d-%H%M%S}"
+    if world > 1:  # one run = one artefact directory: rank 0's time stamp names it on every rank
+        name = [MODEL_OUTPUT_NAME]
+        torch.distributed.broadcast_object_list(name, src=0)
+        MODEL_OUTPUT_NAME = name[0]
     ARTIFACT_DIR = DUMP_DIR / "test_predictions" / MODEL_OUTPUT_NAME
     MODEL_WEIGHTS = DUMP_DIR / f"state_dict/{MODEL_OUTPUT_NAME}/weights"
     LOG_DIR = DUMP_DIR / f"runs/{MODEL_OUTPUT_NAME}"
     TEST_CHUNKS_DIR = ARTIFACT_DIR / "test_chunks"
-    TEST_CHUNKS_DIR.mkdir(parents=True, exist_ok=True)
-    MODEL_WEIGHTS.parent.mkdir(parents=True, exist_ok=True)
+    if rank == 0:
+        TEST_CHUNKS_DIR.mkdir(parents=True, exist_ok=True)
+        MODEL_WEIGHTS.parent.mkdir(parents=True, exist_ok=True)
+    if world > 1:
+        torch.distributed.barrier()
     COLUMNS = [DEFAULT_IMPRESSION_TIMESTAMP_COL, DEFAULT_HISTORY_ARTICLE_ID_COL, DEFAULT_INVIEW_ARTICLES_COL,
                DEFAULT_CLICKED_ARTICLES_COL, DEFAULT_IMPRESSION_ID_COL, DEFAULT_USER_COL]
-    write_json_file(hparams_to_dict(hparams), ARTIFACT_DIR / f"{MODEL_NAME}_hparams.json")
-    write_json_file(vars(args), ARTIFACT_DIR / f"{MODEL_NAME}_argparser.json")
+    if rank == 0:
+        write_json_file(hparams_to_dict(hparams), ARTIFACT_DIR / f"{MODEL_NAME}_hparams.json")
+        write_json_file(vars(args), ARTIFACT_DIR / f"{MODEL_NAME}_argparser.json")
 
     # train + validation together, last day held out (reference lines 158-188)
     df = pd.concat([ebnerd_from_path(PATH / DATASPLIT / "train", history_size=args.history_size, padding=0),
@@ -131,7 +139,10 @@ def run(args, hparams, build_model, article_mapping, MODEL_NAME):
     df = df.sample(frac=args.train_fraction, random_state=SEED)[COLUMNS]
     df = sampling_strategy_wu2019(df, npratio=args.npratio, shuffle=True, with_replacement=True, seed=SEED)
     df = create_binary_labels_column(df)
-    if world > 1:  # data parallel: every rank trains on its own slice of the impressions
+    if world > 1:
+        # data parallel: every rank trains and validates on its own slice of the impressions.  fit() runs the same
+        # number of steps on every rank (the shortest shard decides) and all-reduces the epoch logs, so the callbacks
+        # below (early stopping, LR schedule, best-weights restore) take identical decisions on every rank.
         df = df.iloc[rank::world]
     days = pd.to_datetime(df[DEFAULT_IMPRESSION_TIMESTAMP_COL]).dt.date
     last_dt = days.max() - dt.timedelta(days=1)
@@ -158,13 +169,23 @@ def run(args, hparams, build_model, article_mapping, MODEL_NAME):
     df_val_eval = df_validation.reset_index(drop=True)
     pred_val = model.scorer.predict(mk(df_val_eval, True, args.bs_test))
     df_val_eval = add_prediction_scores(df_val_eval, pred_val.tolist())
-    metrics = MetricEvaluator(labels=df_val_eval[DEFAULT_LABELS_COL].tolist(), predictions=df_val_eval["scores"].tolist(),
+    labels, scores = df_val_eval[DEFAULT_LABELS_COL].tolist(), df_val_eval["scores"].tolist()
+    if world > 1:  # each rank scored its own shard of the held-out day; the metrics are over all of it, on every rank
+        parts = [None] * world
+        torch.distributed.all_gather_object(parts, ([list(l) for l in labels], [list(x) for x in scores]))
+        labels, scores = [l for p in parts for l in p[0]], [x for p in parts for x in p[1]]
+    metrics = MetricEvaluator(labels=labels, predictions=scores,
                               metric_functions=[AucScore(), MrrScore(), NdcgScore(k=5), NdcgScore(k=10)]).evaluate()
-    print(metrics)
-    write_json_file(metrics.evaluations, ARTIFACT_DIR / "validation_metrics.json")
+    if rank == 0:
+        print(metrics)
+        write_json_file(metrics.evaluations, ARTIFACT_DIR / "validation_metrics.json")
 
-    if rank != 0:
+    # Test prediction is rank 0's job.  With a row-sharded table every lookup is a collective, so the other ranks run
+    # the same frames alongside (identical call sequence) and simply do not write; with a replicated table they leave.
+    sharded = bool(getattr(args, "shard_table", False)) and world > 1
+    if rank != 0 and not sharded:
         return hist, metrics.evaluations
+    writer = rank == 0
     # ---- test set: fake labels, BA split, chunked prediction with resume (reference lines 263-365)
     print("Initiating testset...")
     df_test = ebnerd_from_path(PATH / "ebnerd_testset" / "test", history_size=args.history_size, padding=0)
@@ -183,18 +204,24 @@ def run(args, hparams, build_model, article_mapping, MODEL_NAME):
     # --chunks_done N resumes a crashed run: finished chunks are re-read from <dump_dir>/resume (the reference
     # keeps them under its time-stamped artefact directory, where a restarted run cannot find them)
     RESUME_DIR = Path(args.dump_dir) / "resume"
-    RESUME_DIR.mkdir(parents=True, exist_ok=True)
+    if writer:
+        RESUME_DIR.mkdir(parents=True, exist_ok=True)
+    if sharded:
+        torch.distributed.barrier()
     chunks = split_df_chunks(df_wo, n_chunks=args.n_chunks_test)
     done = [pd.read_parquet(RESUME_DIR / f"pred_wo_ba_{i}.parquet") for i in range(1, args.chunks_done + 1)]
     for i, chunk in enumerate(chunks[args.chunks_done:], start=1 + args.chunks_done):
         print(f"Test chunk: {i}/{len(chunks)}")
         chunk = predict_frame(chunk, args.batch_size_test_wo_b)[[DEFAULT_IMPRESSION_ID_COL, "ranked_scores"]]
-        chunk.to_parquet(TEST_CHUNKS_DIR / f"pred_wo_ba_{i}.parquet")
-        chunk.to_parquet(RESUME_DIR / f"pred_wo_ba_{i}.parquet")
+        if writer:
+            chunk.to_parquet(TEST_CHUNKS_DIR / f"pred_wo_ba_{i}.parquet")
+            chunk.to_parquet(RESUME_DIR / f"pred_wo_ba_{i}.parquet")
         done.append(chunk)
         gc.collect()
     print("Initiating testset with beyond-accuracy...")
     pred_w = predict_frame(df_w, args.batch_size_test_w_b)[[DEFAULT_IMPRESSION_ID_COL, "ranked_scores"]] if len(df_w) else None
+    if not writer:
+        return hist, metrics.evaluations
     df_out = pd.concat(done + ([pred_w] if pred_w is not None else []), ignore_index=True)
     df_out.to_parquet(ARTIFACT_DIR / "test_predictions.parquet")
     shutil.rmtree(TEST_CHUNKS_DIR, ignore_errors=True)

@@ -90,6 +90,21 @@ int ebn_embedding_grad_scatter_fixed(const int32_t* ids, const float* dX, int64_
                                      float drop_p, ebn_stream_t stream);
 int ebn_fixed_to_f32(int64_t* acc, float* out, int64_t n, ebn_stream_t stream);
 
+/* ---- row-sharded Embedding (BASELINE.json configs[4]; no reference counterpart: nrms.py:125-134 keeps one table on
+ * one device) -- device-side plan of a lookup into a table whose rows are split over `world` ranks (rank o owns the
+ * block [o*per, (o+1)*per), per = ceil(V/world); or, cyclic != 0, the ids = o mod world).  Dedups the n_tok local ids
+ * and lays the distinct ones out in FIXED-CAPACITY per-owner request lists, so the two exchanges of a lookup are
+ * equal-split all-to-alls with host-known sizes (no host sync, hipGraph-capturable):
+ *   slot_rows[o*cap + j]  owner-local row number of the j-th distinct id wanted from owner o (ascending), -1 = padding
+ *                         (what ebn_gather_rows_f32 / ebn_embedding_grad_scatter_f32 take as `ids` on the owner's side)
+ *   inv[t]                o*cap + j of token t: its row in the received (world*cap, D) buffer; -1 for an id outside [0,V)
+ *   counts[0..world)      distinct ids wanted from each owner;  counts[world] = 1 when a list overflowed `cap` (ids were
+ *                         dropped: the caller must fail the step);  counts[world+1] = 1 when an id was out of range
+ * `workspace`: ebn_shard_plan_workspace_ints(V, world) int32 of scratch.  Integer work only, deterministic.          */
+int64_t ebn_shard_plan_workspace_ints(int64_t V, int32_t world);
+int ebn_shard_plan_i32(const int32_t* ids, int64_t n_tok, int64_t V, int32_t world, int32_t cyclic, int64_t cap,
+                       int32_t* workspace, int32_t* slot_rows, int32_t* inv, int32_t* counts, ebn_stream_t stream);
+
 /* ---- K.dot / Dense matmuls (layers.py:65,214,220,226; nrms_docvec.py:116,130) ----
  * C[M,N] = alpha * op(A)[M,K] * op(B)[K,N] + beta * C, exact-fp32 MFMA
  * (v_mfma_f32_32x32x2_f32). transA=0: A is [M,K] (lda>=K); transA=1: A is [K,M].

@@ -62,7 +62,7 @@ def _sharded_lookup_worker(rank, world, mode, V, D):
     # backward: every rank contributes d(rows); owners accumulate
     d_uniq = torch.ones(plan.uniq.numel(), D) * (rank + 1)
     shard_grad = torch.zeros(hi - lo, D)
-    if mode == "alltoall":
+    if mode == "alltoall_exact":
         ex.scatter_grads(plan, d_uniq, lambda loc, gr: shard_grad.index_add_(0, loc.long(), gr))
         dense = torch.zeros(V, D)
         dense[plan.uniq] = d_uniq
@@ -70,14 +70,127 @@ def _sharded_lookup_worker(rank, world, mode, V, D):
         assert torch.allclose(shard_grad, dense[lo:hi])
 
 
-@pytest.mark.parametrize("mode", ["alltoall", "allgather"])
+@pytest.mark.parametrize("mode", ["alltoall_exact", "allgather"])
 @pytest.mark.parametrize("world,V", [(2, 1001), (3, 64)])
 def test_row_sharded_lookup_routes_rows_exactly(mode, world, V):
     _run(_sharded_lookup_worker, world, mode, V, 12)
 
 
+def torch_plan(ex, ids, n_tok, cap, ws, slot_rows, inv, counts):
+    """torch stand-in for ebn_shard_plan_i32 (the contract of include/ebnerd_hip.h, restated with sorts)."""
+    W, per, V = ex.world, ex.per, ex.V
+    ids = ids[:n_tok].long()
+    slot_rows.fill_(-1)
+    inv[:n_tok] = -1
+    counts.zero_()
+    ok = (ids >= 0) & (ids < V)
+    if (~ok).any():
+        counts[W + 1] = 1
+    owner = torch.where(ok, (ids % W) if ex.cyclic else (ids // per), torch.zeros_like(ids))
+    local = torch.where(ok, (ids // W) if ex.cyclic else (ids - owner * per), torch.zeros_like(ids))
+    for o in range(W):
+        mine = ok & (owner == o)
+        rows = torch.unique(local[mine], sorted=True)
+        counts[o] = rows.numel()
+        if rows.numel() > cap:
+            counts[W] = 1
+        kept = rows[:cap]
+        slot_rows[o * cap: o * cap + kept.numel()] = kept.int()
+        pos = torch.searchsorted(kept, local[mine]) if kept.numel() else torch.zeros(int(mine.sum()), dtype=torch.long)
+        hit = (pos < kept.numel())
+        hit[hit.clone()] = kept[pos[hit]] == local[mine][hit]
+        tok = torch.nonzero(mine).reshape(-1)
+        inv[tok[hit]] = (o * cap + pos[hit]).int()
+
+
+def _planned_lookup_worker(rank, world, partition, V, D, factor):
+    """Device-planned fixed-capacity exchange (mode 'alltoall') with torch stand-ins for the three HIP kernels: the
+    routing, the equal-split all-to-alls and the backward must reproduce a plain table lookup / dense gradient."""
+    from ebrec.models.newsrec._dist import PlannedBuffers
+
+    full = torch.from_numpy(np.random.default_rng(0).standard_normal((V, D)).astype(np.float32))
+    ex = ShardedTableExchange(V, D, partition=partition, capacity_factor=factor)
+    shard = ex.shard_of(full).clone()
+    assert shard.shape[0] == ex.n_local
+    g = torch.Generator().manual_seed(100 + rank)
+    n_tok = 400
+    ids = torch.randint(0, V, (n_tok,), generator=g, dtype=torch.int32)
+    ids[:50] = 0  # hot row owned by rank 0, requested by everyone
+    ids[-7:] = V - 1
+    b = PlannedBuffers(ex, n_tok, "cpu", need_grad=True, ws_ints=1)
+    plan = lambda *a: torch_plan(ex, *a)
+
+    def gather(local_rows, out):
+        okr = local_rows >= 0
+        out.zero_()
+        out[okr] = shard[local_rows[okr].long()]
+
+    ex.planned_lookup(ids, n_tok, b, plan, gather)
+    ex.check(b)
+    assert int(b.inv.min()) >= 0
+    assert torch.equal(b.rows[b.inv.long()], full[ids.long()])  # bit-exact: rows only move
+    # the request lists are distinct and ascending per owner, padded with -1
+    cap = ex.capacity(n_tok)
+    for o in range(world):
+        lst = b.slot_rows[o * cap: (o + 1) * cap]
+        k = int(b.counts[o])
+        assert (lst[k:] == -1).all() and (lst[:k] >= 0).all() and (lst[1:k] > lst[: max(k - 1, 0)]).all()
+    # backward: d(token) = rank+1 everywhere; owners accumulate what every rank sends
+    shard_grad = torch.zeros_like(shard)
+
+    def reduce_local(inv, d_slot):
+        d_slot.zero_()
+        d_slot.index_add_(0, inv.long(), torch.full((n_tok, D), float(rank + 1)))
+
+    def accumulate(local_rows, grads):
+        okr = local_rows >= 0
+        shard_grad.zero_()
+        shard_grad.index_add_(0, local_rows[okr].long(), grads[okr])
+
+    ex.planned_scatter_grads(n_tok, b, reduce_local, accumulate)
+    dense = torch.zeros(V, D)
+    dense.index_add_(0, ids.long(), torch.full((n_tok, D), float(rank + 1)))
+    dist.all_reduce(dense)  # reference: dense all-reduce of per-rank gradients
+    assert torch.equal(shard_grad, ex.shard_of(dense))
+    # unshard(shard_of(x)) == x
+    pad = torch.zeros(ex.per, D)
+    pad[: shard.shape[0]] = shard
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad)
+    assert torch.equal(ex.unshard(parts), full)
+    st = ex.stats()
+    assert st["bytes_sent_per_lookup_remote"]["rows"] == (world - 1) * cap * D * 4
+
+
+@pytest.mark.parametrize("partition", ["block", "cyclic"])
+@pytest.mark.parametrize("world,V", [(2, 1001), (3, 64)])
+def test_device_planned_exchange_routes_rows_exactly(partition, world, V):
+    _run(_planned_lookup_worker, world, partition, V, 12, float(world))
+
+
+def _planned_overflow_worker(rank, world):
+    from ebrec.models.newsrec._dist import PlannedBuffers
+
+    V, D, n_tok = 100000, 4, 4096
+    ex = ShardedTableExchange(V, D, capacity_factor=1.0)
+    assert ex.capacity(n_tok) == 2048
+    ids = torch.arange(n_tok, dtype=torch.int32)  # every id distinct and owned by rank 0: 4096 > capacity 2048
+    b = PlannedBuffers(ex, n_tok, "cpu", need_grad=False, ws_ints=1)
+    ex.planned_lookup(ids, n_tok, b, lambda *a: torch_plan(ex, *a), lambda rows, out: out.zero_())
+    with pytest.raises(RuntimeError, match="overflowed"):
+        ex.check(b)
+    ids[5] = V  # out of range beats overflow
+    ex.planned_lookup(ids, n_tok, b, lambda *a: torch_plan(ex, *a), lambda rows, out: out.zero_())
+    with pytest.raises(IndexError):
+        ex.check(b)
+
+
+def test_planned_exchange_flags_overflow_and_out_of_range_ids():
+    _run(_planned_overflow_worker, 2)
+
+
 def _out_of_range_worker(rank, world):
-    ex = ShardedTableExchange(10, 4)
+    ex = ShardedTableExchange(10, 4, mode="alltoall_exact")
     with pytest.raises(IndexError):
         ex.plan(torch.tensor([1, 10]))
 

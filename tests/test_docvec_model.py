@@ -132,3 +132,25 @@ def test_docvec_graph_replay_and_indexed_batches_match_eager_host_batches(docvec
         assert l0 == l1 == l2, (step, l0, l1, l2)
     w = [m.model.get_weights() for m in ms]
     assert all(np.array_equal(a, b) and np.array_equal(a, c) for a, b, c in zip(*w))
+
+
+def test_docvec_graphs_survive_an_eval_pass_that_grows_the_buffers(docvec):
+    """fit(train, validation_data=val) with hipGraphs: the validation pass encodes the whole article matrix, which
+    re-allocates the MLP buffers a captured training graph points into -- the graph must be re-captured, not replayed."""
+    hp = make_hp(title_size=32, newsencoder_units_per_layer=[24, 16], head_num=2, head_dim=8, attention_hidden_dim=6, history_size=4,
+                 learning_rate=1e-3)
+    rng = np.random.default_rng(11)
+    matrix = rng.standard_normal((400, 32)).astype(np.float32)  # 400 rows > B*(H+C) = 54: encode_news grows the buffers
+    eager, graph = docvec(hp, seed=3), docvec(hp, seed=3)
+    graph._engine.enable_graphs()
+    for step in range(4):
+        hi, pi = rng.integers(0, 400, (6, 4)), rng.integers(0, 400, (6, 5))
+        y = np.eye(5, dtype=np.float32)[rng.integers(0, 5, 6)]
+        l0 = float(eager.train_step(matrix[hi], matrix[pi], y).item())
+        l1 = float(graph.train_step(matrix[hi], matrix[pi], y).item())
+        assert l0 == l1, (step, l0, l1)
+        if step == 1:
+            a, b = eager._engine.encode_news(matrix), graph._engine.encode_news(matrix)
+            assert np.array_equal(a.cpu().numpy(), b.cpu().numpy())
+    for a, b in zip(eager.model.get_weights(), graph.model.get_weights()):
+        assert np.array_equal(a, b)

@@ -154,7 +154,9 @@ ATTN_CASES = [(4, 30, 20, 20), (3, 20, 20, 20), (2, 50, 16, 16), (5, 1, 2, 4), (
               # the other instantiations of the MFMA path (L <= 32, d in {16, 20, 32}), incl. its largest LDS footprint
               (2, 32, 4, 32), (3, 17, 2, 16), (2, 32, 2, 16), (1, 5, 3, 32), (9, 1, 1, 20),
               # long sequences (64 < L <= 256): recompute-based kernels
-              (2, 100, 2, 20), (1, 256, 1, 32), (3, 65, 3, 16)]
+              (2, 100, 2, 20), (1, 256, 1, 32), (3, 65, 3, 16),
+              # the backward image of the one-wave kernel exceeds 64 KB here (forward fits): must route to the long kernels
+              (2, 64, 2, 32), (2, 50, 20, 20)]
 
 
 def _qkv_case(n_seq, L, h, d, seed):

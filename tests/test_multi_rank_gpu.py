@@ -1,0 +1,218 @@
+"""BASELINE.json configs[3] (data parallel, H=50) and configs[4] (row-sharded table) on the GPU box (gpu-marked).
+
+The box has ONE GPU, and RCCL refuses two ranks on one device, so the multi-rank tests run the REAL engine (HIP kernels
+through the C ABI, hipGraph segments, the engine's own collectives) with two processes sharing cuda:0 over gloo.  What
+is compared is arithmetic, not transport: the averaged update of the ranks must equal the single-process full-batch
+step of the float64 oracle.  The 8-GPU RCCL run itself is the driver's (bench.py --gpus 8).
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nrms_numpy as on
+from tests.hip_testutil import assert_close
+from tests.test_distributed_cpu import torch_plan
+from tests.test_nrms_model import batch, make_hp, weight_list
+
+pytestmark = pytest.mark.gpu
+
+
+# ---------------------------------------------------------------- c4: H=50 training parity at the per-GPU shape
+@pytest.mark.parametrize("loss", ["cross_entropy_loss", "log_loss"])
+def test_c4_shape_training_step_matches_oracle(hip, loss):
+    """history_size=50, 20 heads x 20, trainable 300-d table (configs[3] per-GPU shape, smaller batch/vocabulary):
+    loss, every dense gradient and the embedding gradient of one training step vs the float64 oracle, then two more
+    steps of the Adam trajectory.  L=50 runs the user-level attention kernels that L=20 never touches."""
+    from ebrec.models.newsrec import NRMSModel
+
+    hp = make_hp(history_size=50, dropout=0.2, learning_rate=1e-3, loss=loss)
+    V, D, seed, B, C = 2000, 300, 5, 4, 5
+    rng = np.random.default_rng(50)
+    P = on.random_nrms_params(V, D, hp.head_num, hp.head_dim, hp.attention_hidden_dim, seed=8)
+    m = NRMSModel(hp, word2vec_embedding=P["emb"], seed=seed).from_keras_weight_list(weight_list(P))
+    P = {k: v.astype(np.float32).astype(np.float64) for k, v in P.items()}
+    P0 = {k: v.copy() for k, v in P.items()}
+    mom = {k: (np.zeros_like(v), np.zeros_like(v)) for k, v in P.items()}
+    eng = m._engine
+    for t in range(1, 4):
+        his, pred, y = batch(rng, B, 50, C, hp.title_size, V)
+        L, _, g = on.nrms_loss_and_grads(his, pred, y, P, hp.head_num, hp.head_dim, loss, on.Drop(0.2, seed, t))
+        got_L = float(m.train_step(his, pred, y).item())
+        assert abs(got_L - L) <= 2e-5 * max(1.0, abs(L)), (t, got_L, L)
+        if t == 1:
+            for pre in ("n", "u"):
+                want = np.concatenate([g[f"{pre}_WQ"], g[f"{pre}_WK"], g[f"{pre}_WV"]], 1)
+                assert_close(eng.params.g(f"{pre}_Wqkv").cpu().numpy(), want, rtol=1e-4, atol=1e-6 + 1e-4 * np.abs(want).max(), what=f"{pre} dWqkv")
+                for nm in ("W", "b", "q"):
+                    want = g[f"{pre}_{nm}"].reshape(eng.params.shapes[f"{pre}_{nm}"])
+                    assert_close(eng.params.g(f"{pre}_{nm}").cpu().numpy(), want, rtol=1e-4, atol=1e-6 + 1e-4 * np.abs(want).max(), what=f"{pre} d{nm}")
+            assert_close(eng.table_grad.cpu().numpy(), g["emb"], rtol=1e-4, atol=1e-6 + 1e-4 * np.abs(g["emb"]).max(), what="dEmb")
+        for k in P:
+            on.adam_keras_step(P[k], g[k], mom[k][0], mom[k][1], t, lr=1e-3)
+    got = dict(zip(on.PARAM_ORDER, m.model.get_weights()))
+    for k in on.PARAM_ORDER:
+        step = np.abs(P[k] - P0[k])
+        assert_close(got[k].reshape(P[k].shape), P[k], rtol=0, atol=2e-5 + 0.02 * float(step.max()), what=f"weights {k} after 3 steps")
+
+
+# ---------------------------------------------------------------- c5: the device-side lookup plan
+@pytest.mark.parametrize("world,cyclic", [(1, 0), (2, 0), (8, 0), (8, 1), (3, 1), (5, 0)])
+@pytest.mark.parametrize("V,n_tok,cap", [(250002, 48000, 48000), (1001, 700, 64), (37, 1000, 37), (5000, 0, 8), (4099, 5000, 100)])
+def test_shard_plan_kernel_is_the_reference_plan_bit_for_bit(hip, world, cyclic, V, n_tok, cap):
+    """ebn_shard_plan_i32 for ANY world size runs on one GPU (the plan is local): request lists, token->slot map,
+    per-owner counts, overflow and out-of-range flags vs the sort-based restatement in tests/test_distributed_cpu.py."""
+    from ebrec.models.newsrec._dist import ShardedTableExchange
+
+    P_, S_ = hip.ptr, hip.stream_handle
+    rng = np.random.default_rng(world * 131 + V)
+    ex = ShardedTableExchange.__new__(ShardedTableExchange)  # geometry only (no process group needed for a plan)
+    ex.V, ex.world, ex.per, ex.partition = V, world, -(-V // world), "cyclic" if cyclic else "block"
+    ids = rng.integers(0, V, n_tok).astype(np.int32)
+    if n_tok > 100:
+        ids[:40] = 0  # a hot row (padded titles)
+        ids[40:60] = V - 1
+        ids[77] = V  # one id out of range
+        ids[78] = -3
+    cap = min(cap, max(n_tok, 1))
+    d_ids = torch.from_numpy(ids).cuda() if n_tok else torch.zeros(1, dtype=torch.int32, device="cuda")
+    ws = torch.empty(max(int(hip.lib().ebn_shard_plan_workspace_ints(V, world)), 1), dtype=torch.int32, device="cuda")
+    slot = torch.empty(world * cap, dtype=torch.int32, device="cuda")
+    inv = torch.full((max(n_tok, 1),), -7, dtype=torch.int32, device="cuda")
+    counts = torch.full((world + 2,), -7, dtype=torch.int32, device="cuda")
+    hip.call("ebn_shard_plan_i32", P_(d_ids), n_tok, V, world, cyclic, cap, P_(ws), P_(slot), P_(inv), P_(counts), S_())
+    w_slot, w_inv, w_counts = torch.empty(world * cap, dtype=torch.int32), torch.full((max(n_tok, 1),), -7, dtype=torch.int32), torch.empty(world + 2, dtype=torch.int32)
+    torch_plan(ex, torch.from_numpy(ids), n_tok, cap, None, w_slot, w_inv, w_counts)
+    assert torch.equal(counts.cpu(), w_counts), (counts.cpu().tolist(), w_counts.tolist())
+    assert torch.equal(slot.cpu(), w_slot)
+    assert torch.equal(inv.cpu()[:n_tok], w_inv[:n_tok])
+    # replay on the same buffers (a captured graph does exactly this): the plan re-initialises everything it reads
+    hip.call("ebn_shard_plan_i32", P_(d_ids), n_tok, V, world, cyclic, cap, P_(ws), P_(slot), P_(inv), P_(counts), S_())
+    assert torch.equal(slot.cpu(), w_slot) and torch.equal(counts.cpu(), w_counts)
+
+
+@pytest.mark.parametrize("mode,partition,graph", [("alltoall", "block", False), ("alltoall", "cyclic", False), ("alltoall", "block", True),
+                                                  ("alltoall_exact", "block", False), ("allgather", "block", False)])
+@pytest.mark.parametrize("train_embedding", [False, True])
+def test_every_row_sharded_form_on_one_rank_equals_the_replicated_table(hip, mode, partition, graph, train_embedding):
+    from ebrec.models.newsrec import NRMSModel
+
+    hp = make_hp(dropout=0.2, learning_rate=1e-3)
+    rng = np.random.default_rng(31)
+    V = 257
+    emb = rng.standard_normal((V, 64)).astype(np.float32)
+    a = NRMSModel(hp, word2vec_embedding=emb, seed=3, train_embedding=train_embedding, deterministic=False)
+    b = NRMSModel(hp, word2vec_embedding=emb, seed=3, train_embedding=train_embedding, shard_table=True, shard_mode=mode,
+                  shard_partition=partition)
+    assert b._engine.graph_capable == (mode == "alltoall")
+    if graph:
+        b._engine.enable_graphs()
+    his, pred, y = batch(rng, 5, hp.history_size, 5, hp.title_size, V)
+    assert np.array_equal(a.model.predict((his, pred)), b.model.predict((his, pred)))
+    for _ in range(3):
+        la, lb = float(a.train_step(his, pred, y).item()), float(b.train_step(his, pred, y).item())
+        assert abs(la - lb) <= 1e-6 * max(1.0, abs(la))
+    b._engine.check_oob()
+    for wa, wb in zip(a.model.get_weights(), b.model.get_weights()):
+        assert np.allclose(wa, wb, rtol=1e-4, atol=1e-6)
+    if mode == "alltoall":
+        his[0, 0, 0] = V  # out of range on a device-planned lookup: flagged by the plan, raised at the epoch check
+        b._engine.train_step(torch.from_numpy(his.astype(np.int32)).cuda(), torch.from_numpy(pred.astype(np.int32)).cuda(),
+                             torch.from_numpy(y.astype(np.float32)).cuda())
+        with pytest.raises(IndexError):
+            b._engine.check_oob()
+
+
+# ---------------------------------------------------------------- two ranks, one GPU, the real engine
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _spawn(fn, world, *args):
+    import torch.multiprocessing as mp
+
+    port = _free_port()
+    mp.spawn(_entry, args=(world, port, fn, args), nprocs=world, join=True)
+
+
+def _entry(rank, world, port, fn, args):
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    for p in (str(root), str(root / "ebnerd-benchmark_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+
+    torch.cuda.set_device(0)  # both ranks on the one GPU: gloo moves the buffers, the kernels are the product's
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        fn(rank, world, *args)
+    finally:
+        dist.destroy_process_group()
+
+
+def _dp_worker(rank, world, shard, partition, graph, train_embedding, H):
+    from ebrec.models.newsrec import NRMSModel
+
+    hp = make_hp(history_size=H, dropout=0.0, learning_rate=1e-3)
+    V, D, seed, B, C = 600, 64, 5, 3, 5  # B per rank
+    rng = np.random.default_rng(77)
+    P = on.random_nrms_params(V, D, hp.head_num, hp.head_dim, hp.attention_hidden_dim, seed=8)
+    m = NRMSModel(hp, word2vec_embedding=P["emb"], seed=seed, train_embedding=train_embedding, shard_table=shard,
+                  shard_partition=partition, shard_capacity_factor=float(world), deterministic=not shard)
+    m.from_keras_weight_list(weight_list(P))
+    eng = m._engine
+    assert eng.world == world
+    if graph:
+        eng.enable_graphs()
+    P = {k: v.astype(np.float32).astype(np.float64) for k, v in P.items()}
+    P0 = {k: v.copy() for k, v in P.items()}
+    mom = {k: (np.zeros_like(v), np.zeros_like(v)) for k, v in P.items()}
+    for t in range(1, 4):
+        his, pred, y = batch(rng, B * world, H, C, hp.title_size, V)  # the GLOBAL batch, identical on every rank
+        L, _, g = on.nrms_loss_and_grads(his, pred, y, P, hp.head_num, hp.head_dim, "cross_entropy_loss", None)
+        sl = slice(rank * B, (rank + 1) * B)
+        L_loc, _, _ = on.nrms_loss_and_grads(his[sl], pred[sl], y[sl], P, hp.head_num, hp.head_dim, "cross_entropy_loss", None)
+        got = float(eng.train_step(his[sl], pred[sl], y[sl]).item())  # each rank steps on ITS rows
+        assert abs(got - L_loc) <= 2e-5 * max(1.0, abs(L_loc)), (rank, t, got, L_loc)
+        if t == 1 and not shard:
+            # after the all-reduce (SUM) the gradient buffers hold world x the full-batch mean gradient
+            want = np.concatenate([g["n_WQ"], g["n_WK"], g["n_WV"]], 1) * world
+            assert_close(eng.params.g("n_Wqkv").cpu().numpy(), want, rtol=1e-4, atol=1e-6 + 1e-4 * np.abs(want).max(), what="all-reduced dWqkv")
+        for k in P:
+            if k == "emb" and not train_embedding:
+                continue
+            on.adam_keras_step(P[k], g[k], mom[k][0], mom[k][1], t, lr=1e-3)
+    eng.check_oob()
+    got = dict(zip(on.PARAM_ORDER, m.model.get_weights()))  # (a collective with a sharded table: gathers the shards)
+    for k in on.PARAM_ORDER:
+        step = np.abs(P[k] - P0[k])
+        assert_close(got[k].reshape(P[k].shape), P[k], rtol=0, atol=2e-5 + 0.02 * float(step.max()), what=f"rank {rank}: weights {k} after 3 DP steps")
+    if shard:
+        st = eng.exchange.stats()
+        assert st["world"] == world and st["bytes_sent_per_lookup_remote"]["rows"] > 0
+        if train_embedding:
+            assert st["bytes_sent_per_lookup_remote"]["grads"] > 0
+
+
+@pytest.mark.parametrize("graph", [False, True])
+@pytest.mark.parametrize("H", [20, 50])
+def test_two_rank_data_parallel_step_equals_the_full_batch_oracle_step(hip, graph, H):
+    """configs[3]: the engine's own DP step (hipGraph(fwd+bwd) -> all-reduce -> hipGraph(Adam)) on two ranks; every rank
+    must end on the weights of the float64 oracle stepping on the whole global batch."""
+    _spawn(_dp_worker, 2, False, "block", graph, True, H)
+
+
+@pytest.mark.parametrize("partition,graph,train_embedding", [("block", False, True), ("cyclic", True, True), ("block", True, False)])
+def test_two_rank_row_sharded_table_step_equals_the_full_batch_oracle_step(hip, partition, graph, train_embedding):
+    """configs[4]: table rows split over two ranks, device-planned lookups, equal-split all-to-alls between the captured
+    kernel segments, row gradients routed to their owners (never all-reduced)."""
+    _spawn(_dp_worker, 2, True, partition, graph, train_embedding, 20)
