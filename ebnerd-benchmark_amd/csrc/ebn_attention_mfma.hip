@@ -1,4 +1,4 @@
-// a3 / a6 fast path: the SelfAttention core (layers.py:231-252) for L <= 32, d in {16,20,32},
+// a3 / a6 fast path: the SelfAttention core (layers.py:231-252) for L <= 64 (one or 2 x 2 MFMA tiles), d in {16,20,32},
 // entirely on the matrix cores -- one 64-lane wave per (sequence, head), no workgroup barriers.
 //
 // Memory side: the wave copies its L x d slices of Q, K, V (and dO) ONCE, as coalesced 16-byte loads, into a
@@ -418,12 +418,285 @@ __global__ __launch_bounds__(64 * ATT_WAVES) void attn_mfma_bwd_kernel(MfmaAttnA
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 32 < L <= 64 (history_size = 50 of BASELINE.json configs[3]: the news-level SelfAttention of the user encoder, nrms.py:
+// 108-110).  Same dataflow with the L x L attention matrix as a 2 x 2 grid of 32 x 32 tiles: block ib of the softmax-row
+// index i, block jb of the column index j.  Row statistics need both column blocks of a row (two tiles live), the
+// P^T.V / dV / dQ / dK contractions accumulate over the two blocks of their contraction index.  Still one wave per
+// (sequence, head) and no workgroup barrier; operands of both blocks are pulled into registers up front so the LDS
+// regions can be reused for the results.
+constexpr int ATT2_WAVES = 2;
+constexpr int NB2 = 2;
+
+__device__ __forceinline__ void mm_col_tile_acc(f32x16& acc, const float (&a)[16], const f32x16& z) {
+#pragma unroll
+  for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], z[s], acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ f32x16 zero_tile() {
+  f32x16 z;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) z[r] = 0.f;
+  return z;
+}
+
+// t[jb][r] = T[j = 32 jb + crow(r,hi)][i = this lane's row]; returns c_i = max2 + log2 Z over j < L (both blocks);
+// with TO_P the tiles are turned into P_ij (zero for j >= L).
+template <bool TO_P>
+__device__ __forceinline__ float softmax2_in_lane(f32x16 (&t)[NB2], int L, int hi, float inv2) {
+  float m = -INFINITY;
+#pragma unroll
+  for (int jb = 0; jb < NB2; ++jb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      t[jb][r] *= inv2;
+      if (32 * jb + crow(r, hi) < L) m = fmaxf(m, t[jb][r]);
+    }
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  float z = 0.f;
+#pragma unroll
+  for (int jb = 0; jb < NB2; ++jb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z += (32 * jb + crow(r, hi) < L) ? __builtin_amdgcn_exp2f(t[jb][r] - m) : 0.f;
+  z += __shfl_xor(z, 32, 64);
+  const float c = m + __builtin_amdgcn_logf(z);
+  if (TO_P) {
+#pragma unroll
+    for (int jb = 0; jb < NB2; ++jb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t[jb][r] = (32 * jb + crow(r, hi) < L) ? __builtin_amdgcn_exp2f(t[jb][r] - c) : 0.f;
+  }
+  return c;
+}
+
+// s[r] = S[i = 32 ib + crow(r,hi)][j = this lane's column] -> P_ij with c_i fetched from lane (i & 31) of block ib's stats
+__device__ __forceinline__ void softmax2_from_stats(f32x16& s, int L, int ib, int hi, float inv2, float c_ib) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int il = crow(r, hi);
+    const float ci = __shfl(c_ib, il, 64);
+    s[r] = (32 * ib + il < L) ? __builtin_amdgcn_exp2f(s[r] * inv2 - ci) : 0.f;
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(64 * ATT2_WAVES) void attn_mfma2_fwd_kernel(MfmaAttnArgs a) {
+  using T = Tile<D>;
+  constexpr int KH = D / 2;
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // ATT2_WAVES x 3 regions x L x STRIDE
+  const int lane = threadIdx.x & 63;
+  const int64_t prob = static_cast<int64_t>(blockIdx.x) * ATT2_WAVES + (threadIdx.x >> 6);
+  if (prob >= a.n_prob) return;
+  const int L = a.L, E = a.h * D;
+  const int region = L * T::STRIDE;
+  float* sq = smem + (threadIdx.x >> 6) * 3 * region;
+  float* sk = sq + region;
+  float* sv = sk + region;
+  const int row = lane & 31, hi = lane >> 5;
+  const int64_t seq = prob / a.h;
+  const int head = static_cast<int>(prob - seq * a.h);
+  const int64_t row0 = seq * L;
+  const float* qb = a.qkv + row0 * a.ld_qkv + head * D;
+  const float inv2 = 1.44269504088896341f / sqrtf(static_cast<float>(D));
+  {
+    Staged<D> tq[NB2], tk[NB2], tv[NB2];
+#pragma unroll
+    for (int b = 0; b < NB2; ++b) {
+      stage_load<D>(tq[b], qb + 32 * b * a.ld_qkv, a.ld_qkv, L - 32 * b, lane);
+      stage_load<D>(tk[b], qb + E + 32 * b * a.ld_qkv, a.ld_qkv, L - 32 * b, lane);
+      stage_load<D>(tv[b], qb + 2 * E + 32 * b * a.ld_qkv, a.ld_qkv, L - 32 * b, lane);
+    }
+#pragma unroll
+    for (int b = 0; b < NB2; ++b) {
+      stage_store<D, false>(sq + 32 * b * T::STRIDE, tq[b], L - 32 * b, lane, 0u, 0u, 0, 0u, 0.f);
+      stage_store<D, false>(sk + 32 * b * T::STRIDE, tk[b], L - 32 * b, lane, 0u, 0u, 0, 0u, 0.f);
+      stage_store<D, false>(sv + 32 * b * T::STRIDE, tv[b], L - 32 * b, lane, 0u, 0u, 0, 0u, 0.f);
+    }
+  }
+  wave_lds_sync();
+  float qr[NB2][KH], kr[NB2][KH], vc[NB2][16];
+#pragma unroll
+  for (int b = 0; b < NB2; ++b) {
+    lds_row_form<D>(qr[b], sq + 32 * b * T::STRIDE, L - 32 * b, row, hi);
+    lds_row_form<D>(kr[b], sk + 32 * b * T::STRIDE, L - 32 * b, row, hi);
+    lds_col_form<D>(vc[b], sv + 32 * b * T::STRIDE, L - 32 * b, row, hi);
+  }
+  float c[NB2];
+#pragma unroll
+  for (int ib = 0; ib < NB2; ++ib) {
+    f32x16 t[NB2];
+#pragma unroll
+    for (int jb = 0; jb < NB2; ++jb) t[jb] = mm_rows<KH>(kr[jb], qr[ib]);  // T[j][i]: lane i, regs j
+    c[ib] = softmax2_in_lane<false>(t, L, hi, inv2);
+  }
+  wave_lds_sync();  // every operand is in registers: sq becomes the output staging area
+#pragma unroll
+  for (int jb = 0; jb < NB2; ++jb) {
+    f32x16 O = zero_tile();
+#pragma unroll
+    for (int ib = 0; ib < NB2; ++ib) {
+      f32x16 S = mm_rows<KH>(qr[ib], kr[jb]);  // S[i][j]: lane j, regs i
+      softmax2_from_stats(S, L, ib, hi, inv2, c[ib]);
+      mm_col_tile_acc(O, vc[ib], S);  // O^T[c][j] += sum_{i in block ib} V[i][c] P[i][j]
+    }
+    tile_rows_to_lds<D>(sq + 32 * jb * T::STRIDE, O, L - 32 * jb, row, hi, 1.0f);
+  }
+  wave_lds_sync();
+  float* ob = a.out + row0 * a.ld_out + head * D;
+  const uint64_t e0 = static_cast<uint64_t>(row0) * E + head * D;
+#pragma unroll
+  for (int b = 0; b < NB2; ++b) {
+    if (a.key_ptr != nullptr)
+      stage_out<D, true>(sq + 32 * b * T::STRIDE, ob + 32 * b * a.ld_out, a.ld_out, L - 32 * b, lane, *a.key_ptr,
+                         e0 + static_cast<uint64_t>(32 * b) * E, E, a.thresh, a.scale);
+    else
+      stage_out<D, false>(sq + 32 * b * T::STRIDE, ob + 32 * b * a.ld_out, a.ld_out, L - 32 * b, lane, 0u, 0u, 0, 0u, 0.f);
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(64 * ATT2_WAVES) void attn_mfma2_bwd_kernel(MfmaAttnArgs a) {
+  using T = Tile<D>;
+  constexpr int KH = D / 2;
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // ATT2_WAVES x 4 regions x L x STRIDE
+  const int lane = threadIdx.x & 63;
+  const int64_t prob = static_cast<int64_t>(blockIdx.x) * ATT2_WAVES + (threadIdx.x >> 6);
+  if (prob >= a.n_prob) return;
+  const int L = a.L, E = a.h * D;
+  const int region = L * T::STRIDE;
+  float* sq = smem + (threadIdx.x >> 6) * 4 * region;
+  float* sk = sq + region;
+  float* sv = sk + region;  // V, then the staging buffer of the result tiles
+  float* sg = sv + region;  // dO with the forward dropout mask applied
+  const int row = lane & 31, hi = lane >> 5;
+  const int64_t seq = prob / a.h;
+  const int head = static_cast<int>(prob - seq * a.h);
+  const int64_t row0 = seq * L;
+  const float* qb = a.qkv + row0 * a.ld_qkv + head * D;
+  const float* gb = a.dout + row0 * a.ld_dout + head * D;
+  const float inv = 1.0f / sqrtf(static_cast<float>(D));
+  const float inv2 = inv * 1.44269504088896341f;
+#pragma unroll
+  for (int b = 0; b < NB2; ++b) {  // (one block at a time: four staged matrices = 4 x ROUNDS float4 in flight)
+    Staged<D> tq, tk, tv, tg;
+    const int Lb = L - 32 * b;
+    stage_load<D>(tq, qb + 32 * b * a.ld_qkv, a.ld_qkv, Lb, lane);
+    stage_load<D>(tk, qb + E + 32 * b * a.ld_qkv, a.ld_qkv, Lb, lane);
+    stage_load<D>(tv, qb + 2 * E + 32 * b * a.ld_qkv, a.ld_qkv, Lb, lane);
+    stage_load<D>(tg, gb + 32 * b * a.ld_dout, a.ld_dout, Lb, lane);
+    stage_store<D, false>(sq + 32 * b * T::STRIDE, tq, Lb, lane, 0u, 0u, 0, 0u, 0.f);
+    stage_store<D, false>(sk + 32 * b * T::STRIDE, tk, Lb, lane, 0u, 0u, 0, 0u, 0.f);
+    stage_store<D, false>(sv + 32 * b * T::STRIDE, tv, Lb, lane, 0u, 0u, 0, 0u, 0.f);
+    if (a.key_ptr != nullptr)
+      stage_store<D, true>(sg + 32 * b * T::STRIDE, tg, Lb, lane, *a.key_ptr,
+                           static_cast<uint64_t>(row0 + 32 * b) * E + head * D, E, a.thresh, a.scale);
+    else
+      stage_store<D, false>(sg + 32 * b * T::STRIDE, tg, Lb, lane, 0u, 0u, 0, 0u, 0.f);
+  }
+  wave_lds_sync();
+
+  float* ob = a.out + row0 * a.ld_out + head * D;
+  float c[NB2], rowdot[NB2];
+  float vr[NB2][KH];  // row forms of V: read before sv turns into the staging buffer
+#pragma unroll
+  for (int b = 0; b < NB2; ++b) lds_row_form<D>(vr[b], sv + 32 * b * T::STRIDE, L - 32 * b, row, hi);
+  wave_lds_sync();
+  // ---- lane-i layout (i = 32 ib + lane row on lanes, j on registers) -> dV, dQ of row block ib
+#pragma unroll
+  for (int ib = 0; ib < NB2; ++ib) {
+    f32x16 P[NB2], dP[NB2];
+    {
+      float qr[KH];
+      lds_row_form<D>(qr, sq + 32 * ib * T::STRIDE, L - 32 * ib, row, hi);
+#pragma unroll
+      for (int jb = 0; jb < NB2; ++jb) {
+        float kr[KH];
+        lds_row_form<D>(kr, sk + 32 * jb * T::STRIDE, L - 32 * jb, row, hi);
+        P[jb] = mm_rows<KH>(kr, qr);  // T[j][i]
+      }
+    }
+    c[ib] = softmax2_in_lane<true>(P, L, hi, inv2);
+    float rd = 0.f;
+#pragma unroll
+    for (int jb = 0; jb < NB2; ++jb) {
+      float gr[KH];
+      lds_row_form<D>(gr, sg + 32 * jb * T::STRIDE, L - 32 * jb, row, hi);
+      dP[jb] = mm_rows<KH>(gr, vr[ib]);  // dP[i][j] = V[i].dO[j]
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rd = fmaf(P[jb][r], dP[jb][r], rd);
+    }
+    rd += __shfl_xor(rd, 32, 64);
+    rowdot[ib] = rd;
+    float col[16];
+    {  // dV^T[c][i] = sum_j dO[j][c] P[i][j]
+      f32x16 dV = zero_tile();
+#pragma unroll
+      for (int jb = 0; jb < NB2; ++jb) {
+        lds_col_form<D>(col, sg + 32 * jb * T::STRIDE, L - 32 * jb, row, hi);
+        mm_col_tile_acc(dV, col, P[jb]);
+      }
+      wave_lds_sync();
+      tile_rows_to_lds<D>(sv + 32 * ib * T::STRIDE, dV, L - 32 * ib, row, hi, 1.0f);
+      wave_lds_sync();
+      stage_out<D, false>(sv + 32 * ib * T::STRIDE, ob + 2 * E + 32 * ib * a.ld_out, a.ld_out, L - 32 * ib, lane, 0u, 0u, 0, 0u, 0.f);
+    }
+#pragma unroll
+    for (int jb = 0; jb < NB2; ++jb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) P[jb][r] = P[jb][r] * (dP[jb][r] - rd);  // dS[i][j]
+    {  // dQ^T[c][i] = inv * sum_j K[j][c] dS[i][j]
+      f32x16 dQ = zero_tile();
+#pragma unroll
+      for (int jb = 0; jb < NB2; ++jb) {
+        lds_col_form<D>(col, sk + 32 * jb * T::STRIDE, L - 32 * jb, row, hi);
+        mm_col_tile_acc(dQ, col, P[jb]);
+      }
+      wave_lds_sync();
+      tile_rows_to_lds<D>(sv + 32 * ib * T::STRIDE, dQ, L - 32 * ib, row, hi, inv);
+      wave_lds_sync();
+      stage_out<D, false>(sv + 32 * ib * T::STRIDE, ob + 32 * ib * a.ld_out, a.ld_out, L - 32 * ib, lane, 0u, 0u, 0, 0u, 0.f);
+    }
+  }
+  // ---- lane-j layout (j = 32 jb + lane row on lanes, i on registers) -> dK of row block jb
+#pragma unroll
+  for (int jb = 0; jb < NB2; ++jb) {
+    float kr[KH], gr[KH];
+    lds_row_form<D>(kr, sk + 32 * jb * T::STRIDE, L - 32 * jb, row, hi);
+    lds_row_form<D>(gr, sg + 32 * jb * T::STRIDE, L - 32 * jb, row, hi);
+    f32x16 dK = zero_tile();
+#pragma unroll
+    for (int ib = 0; ib < NB2; ++ib) {
+      f32x16 P, dP;
+      {
+        float qr[KH];
+        lds_row_form<D>(qr, sq + 32 * ib * T::STRIDE, L - 32 * ib, row, hi);
+        P = mm_rows<KH>(qr, kr);  // S[i][j]: lane j, regs i
+      }
+      softmax2_from_stats(P, L, ib, hi, inv2, c[ib]);
+      dP = mm_rows<KH>(vr[ib], gr);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float rdi = __shfl(rowdot[ib], crow(r, hi), 64);
+        P[r] = P[r] * (dP[r] - rdi);  // dS[i][j]
+      }
+      float col[16];
+      lds_col_form<D>(col, sq + 32 * ib * T::STRIDE, L - 32 * ib, row, hi);
+      mm_col_tile_acc(dK, col, P);  // dK^T[c][j] += sum_{i in block ib} Q[i][c] dS[i][j]
+    }
+    wave_lds_sync();
+    tile_rows_to_lds<D>(sv + 32 * jb * T::STRIDE, dK, L - 32 * jb, row, hi, inv);
+    wave_lds_sync();
+    stage_out<D, false>(sv + 32 * jb * T::STRIDE, ob + E + 32 * jb * a.ld_out, a.ld_out, L - 32 * jb, lane, 0u, 0u, 0, 0u, 0.f);
+  }
+}
+
 }  // namespace
 
 // Returns 1 when the MFMA path handles (L, d, leading dims, alignment); the caller falls back otherwise.
 static bool mfma_path_ok(int32_t L, int32_t d, int64_t lda, int64_t ldb, int64_t ldc, const void* p0,
                          const void* p1, const void* p2) {
-  if (L > 32 || !(d == 16 || d == 20 || d == 32)) return false;
+  if (L > 64 || !(d == 16 || d == 20 || d == 32)) return false;  // L <= 32: one 32x32 tile; 32 < L <= 64: 2 x 2 tiles
   if ((lda % 4) || (ldb % 4) || (ldc % 4)) return false;
   return ebn_aligned16(p0) && ebn_aligned16(p1) && ebn_aligned16(p2);
 }
@@ -434,11 +707,31 @@ static void allow_lds(K kernel, size_t bytes) {
   if (bytes > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
 }
 
+template <int D>
+static void launch_mfma2(bool bwd, const MfmaAttnArgs& a, hipStream_t s) {
+  const dim3 grid(static_cast<unsigned>(ebn_ceil_div(a.n_prob, ATT2_WAVES))), block(64 * ATT2_WAVES);
+  const size_t lds = static_cast<size_t>(ATT2_WAVES) * (bwd ? 4 : 3) * a.L * Tile<D>::STRIDE * sizeof(float);
+  if (bwd) {
+    allow_lds(attn_mfma2_bwd_kernel<D>, lds);
+    hipLaunchKernelGGL(attn_mfma2_bwd_kernel<D>, grid, block, lds, s, a);
+  } else {
+    allow_lds(attn_mfma2_fwd_kernel<D>, lds);
+    hipLaunchKernelGGL(attn_mfma2_fwd_kernel<D>, grid, block, lds, s, a);
+  }
+}
+
 int ebn_attn_mfma_fwd(const float* qkv, int64_t ld_qkv, float* out, int64_t ld_out, int64_t n_seq, int32_t L,
                       int32_t h, int32_t d, const EbnDrop& dr, hipStream_t s, bool* handled) {
   *handled = mfma_path_ok(L, d, ld_qkv, ld_out, ld_out, qkv, out, out);
   if (!*handled) return EBN_OK;
   MfmaAttnArgs a{qkv, ld_qkv, nullptr, 0, out, ld_out, n_seq * h, L, h, dr.key_ptr, dr.thresh, dr.scale};
+  if (L > 32) {
+    if (d == 16) launch_mfma2<16>(false, a, s);
+    else if (d == 20) launch_mfma2<20>(false, a, s);
+    else launch_mfma2<32>(false, a, s);
+    EBN_CHECK_LAUNCH();
+    return EBN_OK;
+  }
   const dim3 grid(static_cast<unsigned>(ebn_ceil_div(a.n_prob, ATT_WAVES))), block(64 * ATT_WAVES);
   const size_t lds = static_cast<size_t>(ATT_WAVES) * 3 * L * sizeof(float);  // x STRIDE below
   if (d == 16) hipLaunchKernelGGL(attn_mfma_fwd_kernel<16>, grid, block, lds * Tile<16>::STRIDE, s, a);
@@ -457,6 +750,13 @@ int ebn_attn_mfma_bwd(const float* qkv, int64_t ld_qkv, const float* dout, int64
   *handled = mfma_path_ok(L, d, ld_qkv, ld_dout, ld_dqkv, qkv, dout, dqkv);
   if (!*handled) return EBN_OK;
   MfmaAttnArgs a{qkv, ld_qkv, dout, ld_dout, dqkv, ld_dqkv, n_seq * h, L, h, dr.key_ptr, dr.thresh, dr.scale};
+  if (L > 32) {
+    if (d == 16) launch_mfma2<16>(true, a, s);
+    else if (d == 20) launch_mfma2<20>(true, a, s);
+    else launch_mfma2<32>(true, a, s);
+    EBN_CHECK_LAUNCH();
+    return EBN_OK;
+  }
   const dim3 grid(static_cast<unsigned>(ebn_ceil_div(a.n_prob, ATT_WAVES))), block(64 * ATT_WAVES);
   const size_t lds = static_cast<size_t>(ATT_WAVES) * 4 * L * sizeof(float);  // x STRIDE below
   if (d == 16) hipLaunchKernelGGL(attn_mfma_bwd_kernel<16>, grid, block, lds * Tile<16>::STRIDE, s, a);

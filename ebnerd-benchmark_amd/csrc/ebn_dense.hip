@@ -484,8 +484,20 @@ struct Copy3 {
   const uint32_t* s[3];
   uint32_t* d[3];
   int64_t n[3];  // dwords
+  ebn_step_state* st;  // non-null: also advance the step state (ebn_copy3_advance)
+  double beta1, beta2;
 };
 __global__ __launch_bounds__(256) void copy3_kernel(Copy3 c) {
+  if (c.st != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    // ebn_step_advance folded into the staging copy of a training step (one launch fewer on the step's critical path)
+    ebn_step_state* st = c.st;
+    const uint32_t t = st->step + 1u;
+    st->step = t;
+    const double b1t = pow(c.beta1, static_cast<double>(t));
+    const double b2t = pow(c.beta2, static_cast<double>(t));
+    st->adam_alpha = static_cast<float>(static_cast<double>(st->lr) * sqrt(1.0 - b2t) / (1.0 - b1t));
+    for (uint32_t s = 0; s < EBN_N_SITES; ++s) st->drop_key[s] = ebn_dropout_key(st->seed, t, s);
+  }
   const int which = blockIdx.y;
   const uint32_t* __restrict__ s = c.s[which];
   uint32_t* __restrict__ d = c.d[which];
@@ -494,12 +506,15 @@ __global__ __launch_bounds__(256) void copy3_kernel(Copy3 c) {
 }
 }  // namespace
 
-extern "C" int ebn_copy3(const void* s0, void* d0, int64_t n0, const void* s1, void* d1, int64_t n1, const void* s2,
-                         void* d2, int64_t n2, ebn_stream_t stream) {
+static int copy3_launch(const void* s0, void* d0, int64_t n0, const void* s1, void* d1, int64_t n1, const void* s2,
+                        void* d2, int64_t n2, ebn_step_state* st, double beta1, double beta2, ebn_stream_t stream) {
   const void* ss[3] = {s0, s1, s2};
   void* dd[3] = {d0, d1, d2};
   int64_t nn[3] = {n0, n1, n2};
   Copy3 c;
+  c.st = st;
+  c.beta1 = beta1;
+  c.beta2 = beta2;
   int64_t most = 0;
   for (int i = 0; i < 3; ++i) {
     EBN_REQUIRE(nn[i] >= 0 && (nn[i] % 4) == 0, EBN_ERR_BAD_ARG);
@@ -510,12 +525,25 @@ extern "C" int ebn_copy3(const void* s0, void* d0, int64_t n0, const void* s1, v
     c.n[i] = nn[i] / 4;
     if (c.n[i] > most) most = c.n[i];
   }
-  if (most == 0) return EBN_OK;
+  if (most == 0 && st == nullptr) return EBN_OK;
   int64_t gx = ebn_ceil_div(most, 256);
   if (gx > 1024) gx = 1024;
+  if (gx < 1) gx = 1;
   hipLaunchKernelGGL(copy3_kernel, dim3(static_cast<unsigned>(gx), 3), dim3(256), 0, ebn_stream(stream), c);
   EBN_CHECK_LAUNCH();
   return EBN_OK;
+}
+
+extern "C" int ebn_copy3(const void* s0, void* d0, int64_t n0, const void* s1, void* d1, int64_t n1, const void* s2,
+                         void* d2, int64_t n2, ebn_stream_t stream) {
+  return copy3_launch(s0, d0, n0, s1, d1, n1, s2, d2, n2, nullptr, 0.0, 0.0, stream);
+}
+
+extern "C" int ebn_copy3_advance(const void* s0, void* d0, int64_t n0, const void* s1, void* d1, int64_t n1,
+                                 const void* s2, void* d2, int64_t n2, ebn_step_state* st, double beta1, double beta2,
+                                 ebn_stream_t stream) {
+  EBN_REQUIRE(st, EBN_ERR_BAD_ARG);
+  return copy3_launch(s0, d0, n0, s1, d1, n1, s2, d2, n2, st, beta1, beta2, stream);
 }
 
 extern "C" int ebn_axpy_f32(float a, const float* x, float* y, int64_t n, ebn_stream_t stream) {

@@ -108,12 +108,15 @@ __global__ __launch_bounds__(GATHER_THREADS) void scatter_add_rows_kernel(
 }
 
 constexpr double FIXED_SCALE = 1099511627776.0;  // 2^40
+constexpr float FIXED_TERM_MAX = 2097152.0f;      // 2^21: any single gradient term this large raises the range flag
+constexpr long long FIXED_SUM_MAX = 1ll << 62;    // |accumulated sum| >= 2^22 (as 2^40-scaled int64): range flag
 
 // Deterministic backward: 64-bit integer atomics on a fixed-point accumulator (order-independent sums).
 template <typename IT>
 __global__ __launch_bounds__(GATHER_THREADS) void scatter_add_rows_fixed_kernel(
     const int32_t* __restrict__ ids, const float* __restrict__ dX, long long* __restrict__ acc, int64_t n_items,
-    int32_t D, int64_t V, const uint32_t* __restrict__ key_ptr, uint32_t thresh, float scale) {
+    int32_t D, int64_t V, const uint32_t* __restrict__ key_ptr, uint32_t thresh, float scale,
+    int32_t* __restrict__ range_flag) {
   const bool do_drop = key_ptr != nullptr;
   const uint32_t key = do_drop ? *key_ptr : 0u;
   for (IT it = static_cast<IT>(blockIdx.x) * GATHER_THREADS + threadIdx.x; static_cast<int64_t>(it) < n_items;
@@ -125,6 +128,8 @@ __global__ __launch_bounds__(GATHER_THREADS) void scatter_add_rows_fixed_kernel(
     float g = dX[it];
     if (do_drop) g *= ebn_drop_mult(key, static_cast<uint64_t>(it), thresh, scale);
     if (g != 0.f) {
+      // one term at or beyond 2^21 (or a NaN): the 2^40-scaled sum could leave the int64 range unnoticed -> flag it
+      if (!(fabsf(g) < FIXED_TERM_MAX) && range_flag != nullptr) *range_flag = 1;
       const long long q = __double2ll_rn(static_cast<double>(g) * FIXED_SCALE);
       atomicAdd(reinterpret_cast<unsigned long long*>(&acc[id * D + col]), static_cast<unsigned long long>(q));
     }
@@ -132,13 +137,64 @@ __global__ __launch_bounds__(GATHER_THREADS) void scatter_add_rows_fixed_kernel(
 }
 
 __global__ __launch_bounds__(256) void fixed_to_f32_kernel(long long* __restrict__ acc, float* __restrict__ out,
-                                                           int64_t n) {
+                                                           int64_t n, int32_t* __restrict__ range_flag) {
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n;
        i += static_cast<int64_t>(gridDim.x) * 256) {
     const long long q = acc[i];
     out[i] = static_cast<float>(static_cast<double>(q) * (1.0 / FIXED_SCALE));
-    if (q != 0) acc[i] = 0;
+    if (q != 0) {
+      acc[i] = 0;
+      if ((q >= FIXED_SUM_MAX || q <= -FIXED_SUM_MAX) && range_flag != nullptr) *range_flag = 1;
+    }
   }
+}
+
+// Keras-form Adam (ebn_score_optim.hip: adam_keras_kernel) reading the gradient straight from the fixed-point
+// accumulator: convert, update theta / m / v and re-zero the accumulator in ONE pass over the table -- 4 reads + 4 writes
+// per element where fixed_to_f32 + Adam made 6 reads + 5 writes (the table sweep is what a trainable-table step pays on
+// top of the frozen-table one).  Same arithmetic as the two kernels in sequence.
+__global__ __launch_bounds__(256) void adam_keras_fixed_kernel(float* __restrict__ theta, long long* __restrict__ acc,
+                                                               float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                               const ebn_step_state* __restrict__ st, float omb1,
+                                                               float omb2, float eps, float gscale,
+                                                               int32_t* __restrict__ range_flag) {
+  const float alpha = st->adam_alpha;
+  bool bad = false;
+  for (int64_t i = (static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x) * 2; i < n;
+       i += static_cast<int64_t>(gridDim.x) * 512) {
+    if (i + 1 < n) {  // two elements per thread: 16-byte accumulator load, 8-byte float loads
+      const longlong2 q = *reinterpret_cast<const longlong2*>(acc + i);
+      float2 t = *reinterpret_cast<const float2*>(theta + i), mm = *reinterpret_cast<const float2*>(m + i),
+             vv = *reinterpret_cast<const float2*>(v + i);
+      const float g0 = static_cast<float>(static_cast<double>(q.x) * (1.0 / FIXED_SCALE)) * gscale;
+      const float g1 = static_cast<float>(static_cast<double>(q.y) * (1.0 / FIXED_SCALE)) * gscale;
+      mm.x = mm.x + (g0 - mm.x) * omb1;
+      vv.x = vv.x + (g0 * g0 - vv.x) * omb2;
+      t.x = t.x - alpha * mm.x / (sqrtf(vv.x) + eps);
+      mm.y = mm.y + (g1 - mm.y) * omb1;
+      vv.y = vv.y + (g1 * g1 - vv.y) * omb2;
+      t.y = t.y - alpha * mm.y / (sqrtf(vv.y) + eps);
+      *reinterpret_cast<float2*>(theta + i) = t;
+      *reinterpret_cast<float2*>(m + i) = mm;
+      *reinterpret_cast<float2*>(v + i) = vv;
+      if (q.x != 0 || q.y != 0) {
+        *reinterpret_cast<longlong2*>(acc + i) = make_longlong2(0, 0);
+        bad |= q.x >= FIXED_SUM_MAX || q.x <= -FIXED_SUM_MAX || q.y >= FIXED_SUM_MAX || q.y <= -FIXED_SUM_MAX;
+      }
+    } else {
+      const long long q = acc[i];
+      const float g = static_cast<float>(static_cast<double>(q) * (1.0 / FIXED_SCALE)) * gscale;
+      const float mm = m[i] + (g - m[i]) * omb1, vv = v[i] + (g * g - v[i]) * omb2;
+      m[i] = mm;
+      v[i] = vv;
+      theta[i] = theta[i] - alpha * mm / (sqrtf(vv) + eps);
+      if (q != 0) {
+        acc[i] = 0;
+        bad |= q >= FIXED_SUM_MAX || q <= -FIXED_SUM_MAX;
+      }
+    }
+  }
+  if (bad && range_flag != nullptr) *range_flag = 1;
 }
 
 __global__ __launch_bounds__(GATHER_THREADS) void expand_titles_kernel(const int32_t* __restrict__ art_idx,
@@ -165,7 +221,7 @@ __global__ __launch_bounds__(GATHER_THREADS) void expand_titles_kernel(const int
 
 extern "C" int ebn_embedding_grad_scatter_fixed(const int32_t* ids, const float* dX, int64_t* acc, int64_t n_tok,
                                                 int32_t D, int64_t V, const ebn_step_state* st, int32_t site,
-                                                float drop_p, ebn_stream_t stream) {
+                                                float drop_p, int32_t* range_flag, ebn_stream_t stream) {
   EBN_REQUIRE(ids && dX && acc, EBN_ERR_BAD_ARG);
   EBN_REQUIRE(n_tok >= 0 && D > 0 && V > 0, EBN_ERR_BAD_ARG);
   if (n_tok == 0) return EBN_OK;
@@ -176,22 +232,38 @@ extern "C" int ebn_embedding_grad_scatter_fixed(const int32_t* ids, const float*
   if (n_items + grid * GATHER_THREADS < (static_cast<int64_t>(1) << 32))
     hipLaunchKernelGGL(scatter_add_rows_fixed_kernel<uint32_t>, dim3(static_cast<unsigned>(grid)), dim3(GATHER_THREADS), 0,
                        ebn_stream(stream), ids, dX, reinterpret_cast<long long*>(acc), n_items, D, V, dr.key_ptr,
-                       dr.thresh, dr.scale);
+                       dr.thresh, dr.scale, range_flag);
   else
     hipLaunchKernelGGL(scatter_add_rows_fixed_kernel<int64_t>, dim3(static_cast<unsigned>(grid)), dim3(GATHER_THREADS), 0,
                        ebn_stream(stream), ids, dX, reinterpret_cast<long long*>(acc), n_items, D, V, dr.key_ptr,
-                       dr.thresh, dr.scale);
+                       dr.thresh, dr.scale, range_flag);
   EBN_CHECK_LAUNCH();
   return EBN_OK;
 }
 
-extern "C" int ebn_fixed_to_f32(int64_t* acc, float* out, int64_t n, ebn_stream_t stream) {
+extern "C" int ebn_fixed_to_f32(int64_t* acc, float* out, int64_t n, int32_t* range_flag, ebn_stream_t stream) {
   EBN_REQUIRE(acc && out && n >= 0, EBN_ERR_BAD_ARG);
   if (n == 0) return EBN_OK;
   int64_t grid = ebn_ceil_div(n, 256);
   if (grid > 256 * 16) grid = 256 * 16;
   hipLaunchKernelGGL(fixed_to_f32_kernel, dim3(static_cast<unsigned>(grid)), dim3(256), 0, ebn_stream(stream),
-                     reinterpret_cast<long long*>(acc), out, n);
+                     reinterpret_cast<long long*>(acc), out, n, range_flag);
+  EBN_CHECK_LAUNCH();
+  return EBN_OK;
+}
+
+extern "C" int ebn_adam_keras_step_fixed_f32(float* theta, int64_t* acc, float* m, float* v, int64_t n,
+                                             const ebn_step_state* st, double beta1, double beta2, double eps_d,
+                                             float grad_scale, int32_t* range_flag, ebn_stream_t stream) {
+  EBN_REQUIRE(theta && acc && m && v && st && n >= 0, EBN_ERR_BAD_ARG);
+  EBN_REQUIRE(ebn_aligned16(acc) && (reinterpret_cast<uintptr_t>(theta) & 7u) == 0 && (reinterpret_cast<uintptr_t>(m) & 7u) == 0 &&
+                  (reinterpret_cast<uintptr_t>(v) & 7u) == 0, EBN_ERR_ALIGN);
+  if (n == 0) return EBN_OK;
+  int64_t grid = ebn_ceil_div(ebn_ceil_div(n, 2), 256);
+  if (grid > 256 * 16) grid = 256 * 16;
+  hipLaunchKernelGGL(adam_keras_fixed_kernel, dim3(static_cast<unsigned>(grid)), dim3(256), 0, ebn_stream(stream), theta,
+                     reinterpret_cast<long long*>(acc), m, v, n, st, static_cast<float>(1.0 - beta1),
+                     static_cast<float>(1.0 - beta2), static_cast<float>(eps_d), grad_scale, range_flag);
   EBN_CHECK_LAUNCH();
   return EBN_OK;
 }

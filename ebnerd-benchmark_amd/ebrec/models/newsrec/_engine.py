@@ -174,6 +174,8 @@ class NRMSEngine:
         self._lr = float(learning_rate)
         self._bufs = {}
         self.oob_flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.keep_table_grad = False  # True: always materialise the fp32 dense table gradient (inspection / tests)
+        self.range_flag = torch.zeros(1, dtype=torch.int32, device=self.device)  # fixed-point gradient accumulator left its range
         self.loss_dev = torch.zeros(1, device=self.device)
         self.use_graph = False  # capture the per-shape kernel sequence into hipGraphs (enable_graphs())
         self.kernel_events = None  # dict name -> [(start, stop)] when bench.py asks for kernel timings
@@ -257,6 +259,12 @@ class NRMSEngine:
     def _planned(self) -> bool:
         """row-sharded table with the device-planned fixed-capacity exchange (the graph-capturable form)"""
         return self.exchange is not None and self.exchange.mode == "alltoall"
+
+    @property
+    def _adam_from_acc(self) -> bool:
+        """trainable replicated table on ONE rank with the deterministic accumulator: Adam reads it directly"""
+        return (self.train_embedding and self.deterministic and self.exchange is None and self.world == 1
+                and not self.keep_table_grad)
 
     @property
     def graph_capable(self) -> bool:
@@ -613,6 +621,10 @@ class NRMSEngine:
         if int(self.oob_flag.item()) != 0:
             self.oob_flag.zero_()
             raise IndexError(f"token id out of range [0, {self.V}) for the embedding table")
+        if int(self.range_flag.item()) != 0:
+            self.range_flag.zero_()
+            raise FloatingPointError("embedding gradient left the range of the deterministic fixed-point accumulator (|sum| >= 2^22 "
+                                     "or NaN): the run has diverged; deterministic=False accumulates in fp32 instead")
 
     check_oob = _check_oob  # fit()/evaluate() call this once per epoch (device-resident batches are not range-checked on the host)
 
@@ -656,6 +668,7 @@ class NRMSEngine:
         his = his if isinstance(his, torch.Tensor) else np.asarray(his)
         pred = pred if isinstance(pred, torch.Tensor) else np.asarray(pred)
         B, C = his.shape[0], pred.shape[1]
+        advanced = False  # True once a staging launch has advanced the step state
         if indexed:  # (B,H) / (B,C) article-row numbers of the matrix given to set_article_matrix()
             if his.ndim != 2 or his.shape[1] != self.H or pred.ndim != 2 or pred.shape[0] != B:
                 raise ValueError(f"indexed batches must be (B, {self.H}) and (B, C), got {tuple(his.shape)} {tuple(pred.shape)}")
@@ -665,23 +678,24 @@ class NRMSEngine:
             self._check_shapes(his, pred)
             nb, ub = self._train_bufs(B, C)
             if self._device_batch(his, pred, y):  # batch already in HBM in the step's dtypes: one copy launch, not three
-                nh = his.numel()
-                _hip.call("ebn_copy3", _hip.ptr(his), _hip.ptr(nb.ids), nh * 4, _hip.ptr(pred), _hip.ptr(nb.ids[nh:]),
-                          pred.numel() * 4, _hip.ptr(y), _hip.ptr(nb.labels), y.numel() * 4, _hip.stream_handle())
-                y = None
+                nh = his.numel()              # (and the step-state advance rides in it instead of being a launch of its own)
+                _hip.call("ebn_copy3_advance", _hip.ptr(his), _hip.ptr(nb.ids), nh * 4, _hip.ptr(pred), _hip.ptr(nb.ids[nh:]),
+                          pred.numel() * 4, _hip.ptr(y), _hip.ptr(nb.labels), y.numel() * 4, _hip.ptr(self.state), BETA1, BETA2,
+                          _hip.stream_handle())
+                y, advanced = None, True
             else:
                 self._upload_ids(nb.ids, his, pred)
         if y is not None:
             labels = (y if isinstance(y, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(y, dtype=np.float32))))
             nb.labels[: B * C].copy_(labels.reshape(-1).to(device=self.device, dtype=torch.float32), non_blocking=True)
         if self.use_graph and self.kernel_events is None and self.graph_capable:
-            run = self._graphs.get((B, C))
+            run = self._graphs.get((B, C, advanced))
             if run is None:
-                run = self._capture(B, C)
+                run = self._capture(B, C, advanced)
             for fn in run:
                 fn()
         else:
-            for _kind, fn in self._segments(B, C):
+            for _kind, fn in self._segments(B, C, advanced):
                 fn()
         if return_probs:
             return self.loss_dev, nb.probs[: B * C].view(B, C)
@@ -701,10 +715,10 @@ class NRMSEngine:
             ub.loss_rows = torch.empty(ub.n_seq, device=self.device)
         return nb, ub
 
-    def _capture(self, B, C):
+    def _capture(self, B, C, advanced=False):
         """Runs of kernel-only segments become hipGraphs; collectives stay eager launches between the replays."""
         torch.cuda.synchronize()
-        segs, run, pool, i = self._segments(B, C), [], None, 0
+        segs, run, pool, i = self._segments(B, C, advanced), [], None, 0
         while i < len(segs):
             if segs[i][0] == "c":
                 run.append(segs[i][1])
@@ -721,15 +735,15 @@ class NRMSEngine:
             run.append(g.replay)
             self._graph_objs = getattr(self, "_graph_objs", []) + [g]
             i = j
-        self._graphs[(B, C)] = run
+        self._graphs[(B, C, advanced)] = run
         return run
 
-    def _segments(self, B, C):
+    def _segments(self, B, C, advanced=False):
         """One training step as an ordered list of ("k" = kernels only | "c" = collective, fn)."""
         N = B * (self.H + C)
         nb, _ub = self._train_bufs(B, C)
         multi = self.world > 1
-        segs = [("k", lambda: _hip.call("ebn_step_advance", _hip.ptr(self.state), BETA1, BETA2, _hip.stream_handle()))]
+        segs = [] if advanced else [("k", lambda: _hip.call("ebn_step_advance", _hip.ptr(self.state), BETA1, BETA2, _hip.stream_handle()))]
         if self._planned:
             segs += self._lookup_segments(nb, N)
         segs.append(("k", lambda: self._fwd_bwd_kernels(B, C)))
@@ -749,15 +763,12 @@ class NRMSEngine:
         # ---- forward
         self._news_forward(nb, N, True, B * H, looked_up=True)
         self._encoder_fwd("u", ub, B, nb.out, True)  # history encodings are the first B*H rows
-        cand = nb.out[B * H:]
-        _hip.call("ebn_score_fwd_f32", _hip.ptr(cand), _hip.ptr(ub.out), _hip.ptr(nb.scores), _hip.ptr(nb.probs), B, C,
-                  E, 0, S())
+        cand, dcand = nb.out[B * H:], nb.dNE[B * H:]
+        # scorer + compiled loss + their backward into the representations + the batch loss: one launch
+        _hip.call("ebn_score_loss_train_f32", _hip.ptr(cand), _hip.ptr(ub.out), _hip.ptr(nb.labels), _hip.ptr(nb.scores),
+                  _hip.ptr(nb.probs), _hip.ptr(ub.loss_rows), _hip.ptr(self.loss_dev), _hip.ptr(dcand), _hip.ptr(ub.duser), B, C, E,
+                  LOSS_KIND[self.loss], ctypes.c_float(1.0 / B), S())
         # ---- backward
-        dcand = nb.dNE[B * H:]
-        _hip.call("ebn_score_loss_bwd_f32", _hip.ptr(cand), _hip.ptr(ub.out), _hip.ptr(nb.scores), _hip.ptr(nb.labels),
-                  _hip.ptr(ub.loss_rows), _hip.ptr(dcand), _hip.ptr(ub.duser), B, C, E, LOSS_KIND[self.loss],
-                  ctypes.c_float(1.0 / B), S())
-        _hip.call("ebn_sum_f32", _hip.ptr(ub.loss_rows), B, ctypes.c_float(1.0), _hip.ptr(self.loss_dev), 0, S())
         self._encoder_bwd("u", ub, B, nb.out, ub.duser, nb.dNE)  # writes dNE[:B*H]
         self._encoder_bwd("n", nb, N, nb.X, nb.dNE, nb.dX, B * H)
         if self.train_embedding and not self._planned:
@@ -772,8 +783,10 @@ class NRMSEngine:
                 self.exchange.scatter_grads(nb.plan, d_uniq, self._local_scatter_add)
             elif self.deterministic:
                 _hip.call("ebn_embedding_grad_scatter_fixed", _hip.ptr(nb.ids), _hip.ptr(nb.dX), _hip.ptr(self.table_acc),
-                          N * self.T, self.D, self.V, st, site, ctypes.c_float(p), S())
-                _hip.call("ebn_fixed_to_f32", _hip.ptr(self.table_acc), _hip.ptr(self.table_grad), self.table.numel(), S())
+                          N * self.T, self.D, self.V, st, site, ctypes.c_float(p), _hip.ptr(self.range_flag), S())
+                if not self._adam_from_acc:  # data parallel: the fp32 dense gradient is what gets all-reduced
+                    _hip.call("ebn_fixed_to_f32", _hip.ptr(self.table_acc), _hip.ptr(self.table_grad), self.table.numel(),
+                              _hip.ptr(self.range_flag), S())
             else:
                 _hip.call("ebn_embedding_grad_scatter_f32", _hip.ptr(nb.ids), _hip.ptr(nb.dX), _hip.ptr(self.table_grad),
                           N * self.T, self.D, self.V, st, site, ctypes.c_float(p), S())
@@ -792,6 +805,10 @@ class NRMSEngine:
         P = self.params
         _hip.call("ebn_adam_keras_step_f32", _hip.ptr(P.data), _hip.ptr(P.grad), _hip.ptr(P.m), _hip.ptr(P.v), P.numel,
                   st, BETA1, BETA2, ADAM_EPS, gs, S())
-        if self.train_embedding:
+        if self.train_embedding and self._adam_from_acc:
+            # one rank: the gradient goes from the fixed-point accumulator into Adam in a single sweep over the table
+            _hip.call("ebn_adam_keras_step_fixed_f32", _hip.ptr(self.table), _hip.ptr(self.table_acc), _hip.ptr(self.table_m),
+                      _hip.ptr(self.table_v), self.table.numel(), st, BETA1, BETA2, ADAM_EPS, gs, _hip.ptr(self.range_flag), S())
+        elif self.train_embedding:
             _hip.call("ebn_adam_keras_step_f32", _hip.ptr(self.table), _hip.ptr(self.table_grad), _hip.ptr(self.table_m),
                       _hip.ptr(self.table_v), self.table.numel(), st, BETA1, BETA2, ADAM_EPS, gs, S())

@@ -45,6 +45,7 @@ class DocVecEngine:
         self.state = torch.frombuffer(bytearray(bytes(st)), dtype=torch.uint8).to(self.device)
         self._lr = float(learning_rate)
         self._bufs = {}
+        self.kernel_events = None  # dict name -> [(start, stop)] when bench.py asks for kernel timings (eager launches then)
         self.loss_dev = torch.zeros(1, device=self.device)
         self.reg_dev = torch.zeros(1, device=self.device)
         self.world = 1
@@ -272,9 +273,10 @@ class DocVecEngine:
         ok = lambda t, dt: isinstance(t, torch.Tensor) and same_dev(t) and t.dtype == dt and t.is_contiguous()
         if ok(his_idx, torch.int32) and ok(pred_idx, torch.int32) and ok(y, torch.float32):
             nh = his_idx.numel()
-            _hip.call("ebn_copy3", _hip.ptr(his_idx), _hip.ptr(mb["art_idx"]), nh * 4, _hip.ptr(pred_idx), _hip.ptr(mb["art_idx"][nh:]),
-                      pred_idx.numel() * 4, _hip.ptr(y), _hip.ptr(mb["labels"]), y.numel() * 4, _hip.stream_handle())
-            y = None
+            _hip.call("ebn_copy3_advance", _hip.ptr(his_idx), _hip.ptr(mb["art_idx"]), nh * 4, _hip.ptr(pred_idx), _hip.ptr(mb["art_idx"][nh:]),
+                      pred_idx.numel() * 4, _hip.ptr(y), _hip.ptr(mb["labels"]), y.numel() * 4, _hip.ptr(self.state), BETA1, BETA2,
+                      _hip.stream_handle())
+            y, self._advanced = None, True  # the step-state advance rode in the staging launch
         else:
             off = 0
             for a in (his_idx, pred_idx):
@@ -282,8 +284,15 @@ class DocVecEngine:
                 t = t.reshape(-1)
                 mb["art_idx"][off: off + t.numel()].copy_(t.to(device=self.device, dtype=torch.int32), non_blocking=True)
                 off += t.numel()
+        ev = None
+        if self.kernel_events is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self.kernel_events.setdefault("gather", []).append(ev)
+            ev[0].record()
         _hip.call("ebn_gather_rows_f32", _hip.ptr(mb["art_idx"]), _hip.ptr(self.article_matrix), _hip.ptr(mb["X0"]), n, self.Din,
                   self.article_matrix.shape[0], None, -1, ctypes.c_float(0.0), _hip.ptr(self._oob), _hip.stream_handle())
+        if ev:
+            ev[1].record()
         return y
 
     def train_step(self, his, pred, y, return_probs=False, indexed=False):
@@ -295,6 +304,7 @@ class DocVecEngine:
             raise ValueError(f"indexed batches must be (B, {self.H}) and (B, C), got {tuple(his.shape)} {tuple(pred.shape)}")
         B, C = his.shape[0], pred.shape[1]
         mb, ub = self._mlp_bufs(B * (self.H + C)), self._user_bufs(B)  # (re)allocation clears the captured graphs
+        self._advanced = False
         if indexed:
             y = self._stage_indexed(mb, his, pred, y)
         else:
@@ -302,44 +312,44 @@ class DocVecEngine:
         if y is not None:
             labels = (y if isinstance(y, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(y, dtype=np.float32))))
             mb["labels"][: B * C].copy_(labels.reshape(-1).to(device=self.device, dtype=torch.float32))
-        if getattr(self, "use_graph", False):
+        if self.use_graph and self.kernel_events is None:
             # graph(forward + backward) -> gradient all-reduce over RCCL (eager, data-parallel only) -> graph(Adam)
-            g = self._graphs.get((B, C))
+            adv = self._advanced
+            g = self._graphs.get((B, C, adv))
             if g is None:
                 torch.cuda.synchronize()
                 g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g1):
-                    self._fwd_bwd_kernels(B, C)
+                    self._fwd_bwd_kernels(B, C, adv)
                 with torch.cuda.graph(g2, pool=g1.pool()):
                     self._optimizer_kernels()
-                g = self._graphs[(B, C)] = (g1, g2)
+                g = self._graphs[(B, C, adv)] = (g1, g2)
             g[0].replay()
             self._allreduce_grads()
             g[1].replay()
         else:
-            self._fwd_bwd_kernels(B, C)
+            self._fwd_bwd_kernels(B, C, self._advanced)
             self._allreduce_grads()
             self._optimizer_kernels()
         if return_probs:
             return self.loss_dev, mb["probs"][: B * C].view(B, C)
         return self.loss_dev
 
-    def _fwd_bwd_kernels(self, B, C):
+    def _fwd_bwd_kernels(self, B, C, advanced=False):
         E = self.E
         S = _hip.stream_handle
         mb, ub = self._mlp_bufs(B * (self.H + C)), self._user_bufs(B)
         n_hist, n_cand = B * self.H, B * C
         st = _hip.ptr(self.state)
-        _hip.call("ebn_step_advance", st, BETA1, BETA2, S())
+        if not advanced:
+            _hip.call("ebn_step_advance", st, BETA1, BETA2, S())
         self._news_forward(mb, n_hist, n_cand, True)
         dims, params, acts = self._enc(ub, B, mb["NE"])
         _hip.call("ebn_encoder_fwd_f32", ctypes.byref(dims), ctypes.byref(params), ctypes.byref(acts), ctypes.byref(self._fwd_scratch(ub)), st, S())
         cand = mb["NE"][n_hist:]
-        _hip.call("ebn_score_fwd_f32", _hip.ptr(cand), _hip.ptr(ub.out), _hip.ptr(mb["scores"]), _hip.ptr(mb["probs"]), B, C, E, 0, S())
-        _hip.call("ebn_score_loss_bwd_f32", _hip.ptr(cand), _hip.ptr(ub.out), _hip.ptr(mb["scores"]), _hip.ptr(mb["labels"]),
-                  _hip.ptr(ub.loss_rows), _hip.ptr(mb["dNE"][n_hist:]), _hip.ptr(ub.duser), B, C, E, LOSS_KIND[self.loss],
-                  ctypes.c_float(1.0 / B), S())
-        _hip.call("ebn_sum_f32", _hip.ptr(ub.loss_rows), B, ctypes.c_float(1.0), _hip.ptr(self.loss_dev), 0, S())
+        _hip.call("ebn_score_loss_train_f32", _hip.ptr(cand), _hip.ptr(ub.out), _hip.ptr(mb["labels"]), _hip.ptr(mb["scores"]),
+                  _hip.ptr(mb["probs"]), _hip.ptr(ub.loss_rows), _hip.ptr(self.loss_dev), _hip.ptr(mb["dNE"][n_hist:]), _hip.ptr(ub.duser),
+                  B, C, E, LOSS_KIND[self.loss], ctypes.c_float(1.0 / B), S())
         g = self.params.g
         grads = _hip.EncoderGrads(g("u_Wqkv").data_ptr(), g("u_W").data_ptr(), g("u_b").data_ptr(), g("u_q").data_ptr())
         scratch = _hip.EncoderScratch(ub.dY.data_ptr(), ub.dQKV.data_ptr(), ub.de.data_ptr(), ub.partials.data_ptr(),

@@ -84,11 +84,19 @@ int ebn_embedding_grad_scatter_f32(const int32_t* ids, const float* dX, float* d
 /* Deterministic form of the same backward: gradients are accumulated as 2^40-scaled 64-bit integers (integer
  * atomics are associative, so the result does not depend on the order in which duplicate tokens arrive -- hot rows
  * such as token 0 of padded history get the same bits every run), then ebn_fixed_to_f32 converts the accumulator
- * to the fp32 dense gradient and zeroes it for the next step.  |sum| must stay below 2^23; resolution 9e-13.      */
+ * to the fp32 dense gradient and zeroes it for the next step.  Resolution 9e-13; |sum| must stay below 2^23 -- a single
+ * term >= 2^21 (or NaN) or an accumulated |sum| >= 2^22 sets *range_flag (may be NULL) to 1 instead of wrapping silently:
+ * the host layer raises FloatingPointError.                                                                       */
 int ebn_embedding_grad_scatter_fixed(const int32_t* ids, const float* dX, int64_t* acc, int64_t n_tok,
                                      int32_t D, int64_t V, const ebn_step_state* st, int32_t site,
-                                     float drop_p, ebn_stream_t stream);
-int ebn_fixed_to_f32(int64_t* acc, float* out, int64_t n, ebn_stream_t stream);
+                                     float drop_p, int32_t* range_flag, ebn_stream_t stream);
+int ebn_fixed_to_f32(int64_t* acc, float* out, int64_t n, int32_t* range_flag, ebn_stream_t stream);
+/* ebn_fixed_to_f32 + ebn_adam_keras_step_f32 in one pass over the table: the gradient is read from the accumulator
+ * (which is re-zeroed), never materialised -- the single-GPU step of a trainable table (nrms.py:129 trainable=True with
+ * Keras' dense moment decay).  Same arithmetic as the two calls in sequence.                           */
+int ebn_adam_keras_step_fixed_f32(float* theta, int64_t* acc, float* m, float* v, int64_t n, const ebn_step_state* st,
+                                  double beta1, double beta2, double eps, float grad_scale, int32_t* range_flag,
+                                  ebn_stream_t stream);
 
 /* ---- row-sharded Embedding (BASELINE.json configs[4]; no reference counterpart: nrms.py:125-134 keeps one table on
  * one device) -- device-side plan of a lookup into a table whose rows are split over `world` ranks (rank o owns the
@@ -252,6 +260,12 @@ int ebn_score_loss_bwd_f32(const float* cand, const float* user, const float* sc
                            const float* labels, float* loss_rows, float* dcand, float* duser,
                            int64_t B, int32_t C, int32_t E, int32_t loss_kind, float inv_batch,
                            ebn_stream_t stream);
+/* Training step: ebn_score_fwd_f32 (softmax mode) + ebn_score_loss_bwd_f32 + the batch loss loss_out[0] = sum(loss_rows),
+ * same arithmetic, as ONE launch for the batch sizes of a training step (B <= 256, C <= 64; larger shapes run the three
+ * kernels).  nrms.py:201-202 + nrms.py:56-67 and their backward.                                                        */
+int ebn_score_loss_train_f32(const float* cand, const float* user, const float* labels, float* scores, float* probs,
+                             float* loss_rows, float* loss_out, float* dcand, float* duser, int64_t B, int32_t C,
+                             int32_t E, int32_t loss_kind, float inv_batch, ebn_stream_t stream);
 /* ragged scoring for the eval path (dataloader.py:94-107 + nrms.py:204-205):
  * out[p] = act(user[u_idx[p],:] . news[n_idx[p],:]), act = sigmoid (mode 1) or id (0). */
 int ebn_pair_score_f32(const float* user, const float* news, const int32_t* u_idx,
@@ -296,6 +310,9 @@ int ebn_batchnorm_bwd_f32(const float* dY, const float* xhat, const float* gamma
  * of 4; a NULL source or n_i = 0 skips that pair.                                                                   */
 int ebn_copy3(const void* s0, void* d0, int64_t n0, const void* s1, void* d1, int64_t n1, const void* s2, void* d2,
               int64_t n2, ebn_stream_t stream);
+/* The same copy with ebn_step_advance folded in (the staging launch of a training step on a device-resident batch). */
+int ebn_copy3_advance(const void* s0, void* d0, int64_t n0, const void* s1, void* d1, int64_t n1, const void* s2,
+                      void* d2, int64_t n2, ebn_step_state* st, double beta1, double beta2, ebn_stream_t stream);
 
 /* y = a*x + y over n elements (L2 kernel-regulariser gradient, gradient accumulation). */
 int ebn_axpy_f32(float a, const float* x, float* y, int64_t n, ebn_stream_t stream);

@@ -419,6 +419,32 @@ def test_loss_and_backward_into_representations(hip, kind, B, C, E):
     assert abs(float(tot.item()) - L) <= 3e-6 * max(1, abs(L))
 
 
+@pytest.mark.parametrize("kind", ["cross_entropy_loss", "log_loss"])
+@pytest.mark.parametrize("B,C,E", [(32, 5, 400), (64, 5, 256), (3, 64, 20), (1, 1, 8), (300, 5, 400), (4, 70, 16)])
+def test_fused_train_scorer_equals_the_three_kernels_and_the_oracle(hip, kind, B, C, E):
+    """ebn_score_loss_train_f32: scorer + loss + backward + batch loss in one launch (B <= 256, C <= 64; otherwise the
+    three kernels run) -- bitwise the separate kernels on scores / probabilities / gradients, oracle-close on the loss."""
+    rng = np.random.default_rng(B * 7 + C)
+    cand = (rng.standard_normal((B, C, E)) * 0.4).astype(np.float32)
+    user = (rng.standard_normal((B, E)) * 0.4).astype(np.float32)
+    y = np.zeros((B, C), np.float32)
+    y[np.arange(B), rng.integers(0, C, B)] = 1
+    lk = 0 if kind == "cross_entropy_loss" else 1
+    f = lambda *shape: torch.empty(*shape, device="cuda")
+    sc0, pr0, rows0, dc0, du0, tot0 = f(B, C), f(B, C), f(B), f(B, C, E), f(B, E), torch.zeros(1, device="cuda")
+    hip.call("ebn_score_fwd_f32", P(dev(cand)), P(dev(user)), P(sc0), P(pr0), B, C, E, 0, S())
+    hip.call("ebn_score_loss_bwd_f32", P(dev(cand)), P(dev(user)), P(sc0), P(dev(y)), P(rows0), P(dc0), P(du0), B, C, E, lk, ctypes.c_float(1.0 / B), S())
+    hip.call("ebn_sum_f32", P(rows0), B, ctypes.c_float(1.0), P(tot0), 0, S())
+    sc, pr, rows, dc, du, tot = f(B, C), f(B, C), f(B), f(B, C, E), f(B, E), torch.full((1,), 9.0, device="cuda")
+    hip.call("ebn_score_loss_train_f32", P(dev(cand)), P(dev(user)), P(dev(y)), P(sc), P(pr), P(rows), P(tot), P(dc), P(du), B, C, E, lk,
+             ctypes.c_float(1.0 / B), S())
+    for a, b, what in ((sc, sc0, "scores"), (pr, pr0, "probs"), (rows, rows0, "loss rows"), (dc, dc0, "dcand"), (du, du0, "duser")):
+        assert torch.equal(a, b), what
+    s64 = np.einsum("bce,be->bc", cand.astype(np.float64), user.astype(np.float64))
+    L, _ = on.loss_fwd_bwd(s64, y.astype(np.float64), kind)
+    assert abs(float(tot.item()) - L) <= 3e-6 * max(1, abs(L)) and abs(float(tot.item()) - float(tot0.item())) <= 1e-6 * max(1, abs(L))
+
+
 def test_pair_score_ragged(hip):
     rng = np.random.default_rng(47)
     nu, nn, E, n_pairs = 7, 13, 400, 101
@@ -568,16 +594,57 @@ def test_fixed_point_scatter_is_order_independent_and_accurate(hip):
     dX = (rng.standard_normal((n_tok, D)) * 10 ** rng.uniform(-6, 0, (n_tok, 1))).astype(np.float32)
     want = on.embedding_bwd(ids, dX.astype(np.float64), V)
     outs = []
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
     for perm in (np.arange(n_tok), rng.permutation(n_tok)):  # same multiset of (id, grad row), different arrival order
         acc = torch.zeros(V, D, dtype=torch.int64, device="cuda")
         g = torch.full((V, D), 3.0, device="cuda")
         hip.call("ebn_embedding_grad_scatter_fixed", P(dev(ids[perm], torch.int32)), P(dev(dX[perm])), P(acc), n_tok, D, V, None, -1,
-                 ctypes.c_float(0.0), S())
-        hip.call("ebn_fixed_to_f32", P(acc), P(g), V * D, S())
+                 ctypes.c_float(0.0), P(flag), S())
+        hip.call("ebn_fixed_to_f32", P(acc), P(g), V * D, P(flag), S())
         assert int(acc.abs().max().item()) == 0  # accumulator is left zeroed for the next step
         outs.append(g.cpu().numpy())
     assert np.array_equal(outs[0], outs[1])  # bitwise, whatever the order
     assert_close(outs[0], want, rtol=2e-7, atol=1e-9, what="fixed-point dTable")
+    assert int(flag.item()) == 0
+
+
+def test_fixed_point_range_is_guarded_and_fused_adam_equals_the_two_kernels(hip):
+    """|sum| < 2^23 is the accumulator's range: a term >= 2^21 or an accumulated |sum| >= 2^22 raises the range flag
+    (never a silent wrap); ebn_adam_keras_step_fixed_f32 == ebn_fixed_to_f32 followed by ebn_adam_keras_step_f32, bit
+    for bit, and leaves the accumulator zeroed."""
+    rng = np.random.default_rng(17)
+    V, D, n_tok = 33, 7, 500  # odd element count: the 2-wide fused kernel has a tail
+    ids = rng.integers(0, V, n_tok).astype(np.int32)
+    dX = rng.standard_normal((n_tok, D)).astype(np.float32)
+    st = make_state(seed=3, step=4, lr=1e-3, alpha=7e-4)
+    th0, m0, v0 = rng.standard_normal((V, D)).astype(np.float32), rng.standard_normal((V, D)).astype(np.float32) * 0.1, rng.random((V, D)).astype(np.float32) * 0.01
+    res = []
+    for fused in (False, True):
+        flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+        acc = torch.zeros(V, D, dtype=torch.int64, device="cuda")
+        th, m, v = dev(th0), dev(m0), dev(v0)
+        hip.call("ebn_embedding_grad_scatter_fixed", P(dev(ids, torch.int32)), P(dev(dX)), P(acc), n_tok, D, V, None, -1, ctypes.c_float(0.0), P(flag), S())
+        if fused:
+            hip.call("ebn_adam_keras_step_fixed_f32", P(th), P(acc), P(m), P(v), V * D, P(st), 0.9, 0.999, 1e-7, ctypes.c_float(0.5), P(flag), S())
+        else:
+            g = torch.empty(V, D, device="cuda")
+            hip.call("ebn_fixed_to_f32", P(acc), P(g), V * D, P(flag), S())
+            hip.call("ebn_adam_keras_step_f32", P(th), P(g), P(m), P(v), V * D, P(st), 0.9, 0.999, 1e-7, ctypes.c_float(0.5), S())
+        assert int(acc.abs().max().item()) == 0 and int(flag.item()) == 0
+        res.append([t.cpu().numpy() for t in (th, m, v)])
+    for a, b in zip(*res):
+        assert np.array_equal(a, b)
+    # range guard: a huge term, then a sum of large-but-legal terms that leaves the safe range
+    for vals, expect in (([3.0e6], 1), ([1.5e6] * 4, 1), ([1.0e6] * 2, 0), ([float("nan")], 1)):
+        flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+        acc = torch.zeros(2, 4, dtype=torch.int64, device="cuda")
+        n = len(vals)
+        dXv = np.zeros((n, 4), np.float32)
+        dXv[:, 1] = vals
+        hip.call("ebn_embedding_grad_scatter_fixed", P(dev(np.ones(n), torch.int32)), P(dev(dXv)), P(acc), n, 4, 2, None, -1, ctypes.c_float(0.0), P(flag), S())
+        g = torch.empty(2, 4, device="cuda")
+        hip.call("ebn_fixed_to_f32", P(acc), P(g), 8, P(flag), S())
+        assert int(flag.item()) == expect, (vals, int(flag.item()))
 
 
 @pytest.mark.parametrize("M,N,K", [(800, 512, 768), (160, 256, 512), (37, 20, 12), (1300, 64, 40), (5, 7, 3)])

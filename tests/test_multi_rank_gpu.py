@@ -37,6 +37,7 @@ def test_c4_shape_training_step_matches_oracle(hip, loss):
     P0 = {k: v.copy() for k, v in P.items()}
     mom = {k: (np.zeros_like(v), np.zeros_like(v)) for k, v in P.items()}
     eng = m._engine
+    eng.keep_table_grad = True  # (the fused accumulator->Adam sweep never writes the fp32 gradient)
     for t in range(1, 4):
         his, pred, y = batch(rng, B, 50, C, hp.title_size, V)
         L, _, g = on.nrms_loss_and_grads(his, pred, y, P, hp.head_num, hp.head_dim, loss, on.Drop(0.2, seed, t))

@@ -141,6 +141,7 @@ def test_gradients_match_oracle_directly(nrms):
     P = {k: v.astype(np.float32).astype(np.float64) for k, v in P.items()}
     his, pred, y = batch(rng, 6, hp.history_size, 5, hp.title_size, V)
     L, _, g = on.nrms_loss_and_grads(his, pred, y, P, hp.head_num, hp.head_dim, "cross_entropy_loss", on.Drop(0.2, seed, 1))
+    m._engine.keep_table_grad = True  # (the fused accumulator->Adam sweep never writes the fp32 gradient)
     m.train_step(his, pred, y)
     eng = m._engine
     E = eng.E
@@ -460,6 +461,7 @@ def test_news_encoder_units_per_layer_branch_matches_oracle(nrms, p, l2):
     probs, _, _ = on.nrms_mlp_forward(his, pred, P, 4, 8, training=False)
     assert_close(m.model.predict((his, pred)), probs, rtol=0, atol=2e-5, what="units branch, inference (moving statistics)")
     L, _, g, stats = on.nrms_mlp_loss_and_grads(his, pred, y, P, 4, 8, l2=l2, training=True, drop=on.Drop(p, seed, 1) if p > 0 else None)
+    m._engine.keep_table_grad = True
     got = float(m.train_step(his, pred, y).item())
     assert abs(got - L) <= 3e-5 * max(1.0, abs(L)), (got, L)
     eng = m._engine
