@@ -360,6 +360,151 @@ __global__ __launch_bounds__(1024) void relu_bwd_strip_kernel(const float* __res
   if (cok && lane == 0) dbias[c] = accumulate ? dbias[c] + tot : tot;
 }
 
+// ---- both TimeDistributed call sites of a training step in ONE launch -------------------------------------------------
+// The encoder runs over the history block (rows [0,R0)) and the candidate block (rows [R0,R0+R1)) of one (R0+R1, C) row
+// block: separate batch statistics and two moving-average updates (history first), but one workgroup per 16 columns
+// walks both sites, so a Dense/BN layer costs one BN launch per direction instead of two (plus the ReLU backward of the
+// Dense in front of it, which rides in the BN backward).
+struct Bn2Sites {
+  int R[2];
+  float* mean_out[2];
+  float* istd_out[2];
+};
+
+__global__ __launch_bounds__(1024) void bn2_fwd_strip_kernel(const float* __restrict__ X, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float* __restrict__ mmean,
+                                                             float* __restrict__ mvar, float* __restrict__ Y,
+                                                             float* __restrict__ xhat, Bn2Sites sites, int C,
+                                                             const uint32_t* __restrict__ key_ptr, uint32_t thresh,
+                                                             float scale) {
+  __shared__ float sm[STRIP_LANES + 8][STRIP_COLS + 1];
+  const int cl = threadIdx.x & (STRIP_COLS - 1), lane = threadIdx.x >> 4;
+  const int c = blockIdx.x * STRIP_COLS + cl;
+  const bool cok = c < C;
+  const bool do_drop = key_ptr != nullptr;
+  const uint32_t key = do_drop ? *key_ptr : 0u;
+  const float g = gamma[cok ? c : 0], b = beta[cok ? c : 0];
+  float mm = mmean[cok ? c : 0], mv = mvar[cok ? c : 0];
+  int64_t row0 = 0;
+#pragma unroll 1
+  for (int site = 0; site < 2; ++site) {
+    const int R = sites.R[site];
+    if (R > 0) {
+      const float inv_R = 1.0f / static_cast<float>(R);
+      float x[STRIP_PER];
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < STRIP_PER; ++j) {
+        const int r = lane + STRIP_LANES * j;
+        const bool ok = cok && r < R;
+        const float v = X[ok ? (row0 + r) * C + c : 0];  // unconditional, clamped address
+        x[j] = ok ? v : 0.f;
+        s += x[j];
+      }
+      const float mean = strip_colsum(s, sm, cl, lane) * inv_R;
+      float q = 0.f;
+#pragma unroll
+      for (int j = 0; j < STRIP_PER; ++j) {
+        const int r = lane + STRIP_LANES * j;
+        const float d = (r < R) ? x[j] - mean : 0.f;
+        q = fmaf(d, d, q);
+      }
+      const float var = strip_colsum(q, sm, cl, lane) * inv_R;  // biased, two-pass
+      const float istd = 1.0f / sqrtf(var + BN_EPS);
+      mm = mm * BN_MOM + mean * (1.0f - BN_MOM);  // one moving-average update per call site, history first
+      mv = mv * BN_MOM + var * (1.0f - BN_MOM);
+      if (cok && lane == 0) {
+        sites.mean_out[site][c] = mean;
+        sites.istd_out[site][c] = istd;
+      }
+      if (cok) {
+#pragma unroll
+        for (int j = 0; j < STRIP_PER; ++j) {
+          const int r = lane + STRIP_LANES * j;
+          if (r >= R) break;
+          const int64_t i = (row0 + r) * C + c;
+          const float xh = (x[j] - mean) * istd;
+          xhat[i] = xh;
+          float y = xh * g + b;
+          if (do_drop) y *= ebn_drop_mult(key, static_cast<uint64_t>(i), thresh, scale);
+          Y[i] = y;
+        }
+      }
+    }
+    row0 += R;
+  }
+  if (cok && lane == 0) {
+    mmean[c] = mm;
+    mvar[c] = mv;
+  }
+}
+
+// d(Dense pre-activation) = relu'(Rl) * BN-backward(dY) for both sites; dgamma / dbeta summed over the sites (the batch
+// statistics terms use each site's own sums); dbias = column sums of the result.
+__global__ __launch_bounds__(1024) void bn2_relu_bwd_strip_kernel(const float* __restrict__ dY, const float* __restrict__ xhat,
+                                                                  const float* __restrict__ Rl, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ istd0, const float* __restrict__ istd1,
+                                                                  float* __restrict__ dX, float* __restrict__ dgamma,
+                                                                  float* __restrict__ dbeta, float* __restrict__ dbias, int R0,
+                                                                  int R1, int C, const uint32_t* __restrict__ key_ptr,
+                                                                  uint32_t thresh, float scale) {
+  __shared__ float sm[STRIP_LANES + 8][STRIP_COLS + 1];
+  const int cl = threadIdx.x & (STRIP_COLS - 1), lane = threadIdx.x >> 4;
+  const int c = blockIdx.x * STRIP_COLS + cl;
+  const bool cok = c < C;
+  const bool do_drop = key_ptr != nullptr;
+  const uint32_t key = do_drop ? *key_ptr : 0u;
+  const float gm = gamma[cok ? c : 0];
+  float dg_tot = 0.f, db_tot = 0.f, dbias_part = 0.f;
+  int64_t row0 = 0;
+#pragma unroll 1
+  for (int site = 0; site < 2; ++site) {
+    const int R = site ? R1 : R0;
+    if (R > 0) {
+      float g[STRIP_PER], xh[STRIP_PER], rl[STRIP_PER];
+      float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+      for (int j = 0; j < STRIP_PER; ++j) {
+        const int r = lane + STRIP_LANES * j;
+        const bool ok = cok && r < R;
+        const int64_t i = ok ? (row0 + r) * C + c : 0;  // unconditional, clamped address
+        float gv = dY[i];
+        const float xv = xhat[i];
+        rl[j] = Rl[i];
+        if (do_drop) gv *= ebn_drop_mult(key, static_cast<uint64_t>(i), thresh, scale);
+        g[j] = ok ? gv : 0.f;
+        xh[j] = ok ? xv : 0.f;
+        a0 = fmaf(g[j], xh[j], a0);
+        a1 += g[j];
+      }
+      const float dg = strip_colsum(a0, sm, cl, lane);
+      const float db = strip_colsum(a1, sm, cl, lane);
+      dg_tot += dg;
+      db_tot += db;
+      const float inv_R = 1.0f / static_cast<float>(R);
+      const float k = gm * (site ? istd1 : istd0)[cok ? c : 0];
+      if (cok) {
+#pragma unroll
+        for (int j = 0; j < STRIP_PER; ++j) {
+          const int r = lane + STRIP_LANES * j;
+          if (r >= R) break;
+          float v = (g[j] - db * inv_R - xh[j] * dg * inv_R) * k;
+          v = (rl[j] > 0.f) ? v : 0.f;
+          dX[(row0 + r) * C + c] = v;
+          dbias_part += v;
+        }
+      }
+    }
+    row0 += R;
+  }
+  const float dbs = strip_colsum(dbias_part, sm, cl, lane);
+  if (cok && lane == 0) {
+    dgamma[c] = dg_tot;
+    dbeta[c] = db_tot;
+    dbias[c] = dbs;
+  }
+}
+
 inline unsigned grid_for(int64_t n) {
   int64_t g = ebn_ceil_div(n, 256);
   if (g > 256 * 16) g = 256 * 16;
@@ -475,6 +620,40 @@ extern "C" int ebn_batchnorm_bwd_f32(const float* dY, const float* xhat, const f
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(R * C)), dim3(256), 0, s, dY, xhat, gamma, istd, site_dg,
                      site_db, dX, R * C, C, 1.0f / static_cast<float>(R), training, dr.key_ptr, dr.thresh, dr.scale,
                      elem_offset);
+  EBN_CHECK_LAUNCH();
+  return EBN_OK;
+}
+
+extern "C" int ebn_batchnorm2_fwd_f32(const float* X, const float* gamma, const float* beta, float* moving_mean,
+                                      float* moving_var, float* Y, float* xhat, float* mean_out0, float* istd_out0,
+                                      float* mean_out1, float* istd_out1, int64_t R0, int64_t R1, int32_t Ccols,
+                                      const ebn_step_state* st, int32_t site, float drop_p, ebn_stream_t stream) {
+  EBN_REQUIRE(X && gamma && beta && moving_mean && moving_var && Y && xhat, EBN_ERR_BAD_ARG);
+  EBN_REQUIRE(mean_out0 && istd_out0 && mean_out1 && istd_out1, EBN_ERR_BAD_ARG);
+  EBN_REQUIRE(R0 >= 0 && R1 >= 0 && Ccols > 0, EBN_ERR_BAD_ARG);
+  EBN_REQUIRE(R0 <= STRIP_ROWS && R1 <= STRIP_ROWS, EBN_ERR_UNSUPPORTED);  // larger sites: one ebn_batchnorm_fwd_f32 each
+  if (R0 + R1 == 0) return EBN_OK;
+  const EbnDrop dr = ebn_make_drop(st, site, drop_p);
+  Bn2Sites sites{{static_cast<int>(R0), static_cast<int>(R1)}, {mean_out0, mean_out1}, {istd_out0, istd_out1}};
+  hipLaunchKernelGGL(bn2_fwd_strip_kernel, dim3(static_cast<unsigned>(ebn_ceil_div(Ccols, STRIP_COLS))), dim3(1024), 0,
+                     ebn_stream(stream), X, gamma, beta, moving_mean, moving_var, Y, xhat, sites, Ccols, dr.key_ptr, dr.thresh,
+                     dr.scale);
+  EBN_CHECK_LAUNCH();
+  return EBN_OK;
+}
+
+extern "C" int ebn_batchnorm2_relu_bwd_f32(const float* dY, const float* xhat, const float* relu_out, const float* gamma,
+                                           const float* istd0, const float* istd1, float* dX, float* dgamma, float* dbeta,
+                                           float* dbias, int64_t R0, int64_t R1, int32_t Ccols, const ebn_step_state* st,
+                                           int32_t site, float drop_p, ebn_stream_t stream) {
+  EBN_REQUIRE(dY && xhat && relu_out && gamma && istd0 && istd1 && dX && dgamma && dbeta && dbias, EBN_ERR_BAD_ARG);
+  EBN_REQUIRE(R0 >= 0 && R1 >= 0 && Ccols > 0, EBN_ERR_BAD_ARG);
+  EBN_REQUIRE(R0 <= STRIP_ROWS && R1 <= STRIP_ROWS, EBN_ERR_UNSUPPORTED);
+  if (R0 + R1 == 0) return EBN_OK;
+  const EbnDrop dr = ebn_make_drop(st, site, drop_p);
+  hipLaunchKernelGGL(bn2_relu_bwd_strip_kernel, dim3(static_cast<unsigned>(ebn_ceil_div(Ccols, STRIP_COLS))), dim3(1024), 0,
+                     ebn_stream(stream), dY, xhat, relu_out, gamma, istd0, istd1, dX, dgamma, dbeta, dbias, static_cast<int>(R0),
+                     static_cast<int>(R1), Ccols, dr.key_ptr, dr.thresh, dr.scale);
   EBN_CHECK_LAUNCH();
   return EBN_OK;
 }

@@ -160,40 +160,39 @@ __global__ __launch_bounds__(256) void adam_keras_fixed_kernel(float* __restrict
                                                                int32_t* __restrict__ range_flag) {
   const float alpha = st->adam_alpha;
   bool bad = false;
-  for (int64_t i = (static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x) * 2; i < n;
-       i += static_cast<int64_t>(gridDim.x) * 512) {
-    if (i + 1 < n) {  // two elements per thread: 16-byte accumulator load, 8-byte float loads
-      const longlong2 q = *reinterpret_cast<const longlong2*>(acc + i);
-      float2 t = *reinterpret_cast<const float2*>(theta + i), mm = *reinterpret_cast<const float2*>(m + i),
-             vv = *reinterpret_cast<const float2*>(v + i);
-      const float g0 = static_cast<float>(static_cast<double>(q.x) * (1.0 / FIXED_SCALE)) * gscale;
-      const float g1 = static_cast<float>(static_cast<double>(q.y) * (1.0 / FIXED_SCALE)) * gscale;
-      mm.x = mm.x + (g0 - mm.x) * omb1;
-      vv.x = vv.x + (g0 * g0 - vv.x) * omb2;
-      t.x = t.x - alpha * mm.x / (sqrtf(vv.x) + eps);
-      mm.y = mm.y + (g1 - mm.y) * omb1;
-      vv.y = vv.y + (g1 * g1 - vv.y) * omb2;
-      t.y = t.y - alpha * mm.y / (sqrtf(vv.y) + eps);
-      *reinterpret_cast<float2*>(theta + i) = t;
-      *reinterpret_cast<float2*>(m + i) = mm;
-      *reinterpret_cast<float2*>(v + i) = vv;
-      if (q.x != 0 || q.y != 0) {
-        *reinterpret_cast<longlong2*>(acc + i) = make_longlong2(0, 0);
-        bad |= q.x >= FIXED_SUM_MAX || q.x <= -FIXED_SUM_MAX || q.y >= FIXED_SUM_MAX || q.y <= -FIXED_SUM_MAX;
-      }
-    } else {
-      const long long q = acc[i];
-      const float g = static_cast<float>(static_cast<double>(q) * (1.0 / FIXED_SCALE)) * gscale;
-      const float mm = m[i] + (g - m[i]) * omb1, vv = v[i] + (g * g - v[i]) * omb2;
-      m[i] = mm;
-      v[i] = vv;
-      theta[i] = theta[i] - alpha * mm / (sqrtf(vv) + eps);
-      if (q != 0) {
-        acc[i] = 0;
-        bad |= q >= FIXED_SUM_MAX || q <= -FIXED_SUM_MAX;
-      }
-    }
+#define EBN_ADAMQ(T, Q, M, V)                                                                    \
+  {                                                                                              \
+    const float gg = static_cast<float>(static_cast<double>(Q) * (1.0 / FIXED_SCALE)) * gscale; \
+    (M) = (M) + (gg - (M)) * omb1;                                                               \
+    (V) = (V) + (gg * gg - (V)) * omb2;                                                          \
+    (T) = (T) - alpha * (M) / (sqrtf(V) + eps);                                                  \
+    bad |= (Q) >= FIXED_SUM_MAX || (Q) <= -FIXED_SUM_MAX;                                        \
   }
+  const int64_t n4 = n / 4;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n4; i += static_cast<int64_t>(gridDim.x) * 256) {
+    const longlong2 q0 = reinterpret_cast<const longlong2*>(acc)[2 * i], q1 = reinterpret_cast<const longlong2*>(acc)[2 * i + 1];
+    float4 t = reinterpret_cast<const float4*>(theta)[i], mm = reinterpret_cast<const float4*>(m)[i],
+           vv = reinterpret_cast<const float4*>(v)[i];
+    EBN_ADAMQ(t.x, q0.x, mm.x, vv.x)
+    EBN_ADAMQ(t.y, q0.y, mm.y, vv.y)
+    EBN_ADAMQ(t.z, q1.x, mm.z, vv.z)
+    EBN_ADAMQ(t.w, q1.y, mm.w, vv.w)
+    reinterpret_cast<float4*>(theta)[i] = t;
+    reinterpret_cast<float4*>(m)[i] = mm;
+    reinterpret_cast<float4*>(v)[i] = vv;
+    if ((q0.x | q0.y) != 0) reinterpret_cast<longlong2*>(acc)[2 * i] = make_longlong2(0, 0);
+    if ((q1.x | q1.y) != 0) reinterpret_cast<longlong2*>(acc)[2 * i + 1] = make_longlong2(0, 0);
+  }
+  for (int64_t i = n4 * 4 + static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * 256) {
+    const long long q = acc[i];
+    float t = theta[i], mm = m[i], vv = v[i];
+    EBN_ADAMQ(t, q, mm, vv)
+    theta[i] = t;
+    m[i] = mm;
+    v[i] = vv;
+    if (q != 0) acc[i] = 0;
+  }
+#undef EBN_ADAMQ
   if (bad && range_flag != nullptr) *range_flag = 1;
 }
 
@@ -256,10 +255,9 @@ extern "C" int ebn_adam_keras_step_fixed_f32(float* theta, int64_t* acc, float* 
                                              const ebn_step_state* st, double beta1, double beta2, double eps_d,
                                              float grad_scale, int32_t* range_flag, ebn_stream_t stream) {
   EBN_REQUIRE(theta && acc && m && v && st && n >= 0, EBN_ERR_BAD_ARG);
-  EBN_REQUIRE(ebn_aligned16(acc) && (reinterpret_cast<uintptr_t>(theta) & 7u) == 0 && (reinterpret_cast<uintptr_t>(m) & 7u) == 0 &&
-                  (reinterpret_cast<uintptr_t>(v) & 7u) == 0, EBN_ERR_ALIGN);
+  EBN_REQUIRE(ebn_aligned16(acc) && ebn_aligned16(theta) && ebn_aligned16(m) && ebn_aligned16(v), EBN_ERR_ALIGN);
   if (n == 0) return EBN_OK;
-  int64_t grid = ebn_ceil_div(ebn_ceil_div(n, 2), 256);
+  int64_t grid = ebn_ceil_div(ebn_ceil_div(n, 4), 256);
   if (grid > 256 * 16) grid = 256 * 16;
   hipLaunchKernelGGL(adam_keras_fixed_kernel, dim3(static_cast<unsigned>(grid)), dim3(256), 0, ebn_stream(stream), theta,
                      reinterpret_cast<long long*>(acc), m, v, n, st, static_cast<float>(1.0 - beta1),

@@ -103,35 +103,27 @@ __global__ __launch_bounds__(64) void score_loss_bwd_kernel(const float* __restr
   }
 }
 
-// Training step, small batches: scorer forward, compiled loss, its backward into the representations and the batch loss
-// in ONE single-workgroup launch (the three separate kernels above sit at the ~4.5 us launch floor each and the step is a
-// chain of dependent launches).  16 waves take the impressions round-robin; the per-impression losses meet in LDS and are
-// summed in a fixed order (deterministic).  Same arithmetic, operation for operation, as score_fwd_kernel (mode 0) +
-// score_loss_bwd_kernel + sum_kernel.
-constexpr int TRAIN_WAVES = 16;
-constexpr int TRAIN_CMAX = 64;
-__global__ __launch_bounds__(64 * TRAIN_WAVES) void score_loss_train_kernel(
+// Training step: scorer forward (softmax model, nrms.py:201-202), compiled loss and its backward into the representations
+// in ONE launch, one 4-wave workgroup per impression -- score_fwd_kernel (mode 0) + score_loss_bwd_kernel, operation for
+// operation (each sits at the ~5 us launch floor of a chain of dependent launches when run separately).
+__global__ __launch_bounds__(256) void score_loss_train_kernel(
     const float* __restrict__ cand, const float* __restrict__ user, const float* __restrict__ labels,
-    float* __restrict__ scores, float* __restrict__ probs, float* __restrict__ loss_rows, float* __restrict__ loss_out,
-    float* __restrict__ dcand, float* __restrict__ duser, int B, int C, int E, int loss_kind, float inv_batch) {
-  __shared__ float s_all[TRAIN_WAVES][TRAIN_CMAX];   // scores, then ds, of the impression a wave is working on
-  extern __shared__ float s_loss[];                   // B per-impression losses
+    float* __restrict__ scores, float* __restrict__ probs, float* __restrict__ loss_rows, float* __restrict__ dcand,
+    float* __restrict__ duser, int C, int E, int loss_kind, float inv_batch) {
+  extern __shared__ float sm[];  // C scores, then C ds
+  const int64_t b = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float* sm = s_all[wave];
-  for (int b = wave; b < B; b += TRAIN_WAVES) {
-    const float* u = user + static_cast<int64_t>(b) * E;
-    const float* y = labels + static_cast<int64_t>(b) * C;
-    for (int c = 0; c < C; ++c) {
-      const float* x = cand + (static_cast<int64_t>(b) * C + c) * E;
-      float part = 0.f;
-      for (int e = lane; e < E; e += 64) part = fmaf(x[e], u[e], part);
-      part = ebn_wave_sum(part);
-      if (lane == 0) sm[c] = part;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // softmax output of the train model (nrms.py:202) and the raw scores
+  const float* u = user + b * E;
+  for (int c = wave; c < C; c += 4) {
+    const float* x = cand + (b * C + c) * E;
+    float part = 0.f;
+    for (int e = lane; e < E; e += 64) part = fmaf(x[e], u[e], part);
+    part = ebn_wave_sum(part);
+    if (lane == 0) sm[c] = part;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const float* y = labels + b * C;
     float mx = -INFINITY, ysum = 0.f;
     for (int c = lane; c < C; c += 64) {
       mx = fmaxf(mx, sm[c]);
@@ -142,50 +134,38 @@ __global__ __launch_bounds__(64 * TRAIN_WAVES) void score_loss_train_kernel(
     float se = 0.f;
     for (int c = lane; c < C; c += 64) se += expf(sm[c] - mx);
     se = ebn_wave_sum(se);
+    const float lse = mx + logf(se);
     float loss = 0.f;
-    float dsv = 0.f;  // C <= 64: lane c owns ds[c]
-    if (lane < C) {
-      const float sc = sm[lane];
-      scores[static_cast<int64_t>(b) * C + lane] = sc;
-      probs[static_cast<int64_t>(b) * C + lane] = expf(sc - mx) / se;
+    for (int c = lane; c < C; c += 64) {
+      const float sc = sm[c];
+      scores[b * C + c] = sc;
+      probs[b * C + c] = expf(sc - mx) / se;
+      float ds;
       if (loss_kind == 0) {
-        const float logp = sc - (mx + logf(se));
-        loss = -(y[lane] * logp);
-        dsv = (expf(logp) * ysum - y[lane]) * inv_batch;
+        const float logp = sc - lse;
+        loss -= y[c] * logp;
+        ds = (expf(logp) * ysum - y[c]) * inv_batch;
       } else {
         const float invbc = inv_batch / static_cast<float>(C);
-        loss = fmaxf(sc, 0.f) - sc * y[lane] + log1pf(expf(-fabsf(sc)));
-        dsv = (1.0f / (1.0f + expf(-sc)) - y[lane]) * invbc;
+        loss += fmaxf(sc, 0.f) - sc * y[c] + log1pf(expf(-fabsf(sc)));
+        ds = (1.0f / (1.0f + expf(-sc)) - y[c]) * invbc;
       }
+      sm[C + c] = ds;
     }
     loss = ebn_wave_sum(loss) * (loss_kind == 0 ? inv_batch : inv_batch / static_cast<float>(C));
-    __builtin_amdgcn_wave_barrier();
-    if (lane < C) sm[lane] = dsv;
-    if (lane == 0) {
-      s_loss[b] = loss;
-      loss_rows[b] = loss;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    for (int e = lane; e < E; e += 64) {
-      const float ue = u[e];
-      float du = 0.f;
-      for (int c = 0; c < C; ++c) {
-        const float ds = sm[c];
-        const int64_t off = (static_cast<int64_t>(b) * C + c) * E + e;
-        du = fmaf(ds, cand[off], du);
-        dcand[off] = ds * ue;
-      }
-      duser[static_cast<int64_t>(b) * E + e] = du;
-    }
-    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) loss_rows[b] = loss;
   }
   __syncthreads();
-  if (threadIdx.x == 0) {  // fixed-order sum of at most a few hundred values
-    float t = 0.f;
-    for (int b = 0; b < B; ++b) t += s_loss[b];
-    *loss_out = t;
+  const float* ds = sm + C;
+  for (int e = threadIdx.x; e < E; e += 256) {
+    const float ue = u[e];
+    float du = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const int64_t off = (b * C + c) * E + e;
+      du = fmaf(ds[c], cand[off], du);
+      dcand[off] = ds[c] * ue;
+    }
+    duser[b * E + e] = du;
   }
 }
 
@@ -328,21 +308,13 @@ extern "C" int ebn_score_loss_train_f32(const float* cand, const float* user, co
                                         ebn_stream_t stream) {
   EBN_REQUIRE(cand && user && labels && scores && probs && loss_rows && loss_out && dcand && duser, EBN_ERR_BAD_ARG);
   EBN_REQUIRE(B >= 0 && C > 0 && E > 0, EBN_ERR_BAD_ARG);
-  EBN_REQUIRE(loss_kind == 0 || loss_kind == 1, EBN_ERR_UNSUPPORTED);
+  EBN_REQUIRE(C <= 8192 && (loss_kind == 0 || loss_kind == 1), EBN_ERR_UNSUPPORTED);
   if (B == 0) return EBN_OK;
-  if (B <= 256 && C <= TRAIN_CMAX) {
-    hipLaunchKernelGGL(score_loss_train_kernel, dim3(1), dim3(64 * TRAIN_WAVES), static_cast<size_t>(B) * sizeof(float),
-                       ebn_stream(stream), cand, user, labels, scores, probs, loss_rows, loss_out, dcand, duser,
-                       static_cast<int>(B), C, E, loss_kind, inv_batch);
-    EBN_CHECK_LAUNCH();
-    return EBN_OK;
-  }
-  // large batches / wide candidate lists: one workgroup per impression, three launches
-  int rc = ebn_score_fwd_f32(cand, user, scores, probs, B, C, E, 0, stream);
-  if (rc != EBN_OK) return rc;
-  rc = ebn_score_loss_bwd_f32(cand, user, scores, labels, loss_rows, dcand, duser, B, C, E, loss_kind, inv_batch, stream);
-  if (rc != EBN_OK) return rc;
-  return ebn_sum_f32(loss_rows, B, 1.0f, loss_out, 0, stream);
+  hipLaunchKernelGGL(score_loss_train_kernel, dim3(static_cast<unsigned>(B)), dim3(256), 2 * C * sizeof(float),
+                     ebn_stream(stream), cand, user, labels, scores, probs, loss_rows, dcand, duser, C, E, loss_kind,
+                     inv_batch);
+  EBN_CHECK_LAUNCH();
+  return ebn_sum_f32(loss_rows, B, 1.0f, loss_out, 0, stream);  // fixed-order reduction: deterministic batch loss
 }
 
 extern "C" int ebn_pair_score_f32(const float* user, const float* news, const int32_t* u_idx,

@@ -16,6 +16,7 @@ import torch
 from ebrec import _hip
 
 SITE_MLP0 = 8
+STRIP_ROWS = 1024  # rows per call site the single-launch two-site BatchNorm kernels take (csrc/ebn_dense.hip)
 
 
 class MLPStack:
@@ -81,14 +82,20 @@ class MLPStack:
             R = b["R"][l]
             _hip.call("ebn_dense_relu_fwd_f32", N, u, prev, _hip.ptr(x), prev, _hip.ptr(self._pv(f"d{l}_W")), u,
                       _hip.ptr(self._pv(f"d{l}_b")), _hip.ptr(R), u, _hip.ptr(b["ws"]), b["ws"].numel(), S())
-            for site, (r0, nr) in enumerate(((0, n0), (n0, n1))):
-                if nr == 0:
-                    continue
-                _hip.call("ebn_batchnorm_fwd_f32", _hip.ptr(R[r0:]), _hip.ptr(self._pv(f"bn{l}_g")), _hip.ptr(self._pv(f"bn{l}_b")),
-                          _hip.ptr(self.bn_mean[l]), _hip.ptr(self.bn_var[l]), _hip.ptr(b["Xn"][l][r0:]),
-                          _hip.ptr(b["xhat"][l][r0:]), _hip.ptr(b["mean"][l][site]), _hip.ptr(b["istd"][l][site]),
-                          _hip.ptr(b["partials"]), nr, u, 1 if train else 0, st, SITE_MLP0 + l,
-                          ctypes.c_float(p if train else 0.0), ctypes.c_int64(r0 * u), S())
+            if train and max(n0, n1) <= STRIP_ROWS:  # both call sites in one launch
+                _hip.call("ebn_batchnorm2_fwd_f32", _hip.ptr(R), _hip.ptr(self._pv(f"bn{l}_g")), _hip.ptr(self._pv(f"bn{l}_b")),
+                          _hip.ptr(self.bn_mean[l]), _hip.ptr(self.bn_var[l]), _hip.ptr(b["Xn"][l]), _hip.ptr(b["xhat"][l]),
+                          _hip.ptr(b["mean"][l][0]), _hip.ptr(b["istd"][l][0]), _hip.ptr(b["mean"][l][1]), _hip.ptr(b["istd"][l][1]),
+                          n0, n1, u, st, SITE_MLP0 + l, ctypes.c_float(p), S())
+            else:
+                for site, (r0, nr) in enumerate(((0, n0), (n0, n1))):
+                    if nr == 0:
+                        continue
+                    _hip.call("ebn_batchnorm_fwd_f32", _hip.ptr(R[r0:]), _hip.ptr(self._pv(f"bn{l}_g")), _hip.ptr(self._pv(f"bn{l}_b")),
+                              _hip.ptr(self.bn_mean[l]), _hip.ptr(self.bn_var[l]), _hip.ptr(b["Xn"][l][r0:]),
+                              _hip.ptr(b["xhat"][l][r0:]), _hip.ptr(b["mean"][l][site]), _hip.ptr(b["istd"][l][site]),
+                              _hip.ptr(b["partials"]), nr, u, 1 if train else 0, st, SITE_MLP0 + l,
+                              ctypes.c_float(p if train else 0.0), ctypes.c_int64(r0 * u), S())
             x, prev = b["Xn"][l], u
         return x
 
@@ -102,16 +109,21 @@ class MLPStack:
             u = self.units[l]
             x_in, din = (b["Xn"][l - 1], self.units[l - 1]) if l else (x0, self.din)
             dR = b["dB"][l]
-            for site, (r0, nr) in enumerate(((0, n0), (n0, n1))):
-                if nr == 0:
-                    continue
-                first = (site == 0) or (n0 == 0)
-                _hip.call("ebn_batchnorm_bwd_f32", _hip.ptr(dY[r0:]), _hip.ptr(b["xhat"][l][r0:]), _hip.ptr(self._pv(f"bn{l}_g")),
-                          _hip.ptr(b["istd"][l][site]), _hip.ptr(dR[r0:]), _hip.ptr(self._g(f"bn{l}_g")), _hip.ptr(self._g(f"bn{l}_b")),
-                          _hip.ptr(b["partials"]), nr, u, 1, 0 if first else 1, st, SITE_MLP0 + l, ctypes.c_float(p),
-                          ctypes.c_int64(r0 * u), S())
-            _hip.call("ebn_bias_relu_bwd_f32", _hip.ptr(b["R"][l]), _hip.ptr(dR), _hip.ptr(dR), _hip.ptr(self._g(f"d{l}_b")),
-                      _hip.ptr(b["partials"]), N, u, 0, S())
+            if max(n0, n1) <= STRIP_ROWS:  # BN backward of both call sites + the ReLU backward / bias gradient of the Dense: one launch
+                _hip.call("ebn_batchnorm2_relu_bwd_f32", _hip.ptr(dY), _hip.ptr(b["xhat"][l]), _hip.ptr(b["R"][l]), _hip.ptr(self._pv(f"bn{l}_g")),
+                          _hip.ptr(b["istd"][l][0]), _hip.ptr(b["istd"][l][1]), _hip.ptr(dR), _hip.ptr(self._g(f"bn{l}_g")),
+                          _hip.ptr(self._g(f"bn{l}_b")), _hip.ptr(self._g(f"d{l}_b")), n0, n1, u, st, SITE_MLP0 + l, ctypes.c_float(p), S())
+            else:
+                for site, (r0, nr) in enumerate(((0, n0), (n0, n1))):
+                    if nr == 0:
+                        continue
+                    first = (site == 0) or (n0 == 0)
+                    _hip.call("ebn_batchnorm_bwd_f32", _hip.ptr(dY[r0:]), _hip.ptr(b["xhat"][l][r0:]), _hip.ptr(self._pv(f"bn{l}_g")),
+                              _hip.ptr(b["istd"][l][site]), _hip.ptr(dR[r0:]), _hip.ptr(self._g(f"bn{l}_g")), _hip.ptr(self._g(f"bn{l}_b")),
+                              _hip.ptr(b["partials"]), nr, u, 1, 0 if first else 1, st, SITE_MLP0 + l, ctypes.c_float(p),
+                              ctypes.c_int64(r0 * u), S())
+                _hip.call("ebn_bias_relu_bwd_f32", _hip.ptr(b["R"][l]), _hip.ptr(dR), _hip.ptr(dR), _hip.ptr(self._g(f"d{l}_b")),
+                          _hip.ptr(b["partials"]), N, u, 0, S())
             self.gemm(1, 0, din, u, N, x_in, din, dR, u, 0.0, self._g(f"d{l}_W"), u, b["ws"])
             if l:
                 self.gemm(0, 1, N, din, u, dR, u, self._pv(f"d{l}_W"), u, 0.0, b["dA"][l - 1], din, b["ws"])

@@ -260,9 +260,8 @@ int ebn_score_loss_bwd_f32(const float* cand, const float* user, const float* sc
                            const float* labels, float* loss_rows, float* dcand, float* duser,
                            int64_t B, int32_t C, int32_t E, int32_t loss_kind, float inv_batch,
                            ebn_stream_t stream);
-/* Training step: ebn_score_fwd_f32 (softmax mode) + ebn_score_loss_bwd_f32 + the batch loss loss_out[0] = sum(loss_rows),
- * same arithmetic, as ONE launch for the batch sizes of a training step (B <= 256, C <= 64; larger shapes run the three
- * kernels).  nrms.py:201-202 + nrms.py:56-67 and their backward.                                                        */
+/* Training step: ebn_score_fwd_f32 (softmax mode) + ebn_score_loss_bwd_f32 as ONE launch (same arithmetic), followed by the
+ * batch loss loss_out[0] = sum(loss_rows).  nrms.py:201-202 + nrms.py:56-67 and their backward.                      */
 int ebn_score_loss_train_f32(const float* cand, const float* user, const float* labels, float* scores, float* probs,
                              float* loss_rows, float* loss_out, float* dcand, float* duser, int64_t B, int32_t C,
                              int32_t E, int32_t loss_kind, float inv_batch, ebn_stream_t stream);
@@ -304,6 +303,20 @@ int ebn_batchnorm_bwd_f32(const float* dY, const float* xhat, const float* gamma
                           float* partials, int64_t R, int32_t Ccols, int32_t training,
                           int32_t accumulate, const ebn_step_state* st, int32_t site,
                           float drop_p, int64_t elem_offset, ebn_stream_t stream);
+/* The two TimeDistributed call sites of a TRAINING step in one launch each way (rows [0,R0) = history block, [R0,R0+R1)
+ * = candidate block of one row block; R0, R1 <= 1024, else EBN_ERR_UNSUPPORTED and the caller uses the per-site entry
+ * points): forward = two ebn_batchnorm_fwd_f32 (own batch statistics, two moving-average updates, history first; the
+ * dropout stream is indexed by the element's position in the whole block); backward = two ebn_batchnorm_bwd_f32 with
+ * dgamma/dbeta summed over the sites, followed by ebn_bias_relu_bwd_f32 of the Dense(relu) in front (relu_out = that
+ * Dense's output): dX = d(pre-activation), dbias = its column sums.  nrms_docvec.py:116-124, nrms.py:143-152.          */
+int ebn_batchnorm2_fwd_f32(const float* X, const float* gamma, const float* beta, float* moving_mean, float* moving_var,
+                           float* Y, float* xhat, float* mean_out0, float* istd_out0, float* mean_out1, float* istd_out1,
+                           int64_t R0, int64_t R1, int32_t Ccols, const ebn_step_state* st, int32_t site, float drop_p,
+                           ebn_stream_t stream);
+int ebn_batchnorm2_relu_bwd_f32(const float* dY, const float* xhat, const float* relu_out, const float* gamma,
+                                const float* istd0, const float* istd1, float* dX, float* dgamma, float* dbeta,
+                                float* dbias, int64_t R0, int64_t R1, int32_t Ccols, const ebn_step_state* st, int32_t site,
+                                float drop_p, ebn_stream_t stream);
 
 /* Step prologue: copy up to three device buffers (history ids, candidate ids, labels of a batch handed over as device
  * tensors -- the inputs of nrms.py:170-176) into the step's static buffers with ONE launch; n_i in bytes, multiples

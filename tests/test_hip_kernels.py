@@ -422,8 +422,8 @@ def test_loss_and_backward_into_representations(hip, kind, B, C, E):
 @pytest.mark.parametrize("kind", ["cross_entropy_loss", "log_loss"])
 @pytest.mark.parametrize("B,C,E", [(32, 5, 400), (64, 5, 256), (3, 64, 20), (1, 1, 8), (300, 5, 400), (4, 70, 16)])
 def test_fused_train_scorer_equals_the_three_kernels_and_the_oracle(hip, kind, B, C, E):
-    """ebn_score_loss_train_f32: scorer + loss + backward + batch loss in one launch (B <= 256, C <= 64; otherwise the
-    three kernels run) -- bitwise the separate kernels on scores / probabilities / gradients, oracle-close on the loss."""
+    """ebn_score_loss_train_f32: scorer + loss + backward in one launch (+ the batch-loss reduction) -- bitwise the separate
+    kernels on scores / probabilities / loss rows / gradients, oracle-close on the loss."""
     rng = np.random.default_rng(B * 7 + C)
     cand = (rng.standard_normal((B, C, E)) * 0.4).astype(np.float32)
     user = (rng.standard_normal((B, E)) * 0.4).astype(np.float32)
@@ -645,6 +645,59 @@ def test_fixed_point_range_is_guarded_and_fused_adam_equals_the_two_kernels(hip)
         g = torch.empty(2, 4, device="cuda")
         hip.call("ebn_fixed_to_f32", P(acc), P(g), 8, P(flag), S())
         assert int(flag.item()) == expect, (vals, int(flag.item()))
+
+
+@pytest.mark.parametrize("R0,R1,C,p", [(640, 160, 512, 0.2), (7, 3, 20, 0.0), (1024, 1, 40, 0.5), (5, 0, 16, 0.2)])
+def test_two_site_batchnorm_launches_equal_the_per_site_calls(hip, R0, R1, C, p):
+    """ebn_batchnorm2_fwd_f32 == two ebn_batchnorm_fwd_f32 (history site, then candidate site) bit for bit, and
+    ebn_batchnorm2_relu_bwd_f32 == two ebn_batchnorm_bwd_f32 + ebn_bias_relu_bwd_f32 (bitwise except the bias gradient,
+    whose column sum runs in a different order)."""
+    rng = np.random.default_rng(R0 + C)
+    N = R0 + R1
+    X = np.maximum(rng.standard_normal((N, C)) + 0.3, 0).astype(np.float32)
+    gamma, beta = (1 + 0.1 * rng.standard_normal(C)).astype(np.float32), (0.1 * rng.standard_normal(C)).astype(np.float32)
+    mm0, mv0 = (0.05 * rng.standard_normal(C)).astype(np.float32), (1 + 0.1 * rng.random(C)).astype(np.float32)
+    dY = rng.standard_normal((N, C)).astype(np.float32)
+    st = make_state(seed=3, step=4)
+    site = 9
+    f = lambda *shape: torch.empty(*shape, device="cuda")
+    part = f(int(hip.lib().ebn_colsum_partials_len(N, C)))
+    # reference: per-site entry points
+    mm, mv, Y, xh = dev(mm0), dev(mv0), f(N, C), f(N, C)
+    stats = [[f(C), f(C)], [f(C), f(C)]]
+    dX, dg, db, dbias = f(N, C), f(C), f(C), f(C)
+    Xd, dYd = dev(X), dev(dY)
+    first = True
+    for k, (r0, nr) in enumerate(((0, R0), (R0, R1))):
+        if nr == 0:
+            continue
+        hip.call("ebn_batchnorm_fwd_f32", P(Xd[r0:]), P(dev(gamma)), P(dev(beta)), P(mm), P(mv), P(Y[r0:]), P(xh[r0:]), P(stats[k][0]),
+                 P(stats[k][1]), P(part), nr, C, 1, P(st), site, ctypes.c_float(p), ctypes.c_int64(r0 * C), S())
+    for k, (r0, nr) in enumerate(((0, R0), (R0, R1))):
+        if nr == 0:
+            continue
+        hip.call("ebn_batchnorm_bwd_f32", P(dYd[r0:]), P(xh[r0:]), P(dev(gamma)), P(stats[k][1]), P(dX[r0:]), P(dg), P(db), P(part), nr, C, 1,
+                 0 if first else 1, P(st), site, ctypes.c_float(p), ctypes.c_int64(r0 * C), S())
+        first = False
+    hip.call("ebn_bias_relu_bwd_f32", P(Xd), P(dX), P(dX), P(dbias), P(part), N, C, 0, S())
+    # two-site entry points
+    mm2, mv2, Y2, xh2 = dev(mm0), dev(mv0), f(N, C), f(N, C)
+    stats2 = [[torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")] for _ in range(2)]
+    hip.call("ebn_batchnorm2_fwd_f32", P(Xd), P(dev(gamma)), P(dev(beta)), P(mm2), P(mv2), P(Y2), P(xh2), P(stats2[0][0]), P(stats2[0][1]),
+             P(stats2[1][0]), P(stats2[1][1]), R0, R1, C, P(st), site, ctypes.c_float(p), S())
+    dX2, dg2, db2, dbias2 = f(N, C), f(C), f(C), f(C)
+    hip.call("ebn_batchnorm2_relu_bwd_f32", P(dYd), P(xh2), P(Xd), P(dev(gamma)), P(stats2[0][1]), P(stats2[1][1]), P(dX2), P(dg2), P(db2),
+             P(dbias2), R0, R1, C, P(st), site, ctypes.c_float(p), S())
+    for a, b, what in ((Y2, Y, "Y"), (xh2, xh, "xhat"), (dX2, dX, "dX"), (dg2, dg, "dgamma"), (db2, db, "dbeta")):
+        assert torch.equal(a, b), what
+    for a, b, what in ((mm2, mm, "moving mean"), (mv2, mv, "moving var")):  # two chained updates in registers: fma contraction may differ
+        assert_close(host(a), host(b), rtol=1e-6, atol=1e-8, what=what)
+    for k, nr in enumerate((R0, R1)):
+        if nr:
+            assert torch.equal(stats2[k][0], stats[k][0]) and torch.equal(stats2[k][1], stats[k][1])
+    assert_close(host(dbias2), host(dbias), rtol=1e-5, atol=1e-5, what="dbias")
+    assert hip.lib().ebn_batchnorm2_fwd_f32(P(Xd), P(dev(gamma)), P(dev(beta)), P(mm2), P(mv2), P(Y2), P(xh2), P(stats2[0][0]), P(stats2[0][1]),
+                                            P(stats2[1][0]), P(stats2[1][1]), 1025, 1, C, P(st), site, ctypes.c_float(p), S()) == -2
 
 
 @pytest.mark.parametrize("M,N,K", [(800, 512, 768), (160, 256, 512), (37, 20, 12), (1300, 64, 40), (5, 7, 3)])
