@@ -506,6 +506,173 @@ int launch_gemm(int transA, int transB, int64_t M, int64_t N, int64_t K, float a
   return EBN_OK;
 }
 
+
+// ---- small-output GEMMs: 32x32 block tile from v_mfma_f32_16x16x4_f32, 32-deep K slabs, one launch ---------------
+// The user encoder (640 rows) and the NRMSDocVec MLP (800 rows) multiply matrices whose OUTPUT has only a few hundred
+// 64x64 tiles: fewer workgroups than CUs.  The big-tile kernel above fills the chip by splitting K and paying a second
+// (reduce) launch; at these sizes both launches sit at the ~5 us floor of a dependent chain.  Here a 256-thread
+// workgroup owns a 32x32 tile (4 waves as 2x2, each one 16x16 MFMA tile), so a 640x1200 output is 760 workgroups and
+// needs no split; a slab is 32 deep (fewer barriers per FLOP, 8 MFMAs per wave between them) and both operand tiles sit
+// in LDS as [mn][k] with the lane's 8 contraction indices contiguous (k = 8*quarter + step, identical for A and B), i.e.
+// two ds_read_b128 per operand and slab.  Exact fp32 like the big kernel (an fp32 fma chain per output element).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int SBM = 32, SBN = 32;
+constexpr int SBK = 128;       // slab depth: these GEMMs are load-latency bound (one or two workgroups per CU), so a slab
+                               // carries 4 x 16 bytes per thread and operand -- 4x the bytes in flight of a 32-deep slab
+constexpr int SLD = SBK + 4;   // LDS row stride (floats): 16-byte rows; the 16 rows of a b128 read group cover all 64 banks
+constexpr int SPT = SBM * SBK / 4 / GEMM_THREADS;  // float4 per thread, operand and slab (4)
+
+// One operand tile = SPT float4 per thread.  KC: memory is [mn][k] (k contiguous): item v -> row v/32, k 4*(v%32); else memory
+// is [k][mn]: item v -> k v/8, mn 4*(v%8).  Out-of-range k is zero-filled (it feeds real outputs), out-of-range mn is clamped
+// (it only feeds outputs that are never stored).  VEC: 16-byte loads (aligned base/ld, extents % 4 == 0).  All loads are
+// unconditional with clamped offsets; validity is applied with selects.
+template <bool KC, bool VEC>
+__device__ __forceinline__ void small_load(float4 (&r)[SPT], const float* __restrict__ P, int64_t ld, int64_t mn0, int64_t k0,
+                                           int64_t MN, int64_t Kend, int tid) {
+#pragma unroll
+  for (int i = 0; i < SPT; ++i) {
+    const int v = tid + i * GEMM_THREADS;
+    if (KC) {
+      int64_t mn = mn0 + v / (SBK / 4);
+      mn = mn < MN ? mn : MN - 1;
+      const int64_t k = k0 + (v % (SBK / 4)) * 4;
+      const float* p = P + mn * ld;
+      if (VEC) {
+        const bool ok = k < Kend;  // K % 4 == 0: a float4 is all in or all out
+        const float4 t = *reinterpret_cast<const float4*>(p + (ok ? k : 0));
+        r[i] = make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
+      } else {
+        const float t0 = p[k + 0 < Kend ? k + 0 : 0], t1 = p[k + 1 < Kend ? k + 1 : 0], t2 = p[k + 2 < Kend ? k + 2 : 0],
+                    t3 = p[k + 3 < Kend ? k + 3 : 0];
+        r[i] = make_float4(k + 0 < Kend ? t0 : 0.f, k + 1 < Kend ? t1 : 0.f, k + 2 < Kend ? t2 : 0.f, k + 3 < Kend ? t3 : 0.f);
+      }
+    } else {
+      const int64_t k = k0 + v / (SBM / 4);
+      const bool kok = k < Kend;
+      const float* p = P + (kok ? k : 0) * ld;
+      const int64_t mn = mn0 + (v % (SBM / 4)) * 4;
+      if (VEC) {
+        const float4 t = *reinterpret_cast<const float4*>(p + (mn + 3 < MN ? mn : MN - 4));  // MN % 4 == 0
+        r[i] = make_float4(kok ? t.x : 0.f, kok ? t.y : 0.f, kok ? t.z : 0.f, kok ? t.w : 0.f);
+      } else {
+        const float t0 = p[mn + 0 < MN ? mn + 0 : MN - 1], t1 = p[mn + 1 < MN ? mn + 1 : MN - 1],
+                    t2 = p[mn + 2 < MN ? mn + 2 : MN - 1], t3 = p[mn + 3 < MN ? mn + 3 : MN - 1];
+        r[i] = make_float4(kok ? t0 : 0.f, kok ? t1 : 0.f, kok ? t2 : 0.f, kok ? t3 : 0.f);
+      }
+    }
+  }
+}
+
+template <bool KC>
+__device__ __forceinline__ void small_store(float* __restrict__ S, const float4 (&r)[SPT], int tid) {
+#pragma unroll
+  for (int i = 0; i < SPT; ++i) {
+    const int v = tid + i * GEMM_THREADS;
+    if (KC) {
+      *reinterpret_cast<float4*>(&S[(v / (SBK / 4)) * SLD + (v % (SBK / 4)) * 4]) = r[i];
+    } else {  // k = v/8, rows 4*(v%8)..+3: transposed scalar stores
+      const int k = v / (SBM / 4), m4 = (v % (SBM / 4)) * 4;
+      S[(m4 + 0) * SLD + k] = r[i].x;
+      S[(m4 + 1) * SLD + k] = r[i].y;
+      S[(m4 + 2) * SLD + k] = r[i].z;
+      S[(m4 + 3) * SLD + k] = r[i].w;
+    }
+  }
+}
+
+template <bool TA, bool TB, bool VECA, bool VECB>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_small_kernel(int64_t M, int64_t N, int64_t K, float alpha,
+                                                                  const float* __restrict__ A, int64_t lda,
+                                                                  const float* __restrict__ B, int64_t ldb, float beta,
+                                                                  float* __restrict__ C, int64_t ldc, GemmEpi epi) {
+  extern __shared__ __attribute__((aligned(16))) float smem_small[];  // [2 buffers][A tile | B tile]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t m0 = static_cast<int64_t>(blockIdx.y) * SBM, n0 = static_cast<int64_t>(blockIdx.x) * SBN;
+  const int nk = static_cast<int>((K + SBK - 1) / SBK);
+  constexpr int TILE = SBM * SLD;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  float4 ra[SPT], rb[SPT];
+  small_load<!TA, VECA>(ra, A, lda, m0, 0, M, K, tid);
+  small_load<TB, VECB>(rb, B, ldb, n0, 0, N, K, tid);
+  small_store<!TA>(smem_small, ra, tid);
+  small_store<TB>(smem_small + TILE, rb, tid);
+  __syncthreads();
+  const int r16 = lane & 15, kq = lane >> 4;
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) {  // next slab into registers while this one is multiplied
+      small_load<!TA, VECA>(ra, A, lda, m0, static_cast<int64_t>(kt + 1) * SBK, M, K, tid);
+      small_load<TB, VECB>(rb, B, ldb, n0, static_cast<int64_t>(kt + 1) * SBK, N, K, tid);
+    }
+    const float* ap = smem_small + cur * 2 * TILE + (wm * 16 + r16) * SLD + kq * 8;
+    const float* bp = smem_small + cur * 2 * TILE + TILE + (wn * 16 + r16) * SLD + kq * 8;
+    const int groups = static_cast<int>((K - static_cast<int64_t>(kt) * SBK + 31) / 32);  // 32-deep groups with real k in them
+#pragma unroll
+    for (int g = 0; g < SBK / 32; ++g) {
+      if (g >= groups) break;  // wave-uniform: the zero-filled tail of the last slab is not multiplied
+      // contraction index of MFMA step s in lane quarter kq: k = 32 g + 8 kq + s (the same for A and B)
+      const float4 a0 = *reinterpret_cast<const float4*>(ap + 32 * g), a1 = *reinterpret_cast<const float4*>(ap + 32 * g + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(bp + 32 * g), b1 = *reinterpret_cast<const float4*>(bp + 32 * g + 4);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b1.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b1.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, acc, 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+      small_store<!TA>(smem_small + (cur ^ 1) * 2 * TILE, ra, tid);
+      small_store<TB>(smem_small + (cur ^ 1) * 2 * TILE + TILE, rb, tid);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  // C/D map of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + r
+  const int64_t col = n0 + wn * 16 + r16;
+  if (col >= N) return;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t row = m0 + wm * 16 + 4 * kq + r;
+    if (row >= M) continue;
+    float v = alpha * acc[r];
+    if (beta != 0.f) v += beta * C[row * ldc + col];
+    if (epi.rs != nullptr)
+      v = fmaf(epi.rs[row], epi.cv[static_cast<int64_t>(static_cast<uint32_t>(row) / static_cast<uint32_t>(epi.L)) * epi.ldcv + col], v);
+    if (epi.bias != nullptr) v = fmaxf(v + epi.bias[col], 0.f);
+    C[row * ldc + col] = v;
+  }
+}
+
+int launch_gemm_small(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda,
+                      const float* B, int64_t ldb, float beta, float* C, int64_t ldc, int vecA, int vecB, hipStream_t s,
+                      GemmEpi epi) {
+  const dim3 grid(static_cast<unsigned>(ebn_ceil_div(N, SBN)), static_cast<unsigned>(ebn_ceil_div(M, SBM))), block(GEMM_THREADS);
+  constexpr size_t lds = static_cast<size_t>(2) * 2 * SBM * SLD * sizeof(float);  // 67.6 KB: above the 64 KB default limit
+#define EBN_SMALL_ONE(TA, TB, VA, VB)                                                                                     \
+  do {                                                                                                                     \
+    static const hipError_t attr__ = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_small_kernel<TA, TB, VA, VB>), \
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)); \
+    if (attr__ != hipSuccess) return static_cast<int>(attr__);                                                            \
+    hipLaunchKernelGGL((gemm_small_kernel<TA, TB, VA, VB>), grid, block, lds, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, epi); \
+  } while (0)
+#define EBN_SMALL(TA, TB)                              \
+  do {                                                 \
+    if (vecA && vecB) EBN_SMALL_ONE(TA, TB, true, true); \
+    else EBN_SMALL_ONE(TA, TB, false, false);          \
+  } while (0)
+  if (!transA && !transB) EBN_SMALL(false, false);
+  else if (!transA && transB) EBN_SMALL(false, true);
+  else if (transA && !transB) EBN_SMALL(true, false);
+  else EBN_SMALL(true, true);
+#undef EBN_SMALL
+#undef EBN_SMALL_ONE
+  EBN_CHECK_LAUNCH();
+  return EBN_OK;
+}
+
 }  // namespace
 
 // ---- planner ------------------------------------------------------------------------------------------------
@@ -547,6 +714,21 @@ static GemmPlan gemm_plan(int64_t M, int64_t N, int64_t K, int64_t ws_floats) {
   } kTiles[3] = {{128, 128, 1.15, 1.5, 3}, {256, 64, 1.17, 1.5, 3}, {64, 64, 0.32, 0.48, 4}};
   const double out_mb = static_cast<double>(M) * static_cast<double>(N) * 4e-6;
   GemmPlan best{128, 128, 1, ebn_ceil_div(K > 0 ? K : 1, BK) * BK, 1e300};
+  {
+    // 32x32 tiles, 128-deep slabs, never split (gemm_small_kernel): `W` workgroups on the busiest CU, 2 of them resident
+    // (67 KB of LDS each); a slab costs ~0.8 us per workgroup sharing a CU, ~1.1 us of latency when nothing covers it
+    // (calibrated on tools/gemm_shapes_probe.py c3 / c2: 800x512x768 14.5 us, 640x400x1200 20.9 us, 640x256x200 4.9 us).
+    // Only for outputs that leave the big tiles under-filled and K ranges a single workgroup can walk (no split-K here).
+    const int64_t wgs = ebn_ceil_div(M, SBM) * ebn_ceil_div(N, SBN);
+    const int64_t tiles64 = ebn_ceil_div(M, 64) * ebn_ceil_div(N, 64);
+    if (forced_tile_bm() == 32 || (forced_tile_bm() == 0 && tiles64 <= 256 && K <= 4096)) {
+      const int64_t W = ebn_ceil_div(wgs, 256);
+      const double full = static_cast<double>(W) * 0.8, lone = static_cast<double>(ebn_ceil_div(W, 2)) * 1.1;
+      const double cost = static_cast<double>(ebn_ceil_div(K > 0 ? K : 1, SBK)) * (full > lone ? full : lone) + 3.0;
+      best = GemmPlan{32, 32, 1, ebn_ceil_div(K > 0 ? K : 1, SBK) * SBK, cost};
+      if (forced_tile_bm() == 32) return best;
+    }
+  }
   for (int t = 0; t < 3; ++t) {
     if (kTiles[t].bm == 256 && M < 256) continue;
     if (forced_tile_bm() != 0 && forced_tile_bm() != kTiles[t].bm && !(kTiles[t].bm == 64 && M < 256 && forced_tile_bm() == 256)) continue;
@@ -593,6 +775,8 @@ static int gemm_dispatch(int32_t transA, int32_t transB, int64_t M, int64_t N, i
   const int splits = plan.splits;
   const int64_t kps = plan.kps;
   int rc;
+  if (plan.bm == 32)
+    return launch_gemm_small(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, vecA, vecB, s, epi);
   if (plan.bm == 256)
     rc = launch_gemm<256, 64, 4>(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, vecA, vecB, splits, kps,
                                  workspace, s, site, epi);
