@@ -17,8 +17,9 @@ data-path collective other than the gradient all-reduce.  Inputs are resident in
 timed region starts.
 
 Extra objects on the JSON line:
-  roofline        the time-dominant kernel (the Q|K|V projection GEMM, MFMA-bound), HIP-event timed
-                  inside the timed region
+  roofline        the time-dominant kernel (the Q|K|V projection GEMM, MFMA-bound) on the step's own buffers and
+                  arguments: 10 launches captured into a hipGraph (the launch path of the timed region), HIP events
+                  on the launch stream around 5 replays
   roofline_gather the title-embedding gather (HBM-bound) the metric string names, same method
   cpu_baseline    oracle/nrms_torch.py (fp32 torch-eager port of the reference math; the reference's
                   TF path cannot run here) timed on the host cores over a bounded sample
@@ -155,6 +156,37 @@ def timed_repeats(step_fn, args, sync, world, device):
     return times
 
 
+def time_kernel(fns, sync, reps=10, replays=5):
+    """Average duration of ONE launch of a kernel: `reps` launches (cycling through the launchers `fns` -- e.g. the same
+    gather over the id sets of different batches, so that no launch re-reads rows the previous ones left in the memory-side
+    cache) captured into a hipGraph (the timed region replays graphs too: same launch path, no host in the loop),
+    bracketed by HIP events on the launch stream, replayed `replays` times.  Seconds."""
+    fns = fns if isinstance(fns, (list, tuple)) else [fns]
+    fns[0]()
+    sync()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for i in range(reps):
+            fns[i % len(fns)]()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    g.replay()
+    e1.record()
+    sync()
+    # The chip needs ~50 ms of sustained load after an idle gap before a kernel reaches its steady duration (the first
+    # launches after a host sync run 15-20 % slower: per-launch trace in profiles/r02_gemm_launch_trace.txt), and the timed
+    # region of the benchmark runs in that steady state.  Warm replays without a host sync in between, then the timed ones.
+    warm = int(min(max(0.06 / max(e0.elapsed_time(e1) * 1e-3, 1e-6), 3), 400))
+    for _ in range(warm):
+        g.replay()
+    e0.record()
+    for _ in range(replays):
+        g.replay()
+    e1.record()
+    sync()
+    return e0.elapsed_time(e1) / (reps * replays) * 1e-3
+
+
 def timing_fields(times, args, world, per_gpu_batch):
     """value / ms_per_step from the MEDIAN repeat; spread alongside."""
     ms = sorted(t / args.steps * 1e3 for t in times)
@@ -193,15 +225,14 @@ def bench_docvec(args, c, world, rank, device, sync, dfields):
         batches.append((his, pred, y.to(device)))
     eng.enable_graphs(not args.no_graph)
     times = timed_repeats(lambda k: eng.train_step(*batches[k % 8], indexed=True), args, sync, world, device)
-    # kernel-level roofline: the widest Dense GEMM of the MLP (rows x 768 -> 512), HIP-event timed kernel by kernel
-    eng.kernel_events = {}
-    for k in range(args.steps):
-        eng.train_step(*batches[k % 8], indexed=True)
-    sync()
-    events, eng.kernel_events = eng.kernel_events, None
+    # kernel-level rooflines on the step's own buffers: the document-vector gather (HBM) and the widest Dense GEMM (MFMA)
+    rk = eng.roofline_kernels(c["B"], c["C"])
+    id_sets = [torch.cat([h.reshape(-1), p.reshape(-1)]).contiguous() for h, p, _ in batches]  # the 8 batches' row numbers
+    kt = {"gather": time_kernel([rk["gather"](ids) for ids in id_sets], sync)}
+    if "dense0" in rk:
+        kt["dense0"] = time_kernel(rk["dense0"], sync)
     if rank == 0:
         n_rows = c["B"] * (c["H"] + c["C"])
-        kt = {k: float(np.median([a.elapsed_time(b) for a, b in v])) * 1e-3 for k, v in events.items()}
         line = {"metric": "training impressions/sec", **timing_fields(times, args, world, c["B"]), "unit": "impressions/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup,
                 "launch": "eager" if args.no_graph else "hipGraph replay", "higher_is_better": True, "scaling": "weak",
@@ -211,12 +242,18 @@ def bench_docvec(args, c, world, rank, device, sync, dfields):
                            "global_batch": world * c["B"], "per_gpu_batch": c["B"], "parallelism": f"dp{world}",
                            "final_loss": float(eng.loss_dev.item())}, **dfields}
         gather_bytes = n_rows * (4 + 2 * c["doc"] * 4)
-        if "gather" in kt:
-            line["roofline"] = {"kernel": "gather_rows_vec4_kernel (document-vector gather, the step's only HBM-sized read; the step itself is "
-                                          "launch/latency-bound: ~0.19 GFLOP and 2.5 MB per step)", "bound": "hbm",
-                                "achieved": gather_bytes / kt["gather"] / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": gather_bytes / kt["gather"] / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                                "avg_launch_us": kt["gather"] * 1e6, "algorithmic_bytes_per_launch": gather_bytes}
+        if "dense0" in kt:
+            fl = 2.0 * n_rows * c["doc"] * c["units"][0]
+            line["roofline"] = {"kernel": f"gemm_small_kernel<false, false, true, true> (Dense({c['units'][0]}, relu) over the {n_rows} document vectors of a "
+                                          f"step: {n_rows}x{c['units'][0]}x{c['doc']}; the largest kernel of a step that is launch/latency-bound as a whole: "
+                                          "~0.19 GFLOP and 2.5 MB per step)", "bound": "mfma",
+                                "achieved": fl / kt["dense0"] / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": fl / kt["dense0"] / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                                "avg_launch_us": kt["dense0"] * 1e6, "algorithmic_flops_per_launch": fl}
+        line["roofline_gather"] = {"kernel": "gather_rows_vec4_kernel (document-vector gather)", "bound": "hbm",
+                                   "achieved": gather_bytes / kt["gather"] / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": gather_bytes / kt["gather"] / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                   "avg_launch_us": kt["gather"] * 1e6, "algorithmic_bytes_per_launch": gather_bytes}
         print(json.dumps(line), flush=True)
 
 
@@ -293,20 +330,14 @@ def main():
 
     eng.enable_graphs(not args.no_graph)
     times = timed_repeats(lambda k: eng.train_step(*batches[k % len(batches)]), args, sync, world, device)
-    # Kernel-level rooflines: the same K steps once more, launched kernel by kernel (identical kernels and
-    # arguments; a captured graph cannot carry per-kernel events) with HIP events on the launch stream
-    # around the gather and the Q|K|V projection GEMM.
-    eng.kernel_events = {}
-    t1 = time.perf_counter()
-    for i in range(args.steps):
-        eng.train_step(*batches[i % len(batches)])
-    sync()
-    dt_eager = time.perf_counter() - t1
-    events, eng.kernel_events = eng.kernel_events, None
+    # Kernel-level rooflines: the Q|K|V projection GEMM and the embedding gather of THIS step (same buffers, same
+    # arguments), each captured into a hipGraph of 10 launches and timed with HIP events on the launch stream.
+    rk = eng.roofline_kernels(c["B"], c["C"])
+    id_sets = [torch.cat([h.reshape(-1), p.reshape(-1)]).contiguous() for h, p, _ in batches]  # the 8 batches' token ids
+    kt = {"qkv_gemm": time_kernel(rk["qkv_gemm"], sync), "gather": time_kernel([rk["gather"](ids) for ids in id_sets], sync)}
     loss = float(eng.loss_dev.item())
 
     if rank == 0:
-        kt = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) * 1e-3 for k, v in events.items()}
         n_tok = c["B"] * (c["H"] + c["C"]) * c["T"]
         E = c["h"] * c["d"]
         gemm_flops = 2.0 * n_tok * c["D"] * 3 * E
@@ -325,7 +356,6 @@ def main():
         line = {
             "metric": "training impressions/sec", **timing_fields(times, args, world, c["B"]), "unit": "impressions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step_kernel_by_kernel": dt_eager / args.steps * 1e3,
             "launch": "eager" if (args.no_graph or not eng.graph_capable) else "hipGraph replay",
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"NRMS train step, BASELINE.json configs[{cfg_idx}] "

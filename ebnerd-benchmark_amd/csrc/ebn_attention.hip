@@ -16,7 +16,7 @@ int ebn_attn_mfma_fwd(const float* qkv, int64_t ld_qkv, float* out, int64_t ld_o
                       int32_t h, int32_t d, const EbnDrop& dr, hipStream_t s, bool* handled);
 int ebn_attn_mfma_bwd(const float* qkv, int64_t ld_qkv, const float* dout, int64_t ld_dout, float* dqkv,
                       int64_t ld_dqkv, int64_t n_seq, int32_t L, int32_t h, int32_t d, const EbnDrop& dr,
-                      hipStream_t s, bool* handled);
+                      hipStream_t s, bool* handled, const float* pool_w, const float* pool_d, int64_t ld_pool);
 
 namespace {
 
@@ -486,7 +486,8 @@ extern "C" int ebn_attn_bwd_f32(const float* qkv, int64_t ld_qkv, const float* d
   EBN_REQUIRE(ld_qkv >= 3 * h * d && ld_dqkv >= 3 * h * d && ld_dout >= h * d, EBN_ERR_BAD_ARG);
   const EbnDrop dr = ebn_make_drop(st, site, drop_p);
   bool handled = false;
-  rc = ebn_attn_mfma_bwd(qkv, ld_qkv, dout, ld_dout, dqkv, ld_dqkv, n_seq, L, h, d, dr, ebn_stream(stream), &handled);
+  rc = ebn_attn_mfma_bwd(qkv, ld_qkv, dout, ld_dout, dqkv, ld_dqkv, n_seq, L, h, d, dr, ebn_stream(stream), &handled, nullptr,
+                         nullptr, 0);
   if (rc != EBN_OK || handled) return rc;
   AttnArgs a{qkv, ld_qkv, dout, ld_dout, dqkv, ld_dqkv, n_seq * h, L, h, d, dr.key_ptr, dr.thresh, dr.scale};
   const int LPs = (L & 1) ? L + 2 : L + 1;
@@ -512,4 +513,30 @@ extern "C" int ebn_attn_bwd_f32(const float* qkv, int64_t ld_qkv, const float* d
   }
   EBN_CHECK_LAUNCH();
   return EBN_OK;
+}
+
+// Backward of the attention core when its output fed an AttLayer2 pooling (both encoders, nrms.py:137-156 / 108-111):
+// d(Y) = dpre.W^T (in `dout`) + w (x) d(pooled), the second term added on the fly while dO is staged -- the GEMM that
+// produces the first term then needs no rank-1 epilogue and the [R, E] gradient is not re-read for it.  MFMA path only:
+// returns EBN_ERR_UNSUPPORTED for shapes it does not take (the caller then folds the term into its GEMM instead).
+extern "C" int ebn_attn_bwd_pooled_f32(const float* qkv, int64_t ld_qkv, const float* dout, int64_t ld_dout,
+                                       const float* pool_w, const float* pool_dout, int64_t ld_pool, float* dqkv,
+                                       int64_t ld_dqkv, int64_t n_seq, int32_t L, int32_t h, int32_t d,
+                                       const ebn_step_state* st, int32_t site, float drop_p, ebn_stream_t stream) {
+  int rc = check_attn_args(qkv, dqkv, n_seq, L, h, d);
+  if (rc != EBN_OK) return rc;
+  EBN_REQUIRE(dout && pool_w && pool_dout, EBN_ERR_BAD_ARG);
+  if (n_seq == 0) return EBN_OK;
+  EBN_REQUIRE(ld_qkv >= 3 * h * d && ld_dqkv >= 3 * h * d && ld_dout >= h * d && ld_pool >= h * d, EBN_ERR_BAD_ARG);
+  const EbnDrop dr = ebn_make_drop(st, site, drop_p);
+  bool handled = false;
+  rc = ebn_attn_mfma_bwd(qkv, ld_qkv, dout, ld_dout, dqkv, ld_dqkv, n_seq, L, h, d, dr, ebn_stream(stream), &handled, pool_w,
+                         pool_dout, ld_pool);
+  if (rc != EBN_OK) return rc;
+  return handled ? EBN_OK : EBN_ERR_UNSUPPORTED;
+}
+
+// host-side query: does ebn_attn_bwd_pooled_f32 take this shape?  (leading dimensions / alignment aside)
+extern "C" int32_t ebn_attn_bwd_pooled_supported(int32_t L, int32_t d) {
+  return (L > 0 && L <= 64 && (d == 16 || d == 20 || d == 32)) ? 1 : 0;
 }

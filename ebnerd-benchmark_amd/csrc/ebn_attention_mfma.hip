@@ -44,6 +44,11 @@ struct MfmaAttnArgs {
   const uint32_t* key_ptr;
   uint32_t thresh;
   float scale;
+  // backward only, optional: the AttLayer2 pooling term of d(Y), added while dO is staged --
+  //   dO[r][c] = dout[r][c] + pool_w[row0 + r] * pool_d[seq][head*D + c]      (layers.py:79-81 backward: w (x) d(out))
+  const float* pool_w;
+  const float* pool_d;
+  int64_t ld_pool;
 };
 
 __device__ __forceinline__ int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
@@ -86,6 +91,38 @@ __device__ __forceinline__ void stage_load(Staged<D>& st, const float* __restric
     const int r = v / T::VPR, c4 = v - r * T::VPR;
     const int rc = r < L ? r : 0;
     st.v[t] = *reinterpret_cast<const float4*>(base + static_cast<int64_t>(rc) * ld + c4 * 4);
+  }
+}
+
+// the pooling term's operands for the float4 pieces a lane stages (loaded up front with the tile itself)
+template <int D>
+struct PoolTerm {
+  float w[Tile<D>::ROUNDS];
+  float4 p[Tile<D>::ROUNDS];
+};
+
+template <int D>
+__device__ __forceinline__ void pool_load(PoolTerm<D>& pt, const float* __restrict__ w_rows, const float* __restrict__ d_cols,
+                                          int L, int lane) {
+  using T = Tile<D>;
+#pragma unroll
+  for (int t = 0; t < T::ROUNDS; ++t) {
+    int v = lane + 64 * t;
+    if (T::VECS % 64 != 0 && v >= T::VECS) v = 0;
+    const int r = v / T::VPR, c4 = v - r * T::VPR;
+    pt.w[t] = w_rows[r < L ? r : 0];
+    pt.p[t] = *reinterpret_cast<const float4*>(d_cols + c4 * 4);
+  }
+}
+
+template <int D>
+__device__ __forceinline__ void pool_add(Staged<D>& st, const PoolTerm<D>& pt) {
+#pragma unroll
+  for (int t = 0; t < Tile<D>::ROUNDS; ++t) {
+    st.v[t].x = fmaf(pt.w[t], pt.p[t].x, st.v[t].x);
+    st.v[t].y = fmaf(pt.w[t], pt.p[t].y, st.v[t].y);
+    st.v[t].z = fmaf(pt.w[t], pt.p[t].z, st.v[t].z);
+    st.v[t].w = fmaf(pt.w[t], pt.p[t].w, st.v[t].w);
   }
 }
 
@@ -329,6 +366,11 @@ __global__ __launch_bounds__(64 * ATT_WAVES) void attn_mfma_bwd_kernel(MfmaAttnA
     stage_load<D>(tk, qb + E, a.ld_qkv, L, lane);
     stage_load<D>(tv, qb + 2 * E, a.ld_qkv, L, lane);
     stage_load<D>(tg, gb, a.ld_dout, L, lane);
+    if (a.pool_w != nullptr) {  // wave-uniform
+      PoolTerm<D> pt;
+      pool_load<D>(pt, a.pool_w + row0, a.pool_d + seq * a.ld_pool + head * D, L, lane);
+      pool_add<D>(tg, pt);
+    }
     stage_store<D, false>(sq, tq, L, lane, 0u, 0u, 0, 0u, 0.f);
     stage_store<D, false>(sk, tk, L, lane, 0u, 0u, 0, 0u, 0.f);
     stage_store<D, false>(sv, tv, L, lane, 0u, 0u, 0, 0u, 0.f);
@@ -585,6 +627,11 @@ __global__ __launch_bounds__(64 * ATT2_WAVES) void attn_mfma2_bwd_kernel(MfmaAtt
     stage_load<D>(tk, qb + E + 32 * b * a.ld_qkv, a.ld_qkv, Lb, lane);
     stage_load<D>(tv, qb + 2 * E + 32 * b * a.ld_qkv, a.ld_qkv, Lb, lane);
     stage_load<D>(tg, gb + 32 * b * a.ld_dout, a.ld_dout, Lb, lane);
+    if (a.pool_w != nullptr) {
+      PoolTerm<D> pt;
+      pool_load<D>(pt, a.pool_w + row0 + 32 * b, a.pool_d + seq * a.ld_pool + head * D, Lb, lane);
+      pool_add<D>(tg, pt);
+    }
     stage_store<D, false>(sq + 32 * b * T::STRIDE, tq, Lb, lane, 0u, 0u, 0, 0u, 0.f);
     stage_store<D, false>(sk + 32 * b * T::STRIDE, tk, Lb, lane, 0u, 0u, 0, 0u, 0.f);
     stage_store<D, false>(sv + 32 * b * T::STRIDE, tv, Lb, lane, 0u, 0u, 0, 0u, 0.f);
@@ -724,7 +771,7 @@ int ebn_attn_mfma_fwd(const float* qkv, int64_t ld_qkv, float* out, int64_t ld_o
                       int32_t h, int32_t d, const EbnDrop& dr, hipStream_t s, bool* handled) {
   *handled = mfma_path_ok(L, d, ld_qkv, ld_out, ld_out, qkv, out, out);
   if (!*handled) return EBN_OK;
-  MfmaAttnArgs a{qkv, ld_qkv, nullptr, 0, out, ld_out, n_seq * h, L, h, dr.key_ptr, dr.thresh, dr.scale};
+  MfmaAttnArgs a{qkv, ld_qkv, nullptr, 0, out, ld_out, n_seq * h, L, h, dr.key_ptr, dr.thresh, dr.scale, nullptr, nullptr, 0};
   if (L > 32) {
     if (d == 16) launch_mfma2<16>(false, a, s);
     else if (d == 20) launch_mfma2<20>(false, a, s);
@@ -746,10 +793,11 @@ int ebn_attn_mfma_fwd(const float* qkv, int64_t ld_qkv, float* out, int64_t ld_o
 
 int ebn_attn_mfma_bwd(const float* qkv, int64_t ld_qkv, const float* dout, int64_t ld_dout, float* dqkv,
                       int64_t ld_dqkv, int64_t n_seq, int32_t L, int32_t h, int32_t d, const EbnDrop& dr,
-                      hipStream_t s, bool* handled) {
-  *handled = mfma_path_ok(L, d, ld_qkv, ld_dout, ld_dqkv, qkv, dout, dqkv);
+                      hipStream_t s, bool* handled, const float* pool_w, const float* pool_d, int64_t ld_pool) {
+  *handled = mfma_path_ok(L, d, ld_qkv, ld_dout, ld_dqkv, qkv, dout, dqkv) &&
+             (pool_w == nullptr || ((ld_pool % 4) == 0 && ebn_aligned16(pool_d)));
   if (!*handled) return EBN_OK;
-  MfmaAttnArgs a{qkv, ld_qkv, dout, ld_dout, dqkv, ld_dqkv, n_seq * h, L, h, dr.key_ptr, dr.thresh, dr.scale};
+  MfmaAttnArgs a{qkv, ld_qkv, dout, ld_dout, dqkv, ld_dqkv, n_seq * h, L, h, dr.key_ptr, dr.thresh, dr.scale, pool_w, pool_d, ld_pool};
   if (L > 32) {
     if (d == 16) launch_mfma2<16>(true, a, s);
     else if (d == 20) launch_mfma2<20>(true, a, s);

@@ -178,7 +178,6 @@ class NRMSEngine:
         self.range_flag = torch.zeros(1, dtype=torch.int32, device=self.device)  # fixed-point gradient accumulator left its range
         self.loss_dev = torch.zeros(1, device=self.device)
         self.use_graph = False  # capture the per-shape kernel sequence into hipGraphs (enable_graphs())
-        self.kernel_events = None  # dict name -> [(start, stop)] when bench.py asks for kernel timings
         self.world = 1
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
@@ -339,8 +338,6 @@ class NRMSEngine:
         st = _hip.ptr(self.state) if train else None
         if pre == "n" and self.mlp is not None:
             return self._news_encoder_fwd_mlp(b, n_seq, X, train, n_seq if n_first is None else n_first)
-        if self.kernel_events is not None and pre == "n":
-            return self._encoder_fwd_timed(b, n_seq, X, st, site, p)
         dims, params, acts = self._enc_structs(pre, b, n_seq, X, site, p)
         _hip.call("ebn_encoder_fwd_f32", ctypes.byref(dims), ctypes.byref(params), ctypes.byref(acts),
                   ctypes.byref(self._fwd_scratch(b)), st, _hip.stream_handle())
@@ -385,28 +382,36 @@ class NRMSEngine:
             _hip.call("ebn_gemm_f32_ws", 0, 1, R, b.Din, 3 * E, one, _hip.ptr(b.dQKV), 3 * E, _hip.ptr(pv("n_Wqkv")), 3 * E, zero,
                       _hip.ptr(dX), b.Din, ws, wsn, S())
 
-    def _timed(self, name):
-        """HIP events on the launch stream around one kernel (bench.py roofline figures)."""
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        self.kernel_events.setdefault(name, []).append((e0, e1))
-        return e0, e1
-
-    def _encoder_fwd_timed(self, b, n_seq, X, st, site, p):
-        """Same four launches as ebn_encoder_fwd_f32 for the news encoder, issued one by one so the
-        Q|K|V projection GEMM can be bracketed by events."""
-        S, E, A, R = _hip.stream_handle, self.E, self.A, n_seq * b.L
+    def roofline_kernels(self, B, C):
+        """Launchers of single kernels of the training step at batch shape (B, C), on the step's own buffers and arguments
+        (bench.py captures them into hipGraphs and times them with HIP events on the launch stream): "qkv_gemm" = zero-
+        argument launcher of the news encoder's Q|K|V projection; "gather" = factory ids -> launcher of the title-token
+        embedding gather (+ dropout) for that id set."""
+        N = B * (self.H + C)
+        nb, _ub = self._train_bufs(B, C)
+        S, E, R = _hip.stream_handle, self.E, N * self.T
         pv = self.params.view
-        e0, e1 = self._timed("qkv_gemm")
-        e0.record()
-        _hip.call("ebn_gemm_f32_site", 0, 0, R, 3 * E, b.Din, ctypes.c_float(1.0), _hip.ptr(X), b.Din,
-                  _hip.ptr(pv("n_Wqkv")), 3 * E, ctypes.c_float(0.0), _hip.ptr(b.QKV), 3 * E, _hip.ptr(b.ws), b.ws.numel(), 1, S())
-        e1.record()
-        _hip.call("ebn_attn_fwd_f32", _hip.ptr(b.QKV), 3 * E, _hip.ptr(b.Y), E, n_seq, b.L, self.h, self.d, st, site,
-                  ctypes.c_float(p), S())
-        _hip.call("ebn_gemm_f32_ws", 0, 0, R, A, E, ctypes.c_float(1.0), _hip.ptr(b.Y), E, _hip.ptr(pv("n_W")), A,
-                  ctypes.c_float(0.0), _hip.ptr(b.U), A, _hip.ptr(b.ws), b.ws.numel(), S())
-        _hip.call("ebn_attpool_fwd_f32", _hip.ptr(b.U), _hip.ptr(pv("n_b")), _hip.ptr(pv("n_q")), _hip.ptr(b.Y),
-                  _hip.ptr(b.out), _hip.ptr(b.w), n_seq, b.L, E, A, S())
+        site, p = (0, self.p) if self.p > 0 else (-1, 0.0)
+        st = _hip.ptr(self.state)
+
+        def qkv_gemm():
+            _hip.call("ebn_gemm_f32_site", 0, 0, R, 3 * E, nb.Din, ctypes.c_float(1.0), _hip.ptr(nb.X), nb.Din,
+                      _hip.ptr(pv("n_Wqkv")), 3 * E, ctypes.c_float(0.0), _hip.ptr(nb.QKV), 3 * E, _hip.ptr(nb.ws), nb.ws.numel(), 1, S())
+
+        def make_gather(ids):
+            # `ids`: (R,) int32 token ids on the device.  bench.py passes the id sets of SEVERAL batches and cycles through
+            # them, so that consecutive launches read different table rows (re-reading one batch's rows would be served by
+            # the 256 MB memory-side cache, not HBM).  With a row-sharded table the ids are folded into this rank's shard.
+            table_rows = self.table.shape[0]
+            src = ids if table_rows == self.V else torch.remainder(ids, table_rows).to(torch.int32)
+
+            def gather():
+                _hip.call("ebn_gather_rows_f32", _hip.ptr(src), _hip.ptr(self.table), _hip.ptr(nb.X), R, self.D, table_rows, st, site,
+                          ctypes.c_float(p), _hip.ptr(self.oob_flag), S())
+
+            return gather
+
+        return {"qkv_gemm": qkv_gemm, "gather": make_gather}
 
     def _encoder_bwd(self, pre, b, n_seq, X, dout, dX, n_first=None):
         if pre == "n" and self.mlp is not None:
@@ -456,14 +461,9 @@ class NRMSEngine:
                 for _kind, fn in self._lookup_segments(b, N):
                     fn()
             xb = b.xb
-            ev = self._timed("gather") if (self.kernel_events is not None and train) else None
-            if ev:
-                ev[0].record()
             _hip.call("ebn_gather_rows_f32", _hip.ptr(xb.inv), _hip.ptr(xb.rows), _hip.ptr(b.X), n_tok, self.D,
                       self.exchange.world * self.exchange.capacity(n_tok), st, site, ctypes.c_float(p), _hip.ptr(self.oob_flag),
                       _hip.stream_handle())
-            if ev:
-                ev[1].record()
             return self._encoder_fwd("n", b, N, b.X, train, n_first)
         if self.exchange is not None:
             # validation forms (host-planned, eager only): route the distinct ids to their owners, fetch the rows over
@@ -474,13 +474,8 @@ class NRMSEngine:
                       self.D, b.rows_uniq.shape[0], st, site, ctypes.c_float(p), _hip.ptr(self.oob_flag),
                       _hip.stream_handle())
             return self._encoder_fwd("n", b, N, b.X, train, n_first)
-        ev = self._timed("gather") if self.kernel_events is not None else None
-        if ev:
-            ev[0].record()
         _hip.call("ebn_gather_rows_f32", _hip.ptr(b.ids), _hip.ptr(self.table), _hip.ptr(b.X), n_tok, self.D,
                   self.V, st, site, ctypes.c_float(p), _hip.ptr(self.oob_flag), _hip.stream_handle())
-        if ev:
-            ev[1].record()
         self._encoder_fwd("n", b, N, b.X, train, n_first)
 
     # ---- device-planned row-sharded lookup, as ("k" kernels | "c" collective, fn) segments -------------------------
@@ -688,7 +683,7 @@ class NRMSEngine:
         if y is not None:
             labels = (y if isinstance(y, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(y, dtype=np.float32))))
             nb.labels[: B * C].copy_(labels.reshape(-1).to(device=self.device, dtype=torch.float32), non_blocking=True)
-        if self.use_graph and self.kernel_events is None and self.graph_capable:
+        if self.use_graph and self.graph_capable:
             run = self._graphs.get((B, C, advanced))
             if run is None:
                 run = self._capture(B, C, advanced)

@@ -45,7 +45,6 @@ class DocVecEngine:
         self.state = torch.frombuffer(bytearray(bytes(st)), dtype=torch.uint8).to(self.device)
         self._lr = float(learning_rate)
         self._bufs = {}
-        self.kernel_events = None  # dict name -> [(start, stop)] when bench.py asks for kernel timings (eager launches then)
         self.loss_dev = torch.zeros(1, device=self.device)
         self.reg_dev = torch.zeros(1, device=self.device)
         self.world = 1
@@ -284,15 +283,8 @@ class DocVecEngine:
                 t = t.reshape(-1)
                 mb["art_idx"][off: off + t.numel()].copy_(t.to(device=self.device, dtype=torch.int32), non_blocking=True)
                 off += t.numel()
-        ev = None
-        if self.kernel_events is not None:
-            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            self.kernel_events.setdefault("gather", []).append(ev)
-            ev[0].record()
         _hip.call("ebn_gather_rows_f32", _hip.ptr(mb["art_idx"]), _hip.ptr(self.article_matrix), _hip.ptr(mb["X0"]), n, self.Din,
                   self.article_matrix.shape[0], None, -1, ctypes.c_float(0.0), _hip.ptr(self._oob), _hip.stream_handle())
-        if ev:
-            ev[1].record()
         return y
 
     def train_step(self, his, pred, y, return_probs=False, indexed=False):
@@ -312,7 +304,7 @@ class DocVecEngine:
         if y is not None:
             labels = (y if isinstance(y, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(y, dtype=np.float32))))
             mb["labels"][: B * C].copy_(labels.reshape(-1).to(device=self.device, dtype=torch.float32))
-        if self.use_graph and self.kernel_events is None:
+        if self.use_graph:
             # graph(forward + backward) -> gradient all-reduce over RCCL (eager, data-parallel only) -> graph(Adam)
             adv = self._advanced
             g = self._graphs.get((B, C, adv))
@@ -368,6 +360,33 @@ class DocVecEngine:
         P = self.params
         _hip.call("ebn_adam_keras_step_f32", _hip.ptr(P.data), _hip.ptr(P.grad), _hip.ptr(P.m), _hip.ptr(P.v), P.numel, st,
                   BETA1, BETA2, ADAM_EPS, ctypes.c_float(1.0 / self.world), S())
+
+    def roofline_kernels(self, B, C):
+        """Launchers of single kernels of the training step at batch shape (B, C) on the step's own buffers (bench.py):
+        "gather" = factory rows -> launcher of the document-vector gather, "dense0" = the widest Dense(relu) GEMM of the MLP
+        (rows x Din -> units[0])."""
+        mb = self._mlp_bufs(B * (self.H + C))
+        n = B * (self.H + C)
+        S = _hip.stream_handle
+
+        def make_gather(rows):  # rows: (n,) int32 article-row numbers on the device (bench.py cycles through several sets)
+            def gather():
+                _hip.call("ebn_gather_rows_f32", _hip.ptr(rows), _hip.ptr(self.article_matrix), _hip.ptr(mb["X0"]), n, self.Din,
+                          self.article_matrix.shape[0], None, -1, ctypes.c_float(0.0), _hip.ptr(self._oob), S())
+
+            return gather
+
+        out = {"gather": make_gather}
+        if self.units:
+            u, b = self.units[0], self.mlp.bufs(n)
+            pv = self.params.view
+
+            def dense0():
+                _hip.call("ebn_dense_relu_fwd_f32", n, u, self.Din, _hip.ptr(mb["X0"]), self.Din, _hip.ptr(pv("d0_W")), u, _hip.ptr(pv("d0_b")),
+                          _hip.ptr(b["R"][0]), u, _hip.ptr(b["ws"]), b["ws"].numel(), S())
+
+            out["dense0"] = dense0
+        return out
 
     def check_oob(self):
         """Article-row numbers outside the document-vector matrix raise (device-resident batches are checked here,

@@ -152,6 +152,15 @@ int ebn_attn_fwd_f32(const float* qkv, int64_t ld_qkv, float* out, int64_t ld_ou
 int ebn_attn_bwd_f32(const float* qkv, int64_t ld_qkv, const float* dout, int64_t ld_dout,
                      float* dqkv, int64_t ld_dqkv, int64_t n_seq, int32_t L, int32_t h, int32_t d,
                      const ebn_step_state* st, int32_t site, float drop_p, ebn_stream_t stream);
+/* The same backward when the attention output fed an AttLayer2 pooling (layers.py:79-81): the pooling term of d(Y),
+ * pool_w[n*L + l] * pool_dout[n, :], is added to `dout` on the fly, so the GEMM that produces dout = dpre.W^T needs no
+ * rank-1 epilogue.  MFMA path only (ebn_attn_bwd_pooled_supported(L, d), 16-byte aligned operands, ld % 4 == 0):
+ * EBN_ERR_UNSUPPORTED otherwise -- callers then use ebn_gemm_f32_rank1 + ebn_attn_bwd_f32.                            */
+int ebn_attn_bwd_pooled_f32(const float* qkv, int64_t ld_qkv, const float* dout, int64_t ld_dout, const float* pool_w,
+                            const float* pool_dout, int64_t ld_pool, float* dqkv, int64_t ld_dqkv, int64_t n_seq,
+                            int32_t L, int32_t h, int32_t d, const ebn_step_state* st, int32_t site, float drop_p,
+                            ebn_stream_t stream);
+int32_t ebn_attn_bwd_pooled_supported(int32_t L, int32_t d);
 
 /* C[M,N] = alpha * A[M,K] * B[N,K]^T + row_scale[m] * seq_rows[m / L, n]   (C overwritten; A row-major, B stored [N,K]).
  * The d(x) of AttLayer2 in one pass: dpre.W^T (backward of K.dot(x, W), layers.py:65) plus w[n,l]*dout[n,:] (backward of

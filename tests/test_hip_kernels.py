@@ -237,6 +237,30 @@ def test_attention_backward(hip, n_seq, L, h, d, p):
     assert_close(host(dqkv), want, rtol=3e-5, atol=5e-6, what="attn bwd")
 
 
+@pytest.mark.parametrize("p", [0.0, 0.2])
+@pytest.mark.parametrize("n_seq,L,h,d", [(4, 30, 20, 20), (3, 20, 20, 20), (2, 50, 20, 20), (2, 64, 2, 32), (3, 17, 2, 16), (2, 33, 3, 32), (5, 1, 1, 20)])
+def test_attention_backward_with_the_pooling_term_folded_in(hip, n_seq, L, h, d, p):
+    """ebn_attn_bwd_pooled_f32(dout, w, dpool) == ebn_attn_bwd_f32(dout + w (x) dpool): the AttLayer2 pooling half of d(Y)
+    is added while dO is staged (to rounding: one fma per element instead of a separately rounded sum)."""
+    E = h * d
+    qkv, *_ = _qkv_case(n_seq, L, h, d, 21)
+    rng = np.random.default_rng(22)
+    dY = rng.standard_normal((n_seq * L, E)).astype(np.float32)
+    w = rng.random(n_seq * L).astype(np.float32)
+    dpool = rng.standard_normal((n_seq, E)).astype(np.float32)
+    full = (dY.astype(np.float64) + w[:, None].astype(np.float64) * np.repeat(dpool.astype(np.float64), L, axis=0)).astype(np.float32)
+    assert hip.lib().ebn_attn_bwd_pooled_supported(L, d) == 1
+    st = make_state(seed=5, step=2)
+    q = dev(qkv.reshape(n_seq * L, 3 * E))
+    a, b = torch.full((n_seq * L, 3 * E), float("nan"), device="cuda"), torch.full((n_seq * L, 3 * E), float("nan"), device="cuda")
+    hip.call("ebn_attn_bwd_f32", P(q), 3 * E, P(dev(full)), E, P(a), 3 * E, n_seq, L, h, d, P(st), 1, ctypes.c_float(p), S())
+    hip.call("ebn_attn_bwd_pooled_f32", P(q), 3 * E, P(dev(dY)), E, P(dev(w)), P(dev(dpool)), E, P(b), 3 * E, n_seq, L, h, d, P(st), 1,
+             ctypes.c_float(p), S())
+    assert_close(host(b), host(a), rtol=2e-5, atol=2e-5, what="pooled attn bwd")
+    # shapes outside the MFMA path are refused (the caller keeps the rank-1 GEMM epilogue there)
+    assert hip.lib().ebn_attn_bwd_pooled_supported(65, 20) == 0 and hip.lib().ebn_attn_bwd_pooled_supported(30, 8) == 0
+
+
 def test_attention_rejects_unsupported_shapes(hip):
     x = torch.zeros(10, device="cuda")
     with pytest.raises(hip.HipError):
