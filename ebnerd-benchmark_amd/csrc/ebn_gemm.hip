@@ -32,6 +32,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define EBN_GEMM_GLDS 1  // direct global->LDS tile fetch when both operands are stored [K][mn] (the weight-gradient GEMMs)
 #endif
 
+typedef float f32x4n __attribute__((ext_vector_type(4)));
+// 16-byte load through an explicitly GLOBAL pointer (global_load_dwordx4, never flat_load)
+__device__ __forceinline__ float4 gload4(const __attribute__((address_space(1))) float* p) {
+  const f32x4n t = *reinterpret_cast<const __attribute__((address_space(1))) f32x4n*>(p);
+  return make_float4(t.x, t.y, t.z, t.w);
+}
+
 constexpr int BK = 16;
 constexpr int PAD = 4;
 constexpr int GEMM_THREADS = 256;
@@ -199,8 +206,13 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
   // when done per slab).  Rows / columns past the matrix edge are CLAMPED to the last valid float4 instead of
   // zero-filled: they only feed output rows / columns the epilogue never stores.  Only a partial last slab
   // (K range not a multiple of BK) goes through the guarded, zero-filling loader.
-  const float* pa[LA::PER_THREAD];
-  const float* pb[LB::PER_THREAD];
+  // address_space(1): these pointers are carried through the slab loop and re-selected at its back edge, where the
+  // compiler loses track of their being GLOBAL pointers and emits flat_load -- which also counts on lgkmcnt, so every
+  // s_waitcnt lgkmcnt(0) in front of the MFMAs (meant for the LDS operand reads) would wait for the prefetch of the next
+  // slab as well and put the whole global-load latency on the MFMA critical path.
+  typedef const __attribute__((address_space(1))) float* gptr_t;
+  gptr_t pa[LA::PER_THREAD];
+  gptr_t pb[LB::PER_THREAD];
   const int64_t step_a = TA ? BK * lda : BK;
   const int64_t step_b = TB ? BK : BK * ldb;
   if (VEC) {
@@ -210,11 +222,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
       if (!TA) {  // A is [M][K]
         int64_t row = m0 + v / (BK / 4);
         row = row < M ? row : M - 1;
-        pa[i] = A + row * lda + kbeg + (v % (BK / 4)) * 4;
+        pa[i] = (gptr_t)(A + row * lda + kbeg + (v % (BK / 4)) * 4);
       } else {  // A is [K][M]
         int64_t col = m0 + (v % (BM / 4)) * 4;
         col = col < M ? col : M - 4;
-        pa[i] = A + (kbeg + v / (BM / 4)) * lda + col;
+        pa[i] = (gptr_t)(A + (kbeg + v / (BM / 4)) * lda + col);
       }
     }
 #pragma unroll
@@ -223,11 +235,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
       if (TB) {  // B is [N][K]
         int64_t row = n0 + v / (BK / 4);
         row = row < N ? row : N - 1;
-        pb[i] = B + row * ldb + kbeg + (v % (BK / 4)) * 4;
+        pb[i] = (gptr_t)(B + row * ldb + kbeg + (v % (BK / 4)) * 4);
       } else {  // B is [K][N]
         int64_t col = n0 + (v % (BN / 4)) * 4;
         col = col < N ? col : N - 4;
-        pb[i] = B + (kbeg + v / (BN / 4)) * ldb + col;
+        pb[i] = (gptr_t)(B + (kbeg + v / (BN / 4)) * ldb + col);
       }
     }
   }
@@ -275,11 +287,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
   do {                                                                                   \
   if (VEC && (KT) < nk_full) {                                                           \
     _Pragma("unroll") for (int i = 0; i < LA::PER_THREAD; ++i) {                         \
-      ra[i] = *reinterpret_cast<const float4*>(pa[i]);                                   \
+      ra[i] = gload4(pa[i]);                                                             \
       pa[i] += step_a;                                                                   \
     }                                                                                    \
     _Pragma("unroll") for (int i = 0; i < LB::PER_THREAD; ++i) {                         \
-      rb[i] = *reinterpret_cast<const float4*>(pb[i]);                                   \
+      rb[i] = gload4(pb[i]);                                                             \
       pb[i] += step_b;                                                                   \
     }                                                                                    \
   } else {                                                                               \
