@@ -175,8 +175,9 @@ def time_kernel(fns, sync, reps=10, replays=5):
     sync()
     # The chip needs ~50 ms of sustained load after an idle gap before a kernel reaches its steady duration (the first
     # launches after a host sync run 15-20 % slower: per-launch trace in profiles/r02_gemm_launch_trace.txt), and the timed
-    # region of the benchmark runs in that steady state.  Warm replays without a host sync in between, then the timed ones.
-    warm = int(min(max(0.06 / max(e0.elapsed_time(e1) * 1e-3, 1e-6), 3), 400))
+    # region of the benchmark runs in that steady state.  Warm replays (0.25 s worth, so that the ramp is also a small part of
+    # what a profiler averages over this process) without a host sync in between, then the timed ones.
+    warm = int(min(max(0.25 / max(e0.elapsed_time(e1) * 1e-3, 1e-6), 3), 1000))
     for _ in range(warm):
         g.replay()
     e0.record()
@@ -384,7 +385,7 @@ def main():
         if sharded:
             line["exchange"] = eng.exchange.stats()
         if world > 1:
-            line["allreduce_bytes_per_step"] = eng.allreduce_bytes()
+            line["allreduce_bytes_per_step"] = eng.allreduce_bytes(c["B"] * (c["H"] + c["C"]) * c["T"])
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(c, args.cpu_seconds)
         print(json.dumps(line), flush=True)

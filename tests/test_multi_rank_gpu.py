@@ -160,7 +160,7 @@ def _entry(rank, world, port, fn, args):
         dist.destroy_process_group()
 
 
-def _dp_worker(rank, world, shard, partition, graph, train_embedding, H):
+def _dp_worker(rank, world, shard, partition, graph, train_embedding, H, table_grad_exchange="auto"):
     from ebrec.models.newsrec import NRMSModel
 
     hp = make_hp(history_size=H, dropout=0.0, learning_rate=1e-3)
@@ -168,10 +168,12 @@ def _dp_worker(rank, world, shard, partition, graph, train_embedding, H):
     rng = np.random.default_rng(77)
     P = on.random_nrms_params(V, D, hp.head_num, hp.head_dim, hp.attention_hidden_dim, seed=8)
     m = NRMSModel(hp, word2vec_embedding=P["emb"], seed=seed, train_embedding=train_embedding, shard_table=shard,
-                  shard_partition=partition, shard_capacity_factor=float(world), deterministic=not shard)
+                  shard_partition=partition, shard_capacity_factor=float(world), deterministic=not shard,
+                  table_grad_exchange=table_grad_exchange)
     m.from_keras_weight_list(weight_list(P))
     eng = m._engine
     assert eng.world == world
+    assert eng._sparse_dp(B * (H + C) * hp.title_size) == (table_grad_exchange == "sparse")
     if graph:
         eng.enable_graphs()
     P = {k: v.astype(np.float32).astype(np.float64) for k, v in P.items()}
@@ -184,7 +186,7 @@ def _dp_worker(rank, world, shard, partition, graph, train_embedding, H):
         L_loc, _, _ = on.nrms_loss_and_grads(his[sl], pred[sl], y[sl], P, hp.head_num, hp.head_dim, "cross_entropy_loss", None)
         got = float(eng.train_step(his[sl], pred[sl], y[sl]).item())  # each rank steps on ITS rows
         assert abs(got - L_loc) <= 2e-5 * max(1.0, abs(L_loc)), (rank, t, got, L_loc)
-        if t == 1 and not shard:
+        if t == 1 and not shard and table_grad_exchange != "sparse":
             # after the all-reduce (SUM) the gradient buffers hold world x the full-batch mean gradient
             want = np.concatenate([g["n_WQ"], g["n_WK"], g["n_WV"]], 1) * world
             assert_close(eng.params.g("n_Wqkv").cpu().numpy(), want, rtol=1e-4, atol=1e-6 + 1e-4 * np.abs(want).max(), what="all-reduced dWqkv")
@@ -210,6 +212,13 @@ def test_two_rank_data_parallel_step_equals_the_full_batch_oracle_step(hip, grap
     """configs[3]: the engine's own DP step (hipGraph(fwd+bwd) -> all-reduce -> hipGraph(Adam)) on two ranks; every rank
     must end on the weights of the float64 oracle stepping on the whole global batch."""
     _spawn(_dp_worker, 2, False, "block", graph, True, H)
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_two_rank_sparse_table_gradient_exchange_equals_the_full_batch_oracle_step(hip, graph):
+    """Data parallel with the (id, gradient row) all-gather instead of the dense (V, D) all-reduce: every rank accumulates
+    every rank's token rows in the order-independent fixed-point accumulator -> identical replicas, oracle trajectory."""
+    _spawn(_dp_worker, 2, False, "block", graph, True, 20, "sparse")
 
 
 @pytest.mark.parametrize("partition,graph,train_embedding", [("block", False, True), ("cyclic", True, True), ("block", True, False)])
