@@ -537,6 +537,6 @@ extern "C" int ebn_attn_bwd_pooled_f32(const float* qkv, int64_t ld_qkv, const f
 }
 
 // host-side query: does ebn_attn_bwd_pooled_f32 take this shape?  (leading dimensions / alignment aside)
-extern "C" int32_t ebn_attn_bwd_pooled_supported(int32_t L, int32_t d) {
+extern "C" int ebn_attn_bwd_pooled_supported(int32_t L, int32_t d) {
   return (L > 0 && L <= 64 && (d == 16 || d == 20 || d == 32)) ? 1 : 0;
 }

@@ -160,7 +160,7 @@ int ebn_attn_bwd_pooled_f32(const float* qkv, int64_t ld_qkv, const float* dout,
                             const float* pool_dout, int64_t ld_pool, float* dqkv, int64_t ld_dqkv, int64_t n_seq,
                             int32_t L, int32_t h, int32_t d, const ebn_step_state* st, int32_t site, float drop_p,
                             ebn_stream_t stream);
-int32_t ebn_attn_bwd_pooled_supported(int32_t L, int32_t d);
+int ebn_attn_bwd_pooled_supported(int32_t L, int32_t d);
 
 /* C[M,N] = alpha * A[M,K] * B[N,K]^T + row_scale[m] * seq_rows[m / L, n]   (C overwritten; A row-major, B stored [N,K]).
  * The d(x) of AttLayer2 in one pass: dpre.W^T (backward of K.dot(x, W), layers.py:65) plus w[n,l]*dout[n,:] (backward of
