@@ -487,11 +487,12 @@ __global__ __launch_bounds__(1024) void bn2_relu_bwd_strip_kernel(const float* _
 #pragma unroll
         for (int j = 0; j < STRIP_PER; ++j) {
           const int r = lane + STRIP_LANES * j;
-          if (r >= R) break;
-          float v = (g[j] - db * inv_R - xh[j] * dg * inv_R) * k;
-          v = (rl[j] > 0.f) ? v : 0.f;
-          dX[(row0 + r) * C + c] = v;
-          dbias_part += v;
+          if (r < R) {
+            float v = (g[j] - db * inv_R - xh[j] * dg * inv_R) * k;
+            v = (rl[j] > 0.f) ? v : 0.f;
+            dX[(row0 + r) * C + c] = v;
+            dbias_part += v;
+          }
         }
       }
     }

@@ -728,15 +728,16 @@ static GemmPlan gemm_plan(int64_t M, int64_t N, int64_t K, int64_t ws_floats) {
   GemmPlan best{128, 128, 1, ebn_ceil_div(K > 0 ? K : 1, BK) * BK, 1e300};
   {
     // 32x32 tiles, 128-deep slabs, never split (gemm_small_kernel): `W` workgroups on the busiest CU, 2 of them resident
-    // (67 KB of LDS each); a slab costs ~0.8 us per workgroup sharing a CU, ~1.1 us of latency when nothing covers it
-    // (calibrated on tools/gemm_shapes_probe.py c3 / c2: 800x512x768 14.5 us, 640x400x1200 20.9 us, 640x256x200 4.9 us).
+    // (67 KB of LDS each); calibrated on tools/gemm_shapes_probe.py c2 / c3 / c4: 800x512x768 14.5 us, 640x400x1200 20.9 us,
+    // 640x256x200 4.9 us, 1600x400x1200 39.7 us.
     // Only for outputs that leave the big tiles under-filled and K ranges a single workgroup can walk (no split-K here).
     const int64_t wgs = ebn_ceil_div(M, SBM) * ebn_ceil_div(N, SBN);
     const int64_t tiles64 = ebn_ceil_div(M, 64) * ebn_ceil_div(N, 64);
     if (forced_tile_bm() == 32 || (forced_tile_bm() == 0 && tiles64 <= 256 && K <= 4096)) {
       const int64_t W = ebn_ceil_div(wgs, 256);
-      const double full = static_cast<double>(W) * 0.8, lone = static_cast<double>(ebn_ceil_div(W, 2)) * 1.1;
-      const double cost = static_cast<double>(ebn_ceil_div(K > 0 ? K : 1, SBK)) * (full > lone ? full : lone) + 3.0;
+      // two workgroups fit a CU (LDS): pairs share it at ~2.0 us per 128-deep slab, a lone one takes ~1.2 us
+      const double per_slab = static_cast<double>(W / 2) * 2.0 + static_cast<double>(W % 2) * 1.2;
+      const double cost = static_cast<double>(ebn_ceil_div(K > 0 ? K : 1, SBK)) * per_slab + 3.0;
       best = GemmPlan{32, 32, 1, ebn_ceil_div(K > 0 ? K : 1, SBK) * SBK, cost};
       if (forced_tile_bm() == 32) return best;
     }

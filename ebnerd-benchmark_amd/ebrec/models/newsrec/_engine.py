@@ -736,7 +736,9 @@ class NRMSEngine:
             while j < len(segs) and segs[j][0] == "k":
                 j += 1
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool):
+            # thread_local: the RCCL watchdog thread of torch.distributed polls events while this thread captures -- in the default
+            # "global" mode any such call from another thread invalidates the capture
+            with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
                 for _kind, fn in segs[i:j]:
                     fn()
             pool = pool or g.pool()

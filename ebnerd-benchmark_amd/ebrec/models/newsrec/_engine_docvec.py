@@ -311,9 +311,9 @@ class DocVecEngine:
             if g is None:
                 torch.cuda.synchronize()
                 g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g1):
+                with torch.cuda.graph(g1, capture_error_mode="thread_local"):
                     self._fwd_bwd_kernels(B, C, adv)
-                with torch.cuda.graph(g2, pool=g1.pool()):
+                with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode="thread_local"):
                     self._optimizer_kernels()
                 g = self._graphs[(B, C, adv)] = (g1, g2)
             g[0].replay()

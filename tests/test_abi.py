@@ -59,7 +59,8 @@ def test_gemm_planner_is_a_pure_host_query_with_sane_plans():
             assert _plan(M, N, K, sp * M * N - 1)[2] < sp
     assert _plan(24000, 1200, 1024) == (256, 64, 1)  # Q|K|V projection: 1786 workgroups = 6.98 turns, N pads to 1216
     assert _plan(1024, 1200, 24000)[:2] == (256, 64) and _plan(1024, 1200, 24000)[2] > 1  # its weight gradient: split-K
-    assert _plan(640, 1200, 400) == (32, 32, 1)  # user-encoder projection: 760 small workgroups, one launch, no split
+    assert _plan(640, 1200, 400)[2] == 1  # user-encoder projection: one launch, a reduce would cost more than it saves
+    assert _plan(800, 512, 768) == (32, 32, 1)  # DocVec Dense layer: 400 small workgroups instead of split-K + reduce
     assert _hip.lib().ebn_gemm_plan(-1, 1, 1, 0, None, None, None) == -1
 
 

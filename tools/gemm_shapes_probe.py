@@ -13,13 +13,13 @@ sys.path.insert(0, str(ROOT / "ebnerd-benchmark_amd"))
 from ebrec import _hip  # noqa: E402
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "c2"
-D = {"c1": 300, "c2": 1024, "c3": 768}[cfg]
-R, E, A, Ru = 24000, 400, 200, 640
+D = {"c1": 300, "c2": 1024, "c3": 768, "c4": 300}[cfg]
+R, E, A, Ru = (52800, 400, 200, 1600) if cfg == "c4" else (24000, 400, 200, 640)
 SHAPES = [  # (name, tA, tB, M, N, K)
     ("n QKV fwd", 0, 0, R, 3 * E, D), ("n dWqkv", 1, 0, D, 3 * E, R), ("n U=Y.W", 0, 0, R, A, E), ("n dW", 1, 0, E, A, R),
     ("n dY=dpre.W^T", 0, 1, R, E, A), ("u QKV fwd", 0, 0, Ru, 3 * E, E), ("u dWqkv", 1, 0, E, 3 * E, Ru), ("u U", 0, 0, Ru, A, E),
     ("u dW", 1, 0, E, A, Ru), ("u dY", 0, 1, Ru, E, A), ("u dX", 0, 1, Ru, E, 3 * E)]
-if cfg == "c1":
+if cfg in ("c1", "c4"):
     SHAPES.insert(2, ("n dX", 0, 1, R, D, 3 * E))
 if cfg == "c3":  # NRMSDocVec: 800 document vectors per step through Dense 768-512-512-512-256, user encoder 16 heads x 16
     Rn, E3 = 800, 256
