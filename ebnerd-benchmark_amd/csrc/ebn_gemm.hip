@@ -735,8 +735,10 @@ static GemmPlan gemm_plan(int64_t M, int64_t N, int64_t K, int64_t ws_floats) {
     const int64_t tiles64 = ebn_ceil_div(M, 64) * ebn_ceil_div(N, 64);
     if (forced_tile_bm() == 32 || (forced_tile_bm() == 0 && tiles64 <= 256 && K <= 4096)) {
       const int64_t W = ebn_ceil_div(wgs, 256);
-      // two workgroups fit a CU (LDS): pairs share it at ~2.0 us per 128-deep slab, a lone one takes ~1.2 us
-      const double per_slab = static_cast<double>(W / 2) * 2.0 + static_cast<double>(W % 2) * 1.2;
+      // two workgroups fit a CU (LDS): a pair shares it at ~1.6 us per 128-deep slab, a lone one takes ~1.1 us; from the
+      // third workgroup of a CU on (a second round) the measured cost grows faster than that (1600x400x1200: 3.7 us)
+      double per_slab = static_cast<double>(W / 2) * 1.6 + static_cast<double>(W % 2) * 1.1;
+      if (W >= 3) per_slab *= 1.3;
       const double cost = static_cast<double>(ebn_ceil_div(K > 0 ? K : 1, SBK)) * per_slab + 3.0;
       best = GemmPlan{32, 32, 1, ebn_ceil_div(K > 0 ? K : 1, SBK) * SBK, cost};
       if (forced_tile_bm() == 32) return best;
