@@ -371,76 +371,112 @@ struct Bn2Sites {
   float* istd_out[2];
 };
 
+// column sums of TWO values per thread over the 64 row lanes in one pass (same fixed order as strip_colsum)
+__device__ __forceinline__ void strip_colsum2(float v0, float v1, float (*sm)[2][STRIP_COLS + 1], int c, int lane, float& t0,
+                                              float& t1) {
+  __syncthreads();  // sm may still be read from a previous call
+  sm[lane][0][c] = v0;
+  sm[lane][1][c] = v1;
+  __syncthreads();
+  if (lane < 8) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      a += sm[lane * 8 + k][0][c];
+      b += sm[lane * 8 + k][1][c];
+    }
+    sm[STRIP_LANES + lane][0][c] = a;
+    sm[STRIP_LANES + lane][1][c] = b;
+  }
+  __syncthreads();
+  t0 = 0.f;
+  t1 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    t0 += sm[STRIP_LANES + k][0][c];
+    t1 += sm[STRIP_LANES + k][1][c];
+  }
+}
+
+// Both call sites in ONE pass over the R0 + R1 <= 1024 rows of the block: thread (column, row lane) keeps its <= 16 rows in
+// registers whichever site they belong to, the per-site sums travel through LDS two at a time -- one load phase, four
+// barrier rounds and one store phase for both sites (walking the sites one after the other paid each of them twice).
 __global__ __launch_bounds__(1024) void bn2_fwd_strip_kernel(const float* __restrict__ X, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float* __restrict__ mmean,
                                                              float* __restrict__ mvar, float* __restrict__ Y,
                                                              float* __restrict__ xhat, Bn2Sites sites, int C,
                                                              const uint32_t* __restrict__ key_ptr, uint32_t thresh,
                                                              float scale) {
-  __shared__ float sm[STRIP_LANES + 8][STRIP_COLS + 1];
+  __shared__ float sm[STRIP_LANES + 8][2][STRIP_COLS + 1];
   const int cl = threadIdx.x & (STRIP_COLS - 1), lane = threadIdx.x >> 4;
   const int c = blockIdx.x * STRIP_COLS + cl;
   const bool cok = c < C;
   const bool do_drop = key_ptr != nullptr;
   const uint32_t key = do_drop ? *key_ptr : 0u;
+  const int R0 = sites.R[0], R1 = sites.R[1], RN = R0 + R1;
   const float g = gamma[cok ? c : 0], b = beta[cok ? c : 0];
-  float mm = mmean[cok ? c : 0], mv = mvar[cok ? c : 0];
-  int64_t row0 = 0;
-#pragma unroll 1
-  for (int site = 0; site < 2; ++site) {
-    const int R = sites.R[site];
-    if (R > 0) {
-      const float inv_R = 1.0f / static_cast<float>(R);
-      float x[STRIP_PER];
-      float s = 0.f;
+  const float mm0 = mmean[cok ? c : 0], mv0 = mvar[cok ? c : 0];
+  float x[STRIP_PER];
+  float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-      for (int j = 0; j < STRIP_PER; ++j) {
-        const int r = lane + STRIP_LANES * j;
-        const bool ok = cok && r < R;
-        const float v = X[ok ? (row0 + r) * C + c : 0];  // unconditional, clamped address
-        x[j] = ok ? v : 0.f;
-        s += x[j];
-      }
-      const float mean = strip_colsum(s, sm, cl, lane) * inv_R;
-      float q = 0.f;
-#pragma unroll
-      for (int j = 0; j < STRIP_PER; ++j) {
-        const int r = lane + STRIP_LANES * j;
-        const float d = (r < R) ? x[j] - mean : 0.f;
-        q = fmaf(d, d, q);
-      }
-      const float var = strip_colsum(q, sm, cl, lane) * inv_R;  // biased, two-pass
-      const float istd = 1.0f / sqrtf(var + BN_EPS);
-      mm = mm * BN_MOM + mean * (1.0f - BN_MOM);  // one moving-average update per call site, history first
-      mv = mv * BN_MOM + var * (1.0f - BN_MOM);
-      if (cok && lane == 0) {
-        sites.mean_out[site][c] = mean;
-        sites.istd_out[site][c] = istd;
-      }
-      if (cok) {
-#pragma unroll
-        for (int j = 0; j < STRIP_PER; ++j) {
-          const int r = lane + STRIP_LANES * j;
-          if (r >= R) break;
-          const int64_t i = (row0 + r) * C + c;
-          const float xh = (x[j] - mean) * istd;
-          xhat[i] = xh;
-          float y = xh * g + b;
-          if (do_drop) y *= ebn_drop_mult(key, static_cast<uint64_t>(i), thresh, scale);
-          Y[i] = y;
-        }
-      }
-    }
-    row0 += R;
+  for (int j = 0; j < STRIP_PER; ++j) {
+    const int r = lane + STRIP_LANES * j;
+    const bool ok = cok && r < RN;
+    const float v = X[ok ? static_cast<int64_t>(r) * C + c : 0];  // unconditional, clamped address
+    x[j] = ok ? v : 0.f;
+    s0 += (r < R0) ? x[j] : 0.f;
+    s1 += (r < R0) ? 0.f : x[j];
   }
-  if (cok && lane == 0) {
+  float mean0, mean1;
+  strip_colsum2(s0, s1, sm, cl, lane, mean0, mean1);
+  mean0 = R0 > 0 ? mean0 / static_cast<float>(R0) : 0.f;
+  mean1 = R1 > 0 ? mean1 / static_cast<float>(R1) : 0.f;
+  float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+  for (int j = 0; j < STRIP_PER; ++j) {
+    const int r = lane + STRIP_LANES * j;
+    const float d0 = (r < R0) ? x[j] - mean0 : 0.f;
+    const float d1 = (r >= R0 && r < RN) ? x[j] - mean1 : 0.f;
+    q0 = fmaf(d0, d0, q0);
+    q1 = fmaf(d1, d1, q1);
+  }
+  float var0, var1;
+  strip_colsum2(q0, q1, sm, cl, lane, var0, var1);  // biased, two-pass
+  var0 = R0 > 0 ? var0 / static_cast<float>(R0) : 0.f;
+  var1 = R1 > 0 ? var1 / static_cast<float>(R1) : 0.f;
+  const float istd0 = 1.0f / sqrtf(var0 + BN_EPS), istd1 = 1.0f / sqrtf(var1 + BN_EPS);
+  if (!cok) return;
+  if (lane == 0) {
+    float mm = mm0, mv = mv0;  // one moving-average update per call site, history first
+    if (R0 > 0) {
+      mm = mm * BN_MOM + mean0 * (1.0f - BN_MOM);
+      mv = mv * BN_MOM + var0 * (1.0f - BN_MOM);
+      sites.mean_out[0][c] = mean0;
+      sites.istd_out[0][c] = istd0;
+    }
+    if (R1 > 0) {
+      mm = mm * BN_MOM + mean1 * (1.0f - BN_MOM);
+      mv = mv * BN_MOM + var1 * (1.0f - BN_MOM);
+      sites.mean_out[1][c] = mean1;
+      sites.istd_out[1][c] = istd1;
+    }
     mmean[c] = mm;
     mvar[c] = mv;
   }
+  for (int j = 0; j < STRIP_PER; ++j) {  // (runtime early exit, not a predicated unrolled loop: see bn2_relu_bwd_strip_kernel)
+    const int r = lane + STRIP_LANES * j;
+    if (r >= RN) break;
+    const int64_t i = static_cast<int64_t>(r) * C + c;
+    const float xh = (r < R0) ? (x[j] - mean0) * istd0 : (x[j] - mean1) * istd1;
+    xhat[i] = xh;
+    float y = xh * g + b;
+    if (do_drop) y *= ebn_drop_mult(key, static_cast<uint64_t>(i), thresh, scale);
+    Y[i] = y;
+  }
 }
 
-// d(Dense pre-activation) = relu'(Rl) * BN-backward(dY) for both sites; dgamma / dbeta summed over the sites (the batch
-// statistics terms use each site's own sums); dbias = column sums of the result.
+// d(Dense pre-activation) = relu'(Rl) * BN-backward(dY) for both sites in one pass; dgamma / dbeta summed over the sites
+// (the batch-statistics terms use each site's own sums); dbias = column sums of the result.
 __global__ __launch_bounds__(1024) void bn2_relu_bwd_strip_kernel(const float* __restrict__ dY, const float* __restrict__ xhat,
                                                                   const float* __restrict__ Rl, const float* __restrict__ gamma,
                                                                   const float* __restrict__ istd0, const float* __restrict__ istd1,
@@ -448,58 +484,54 @@ __global__ __launch_bounds__(1024) void bn2_relu_bwd_strip_kernel(const float* _
                                                                   float* __restrict__ dbeta, float* __restrict__ dbias, int R0,
                                                                   int R1, int C, const uint32_t* __restrict__ key_ptr,
                                                                   uint32_t thresh, float scale) {
-  __shared__ float sm[STRIP_LANES + 8][STRIP_COLS + 1];
+  __shared__ float sm[STRIP_LANES + 8][2][STRIP_COLS + 1];
   const int cl = threadIdx.x & (STRIP_COLS - 1), lane = threadIdx.x >> 4;
   const int c = blockIdx.x * STRIP_COLS + cl;
   const bool cok = c < C;
   const bool do_drop = key_ptr != nullptr;
   const uint32_t key = do_drop ? *key_ptr : 0u;
+  const int RN = R0 + R1;
   const float gm = gamma[cok ? c : 0];
-  float dg_tot = 0.f, db_tot = 0.f, dbias_part = 0.f;
-  int64_t row0 = 0;
-#pragma unroll 1
-  for (int site = 0; site < 2; ++site) {
-    const int R = site ? R1 : R0;
-    if (R > 0) {
-      float g[STRIP_PER], xh[STRIP_PER], rl[STRIP_PER];
-      float a0 = 0.f, a1 = 0.f;
+  const float k0 = gm * istd0[cok ? c : 0], k1 = gm * istd1[cok ? c : 0];
+  float g[STRIP_PER], xh[STRIP_PER], rl[STRIP_PER];
+  float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;  // a0s = sum g*xhat of site s, a1s = sum g of site s
 #pragma unroll
-      for (int j = 0; j < STRIP_PER; ++j) {
-        const int r = lane + STRIP_LANES * j;
-        const bool ok = cok && r < R;
-        const int64_t i = ok ? (row0 + r) * C + c : 0;  // unconditional, clamped address
-        float gv = dY[i];
-        const float xv = xhat[i];
-        rl[j] = Rl[i];
-        if (do_drop) gv *= ebn_drop_mult(key, static_cast<uint64_t>(i), thresh, scale);
-        g[j] = ok ? gv : 0.f;
-        xh[j] = ok ? xv : 0.f;
-        a0 = fmaf(g[j], xh[j], a0);
-        a1 += g[j];
-      }
-      const float dg = strip_colsum(a0, sm, cl, lane);
-      const float db = strip_colsum(a1, sm, cl, lane);
-      dg_tot += dg;
-      db_tot += db;
-      const float inv_R = 1.0f / static_cast<float>(R);
-      const float k = gm * (site ? istd1 : istd0)[cok ? c : 0];
-      if (cok) {
-        for (int j = 0; j < STRIP_PER; ++j) {  // (runtime early exit: the fully unrolled, predicated form of this loop measured 2x slower)
-          const int r = lane + STRIP_LANES * j;
-          if (r >= R) break;
-          float v = (g[j] - db * inv_R - xh[j] * dg * inv_R) * k;
-          v = (rl[j] > 0.f) ? v : 0.f;
-          dX[(row0 + r) * C + c] = v;
-          dbias_part += v;
-        }
-      }
-    }
-    row0 += R;
+  for (int j = 0; j < STRIP_PER; ++j) {
+    const int r = lane + STRIP_LANES * j;
+    const bool ok = cok && r < RN;
+    const int64_t i = ok ? static_cast<int64_t>(r) * C + c : 0;  // unconditional, clamped address
+    float gv = dY[i];
+    const float xv = xhat[i];
+    rl[j] = Rl[i];
+    if (do_drop) gv *= ebn_drop_mult(key, static_cast<uint64_t>(i), thresh, scale);
+    g[j] = ok ? gv : 0.f;
+    xh[j] = ok ? xv : 0.f;
+    const float p = g[j] * xh[j];
+    a00 += (r < R0) ? p : 0.f;
+    a01 += (r < R0) ? 0.f : p;
+    a10 += (r < R0) ? g[j] : 0.f;
+    a11 += (r < R0) ? 0.f : g[j];
   }
-  const float dbs = strip_colsum(dbias_part, sm, cl, lane);
+  float dg0, dg1, db0, db1;
+  strip_colsum2(a00, a01, sm, cl, lane, dg0, dg1);
+  strip_colsum2(a10, a11, sm, cl, lane, db0, db1);
+  const float ir0 = R0 > 0 ? 1.0f / static_cast<float>(R0) : 0.f, ir1 = R1 > 0 ? 1.0f / static_cast<float>(R1) : 0.f;
+  float dbias_part = 0.f;
+  if (cok) {
+    for (int j = 0; j < STRIP_PER; ++j) {  // (runtime early exit: the fully unrolled, predicated form of this loop measured 2x slower)
+      const int r = lane + STRIP_LANES * j;
+      if (r >= RN) break;
+      float v = (r < R0) ? (g[j] - db0 * ir0 - xh[j] * dg0 * ir0) * k0 : (g[j] - db1 * ir1 - xh[j] * dg1 * ir1) * k1;
+      v = (rl[j] > 0.f) ? v : 0.f;
+      dX[static_cast<int64_t>(r) * C + c] = v;
+      dbias_part += v;
+    }
+  }
+  float dbs, unused;
+  strip_colsum2(dbias_part, 0.f, sm, cl, lane, dbs, unused);
   if (cok && lane == 0) {
-    dgamma[c] = dg_tot;
-    dbeta[c] = db_tot;
+    dgamma[c] = dg0 + dg1;
+    dbeta[c] = db0 + db1;
     dbias[c] = dbs;
   }
 }
@@ -630,7 +662,7 @@ extern "C" int ebn_batchnorm2_fwd_f32(const float* X, const float* gamma, const 
   EBN_REQUIRE(X && gamma && beta && moving_mean && moving_var && Y && xhat, EBN_ERR_BAD_ARG);
   EBN_REQUIRE(mean_out0 && istd_out0 && mean_out1 && istd_out1, EBN_ERR_BAD_ARG);
   EBN_REQUIRE(R0 >= 0 && R1 >= 0 && Ccols > 0, EBN_ERR_BAD_ARG);
-  EBN_REQUIRE(R0 <= STRIP_ROWS && R1 <= STRIP_ROWS, EBN_ERR_UNSUPPORTED);  // larger sites: one ebn_batchnorm_fwd_f32 each
+  EBN_REQUIRE(R0 + R1 <= STRIP_ROWS, EBN_ERR_UNSUPPORTED);  // larger blocks: one ebn_batchnorm_fwd_f32 per site
   if (R0 + R1 == 0) return EBN_OK;
   const EbnDrop dr = ebn_make_drop(st, site, drop_p);
   Bn2Sites sites{{static_cast<int>(R0), static_cast<int>(R1)}, {mean_out0, mean_out1}, {istd_out0, istd_out1}};
@@ -647,7 +679,7 @@ extern "C" int ebn_batchnorm2_relu_bwd_f32(const float* dY, const float* xhat, c
                                            int32_t site, float drop_p, ebn_stream_t stream) {
   EBN_REQUIRE(dY && xhat && relu_out && gamma && istd0 && istd1 && dX && dgamma && dbeta && dbias, EBN_ERR_BAD_ARG);
   EBN_REQUIRE(R0 >= 0 && R1 >= 0 && Ccols > 0, EBN_ERR_BAD_ARG);
-  EBN_REQUIRE(R0 <= STRIP_ROWS && R1 <= STRIP_ROWS, EBN_ERR_UNSUPPORTED);
+  EBN_REQUIRE(R0 + R1 <= STRIP_ROWS, EBN_ERR_UNSUPPORTED);
   if (R0 + R1 == 0) return EBN_OK;
   const EbnDrop dr = ebn_make_drop(st, site, drop_p);
   hipLaunchKernelGGL(bn2_relu_bwd_strip_kernel, dim3(static_cast<unsigned>(ebn_ceil_div(Ccols, STRIP_COLS))), dim3(1024), 0,

