@@ -154,3 +154,35 @@ def test_docvec_graphs_survive_an_eval_pass_that_grows_the_buffers(docvec):
             assert np.array_equal(a.cpu().numpy(), b.cpu().numpy())
     for a, b in zip(eager.model.get_weights(), graph.model.get_weights()):
         assert np.array_equal(a, b)
+
+
+def test_docvec_out_of_range_article_rows_raise_at_the_epoch_check_and_val_loss_carries_the_l2_term(docvec):
+    """Device-resident indexed batches are not range-checked on the host: the gather flags a bad row and check_oob()
+    (called by fit / evaluate once per epoch) raises, as TF-CPU's gather would.  evaluate() adds the kernel_regularizer
+    penalty to the loss like Keras does, so `val_loss` is comparable to `loss`."""
+    import torch
+
+    hp = make_hp(title_size=32, newsencoder_units_per_layer=[24, 16], head_num=2, head_dim=8, attention_hidden_dim=6, history_size=4,
+                 dropout=0.0, newsencoder_l2_regularization=1e-2)
+    rng = np.random.default_rng(13)
+    matrix = rng.standard_normal((50, 32)).astype(np.float32)
+    m = docvec(hp, seed=3)
+    eng = m._engine
+    eng.set_article_matrix(matrix)
+    hi = torch.from_numpy(rng.integers(0, 50, (6, 4)).astype(np.int32)).cuda()
+    pi = torch.from_numpy(rng.integers(0, 50, (6, 5)).astype(np.int32)).cuda()
+    y = torch.from_numpy(np.eye(5, dtype=np.float32)[rng.integers(0, 5, 6)]).cuda()
+    eng.train_step(hi, pi, y, indexed=True)
+    eng.check_oob()  # clean batch: nothing raised
+    hi[0, 0] = 50
+    eng.train_step(hi, pi, y, indexed=True)
+    with pytest.raises(IndexError):
+        eng.check_oob()
+    eng.check_oob()  # the flag is cleared by the raise
+    his, pred = matrix[rng.integers(0, 50, (6, 4))], matrix[rng.integers(0, 50, (6, 5))]
+    yy = np.eye(5, dtype=np.float32)[rng.integers(0, 5, 6)]
+    plain = float(eng.eval_loss(his, pred, yy)[0].item())
+    w = m.model.get_weights()
+    penalty = 1e-2 * (float((w[0].astype(np.float64) ** 2).sum()) + float((w[6].astype(np.float64) ** 2).sum()))  # the two hidden Dense kernels
+    got = m.model.evaluate((his, pred), yy, batch_size=6, return_dict=True)["loss"]
+    assert abs(got - (plain + penalty)) <= 1e-5 * max(1.0, abs(got)), (got, plain, penalty)

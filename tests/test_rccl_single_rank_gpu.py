@@ -1,0 +1,72 @@
+"""RCCL smoke on the one GPU of the box (gpu-marked): a single-rank "nccl" process group exercises every collective the
+engines issue -- all-reduce between hipGraph replays (captured in thread-local mode while the RCCL watchdog thread is
+alive), equal-split all-to-all of int32 / fp32, all-gather into a tensor, float64 MAX / MIN reductions, barrier, object
+broadcast / gather -- with the dtypes, shapes and call order of bench.py, fit() and the row-sharded exchange.  It cannot
+show scaling (RCCL refuses two ranks on one device), it shows that nothing in the multi-GPU code path is rejected by the
+backend the driver will run it on."""
+import os
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parents[1]
+
+SCRIPT = r'''
+import os, sys
+sys.path.insert(0, "{root}"); sys.path.insert(0, "{root}/ebnerd-benchmark_amd")
+import numpy as np, torch, torch.distributed as dist
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+from ebrec.models.newsrec import NRMSModel
+
+class hp:
+    title_size, history_size, head_num, head_dim, attention_hidden_dim = 30, 20, 20, 20, 200
+    optimizer, loss, dropout, learning_rate = "adam", "cross_entropy_loss", 0.2, 1e-3
+    newsencoder_units_per_layer, newsencoder_l2_regularization = None, 1e-4
+
+rng = np.random.default_rng(0)
+V = 500
+emb = rng.standard_normal((V, 64)).astype(np.float32)
+m = NRMSModel(hp, word2vec_embedding=emb, seed=1, device=dev)
+eng = m._engine.enable_graphs()
+his, pred = rng.integers(0, V, (4, 20, 30)), rng.integers(0, V, (4, 5, 30))
+y = np.eye(5, dtype=np.float32)[rng.integers(0, 5, 4)]
+for _ in range(3):   # graph(fwd+bwd) -> [all-reduce of the flat gradient bucket, as the DP step does] -> graph(Adam)
+    eng.train_step(his, pred, y)
+    dist.all_reduce(eng.params.grad)
+    dist.all_reduce(eng.table_grad)
+t = torch.tensor([1.5], device=dev, dtype=torch.float64)
+dist.all_reduce(t, op=dist.ReduceOp.MAX); dist.all_reduce(t, op=dist.ReduceOp.MIN)
+a = torch.arange(64, dtype=torch.int32, device=dev); b = torch.empty_like(a)
+dist.all_to_all_single(b, a); assert torch.equal(a, b)
+r = torch.randn(64, 16, device=dev); q = torch.empty_like(r)
+dist.all_to_all_single(q, r); assert torch.equal(q, r)
+g = torch.empty(64, dtype=torch.int32, device=dev); dist.all_gather_into_tensor(g, a); assert torch.equal(g, a)
+g2 = torch.empty(64, 16, device=dev); dist.all_gather_into_tensor(g2, r); assert torch.equal(g2, r)
+dist.barrier()
+obj = ["name"]; dist.broadcast_object_list(obj, src=0)
+parts = [None]; dist.all_gather_object(parts, ([[1, 0]], [[0.5, 0.25]]))
+assert parts[0][0] == [[1, 0]]
+# a second capture while the communicator (and its watchdog thread) is alive
+eng.train_step(his[:2], pred[:2], y[:2])
+torch.cuda.synchronize()
+dist.destroy_process_group()
+print("RCCL_SINGLE_RANK_OK", float(eng.loss_dev.item()))
+'''
+
+
+def test_every_collective_of_the_multi_gpu_paths_is_accepted_by_rccl(hip, tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script = tmp_path / "rccl_single_rank.py"
+    script.write_text(SCRIPT.format(root=str(ROOT)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "RCCL_SINGLE_RANK_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
