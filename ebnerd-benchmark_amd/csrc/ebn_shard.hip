@@ -39,6 +39,19 @@ __device__ __forceinline__ int64_t shard_key(const ShardGeom& g, int64_t id, int
   return o * g.per + local;
 }
 
+// mark = 0, slot_rows = -1 (padding), counts = 0
+__global__ __launch_bounds__(PLAN_THREADS) void shard_init_kernel(int32_t* __restrict__ mark, int64_t n_mark,
+                                                                  int32_t* __restrict__ slot_rows, int64_t n_slot,
+                                                                  int32_t* __restrict__ counts, int32_t n_counts) {
+  const int64_t total = n_mark + n_slot + n_counts;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * PLAN_THREADS + threadIdx.x; i < total;
+       i += static_cast<int64_t>(gridDim.x) * PLAN_THREADS) {
+    if (i < n_mark) mark[i] = 0;
+    else if (i < n_mark + n_slot) slot_rows[i - n_mark] = -1;
+    else counts[i - n_mark - n_slot] = 0;
+  }
+}
+
 __global__ __launch_bounds__(PLAN_THREADS) void shard_mark_kernel(const int32_t* __restrict__ ids, int64_t n_tok,
                                                                   ShardGeom g, int32_t* __restrict__ mark,
                                                                   int32_t* __restrict__ counts) {
@@ -178,12 +191,15 @@ extern "C" int ebn_shard_plan_i32(const int32_t* ids, int64_t n_tok, int64_t V, 
   hipStream_t s = ebn_stream(stream);
   int32_t* mark = workspace;
   int32_t* chunk = workspace + static_cast<int64_t>(world) * g.per;
-  hipError_t e = hipMemsetAsync(mark, 0, static_cast<size_t>(world) * g.per * sizeof(int32_t), s);
-  if (e != hipSuccess) return static_cast<int>(e);
-  e = hipMemsetAsync(slot_rows, 0xFF, static_cast<size_t>(world) * cap * sizeof(int32_t), s);  // -1 = padding
-  if (e != hipSuccess) return static_cast<int>(e);
-  e = hipMemsetAsync(counts, 0, static_cast<size_t>(world + 2) * sizeof(int32_t), s);
-  if (e != hipSuccess) return static_cast<int>(e);
+  // (a kernel, not hipMemsetAsync: memset nodes of a captured hipGraph were seen to leave the tail of `counts` holding
+  // garbage on later replays of the graph -- tests/test_multi_rank_gpu.py::test_two_rank_fit_keeps_ranks_in_lock_step)
+  {
+    const int64_t n_init = static_cast<int64_t>(world) * g.per + static_cast<int64_t>(world) * cap + world + 2;
+    const unsigned init_grid = static_cast<unsigned>(ebn_ceil_div(n_init, PLAN_THREADS) < 2048 ? ebn_ceil_div(n_init, PLAN_THREADS) : 2048);
+    hipLaunchKernelGGL(shard_init_kernel, dim3(init_grid), dim3(PLAN_THREADS), 0, s, mark, static_cast<int64_t>(world) * g.per,
+                       slot_rows, static_cast<int64_t>(world) * cap, counts, world + 2);
+    EBN_CHECK_LAUNCH();
+  }
   const unsigned tok_grid = static_cast<unsigned>(n_tok > 0 ? (ebn_ceil_div(n_tok, PLAN_THREADS) < 4096 ? ebn_ceil_div(n_tok, PLAN_THREADS) : 4096) : 1);
   const unsigned n_chunks = static_cast<unsigned>(world) * static_cast<unsigned>(g.chunks_per_owner);
   if (n_tok > 0) {

@@ -185,7 +185,7 @@ class ShardedTableExchange:
         c = b.counts.cpu().tolist()
         b.counts[self.world:].zero_()
         if c[self.world + 1]:
-            raise IndexError(f"token id out of range [0, {self.V}) for the {what}")
+            raise IndexError(f"token id out of range [0, {self.V}) for the {what} (plan counters {c})")
         if c[self.world]:
             raise RuntimeError(f"row-sharded lookup overflowed its exchange capacity ({b.cap} distinct rows per owner, wanted up to "
                                f"{max(c[: self.world])}): rows were dropped.  Raise capacity_factor (now {self.capacity_factor}; "

@@ -37,6 +37,16 @@ def _allreduce_host(values, eng, op="sum"):
     return t.cpu().tolist()
 
 
+def _full_batches(data) -> int:
+    """number of leading batches of `data` that have the full batch size (all but possibly the last one)"""
+    bs = getattr(data, "batch_size", None) or getattr(data, "bs", None)
+    rows = getattr(data, "X", None)
+    rows = rows if rows is not None else getattr(data, "his", None)
+    if bs is None or rows is None:
+        return len(data)
+    return len(rows) // int(bs)
+
+
 def _is_loader(x):
     return hasattr(x, "__len__") and hasattr(x, "__getitem__") and not isinstance(x, (tuple, list, np.ndarray))
 
@@ -177,14 +187,19 @@ class TrainModel:
         rank, world, _group = _dist_of(eng)
         # data parallel: every step ends in a gradient all-reduce, so every rank must run the SAME number of steps per
         # epoch -- the shortest shard decides (the surplus batches of longer shards rotate in through the shuffle)
-        n_steps = int(_allreduce_host([len(data)], eng, "min")[0]) if world > 1 else len(data)
+        n_batches = len(data)
+        if world > 1 and getattr(eng, "exchange", None) is not None:
+            # row-sharded table: the lookup's all-to-alls are sized by the batch SHAPE, which must therefore be the same on
+            # every rank in every step -- a shard's short last batch is left out (it is always the last index)
+            n_batches = _full_batches(data)
+        n_steps = int(_allreduce_host([n_batches], eng, "min")[0]) if world > 1 else n_batches
         for cb in cbs:
             cb.on_train_begin()
         for epoch in range(initial_epoch, epochs):
             for cb in cbs:
                 cb.on_epoch_begin(epoch)
             t0 = time.time()
-            order = rng.permutation(len(data)) if shuffle else np.arange(len(data))  # Keras shuffles batch ORDER only
+            order = rng.permutation(n_batches) if shuffle else np.arange(n_batches)  # Keras shuffles batch ORDER only
             order = order[:n_steps]
             loss_sum = torch.zeros(1, device=eng.device)
             n_rows = 0

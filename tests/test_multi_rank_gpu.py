@@ -226,3 +226,44 @@ def test_two_rank_row_sharded_table_step_equals_the_full_batch_oracle_step(hip, 
     """configs[4]: table rows split over two ranks, device-planned lookups, equal-split all-to-alls between the captured
     kernel segments, row gradients routed to their owners (never all-reduced)."""
     _spawn(_dp_worker, 2, True, partition, graph, train_embedding, 20)
+
+
+def _fit_worker(rank, world, shard, tmpdir):
+    """model.fit under two ranks whose shards have DIFFERENT numbers of batches (and ragged last batches): same number of
+    steps everywhere, all-reduced epoch logs -> identical callback decisions, identical replicas, one checkpoint file."""
+    import torch.distributed as dist
+    from ebrec.models.newsrec import NRMSModel
+    from ebrec.models.newsrec.callbacks import EarlyStopping, ModelCheckpoint, ReduceLROnPlateau
+
+    hp = make_hp(dropout=0.2, learning_rate=1e-3)
+    V, D = 300, 32
+    rng = np.random.default_rng(5)
+    emb = rng.standard_normal((V, D)).astype(np.float32)
+    m = NRMSModel(hp, word2vec_embedding=emb, seed=3, train_embedding=True, shard_table=shard, shard_partition="cyclic",
+                  shard_capacity_factor=float(world), deterministic=not shard)
+    m._engine.enable_graphs()
+    n_rows = 70 if rank == 0 else 50  # batch 16: 5 batches (last one 6 rows) vs 4 batches (last one 2 rows)
+    r2 = np.random.default_rng(100 + rank)
+    his, pred, y = batch(r2, n_rows, hp.history_size, 5, hp.title_size, V)
+    vhis, vpred, vy = batch(r2, 20 + 4 * rank, hp.history_size, 5, hp.title_size, V)
+    ckpt = os.path.join(tmpdir, "weights")
+    m.model.compile(optimizer=m.model.optimizer, loss=m.model.loss, metrics=["AUC"])
+    cbs = [EarlyStopping(monitor="val_auc", mode="max", patience=1, restore_best_weights=True),
+           ModelCheckpoint(filepath=ckpt, monitor="val_auc", mode="max", save_best_only=True, save_weights_only=True),
+           ReduceLROnPlateau(monitor="val_auc", mode="max", factor=0.2, patience=1, min_lr=1e-6)]
+    h = m.model.fit((his, pred), y.astype(np.float32), batch_size=16, epochs=3, verbose=0, callbacks=cbs,
+                    validation_data=((vhis, vpred), vy.astype(np.float32)))
+    assert m._engine.read_state().step % (3 if shard else 4) == 0  # 4 steps per epoch (3 when only full batches may run)
+    hist = {k: [float(v) for v in vs] for k, vs in h.history.items()}
+    parts = [None] * world
+    dist.all_gather_object(parts, (hist, [w.tobytes() for w in m.model.get_weights()], float(m.model.optimizer.learning_rate)))
+    assert parts[0][0] == parts[1][0], (parts[0][0], parts[1][0])  # identical epoch logs on both ranks
+    assert parts[0][1] == parts[1][1]  # identical replicas (incl. the gathered table)
+    assert parts[0][2] == parts[1][2]
+    assert os.path.exists(ckpt)
+    m.model.load_weights(ckpt)  # every rank can read rank 0's checkpoint
+
+
+@pytest.mark.parametrize("shard", [False, True])
+def test_two_rank_fit_keeps_ranks_in_lock_step(hip, shard, tmp_path):
+    _spawn(_fit_worker, 2, shard, str(tmp_path))
