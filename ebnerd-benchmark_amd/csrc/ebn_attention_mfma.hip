@@ -284,14 +284,17 @@ __device__ __forceinline__ float softmax_stats_only(const f32x16& t, int L, int 
   return m + __builtin_amdgcn_logf(z);
 }
 
-template <int D>
+// LC: sequence length known at compile time (0 = use a.L).  title_size = 30 and history_size = 20 are what every
+// BASELINE config runs: with L a constant most of the row / column validity masks of a 32-wide tile fold away (only
+// registers 14, 15 of the upper lane half can be rows >= 30), which is a fifth of this VALU-issue-bound kernel.
+template <int D, int LC>
 __global__ __launch_bounds__(64 * ATT_WAVES) void attn_mfma_fwd_kernel(MfmaAttnArgs a) {
   using T = Tile<D>;
   extern __shared__ __attribute__((aligned(16))) float smem[];  // ATT_WAVES x 3 regions x L x STRIDE
   const int lane = threadIdx.x & 63;
   const int64_t prob = static_cast<int64_t>(blockIdx.x) * ATT_WAVES + (threadIdx.x >> 6);
   if (prob >= a.n_prob) return;  // wave-uniform; no workgroup barriers in this kernel
-  const int L = a.L, E = a.h * D;
+  const int L = LC ? LC : a.L, E = a.h * D;
   const int region = L * T::STRIDE;
   float* sq = smem + (threadIdx.x >> 6) * 3 * region;
   float* sk = sq + region;
@@ -337,7 +340,7 @@ __global__ __launch_bounds__(64 * ATT_WAVES) void attn_mfma_fwd_kernel(MfmaAttnA
 
 // Backward.  The "lane i" tiles (P, dP -> dV, dQ) are finished before the "lane j" tiles (-> dK) are started, so
 // that at most two 32x32 tiles are live at a time: the kernel fits 128 registers = 4 waves per SIMD.
-template <int D>
+template <int D, int LC>
 __global__ __launch_bounds__(64 * ATT_WAVES) void attn_mfma_bwd_kernel(MfmaAttnArgs a) {
   using T = Tile<D>;
   constexpr int KH = D / 2;
@@ -345,7 +348,7 @@ __global__ __launch_bounds__(64 * ATT_WAVES) void attn_mfma_bwd_kernel(MfmaAttnA
   const int lane = threadIdx.x & 63;
   const int64_t prob = static_cast<int64_t>(blockIdx.x) * ATT_WAVES + (threadIdx.x >> 6);
   if (prob >= a.n_prob) return;
-  const int L = a.L, E = a.h * D;
+  const int L = LC ? LC : a.L, E = a.h * D;
   const int region = L * T::STRIDE;
   float* sq = smem + (threadIdx.x >> 6) * 4 * region;
   float* sk = sq + region;
@@ -781,11 +784,13 @@ int ebn_attn_mfma_fwd(const float* qkv, int64_t ld_qkv, float* out, int64_t ld_o
   }
   const dim3 grid(static_cast<unsigned>(ebn_ceil_div(a.n_prob, ATT_WAVES))), block(64 * ATT_WAVES);
   const size_t lds = static_cast<size_t>(ATT_WAVES) * 3 * L * sizeof(float);  // x STRIDE below
-  if (d == 16) hipLaunchKernelGGL(attn_mfma_fwd_kernel<16>, grid, block, lds * Tile<16>::STRIDE, s, a);
-  else if (d == 20) hipLaunchKernelGGL(attn_mfma_fwd_kernel<20>, grid, block, lds * Tile<20>::STRIDE, s, a);
+  if (d == 16) hipLaunchKernelGGL((attn_mfma_fwd_kernel<16, 0>), grid, block, lds * Tile<16>::STRIDE, s, a);
+  else if (d == 20 && L == 30) hipLaunchKernelGGL((attn_mfma_fwd_kernel<20, 30>), grid, block, lds * Tile<20>::STRIDE, s, a);
+  else if (d == 20 && L == 20) hipLaunchKernelGGL((attn_mfma_fwd_kernel<20, 20>), grid, block, lds * Tile<20>::STRIDE, s, a);
+  else if (d == 20) hipLaunchKernelGGL((attn_mfma_fwd_kernel<20, 0>), grid, block, lds * Tile<20>::STRIDE, s, a);
   else {
-    allow_lds(attn_mfma_fwd_kernel<32>, lds * Tile<32>::STRIDE);
-    hipLaunchKernelGGL(attn_mfma_fwd_kernel<32>, grid, block, lds * Tile<32>::STRIDE, s, a);
+    allow_lds(attn_mfma_fwd_kernel<32, 0>, lds * Tile<32>::STRIDE);
+    hipLaunchKernelGGL((attn_mfma_fwd_kernel<32, 0>), grid, block, lds * Tile<32>::STRIDE, s, a);
   }
   EBN_CHECK_LAUNCH();
   return EBN_OK;
@@ -807,11 +812,13 @@ int ebn_attn_mfma_bwd(const float* qkv, int64_t ld_qkv, const float* dout, int64
   }
   const dim3 grid(static_cast<unsigned>(ebn_ceil_div(a.n_prob, ATT_WAVES))), block(64 * ATT_WAVES);
   const size_t lds = static_cast<size_t>(ATT_WAVES) * 4 * L * sizeof(float);  // x STRIDE below
-  if (d == 16) hipLaunchKernelGGL(attn_mfma_bwd_kernel<16>, grid, block, lds * Tile<16>::STRIDE, s, a);
-  else if (d == 20) hipLaunchKernelGGL(attn_mfma_bwd_kernel<20>, grid, block, lds * Tile<20>::STRIDE, s, a);
+  if (d == 16) hipLaunchKernelGGL((attn_mfma_bwd_kernel<16, 0>), grid, block, lds * Tile<16>::STRIDE, s, a);
+  else if (d == 20 && L == 30) hipLaunchKernelGGL((attn_mfma_bwd_kernel<20, 30>), grid, block, lds * Tile<20>::STRIDE, s, a);
+  else if (d == 20 && L == 20) hipLaunchKernelGGL((attn_mfma_bwd_kernel<20, 20>), grid, block, lds * Tile<20>::STRIDE, s, a);
+  else if (d == 20) hipLaunchKernelGGL((attn_mfma_bwd_kernel<20, 0>), grid, block, lds * Tile<20>::STRIDE, s, a);
   else {
-    allow_lds(attn_mfma_bwd_kernel<32>, lds * Tile<32>::STRIDE);
-    hipLaunchKernelGGL(attn_mfma_bwd_kernel<32>, grid, block, lds * Tile<32>::STRIDE, s, a);
+    allow_lds(attn_mfma_bwd_kernel<32, 0>, lds * Tile<32>::STRIDE);
+    hipLaunchKernelGGL((attn_mfma_bwd_kernel<32, 0>), grid, block, lds * Tile<32>::STRIDE, s, a);
   }
   EBN_CHECK_LAUNCH();
   return EBN_OK;
