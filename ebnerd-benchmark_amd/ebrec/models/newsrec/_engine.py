@@ -671,8 +671,9 @@ class NRMSEngine:
         """One optimizer step (forward, loss, backward, gradient all-reduce, Keras Adam).
         Returns the batch loss as a 1-element device tensor (no host sync).  With
         ``use_graph`` the kernel sequence of a (B, C) shape is captured once into hipGraphs and
-        replayed: ~50 launches per step become two graph launches (step-dependent scalars live in
-        the device ebn_step_state, so the replay sees fresh dropout keys / Adam step sizes)."""
+        replayed: the ~30 launches of a step become graph launches with only the collectives of a
+        multi-rank step between them (step-dependent scalars live in the device ebn_step_state, so
+        the replay sees fresh dropout keys / Adam step sizes)."""
         his = his if isinstance(his, torch.Tensor) else np.asarray(his)
         pred = pred if isinstance(pred, torch.Tensor) else np.asarray(pred)
         B, C = his.shape[0], pred.shape[1]
