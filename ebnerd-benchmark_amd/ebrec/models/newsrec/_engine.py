@@ -653,19 +653,49 @@ class NRMSEngine:
         self.article_matrix = torch.from_numpy(np.ascontiguousarray(m.astype(np.int32))).to(self.device)
         self._article_matrix_src = matrix
 
-    def _stage_indexed(self, nb, his_idx, pred_idx):
+    def _stage_indexed(self, nb, his_idx, pred_idx, y=None):
+        """Article-row numbers (+ labels) of a batch -> device, then the token ids are expanded on the device.  Host batches
+        (what the loaders hand over) travel as ONE asynchronous copy out of a pinned, double-buffered staging area, and the
+        step-state advance rides in the kernel that unpacks it: the host never waits for the GPU and runs a step ahead.
+        Returns (y still to be uploaded or None, whether the step state has been advanced)."""
         B, C = his_idx.shape[0], pred_idx.shape[1]
-        n_titles = B * (self.H + C)
+        n_titles, n_lab = B * (self.H + C), B * C
         if not hasattr(nb, "art_idx") or nb.art_idx.numel() < n_titles:
             nb.art_idx = torch.empty(nb.n_seq, dtype=torch.int32, device=self.device)
-        off = 0
-        for a in (his_idx, pred_idx):
-            t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(a).reshape(-1).astype(np.int32, copy=False)))
-            t = t.reshape(-1)
-            nb.art_idx[off: off + t.numel()].copy_(t.to(device=self.device, dtype=torch.int32), non_blocking=True)
-            off += t.numel()
+        advanced = False
+        host = not isinstance(his_idx, torch.Tensor) and not isinstance(pred_idx, torch.Tensor) and y is not None and \
+            not isinstance(y, torch.Tensor)
+        if host:
+            n = n_titles + n_lab
+            st = getattr(self, "_host_stage", None)
+            if st is None or st["pinned"][0].numel() < n:
+                st = self._host_stage = {"pinned": [torch.empty(2 * n, dtype=torch.int32).pin_memory() for _ in range(2)],
+                                         "dev": torch.empty(2 * n, dtype=torch.int32, device=self.device), "ev": [None, None], "k": 0}
+            k = st["k"] = st["k"] ^ 1
+            if st["ev"][k] is not None:
+                st["ev"][k].synchronize()  # the copy that last read this pinned buffer (two steps ago) has long finished
+            hs = st["pinned"][k].numpy()
+            nh = B * self.H
+            hs[:nh] = np.asarray(his_idx).reshape(-1)
+            hs[nh:n_titles] = np.asarray(pred_idx).reshape(-1)
+            hs[n_titles:n].view(np.float32)[:] = np.asarray(y, dtype=np.float32).reshape(-1)
+            st["dev"][:n].copy_(st["pinned"][k][:n], non_blocking=True)
+            st["ev"][k] = torch.cuda.Event()
+            st["ev"][k].record()
+            _hip.call("ebn_copy3_advance", _hip.ptr(st["dev"]), _hip.ptr(nb.art_idx), n_titles * 4, None, None, 0,
+                      _hip.ptr(st["dev"][n_titles:]), _hip.ptr(nb.labels), n_lab * 4, _hip.ptr(self.state), BETA1, BETA2,
+                      _hip.stream_handle())
+            y, advanced = None, True
+        else:
+            off = 0
+            for a in (his_idx, pred_idx):
+                t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(a).reshape(-1).astype(np.int32, copy=False)))
+                t = t.reshape(-1)
+                nb.art_idx[off: off + t.numel()].copy_(t.to(device=self.device, dtype=torch.int32), non_blocking=True)
+                off += t.numel()
         _hip.call("ebn_expand_titles_i32", _hip.ptr(nb.art_idx), _hip.ptr(self.article_matrix), _hip.ptr(nb.ids), n_titles,
                   self.T, self.article_matrix.shape[0], _hip.ptr(self.oob_flag), _hip.stream_handle())
+        return y, advanced
 
     def train_step(self, his, pred, y, return_probs=False, indexed=False):
         """One optimizer step (forward, loss, backward, gradient all-reduce, Keras Adam).
@@ -682,7 +712,7 @@ class NRMSEngine:
             if his.ndim != 2 or his.shape[1] != self.H or pred.ndim != 2 or pred.shape[0] != B:
                 raise ValueError(f"indexed batches must be (B, {self.H}) and (B, C), got {tuple(his.shape)} {tuple(pred.shape)}")
             nb, ub = self._train_bufs(B, C)
-            self._stage_indexed(nb, his, pred)
+            y, advanced = self._stage_indexed(nb, his, pred, y)
         else:
             self._check_shapes(his, pred)
             nb, ub = self._train_bufs(B, C)

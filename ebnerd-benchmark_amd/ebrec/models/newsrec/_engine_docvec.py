@@ -276,6 +276,29 @@ class DocVecEngine:
                       pred_idx.numel() * 4, _hip.ptr(y), _hip.ptr(mb["labels"]), y.numel() * 4, _hip.ptr(self.state), BETA1, BETA2,
                       _hip.stream_handle())
             y, self._advanced = None, True  # the step-state advance rode in the staging launch
+        elif not isinstance(his_idx, torch.Tensor) and not isinstance(pred_idx, torch.Tensor) and y is not None and not isinstance(y, torch.Tensor):
+            # host batch (what the loaders hand over): ONE asynchronous copy out of a pinned, double-buffered staging area; the
+            # kernel that unpacks it also advances the step state -- the host never waits for the GPU
+            B, C = his_idx.shape[0], pred_idx.shape[1]
+            n_lab, tot = B * C, n + B * C
+            st = getattr(self, "_host_stage", None)
+            if st is None or st["pinned"][0].numel() < tot:
+                st = self._host_stage = {"pinned": [torch.empty(2 * tot, dtype=torch.int32).pin_memory() for _ in range(2)],
+                                         "dev": torch.empty(2 * tot, dtype=torch.int32, device=self.device), "ev": [None, None], "k": 0}
+            k = st["k"] = st["k"] ^ 1
+            if st["ev"][k] is not None:
+                st["ev"][k].synchronize()
+            hs = st["pinned"][k].numpy()
+            nh = B * self.H
+            hs[:nh] = np.asarray(his_idx).reshape(-1)
+            hs[nh:n] = np.asarray(pred_idx).reshape(-1)
+            hs[n:tot].view(np.float32)[:] = np.asarray(y, dtype=np.float32).reshape(-1)
+            st["dev"][:tot].copy_(st["pinned"][k][:tot], non_blocking=True)
+            st["ev"][k] = torch.cuda.Event()
+            st["ev"][k].record()
+            _hip.call("ebn_copy3_advance", _hip.ptr(st["dev"]), _hip.ptr(mb["art_idx"]), n * 4, None, None, 0, _hip.ptr(st["dev"][n:]),
+                      _hip.ptr(mb["labels"]), n_lab * 4, _hip.ptr(self.state), BETA1, BETA2, _hip.stream_handle())
+            y, self._advanced = None, True
         else:
             off = 0
             for a in (his_idx, pred_idx):
