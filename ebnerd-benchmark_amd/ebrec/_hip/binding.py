@@ -98,6 +98,11 @@ def lib() -> ctypes.CDLL:
                     f"{path} not found: the MI355X HIP extension is not built. Run "
                     "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C "
                     "ebnerd-benchmark_amd/csrc`). There is no CPU fallback for the model path.")
+            # torch FIRST: it ships its own libamdhip64 and this library must bind to the SAME runtime (its device pointers
+            # and streams come from torch).  Loaded before torch, the library pulls in /opt/rocm's copy, torch then brings
+            # its own, and every launch fails with hipErrorNoDevice ("no ROCm-capable device is detected").
+            import torch  # noqa: F401
+
             handle = ctypes.CDLL(str(path))
             for name, (res, argt) in declared_functions().items():
                 fn = getattr(handle, name)  # AttributeError -> header/library mismatch
