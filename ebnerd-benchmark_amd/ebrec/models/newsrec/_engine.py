@@ -653,6 +653,33 @@ class NRMSEngine:
         self.article_matrix = torch.from_numpy(np.ascontiguousarray(m.astype(np.int32))).to(self.device)
         self._article_matrix_src = matrix
 
+    def _stage_host(self, int_arrays, dst_int: torch.Tensor, y, dst_lab: torch.Tensor) -> None:
+        """Host integers (token ids or article-row numbers) + labels -> device in ONE asynchronous copy out of a pinned,
+        double-buffered staging area; the kernel that unpacks it into `dst_int` / `dst_lab` also advances the step state.
+        The host never waits for the GPU and runs up to two steps ahead."""
+        flat = [np.asarray(a).reshape(-1) for a in int_arrays]
+        n_int = sum(a.size for a in flat)
+        lab = np.asarray(y, dtype=np.float32).reshape(-1)
+        n = n_int + lab.size
+        st = getattr(self, "_host_stage", None)
+        if st is None or st["pinned"][0].numel() < n:
+            st = self._host_stage = {"pinned": [torch.empty(2 * n, dtype=torch.int32).pin_memory() for _ in range(2)],
+                                     "dev": torch.empty(2 * n, dtype=torch.int32, device=self.device), "ev": [None, None], "k": 0}
+        k = st["k"] = st["k"] ^ 1
+        if st["ev"][k] is not None:
+            st["ev"][k].synchronize()  # the copy that last read this pinned buffer (two steps ago) has long finished
+        hs = st["pinned"][k].numpy()
+        off = 0
+        for a in flat:
+            hs[off: off + a.size] = a
+            off += a.size
+        hs[n_int:n].view(np.float32)[:] = lab
+        st["dev"][:n].copy_(st["pinned"][k][:n], non_blocking=True)
+        st["ev"][k] = torch.cuda.Event()
+        st["ev"][k].record()
+        _hip.call("ebn_copy3_advance", _hip.ptr(st["dev"]), _hip.ptr(dst_int), n_int * 4, None, None, 0, _hip.ptr(st["dev"][n_int:]),
+                  _hip.ptr(dst_lab), lab.size * 4, _hip.ptr(self.state), BETA1, BETA2, _hip.stream_handle())
+
     def _stage_indexed(self, nb, his_idx, pred_idx, y=None):
         """Article-row numbers (+ labels) of a batch -> device, then the token ids are expanded on the device.  Host batches
         (what the loaders hand over) travel as ONE asynchronous copy out of a pinned, double-buffered staging area, and the
@@ -666,25 +693,7 @@ class NRMSEngine:
         host = not isinstance(his_idx, torch.Tensor) and not isinstance(pred_idx, torch.Tensor) and y is not None and \
             not isinstance(y, torch.Tensor)
         if host:
-            n = n_titles + n_lab
-            st = getattr(self, "_host_stage", None)
-            if st is None or st["pinned"][0].numel() < n:
-                st = self._host_stage = {"pinned": [torch.empty(2 * n, dtype=torch.int32).pin_memory() for _ in range(2)],
-                                         "dev": torch.empty(2 * n, dtype=torch.int32, device=self.device), "ev": [None, None], "k": 0}
-            k = st["k"] = st["k"] ^ 1
-            if st["ev"][k] is not None:
-                st["ev"][k].synchronize()  # the copy that last read this pinned buffer (two steps ago) has long finished
-            hs = st["pinned"][k].numpy()
-            nh = B * self.H
-            hs[:nh] = np.asarray(his_idx).reshape(-1)
-            hs[nh:n_titles] = np.asarray(pred_idx).reshape(-1)
-            hs[n_titles:n].view(np.float32)[:] = np.asarray(y, dtype=np.float32).reshape(-1)
-            st["dev"][:n].copy_(st["pinned"][k][:n], non_blocking=True)
-            st["ev"][k] = torch.cuda.Event()
-            st["ev"][k].record()
-            _hip.call("ebn_copy3_advance", _hip.ptr(st["dev"]), _hip.ptr(nb.art_idx), n_titles * 4, None, None, 0,
-                      _hip.ptr(st["dev"][n_titles:]), _hip.ptr(nb.labels), n_lab * 4, _hip.ptr(self.state), BETA1, BETA2,
-                      _hip.stream_handle())
+            self._stage_host([his_idx, pred_idx], nb.art_idx, y, nb.labels)
             y, advanced = None, True
         else:
             off = 0
@@ -721,6 +730,12 @@ class NRMSEngine:
                 _hip.call("ebn_copy3_advance", _hip.ptr(his), _hip.ptr(nb.ids), nh * 4, _hip.ptr(pred), _hip.ptr(nb.ids[nh:]),
                           pred.numel() * 4, _hip.ptr(y), _hip.ptr(nb.labels), y.numel() * 4, _hip.ptr(self.state), BETA1, BETA2,
                           _hip.stream_handle())
+                y, advanced = None, True
+            elif not isinstance(his, torch.Tensor) and not isinstance(pred, torch.Tensor) and not isinstance(y, torch.Tensor):
+                for a in (his, pred):  # ids outside [0, V) raise like TF-CPU's Embedding does
+                    if a.size and (a.min() < 0 or a.max() >= self.V):
+                        raise IndexError(f"token id out of range [0, {self.V}) for the embedding table")
+                self._stage_host([his, pred], nb.ids, y, nb.labels)
                 y, advanced = None, True
             else:
                 self._upload_ids(nb.ids, his, pred)
