@@ -169,6 +169,25 @@ __global__ __launch_bounds__(256) void score_loss_train_kernel(
   }
 }
 
+// Streaming AUC of compile(metrics=["AUC"]) (ebnerd_nrms.py:244-248; tf.keras.metrics.AUC: 200 thresholds): bucket every
+// (label, prediction) pair of a batch into the positive / negative histograms -- bucket = number of thresholds strictly
+// below the prediction (lower bound in the ascending float64 threshold list), integer atomics (order-independent).
+__global__ __launch_bounds__(256) void auc_hist_kernel(const float* __restrict__ probs, const float* __restrict__ labels,
+                                                       int64_t n, const double* __restrict__ thr, int n_thr,
+                                                       unsigned long long* __restrict__ pos_hist,
+                                                       unsigned long long* __restrict__ neg_hist) {
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * 256) {
+    const double p = static_cast<double>(probs[i]);
+    int lo = 0, hi = n_thr;  // first index with thr[idx] >= p
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (thr[mid] < p) lo = mid + 1;
+      else hi = mid;
+    }
+    atomicAdd((labels[i] > 0.f) ? &pos_hist[lo] : &neg_hist[lo], 1ull);
+  }
+}
+
 // 4 pairs per 256-thread block, one wave per pair
 __global__ __launch_bounds__(256) void pair_score_kernel(const float* __restrict__ user,
                                                          const float* __restrict__ news,
@@ -315,6 +334,20 @@ extern "C" int ebn_score_loss_train_f32(const float* cand, const float* user, co
                      inv_batch);
   EBN_CHECK_LAUNCH();
   return ebn_sum_f32(loss_rows, B, 1.0f, loss_out, 0, stream);  // fixed-order reduction: deterministic batch loss
+}
+
+extern "C" int ebn_auc_hist_f32(const float* probs, const float* labels, int64_t n, const double* thresholds,
+                                int32_t n_thresholds, int64_t* pos_hist, int64_t* neg_hist, ebn_stream_t stream) {
+  EBN_REQUIRE(probs && labels && thresholds && pos_hist && neg_hist, EBN_ERR_BAD_ARG);
+  EBN_REQUIRE(n >= 0 && n_thresholds > 0, EBN_ERR_BAD_ARG);
+  if (n == 0) return EBN_OK;
+  int64_t grid = ebn_ceil_div(n, 256);
+  if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(auc_hist_kernel, dim3(static_cast<unsigned>(grid)), dim3(256), 0, ebn_stream(stream), probs, labels, n,
+                     thresholds, n_thresholds, reinterpret_cast<unsigned long long*>(pos_hist),
+                     reinterpret_cast<unsigned long long*>(neg_hist));
+  EBN_CHECK_LAUNCH();
+  return EBN_OK;
 }
 
 extern "C" int ebn_pair_score_f32(const float* user, const float* news, const int32_t* u_idx,

@@ -751,8 +751,8 @@ class NRMSEngine:
         else:
             for _kind, fn in self._segments(B, C, advanced):
                 fn()
-        if return_probs:
-            return self.loss_dev, nb.probs[: B * C].view(B, C)
+        if return_probs:  # (loss, probabilities, the labels as staged on the device: the streaming AUC needs no second upload)
+            return self.loss_dev, nb.probs[: B * C].view(B, C), nb.labels[: B * C].view(B, C)
         return self.loss_dev
 
     def _train_bufs(self, B, C):

@@ -347,7 +347,7 @@ class DocVecEngine:
             self._allreduce_grads()
             self._optimizer_kernels()
         if return_probs:
-            return self.loss_dev, mb["probs"][: B * C].view(B, C)
+            return self.loss_dev, mb["probs"][: B * C].view(B, C), mb["labels"][: B * C].view(B, C)
         return self.loss_dev
 
     def _fwd_bwd_kernels(self, B, C, advanced=False):

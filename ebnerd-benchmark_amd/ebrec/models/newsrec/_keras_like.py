@@ -215,8 +215,8 @@ class TrainModel:
                 (his, pred), yb = data.index_batch(int(idx)) if indexed else data[int(idx)]
                 nb = len(his)
                 if want_auc:
-                    loss, probs = eng.train_step(his, pred, yb, return_probs=True, **({"indexed": True} if indexed else {}))
-                    auc.update_device(torch.as_tensor(np.asarray(yb)).to(eng.device), probs)
+                    loss, probs, labels_dev = eng.train_step(his, pred, yb, return_probs=True, **({"indexed": True} if indexed else {}))
+                    auc.update_device(labels_dev, probs)
                 else:
                     loss = eng.train_step(his, pred, yb, **({"indexed": True} if indexed else {}))
                 loss_sum += loss * nb
@@ -268,7 +268,7 @@ class TrainModel:
             loss_sum += loss * len(his)  # stays on the device: one host sync per evaluate(), not per batch
             n_rows += len(his)
             if auc is not None:
-                auc.update_device(torch.as_tensor(np.asarray(yb)).to(eng.device), probs)
+                auc.update_device(torch.as_tensor(np.asarray(yb, dtype=np.float32)).to(eng.device).reshape(probs.shape).contiguous(), probs)
         ls, nr = _allreduce_host([float(loss_sum.item()), n_rows], eng)  # every rank evaluates its shard; the result is global
         out = {"loss": ls / max(nr, 1)}
         if hasattr(eng, "check_oob"):

@@ -210,28 +210,36 @@ class StreamingAUC:
         self.neg_hist += np.bincount(k, weights=(y <= 0).astype(np.float64), minlength=self.num_thresholds + 1)
 
     def update_device(self, y_true, y_pred):
-        """Same accumulation with torch ops on the device (no host sync per step)."""
+        """Same accumulation on the device with no host sync: one launch of ebn_auc_hist_f32 for fp32 device tensors (the
+        training / validation loops), torch ops otherwise."""
         import torch
 
+        dev = y_pred.device
         if self._dev is None:
-            dev = y_pred.device
-            self._dev = (torch.from_numpy(self.thresholds).to(dev), torch.zeros(self.num_thresholds + 1, dtype=torch.float64, device=dev),
-                         torch.zeros(self.num_thresholds + 1, dtype=torch.float64, device=dev))
+            self._dev = (torch.from_numpy(self.thresholds).to(dev), torch.zeros(self.num_thresholds + 1, dtype=torch.int64, device=dev),
+                         torch.zeros(self.num_thresholds + 1, dtype=torch.int64, device=dev))
         thr, ph, nh = self._dev
+        if y_pred.is_cuda and y_pred.dtype == torch.float32 and y_true.dtype == torch.float32 and y_true.is_cuda and \
+                y_pred.is_contiguous() and y_true.is_contiguous():
+            from ebrec import _hip
+
+            _hip.call("ebn_auc_hist_f32", _hip.ptr(y_pred), _hip.ptr(y_true), y_pred.numel(), _hip.ptr(thr), self.num_thresholds,
+                      _hip.ptr(ph), _hip.ptr(nh), _hip.stream_handle())
+            return
         p = y_pred.reshape(-1).to(torch.float64)
         y = y_true.reshape(-1)
         k = torch.searchsorted(thr, p, right=False)
-        pos = (y > 0).to(torch.float64)
+        pos = (y > 0).to(torch.int64)
         ph.index_add_(0, k, pos)
-        nh.index_add_(0, k, 1.0 - pos)
+        nh.index_add_(0, k, 1 - pos)
 
     def result(self, engine=None) -> float:
         """AUC of everything accumulated; with a data-parallel `engine` (world > 1) the histograms of all ranks are summed
         first, so every rank reports the same global value (callbacks then act identically on every rank)."""
         pos, neg = self.pos_hist.copy(), self.neg_hist.copy()
         if self._dev is not None:
-            pos += self._dev[1].cpu().numpy()
-            neg += self._dev[2].cpu().numpy()
+            pos += self._dev[1].cpu().numpy().astype(np.float64)
+            neg += self._dev[2].cpu().numpy().astype(np.float64)
         if engine is not None and int(getattr(engine, "world", 1)) > 1:
             import torch
 

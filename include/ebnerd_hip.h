@@ -274,6 +274,11 @@ int ebn_score_loss_bwd_f32(const float* cand, const float* user, const float* sc
 int ebn_score_loss_train_f32(const float* cand, const float* user, const float* labels, float* scores, float* probs,
                              float* loss_rows, float* loss_out, float* dcand, float* duser, int64_t B, int32_t C,
                              int32_t E, int32_t loss_kind, float inv_batch, ebn_stream_t stream);
+/* Streaming AUC of compile(metrics=["AUC"]) (ebnerd_nrms.py:244-248; tf.keras.metrics.AUC defaults): every (label,
+ * prediction) pair of a batch goes into pos_hist / neg_hist [n_thresholds + 1] at bucket = number of thresholds strictly
+ * below the prediction (`thresholds`: ascending float64 on the device).  Integer atomics: order-independent.           */
+int ebn_auc_hist_f32(const float* probs, const float* labels, int64_t n, const double* thresholds, int32_t n_thresholds,
+                     int64_t* pos_hist, int64_t* neg_hist, ebn_stream_t stream);
 /* ragged scoring for the eval path (dataloader.py:94-107 + nrms.py:204-205):
  * out[p] = act(user[u_idx[p],:] . news[n_idx[p],:]), act = sigmoid (mode 1) or id (0). */
 int ebn_pair_score_f32(const float* user, const float* news, const int32_t* u_idx,

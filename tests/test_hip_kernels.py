@@ -753,3 +753,25 @@ def test_l2_regulariser_of_a_stack_in_two_launches(hip):
         assert_close(host(d), g.astype(np.float64) + 2 * lam * w.astype(np.float64), rtol=1e-6, atol=1e-7, what="gW += 2 lambda W")
     want = 2.5 + lam * sum(float((w.astype(np.float64) ** 2).sum()) for w in Ws)
     assert abs(float(loss.item()) - want) <= 1e-5 * want
+
+
+def test_streaming_auc_histogram_kernel_equals_the_numpy_accumulation(hip):
+    """ebn_auc_hist_f32 (one launch per batch, device labels) == StreamingAUC.update_numpy bucket for bucket, including
+    predictions exactly on a threshold, 0, 1 and ties; and through StreamingAUC.update_device end to end."""
+    from ebrec.models.newsrec.callbacks import StreamingAUC
+
+    rng = np.random.default_rng(71)
+    n = 5003
+    p = rng.random(n).astype(np.float32)
+    p[:300] = (np.arange(300) / 199.0).astype(np.float32)[:300] % 1.0  # values on / next to the 200 thresholds
+    p[300:310] = 0.0
+    p[310:320] = 1.0
+    p[320:340] = 0.5
+    y = (rng.random(n) < 0.2).astype(np.float32)
+    ref, got = StreamingAUC(), StreamingAUC()
+    ref.update_numpy(y, p)
+    for s in range(0, n, 1000):  # several "batches"
+        got.update_device(dev(y[s:s + 1000]), dev(p[s:s + 1000]))
+    assert np.array_equal(got._dev[1].cpu().numpy().astype(np.float64), ref.pos_hist)
+    assert np.array_equal(got._dev[2].cpu().numpy().astype(np.float64), ref.neg_hist)
+    assert got.result() == ref.result()

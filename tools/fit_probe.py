@@ -1,5 +1,5 @@
 """End-to-end model.fit() throughput on a synthetic train loader at c2 sizes (host loop + loader + device step), or with
---docvec at c3 sizes (NRMSDocVec on 768-d document vectors).   usage: fit_probe.py [n_impressions] [--no-graph] [--docvec]"""
+--docvec at c3 sizes (NRMSDocVec on 768-d document vectors).   usage: fit_probe.py [n_impressions] [--no-graph] [--docvec] [--auc]"""
 import sys
 import time
 from pathlib import Path
@@ -36,6 +36,8 @@ else:
     table = (rng.standard_normal((V, D), dtype=np.float32) * 0.02)
     m = NRMSModel(hp, word2vec_embedding=table, seed=1, train_embedding=False)
 m._engine.enable_graphs("--no-graph" not in sys.argv)
+if "--auc" in sys.argv:  # the reproducibility driver compiles with metrics=["AUC"]: streaming AUC over every batch
+    m.model.compile(optimizer=m.model.optimizer, loss=m.model.loss, metrics=["AUC"])
 m.model.fit(loader, epochs=1, verbose=0)  # warm-up: buffers, graph capture
 torch.cuda.synchronize()
 t0 = time.perf_counter()
