@@ -25,12 +25,34 @@ from ebrec.utils._frames import list_column, to_pandas
 from ebrec.utils._python import create_lookup_objects, repeat_by_list_values_from_matrix
 
 
-def _map_ids(lists: list[list], mapping: dict) -> tuple[np.ndarray, np.ndarray]:
-    """ragged article ids -> (flat lookup rows int32, offsets); unknown / None -> 0."""
-    lens = np.fromiter((len(l) for l in lists), dtype=np.int64, count=len(lists))
+def _map_ids(cells, mapping: dict) -> tuple[np.ndarray, np.ndarray]:
+    """Ragged article ids (the cells of a list-valued column: lists, tuples, numpy arrays; None = a null list) -> (flat lookup
+    rows int32, offsets); unknown / null ids -> row 0.  A null cell counts as ONE null id (polars explodes null -> null), like
+    ``as_list``.  Integer columns take a vectorised path (one concatenate + one binary search over the sorted article ids:
+    the reference's per-row polars transform and ``to_list()`` were where its loader time went); anything
+    else (None inside a list, mixed types) falls back to the per-element dictionary lookup."""
+    cells = list(cells)
+    lens = np.fromiter((1 if c is None or isinstance(c, float) else len(c) for c in cells), dtype=np.int64, count=len(cells))
     offsets = np.concatenate(([0], np.cumsum(lens)))
+    total = int(offsets[-1])
+    if total and mapping:
+        try:
+            null = np.array([np.iinfo(np.int64).min], dtype=np.int64)
+            flat_ids = np.concatenate([null if (c is None or isinstance(c, float)) else np.asarray(c) for c in cells])
+        except ValueError:
+            flat_ids = None
+        if flat_ids is not None and flat_ids.dtype.kind in "iu" and flat_ids.size == total:
+            keys = np.fromiter(mapping.keys(), dtype=np.int64, count=len(mapping))
+            rows = np.fromiter(mapping.values(), dtype=np.int32, count=len(mapping))
+            order = np.argsort(keys, kind="stable")
+            keys, rows = keys[order], rows[order]
+            flat_ids = flat_ids.astype(np.int64, copy=False)
+            pos = np.minimum(np.searchsorted(keys, flat_ids), len(keys) - 1)
+            return np.where(keys[pos] == flat_ids, rows[pos], 0).astype(np.int32), offsets
     get = mapping.get
-    flat = np.fromiter((get(a, 0) for l in lists for a in l), dtype=np.int32, count=int(offsets[-1]))
+    flat = np.fromiter((get(a, 0) for c in cells for a in ([None] if (c is None or isinstance(c, float)) else
+                                                          (c.tolist() if isinstance(c, np.ndarray) else c))),
+                       dtype=np.int32, count=total)
     return flat, offsets
 
 
@@ -82,8 +104,8 @@ class NRMSDataLoader(NewsrecDataLoader):
 
     def __post_init__(self):
         super().__post_init__()
-        self._his_flat, self._his_off = _map_ids(list_column(self.X, self.history_column), self.lookup_article_index)
-        self._inv_flat, self._inv_off = _map_ids(list_column(self.X, self.inview_col), self.lookup_article_index)
+        self._his_flat, self._his_off = _map_ids(self.X[self.history_column].tolist(), self.lookup_article_index)
+        self._inv_flat, self._inv_off = _map_ids(self.X[self.inview_col].tolist(), self.lookup_article_index)
         self._y_flat = np.concatenate([np.asarray(l, dtype=np.int64) for l in self.y]) if len(self.y) else np.zeros(0, np.int64)
         hl = np.diff(self._his_off)
         if len(hl) and hl.min() != hl.max():
