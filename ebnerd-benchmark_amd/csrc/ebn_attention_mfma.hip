@@ -82,15 +82,17 @@ struct Staged {
 };
 
 template <int D>
-__device__ __forceinline__ void stage_load(Staged<D>& st, const float* __restrict__ base, int64_t ld, int L, int lane) {
+__device__ __forceinline__ void stage_load(Staged<D>& st, const float* __restrict__ base, uint32_t ld, int L, int lane) {
   using T = Tile<D>;
 #pragma unroll
   for (int t = 0; t < T::ROUNDS; ++t) {
     int v = lane + 64 * t;
     if (T::VECS % 64 != 0 && v >= T::VECS) v = 0;
     const int r = v / T::VPR, c4 = v - r * T::VPR;
-    const int rc = r < L ? r : 0;
-    st.v[t] = *reinterpret_cast<const float4*>(base + static_cast<int64_t>(rc) * ld + c4 * 4);
+    const uint32_t rc = r < L ? r : 0;
+    // wave-uniform base + 32-bit lane offset (<= 64 rows x ld < 2^24, checked by the launcher): scalar-base addressing,
+    // no 64-bit multiply-add per piece
+    st.v[t] = *reinterpret_cast<const float4*>(base + (rc * ld + static_cast<uint32_t>(c4 * 4)));
   }
 }
 
@@ -138,8 +140,9 @@ __device__ __forceinline__ void stage_store(float* __restrict__ lds, const Stage
     if (r >= L) continue;
     float4 y = st.v[t];
     if (DROP) {
-      const uint64_t e = e0 + static_cast<uint64_t>(r) * E + c4 * 4;  // multiple of 4: two aligned pairs
-      const uint32_t h0 = ebn_dropout_pair_hash(key, e >> 1), h1 = ebn_dropout_pair_hash(key, (e >> 1) + 1);
+      // e0, r * E and c4 * 4 are multiples of 4: two aligned pairs; wave-uniform 64-bit part + 32-bit lane part
+      const uint64_t pr = (e0 >> 1) + ((static_cast<uint32_t>(r) * static_cast<uint32_t>(E) + static_cast<uint32_t>(c4 * 4)) >> 1);
+      const uint32_t h0 = ebn_dropout_pair_hash(key, pr), h1 = ebn_dropout_pair_hash(key, pr + 1);
       y.x *= ((h0 & 0xFFFFu) >= thresh) ? scale : 0.f;
       y.y *= ((h0 >> 16) >= thresh) ? scale : 0.f;
       y.z *= ((h1 & 0xFFFFu) >= thresh) ? scale : 0.f;
@@ -151,7 +154,7 @@ __device__ __forceinline__ void stage_store(float* __restrict__ lds, const Stage
 
 // lds[32][STRIDE] -> global M[L][D], optionally through the dropout mask
 template <int D, bool DROP>
-__device__ __forceinline__ void stage_out(const float* __restrict__ lds, float* __restrict__ base, int64_t ld, int L,
+__device__ __forceinline__ void stage_out(const float* __restrict__ lds, float* __restrict__ base, uint32_t ld, int L,
                                           int lane, uint32_t key, uint64_t e0, int E, uint32_t thresh, float scale) {
   using T = Tile<D>;
 #pragma unroll
@@ -162,42 +165,48 @@ __device__ __forceinline__ void stage_out(const float* __restrict__ lds, float* 
     if (r >= L) continue;
     float4 y = *reinterpret_cast<const float4*>(lds + r * T::STRIDE + c4 * 4);
     if (DROP) {
-      const uint64_t e = e0 + static_cast<uint64_t>(r) * E + c4 * 4;
-      const uint32_t h0 = ebn_dropout_pair_hash(key, e >> 1), h1 = ebn_dropout_pair_hash(key, (e >> 1) + 1);
+      const uint64_t pr = (e0 >> 1) + ((static_cast<uint32_t>(r) * static_cast<uint32_t>(E) + static_cast<uint32_t>(c4 * 4)) >> 1);
+      const uint32_t h0 = ebn_dropout_pair_hash(key, pr), h1 = ebn_dropout_pair_hash(key, pr + 1);
       y.x *= ((h0 & 0xFFFFu) >= thresh) ? scale : 0.f;
       y.y *= ((h0 >> 16) >= thresh) ? scale : 0.f;
       y.z *= ((h1 & 0xFFFFu) >= thresh) ? scale : 0.f;
       y.w *= ((h1 >> 16) >= thresh) ? scale : 0.f;
     }
-    *reinterpret_cast<float4*>(base + static_cast<int64_t>(r) * ld + c4 * 4) = y;
+    *reinterpret_cast<float4*>(base + (static_cast<uint32_t>(r) * ld + static_cast<uint32_t>(c4 * 4))) = y;
   }
 }
 
-// The LDS regions hold L rows (not 32): rows >= L are predicated to zero on the way into the registers.
+// The LDS regions hold L rows (not 32).  Rows >= L are NOT zeroed on the way into the registers: the row index is clamped
+// (row 0 is read again), so every operand element is a finite value of the problem's own data, and zeros are only needed
+// -- and only produced, by the softmax masks -- where a row >= L is a CONTRACTION index:
+//   * row-form operands feed mm_rows, which contracts over the head dimension: a clamped lane only changes tile entries
+//     whose lane or register index is >= L.  Register indices >= L are masked by the softmax (P = 0 there, and
+//     dS = P (dP - rowdot) = 0 with a finite dP); lanes >= L only reach output columns >= L, which are never stored, and
+//     their statistics are fetched (__shfl) only for masked entries;
+//   * column-form operands feed mm_col_tile, which contracts over the row index against a P / dS tile that is zero there.
+//     Columns >= D only produce output rows >= D (never stored): the column index is clamped as well.
+// (Value selects on every element were a tenth of the VALU instructions of these VALU-issue-bound kernels.)
 // lane (row = lane&31, hi): x[s] = M[row][hi*KH + s].  8-byte LDS reads.
 template <int D>
 __device__ __forceinline__ void lds_row_form(float (&x)[D / 2], const float* __restrict__ lds, int L, int row, int hi) {
   constexpr int KH = D / 2;
-  const bool ok = row < L;
-  const float2* p = reinterpret_cast<const float2*>(lds + (ok ? row : 0) * Tile<D>::STRIDE + hi * KH);
+  const float2* p = reinterpret_cast<const float2*>(lds + (row < L ? row : 0) * Tile<D>::STRIDE + hi * KH);
 #pragma unroll
   for (int s = 0; s < KH / 2; ++s) {
     const float2 v = p[s];
-    x[2 * s] = ok ? v.x : 0.f;
-    x[2 * s + 1] = ok ? v.y : 0.f;
+    x[2 * s] = v.x;
+    x[2 * s + 1] = v.y;
   }
 }
 
-// lane (c = lane&31, hi): y[s] = M[crow(s,hi)][c]; zero for c >= D or a row >= L.
+// lane (c = lane&31, hi): y[s] = M[crow(s,hi)][c] (row and column clamped, see above).
 template <int D>
 __device__ __forceinline__ void lds_col_form(float (&y)[16], const float* __restrict__ lds, int L, int c, int hi) {
-  const int cc = (c < D) ? c : 0;
+  const float* p = lds + ((c < D) ? c : 0);
 #pragma unroll
   for (int s = 0; s < 16; ++s) {
     const int r = crow(s, hi);
-    const bool ok = (c < D) && (r < L);
-    const float v = lds[(r < L ? r : 0) * Tile<D>::STRIDE + cc];
-    y[s] = ok ? v : 0.f;
+    y[s] = p[(r < L ? r : 0) * Tile<D>::STRIDE];
   }
 }
 
@@ -236,13 +245,52 @@ __device__ __forceinline__ void tile_rows_to_lds(float* __restrict__ lds, const 
   }
 }
 
+// The same tile straight to global memory (optionally through the dropout mask): lane (row, hi) owns the 16-byte pieces
+// at columns 8g + 4hi of its row -- as many store instructions as the staged, 80-bytes-per-row form issues, without the
+// LDS round trip (write, wait, read, wait) in front of them and without a staging region.
+template <int D, bool DROP>
+__device__ __forceinline__ void tile_rows_to_global(float* __restrict__ base, uint32_t ld, const f32x16& acc, int L, int row,
+                                                    int hi, float mul, uint32_t key, uint64_t e0, int E, uint32_t thresh,
+                                                    float scale) {
+  if (row >= L) return;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int c0 = 8 * g + 4 * hi;
+    if (c0 < D) {
+      float4 y = make_float4(acc[4 * g] * mul, acc[4 * g + 1] * mul, acc[4 * g + 2] * mul, acc[4 * g + 3] * mul);
+      if (DROP) {
+        const uint64_t pr = (e0 >> 1) + ((static_cast<uint32_t>(row) * static_cast<uint32_t>(E) + static_cast<uint32_t>(c0)) >> 1);
+        const uint32_t h0 = ebn_dropout_pair_hash(key, pr), h1 = ebn_dropout_pair_hash(key, pr + 1);
+        y.x *= ((h0 & 0xFFFFu) >= thresh) ? scale : 0.f;
+        y.y *= ((h0 >> 16) >= thresh) ? scale : 0.f;
+        y.z *= ((h1 & 0xFFFFu) >= thresh) ? scale : 0.f;
+        y.w *= ((h1 >> 16) >= thresh) ? scale : 0.f;
+      }
+      *reinterpret_cast<float4*>(base + (static_cast<uint32_t>(row) * ld + static_cast<uint32_t>(c0))) = y;
+    }
+  }
+}
+
+// Row form straight from global memory: lane (row, hi) reads its D/2 consecutive floats (8-byte pieces: the half-row
+// offset hi * D/2 floats is 40 bytes for D = 20).  For operands that are needed in row form only.
+template <int D>
+__device__ __forceinline__ void global_row_form(float (&x)[D / 2], const float* __restrict__ base, uint32_t ld, int L, int row, int hi) {
+  constexpr int KH = D / 2;
+  const float2* p = reinterpret_cast<const float2*>(base + (static_cast<uint32_t>(row < L ? row : 0) * ld + static_cast<uint32_t>(hi * KH)));
+#pragma unroll
+  for (int s = 0; s < KH / 2; ++s) {
+    const float2 v = p[s];
+    x[2 * s] = v.x;
+    x[2 * s + 1] = v.y;
+  }
+}
+
 // Softmax in the exp2 domain: `inv2` = log2(e)/sqrt(d), so exp(x/sqrt(d) - max) = exp2(x*inv2 - max2) and one
 // v_exp_f32 per element replaces the ~20-instruction expf expansion (the softmax of 2 x 32 x 32 scores was the VALU
 // bottleneck of these kernels).  Arguments are <= 0, flush-to-zero below 2^-126 is the correct limit.
 //
-// Statistics of row i, held by lane i (both halves end with the same values): t[r] = T[j=crow(r,hi)][i].
-// Returns c = max2 + log2(Z), so that P_ij = exp2(t_ij*inv2 - c) in either layout; turns t into P_ij (zero for j >= L).
-__device__ __forceinline__ float softmax_in_lane(f32x16& t, int L, int hi, float inv2) {
+// Row i is held by lane i (both lane halves together): t[r] = T[j=crow(r,hi)][i].  Turns t into P_ij (zero for j >= L).
+__device__ __forceinline__ void softmax_in_lane(f32x16& t, int L, int hi, float inv2) {
   float m = -INFINITY;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -252,214 +300,202 @@ __device__ __forceinline__ float softmax_in_lane(f32x16& t, int L, int hi, float
   m = fmaxf(m, __shfl_xor(m, 32, 64));
   float z = 0.f;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) z += (crow(r, hi) < L) ? __builtin_amdgcn_exp2f(t[r] - m) : 0.f;
-  z += __shfl_xor(z, 32, 64);
-  const float c = m + __builtin_amdgcn_logf(z);  // v_log_f32 = log2; z in [1, 32]
-#pragma unroll
-  for (int r = 0; r < 16; ++r) t[r] = (crow(r, hi) < L) ? __builtin_amdgcn_exp2f(t[r] - c) : 0.f;
-  return c;
-}
-
-// s[r] = S[i=crow(r,hi)][j] -> P_ij using c_i fetched from lane i
-__device__ __forceinline__ void softmax_from_stats(f32x16& s, int L, int hi, float inv2, float c) {
-#pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int i = crow(r, hi);
-    const float ci = __shfl(c, i, 64);
-    s[r] = (i < L) ? __builtin_amdgcn_exp2f(s[r] * inv2 - ci) : 0.f;
+    t[r] = (crow(r, hi) < L) ? __builtin_amdgcn_exp2f(t[r] - m) : 0.f;
+    z += t[r];
   }
+  z += __shfl_xor(z, 32, 64);
+  const float rz = 1.0f / z;  // z in [1, 32]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) t[r] *= rz;
 }
 
-// forward only needs the statistics from the T layout
-__device__ __forceinline__ float softmax_stats_only(const f32x16& t, int L, int hi, float inv2) {
-  float m = -INFINITY;
+// 32 x 32 tile transpose through wave-private LDS.  In: lane (a = lane&31, hi), register r <-> element (a, b = crow(r,hi)).
+// Out: lane (b, hi), register r <-> element (a = crow(r,hi), b), with the registers of rows a >= L set to zero (they are
+// contraction indices of the product that follows; the source lanes a >= L hold finite duplicates of row 0, see above).
+// 16 ds_write_b32 (32 consecutive floats per lane half: conflict-free) and 4 ds_read_b128 (rows 8g + 4hi + 0..3 of the
+// output are contiguous; row stride 36 floats spreads 16 lanes x 16 bytes over all 64 banks).
+//
+// Why transposes instead of computing a tile twice with the operands swapped (which is what round 1 did, moving only
+// the per-row softmax statistics between the layouts): on gfx950 the exact-fp32 MFMA and the vector ALU do NOT overlap --
+// tools/microbench/mfma_valu_overlap.hip: matrix loop 231 us, vector loop 135 us, both in one wave 446 us, split over
+// two waves of a SIMD 361 us -- so these kernels cost (MFMAs x 64 cycles + VALU cycles) per SIMD, and a recomputed
+// 32 x 32 x 20 tile is 640 of those cycles where the LDS pipe does the same job on the side.
+constexpr int TP_STRIDE = 36;
+constexpr int TP_FLOATS = 32 * TP_STRIDE;
+
+__device__ __forceinline__ void tile_transpose(f32x16& t, float* __restrict__ buf, int L, int lane_row, int hi) {
+  float* w = buf + 4 * hi * TP_STRIDE + lane_row;
 #pragma unroll
-  for (int r = 0; r < 16; ++r)
-    if (crow(r, hi) < L) m = fmaxf(m, t[r] * inv2);
-  m = fmaxf(m, __shfl_xor(m, 32, 64));
-  float z = 0.f;
+  for (int r = 0; r < 16; ++r) w[((r & 3) + 8 * (r >> 2)) * TP_STRIDE] = t[r];  // element (a, b) -> buf[b][a]
+  wave_lds_sync();
+  const float* rd = buf + lane_row * TP_STRIDE + 4 * hi;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) z += (crow(r, hi) < L) ? __builtin_amdgcn_exp2f(t[r] * inv2 - m) : 0.f;
-  z += __shfl_xor(z, 32, 64);
-  return m + __builtin_amdgcn_logf(z);
+  for (int g = 0; g < 4; ++g) {
+    const float4 v = *reinterpret_cast<const float4*>(rd + 8 * g);
+    t[4 * g] = (8 * g + 4 * hi + 0 < L) ? v.x : 0.f;
+    t[4 * g + 1] = (8 * g + 4 * hi + 1 < L) ? v.y : 0.f;
+    t[4 * g + 2] = (8 * g + 4 * hi + 2 < L) ? v.z : 0.f;
+    t[4 * g + 3] = (8 * g + 4 * hi + 3 < L) ? v.w : 0.f;
+  }
 }
 
 // LC: sequence length known at compile time (0 = use a.L).  title_size = 30 and history_size = 20 are what every
 // BASELINE config runs: with L a constant most of the row / column validity masks of a 32-wide tile fold away (only
-// registers 14, 15 of the upper lane half can be rows >= 30), which is a fifth of this VALU-issue-bound kernel.
+// registers 14, 15 of the upper lane half can be rows >= 30).
+//
+// One problem per wave.  (PERSISTENT waves that walk p, p + stride, ... with the tiles of the next problem prefetched into
+// registers during the MFMA / softmax phase were measured: 36-63 more registers = one or two waves per SIMD fewer, forward
+// 41 -> 39-41 us, backward 73 -> 84-92 us, far worse when the occupancy hint makes the prefetch registers spill.  These
+// kernels are bound by the LENGTH of a wave's dependent chain -- LDS round trips, MFMA chains, cross-lane statistics --
+// and what hides it is the number of resident waves, not a deeper pipeline inside one wave.)
+struct AttnProb {
+  int64_t row0;  // first row of the sequence
+  uint32_t seq;
+  uint32_t head;
+};
+
+// n_prob < 2^31 (checked by the launcher): one 32-bit scalar division per problem
+__device__ __forceinline__ AttnProb attn_prob(int64_t prob, int h, int L) {
+  AttnProb p;
+  p.seq = static_cast<uint32_t>(prob) / static_cast<uint32_t>(h);
+  p.head = static_cast<uint32_t>(prob) - p.seq * static_cast<uint32_t>(h);
+  p.row0 = static_cast<int64_t>(p.seq) * L;
+  return p;
+}
+
+template <int D>
+__host__ __device__ constexpr int fwd_wave_floats(int L) {  // V's region, later the transpose buffer
+  return L * Tile<D>::STRIDE > TP_FLOATS ? L * Tile<D>::STRIDE : TP_FLOATS;
+}
+
 template <int D, int LC>
 __global__ __launch_bounds__(64 * ATT_WAVES) void attn_mfma_fwd_kernel(MfmaAttnArgs a) {
-  using T = Tile<D>;
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // ATT_WAVES x 3 regions x L x STRIDE
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // ATT_WAVES x fwd_wave_floats
   const int lane = threadIdx.x & 63;
-  const int64_t prob = static_cast<int64_t>(blockIdx.x) * ATT_WAVES + (threadIdx.x >> 6);
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform on its face: base pointers stay scalar
+  const int64_t prob = static_cast<int64_t>(blockIdx.x) * ATT_WAVES + wv;
   if (prob >= a.n_prob) return;  // wave-uniform; no workgroup barriers in this kernel
   const int L = LC ? LC : a.L, E = a.h * D;
-  const int region = L * T::STRIDE;
-  float* sq = smem + (threadIdx.x >> 6) * 3 * region;
-  float* sk = sq + region;
-  float* sv = sk + region;
+  float* sv = smem + wv * fwd_wave_floats<D>(L);
   const int row = lane & 31, hi = lane >> 5;
-  const int64_t seq = prob / a.h;
-  const int head = static_cast<int>(prob - seq * a.h);
-  const int64_t row0 = seq * L;
-  const float* qb = a.qkv + row0 * a.ld_qkv + head * D;
   const float inv2 = 1.44269504088896341f / sqrtf(static_cast<float>(D));
+  const bool drop = a.key_ptr != nullptr;
+  const uint32_t key = drop ? *a.key_ptr : 0u;
 
+  const AttnProb p = attn_prob(prob, a.h, L);
+  const float* qb = a.qkv + p.row0 * a.ld_qkv + p.head * D;
+  // Q and K are needed in row form only (T = K Q^T contracts over the head dimension): straight from global memory.
+  // Only V, wanted in column form, goes through LDS.
+  float qr[D / 2], kr[D / 2];
   {
-    Staged<D> tq, tk, tv;
-    stage_load<D>(tq, qb, a.ld_qkv, L, lane);
-    stage_load<D>(tk, qb + E, a.ld_qkv, L, lane);
+    Staged<D> tv;
     stage_load<D>(tv, qb + 2 * E, a.ld_qkv, L, lane);
-    stage_store<D, false>(sq, tq, L, lane, 0u, 0u, 0, 0u, 0.f);
-    stage_store<D, false>(sk, tk, L, lane, 0u, 0u, 0, 0u, 0.f);
+    global_row_form<D>(qr, qb, a.ld_qkv, L, row, hi);
+    global_row_form<D>(kr, qb + E, a.ld_qkv, L, row, hi);
     stage_store<D, false>(sv, tv, L, lane, 0u, 0u, 0, 0u, 0.f);
   }
   wave_lds_sync();
-
-  float qr[D / 2], kr[D / 2];
-  lds_row_form<D>(qr, sq, L, row, hi);
-  lds_row_form<D>(kr, sk, L, row, hi);
   float vc[16];
   lds_col_form<D>(vc, sv, L, row, hi);
 
-  f32x16 Tt = mm_rows<D / 2>(kr, qr);  // T[j][i]: lane i, regs j
-  f32x16 S = mm_rows<D / 2>(qr, kr);   // S[i][j]: lane j, regs i
-  const float c = softmax_stats_only(Tt, L, hi, inv2);
-  softmax_from_stats(S, L, hi, inv2, c);  // P[i][j]: lane j, regs i
-  const f32x16 O = mm_col_tile(vc, S);    // O^T[c][j]: lane j, regs c
-
-  wave_lds_sync();  // every operand read of sq is done: reuse it for the output rows
-  tile_rows_to_lds<D>(sq, O, L, row, hi, 1.0f);
-  wave_lds_sync();
-  float* ob = a.out + row0 * a.ld_out + head * D;
-  const uint64_t e0 = static_cast<uint64_t>(row0) * E + head * D;
-  if (a.key_ptr != nullptr) stage_out<D, true>(sq, ob, a.ld_out, L, lane, *a.key_ptr, e0, E, a.thresh, a.scale);
-  else stage_out<D, false>(sq, ob, a.ld_out, L, lane, 0u, 0u, 0, 0u, 0.f);
+  f32x16 P = mm_rows<D / 2>(kr, qr);  // T[j][i]: lane i, regs j
+  softmax_in_lane(P, L, hi, inv2);    // P[i][j]: lane i, regs j (rows of the softmax in-lane)
+  wave_lds_sync();                    // V's column form is in registers: its region becomes the transpose buffer
+  tile_transpose(P, sv, L, row, hi);  // P[i][j]: lane j, regs i -- the contraction index of P^T V on the registers
+  const f32x16 O = mm_col_tile(vc, P);  // O^T[c][j]: lane j, regs c
+  float* ob = a.out + p.row0 * a.ld_out + p.head * D;
+  const uint64_t e0 = static_cast<uint64_t>(p.row0) * E + p.head * D;
+  if (drop) tile_rows_to_global<D, true>(ob, a.ld_out, O, L, row, hi, 1.0f, key, e0, E, a.thresh, a.scale);
+  else tile_rows_to_global<D, false>(ob, a.ld_out, O, L, row, hi, 1.0f, 0u, 0u, 0, 0u, 0.f);
 }
 
-// Backward.  The "lane i" tiles (P, dP -> dV, dQ) are finished before the "lane j" tiles (-> dK) are started, so
-// that at most two 32x32 tiles are live at a time: the kernel fits 128 registers = 4 waves per SIMD.
+// Backward.  Everything but d(K) is computed in the lane-i layout (softmax row i on the lanes, j on the registers: row
+// statistics and sum_j P dP are in-lane); d(K) contracts over i and gets d(S) through one tile transpose.
+template <int D>
+__host__ __device__ constexpr int bwd_wave_floats(int L) {  // Q | K | dO regions; K, dO later the transpose buffer
+  return 3 * L * Tile<D>::STRIDE > L * Tile<D>::STRIDE + TP_FLOATS ? 3 * L * Tile<D>::STRIDE : L * Tile<D>::STRIDE + TP_FLOATS;
+}
+
 template <int D, int LC>
 __global__ __launch_bounds__(64 * ATT_WAVES) void attn_mfma_bwd_kernel(MfmaAttnArgs a) {
   using T = Tile<D>;
   constexpr int KH = D / 2;
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // ATT_WAVES x 4 regions x L x STRIDE
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // ATT_WAVES x bwd_wave_floats
   const int lane = threadIdx.x & 63;
-  const int64_t prob = static_cast<int64_t>(blockIdx.x) * ATT_WAVES + (threadIdx.x >> 6);
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform on its face: base pointers stay scalar
+  const int64_t prob = static_cast<int64_t>(blockIdx.x) * ATT_WAVES + wv;
   if (prob >= a.n_prob) return;
   const int L = LC ? LC : a.L, E = a.h * D;
   const int region = L * T::STRIDE;
-  float* sq = smem + (threadIdx.x >> 6) * 4 * region;
+  float* sq = smem + wv * bwd_wave_floats<D>(L);
   float* sk = sq + region;
-  float* sv = sk + region;  // V, then the staging buffer of the three result tiles
-  float* sg = sv + region;  // dO with the forward dropout mask applied
+  float* sg = sk + region;  // dO with the pooling term added and the forward dropout mask applied
   const int row = lane & 31, hi = lane >> 5;
-  const int64_t seq = prob / a.h;
-  const int head = static_cast<int>(prob - seq * a.h);
-  const int64_t row0 = seq * L;
-  const float* qb = a.qkv + row0 * a.ld_qkv + head * D;
-  const float* gb = a.dout + row0 * a.ld_dout + head * D;
   const float inv = 1.0f / sqrtf(static_cast<float>(D));
   const float inv2 = inv * 1.44269504088896341f;
+  const bool drop = a.key_ptr != nullptr, pooled = a.pool_w != nullptr;  // wave-uniform
+  const uint32_t key = drop ? *a.key_ptr : 0u;
 
+  const AttnProb p = attn_prob(prob, a.h, L);
+  const float* qb = a.qkv + p.row0 * a.ld_qkv + p.head * D;
+  float vr[KH];  // row form of V (lane = row), the only form V is needed in: straight from global memory
   {
-    Staged<D> tq, tk, tv, tg;
+    Staged<D> tq, tk, tg;
     stage_load<D>(tq, qb, a.ld_qkv, L, lane);
     stage_load<D>(tk, qb + E, a.ld_qkv, L, lane);
-    stage_load<D>(tv, qb + 2 * E, a.ld_qkv, L, lane);
-    stage_load<D>(tg, gb, a.ld_dout, L, lane);
-    if (a.pool_w != nullptr) {  // wave-uniform
+    stage_load<D>(tg, a.dout + p.row0 * a.ld_dout + p.head * D, a.ld_dout, L, lane);
+    global_row_form<D>(vr, qb + 2 * E, a.ld_qkv, L, row, hi);
+    if (pooled) {
       PoolTerm<D> pt;
-      pool_load<D>(pt, a.pool_w + row0, a.pool_d + seq * a.ld_pool + head * D, L, lane);
+      pool_load<D>(pt, a.pool_w + p.row0, a.pool_d + p.seq * a.ld_pool + p.head * D, L, lane);
       pool_add<D>(tg, pt);
     }
     stage_store<D, false>(sq, tq, L, lane, 0u, 0u, 0, 0u, 0.f);
     stage_store<D, false>(sk, tk, L, lane, 0u, 0u, 0, 0u, 0.f);
-    stage_store<D, false>(sv, tv, L, lane, 0u, 0u, 0, 0u, 0.f);
-    if (a.key_ptr != nullptr)
-      stage_store<D, true>(sg, tg, L, lane, *a.key_ptr, static_cast<uint64_t>(row0) * E + head * D, E, a.thresh, a.scale);
-    else
-      stage_store<D, false>(sg, tg, L, lane, 0u, 0u, 0, 0u, 0.f);
+    if (drop) stage_store<D, true>(sg, tg, L, lane, key, static_cast<uint64_t>(p.row0) * E + p.head * D, E, a.thresh, a.scale);
+    else stage_store<D, false>(sg, tg, L, lane, 0u, 0u, 0, 0u, 0.f);
   }
   wave_lds_sync();
 
-  float* ob = a.out + row0 * a.ld_out + head * D;
-  float c, rowdot;
-  float vr[KH];  // row form of V (lane = row): identical in both passes
-  // ---- lane-i layout: P[i][j] and dP[i][j] with i on lanes -> dV, dQ
+  float* ob = a.out + p.row0 * a.ld_out + p.head * D;
+  f32x16 P, dP;
   {
-    f32x16 P, dP;
-    {
-      float qr[KH], kr[KH];
-      lds_row_form<D>(qr, sq, L, row, hi);
-      lds_row_form<D>(kr, sk, L, row, hi);
-      P = mm_rows<KH>(kr, qr);  // T[j][i]: lane i, regs j
-    }
-    c = softmax_in_lane(P, L, hi, inv2);
-    {
-      float gr[KH];
-      lds_row_form<D>(vr, sv, L, row, hi);  // kept for the lane-j pass: sv is about to be reused for the results
-      lds_row_form<D>(gr, sg, L, row, hi);
-      dP = mm_rows<KH>(gr, vr);  // dP[i][j] = V[i].dO[j]: lane i, regs j
-    }
-    rowdot = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) rowdot = fmaf(P[r], dP[r], rowdot);
-    rowdot += __shfl_xor(rowdot, 32, 64);  // sum_j P[i][j] dP[i][j] for i = lane&31
-
-    float col[16];
-    // dV^T[c][i] = sum_j dO[j][c] P[i][j]
-    lds_col_form<D>(col, sg, L, row, hi);
-    {
-      const f32x16 dV = mm_col_tile(col, P);
-      wave_lds_sync();  // the row-form reads of sv are done
-      tile_rows_to_lds<D>(sv, dV, L, row, hi, 1.0f);
-      wave_lds_sync();
-      stage_out<D, false>(sv, ob + 2 * E, a.ld_out, L, lane, 0u, 0u, 0, 0u, 0.f);
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) P[r] = P[r] * (dP[r] - rowdot);  // dS[i][j]: lane i, regs j
-    // dQ^T[c][i] = inv * sum_j K[j][c] dS[i][j]
-    lds_col_form<D>(col, sk, L, row, hi);
-    {
-      const f32x16 dQ = mm_col_tile(col, P);
-      wave_lds_sync();
-      tile_rows_to_lds<D>(sv, dQ, L, row, hi, inv);
-      wave_lds_sync();
-      stage_out<D, false>(sv, ob, a.ld_out, L, lane, 0u, 0u, 0, 0u, 0.f);
-    }
+    float qr[KH], kr[KH];
+    lds_row_form<D>(qr, sq, L, row, hi);
+    lds_row_form<D>(kr, sk, L, row, hi);
+    P = mm_rows<KH>(kr, qr);  // T[j][i]: lane i, regs j
   }
-  // ---- lane-j layout: the same two tiles with j on lanes -> dK
+  softmax_in_lane(P, L, hi, inv2);  // P[i][j]: lane i, regs j
   {
-    f32x16 P, dP;
-    {
-      float qr[KH], kr[KH];
-      lds_row_form<D>(qr, sq, L, row, hi);
-      lds_row_form<D>(kr, sk, L, row, hi);
-      P = mm_rows<KH>(qr, kr);  // S[i][j]: lane j, regs i
-    }
-    softmax_from_stats(P, L, hi, inv2, c);
-    {
-      float gr[KH];
-      lds_row_form<D>(gr, sg, L, row, hi);
-      dP = mm_rows<KH>(vr, gr);  // lane j, regs i
-    }
+    float gr[KH];
+    lds_row_form<D>(gr, sg, L, row, hi);
+    dP = mm_rows<KH>(gr, vr);  // dP[i][j] = V[i].dO[j]: lane i, regs j
+  }
+  float rowdot = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float rd = __shfl(rowdot, crow(r, hi), 64);
-      P[r] = P[r] * (dP[r] - rd);  // dS[i][j]: lane j, regs i
-    }
-    // dK^T[c][j] = inv * sum_i Q[i][c] dS[i][j]
-    float col[16];
-    lds_col_form<D>(col, sq, L, row, hi);
-    {
-      const f32x16 dK = mm_col_tile(col, P);
-      wave_lds_sync();
-      tile_rows_to_lds<D>(sv, dK, L, row, hi, inv);
-      wave_lds_sync();
-      stage_out<D, false>(sv, ob + E, a.ld_out, L, lane, 0u, 0u, 0, 0u, 0.f);
-    }
+  for (int r = 0; r < 16; ++r) rowdot = fmaf(P[r], dP[r], rowdot);
+  rowdot += __shfl_xor(rowdot, 32, 64);  // sum_j P[i][j] dP[i][j] for i = lane&31
+
+  float col[16];
+  lds_col_form<D>(col, sg, L, row, hi);
+  {  // dV^T[c][i] = sum_j dO[j][c] P[i][j]
+    const f32x16 dV = mm_col_tile(col, P);
+    tile_rows_to_global<D, false>(ob + 2 * E, a.ld_out, dV, L, row, hi, 1.0f, 0u, 0u, 0, 0u, 0.f);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) P[r] = P[r] * (dP[r] - rowdot);  // dS[i][j]: lane i, regs j
+  lds_col_form<D>(col, sk, L, row, hi);
+  {  // dQ^T[c][i] = inv * sum_j K[j][c] dS[i][j]
+    const f32x16 dQ = mm_col_tile(col, P);
+    tile_rows_to_global<D, false>(ob, a.ld_out, dQ, L, row, hi, inv, 0u, 0u, 0, 0u, 0.f);
+  }
+  wave_lds_sync();                    // K and dO have been read for the last time: their regions become the transpose buffer
+  tile_transpose(P, sk, L, row, hi);  // dS[i][j]: lane j, regs i
+  lds_col_form<D>(col, sq, L, row, hi);
+  {  // dK^T[c][j] = inv * sum_i Q[i][c] dS[i][j]
+    const f32x16 dK = mm_col_tile(col, P);
+    tile_rows_to_global<D, false>(ob + E, a.ld_out, dK, L, row, hi, inv, 0u, 0u, 0, 0u, 0.f);
   }
 }
 
@@ -531,11 +567,12 @@ __global__ __launch_bounds__(64 * ATT2_WAVES) void attn_mfma2_fwd_kernel(MfmaAtt
   constexpr int KH = D / 2;
   extern __shared__ __attribute__((aligned(16))) float smem[];  // ATT2_WAVES x 3 regions x L x STRIDE
   const int lane = threadIdx.x & 63;
-  const int64_t prob = static_cast<int64_t>(blockIdx.x) * ATT2_WAVES + (threadIdx.x >> 6);
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t prob = static_cast<int64_t>(blockIdx.x) * ATT2_WAVES + wv;
   if (prob >= a.n_prob) return;
   const int L = LC ? LC : a.L, E = a.h * D;
   const int region = L * T::STRIDE;
-  float* sq = smem + (threadIdx.x >> 6) * 3 * region;
+  float* sq = smem + wv * 3 * region;
   float* sk = sq + region;
   float* sv = sk + region;
   const int row = lane & 31, hi = lane >> 5;
@@ -606,11 +643,12 @@ __global__ __launch_bounds__(64 * ATT2_WAVES) void attn_mfma2_bwd_kernel(MfmaAtt
   constexpr int KH = D / 2;
   extern __shared__ __attribute__((aligned(16))) float smem[];  // ATT2_WAVES x 4 regions x L x STRIDE
   const int lane = threadIdx.x & 63;
-  const int64_t prob = static_cast<int64_t>(blockIdx.x) * ATT2_WAVES + (threadIdx.x >> 6);
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t prob = static_cast<int64_t>(blockIdx.x) * ATT2_WAVES + wv;
   if (prob >= a.n_prob) return;
   const int L = LC ? LC : a.L, E = a.h * D;
   const int region = L * T::STRIDE;
-  float* sq = smem + (threadIdx.x >> 6) * 4 * region;
+  float* sq = smem + wv * 4 * region;
   float* sk = sq + region;
   float* sv = sk + region;  // V, then the staging buffer of the result tiles
   float* sg = sv + region;  // dO with the forward dropout mask applied
@@ -748,6 +786,7 @@ static bool mfma_path_ok(int32_t L, int32_t d, int64_t lda, int64_t ldb, int64_t
                          const void* p1, const void* p2) {
   if (L > 64 || !(d == 16 || d == 20 || d == 32)) return false;  // L <= 32: one 32x32 tile; 32 < L <= 64: 2 x 2 tiles
   if ((lda % 4) || (ldb % 4) || (ldc % 4)) return false;
+  if (lda >= (1 << 24) || ldb >= (1 << 24) || ldc >= (1 << 24)) return false;  // 32-bit lane offsets: 64 rows x ld
   return ebn_aligned16(p0) && ebn_aligned16(p1) && ebn_aligned16(p2);
 }
 
@@ -755,6 +794,12 @@ static bool mfma_path_ok(int32_t L, int32_t d, int64_t lda, int64_t ldb, int64_t
 template <class K>
 static void allow_lds(K kernel, size_t bytes) {
   if (bytes > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+}
+
+template <class K>
+static void launch_waves(K kernel, size_t lds, const MfmaAttnArgs& a, hipStream_t s) {
+  allow_lds(kernel, lds);
+  hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(ebn_ceil_div(a.n_prob, ATT_WAVES))), dim3(64 * ATT_WAVES), lds, s, a);
 }
 
 template <int D, int LC>
@@ -780,7 +825,7 @@ static void launch_mfma2(bool bwd, const MfmaAttnArgs& a, hipStream_t s) {
 
 int ebn_attn_mfma_fwd(const float* qkv, int64_t ld_qkv, float* out, int64_t ld_out, int64_t n_seq, int32_t L,
                       int32_t h, int32_t d, const EbnDrop& dr, hipStream_t s, bool* handled) {
-  *handled = mfma_path_ok(L, d, ld_qkv, ld_out, ld_out, qkv, out, out);
+  *handled = mfma_path_ok(L, d, ld_qkv, ld_out, ld_out, qkv, out, out) && n_seq * h < (int64_t{1} << 31);
   if (!*handled) return EBN_OK;
   MfmaAttnArgs a{qkv, ld_qkv, nullptr, 0, out, ld_out, n_seq * h, L, h, dr.key_ptr, dr.thresh, dr.scale, nullptr, nullptr, 0};
   if (L > 32) {
@@ -790,16 +835,12 @@ int ebn_attn_mfma_fwd(const float* qkv, int64_t ld_qkv, float* out, int64_t ld_o
     EBN_CHECK_LAUNCH();
     return EBN_OK;
   }
-  const dim3 grid(static_cast<unsigned>(ebn_ceil_div(a.n_prob, ATT_WAVES))), block(64 * ATT_WAVES);
-  const size_t lds = static_cast<size_t>(ATT_WAVES) * 3 * L * sizeof(float);  // x STRIDE below
-  if (d == 16) hipLaunchKernelGGL((attn_mfma_fwd_kernel<16, 0>), grid, block, lds * Tile<16>::STRIDE, s, a);
-  else if (d == 20 && L == 30) hipLaunchKernelGGL((attn_mfma_fwd_kernel<20, 30>), grid, block, lds * Tile<20>::STRIDE, s, a);
-  else if (d == 20 && L == 20) hipLaunchKernelGGL((attn_mfma_fwd_kernel<20, 20>), grid, block, lds * Tile<20>::STRIDE, s, a);
-  else if (d == 20) hipLaunchKernelGGL((attn_mfma_fwd_kernel<20, 0>), grid, block, lds * Tile<20>::STRIDE, s, a);
-  else {
-    allow_lds(attn_mfma_fwd_kernel<32, 0>, lds * Tile<32>::STRIDE);
-    hipLaunchKernelGGL((attn_mfma_fwd_kernel<32, 0>), grid, block, lds * Tile<32>::STRIDE, s, a);
-  }
+  const size_t wb = static_cast<size_t>(ATT_WAVES) * sizeof(float);
+  if (d == 16) launch_waves(attn_mfma_fwd_kernel<16, 0>, wb * fwd_wave_floats<16>(L), a, s);
+  else if (d == 20 && L == 30) launch_waves(attn_mfma_fwd_kernel<20, 30>, wb * fwd_wave_floats<20>(L), a, s);
+  else if (d == 20 && L == 20) launch_waves(attn_mfma_fwd_kernel<20, 20>, wb * fwd_wave_floats<20>(L), a, s);
+  else if (d == 20) launch_waves(attn_mfma_fwd_kernel<20, 0>, wb * fwd_wave_floats<20>(L), a, s);
+  else launch_waves(attn_mfma_fwd_kernel<32, 0>, wb * fwd_wave_floats<32>(L), a, s);
   EBN_CHECK_LAUNCH();
   return EBN_OK;
 }
@@ -807,7 +848,7 @@ int ebn_attn_mfma_fwd(const float* qkv, int64_t ld_qkv, float* out, int64_t ld_o
 int ebn_attn_mfma_bwd(const float* qkv, int64_t ld_qkv, const float* dout, int64_t ld_dout, float* dqkv,
                       int64_t ld_dqkv, int64_t n_seq, int32_t L, int32_t h, int32_t d, const EbnDrop& dr,
                       hipStream_t s, bool* handled, const float* pool_w, const float* pool_d, int64_t ld_pool) {
-  *handled = mfma_path_ok(L, d, ld_qkv, ld_dout, ld_dqkv, qkv, dout, dqkv) &&
+  *handled = mfma_path_ok(L, d, ld_qkv, ld_dout, ld_dqkv, qkv, dout, dqkv) && n_seq * h < (int64_t{1} << 31) &&
              (pool_w == nullptr || ((ld_pool % 4) == 0 && ebn_aligned16(pool_d)));
   if (!*handled) return EBN_OK;
   MfmaAttnArgs a{qkv, ld_qkv, dout, ld_dout, dqkv, ld_dqkv, n_seq * h, L, h, dr.key_ptr, dr.thresh, dr.scale, pool_w, pool_d, ld_pool};
@@ -818,16 +859,12 @@ int ebn_attn_mfma_bwd(const float* qkv, int64_t ld_qkv, const float* dout, int64
     EBN_CHECK_LAUNCH();
     return EBN_OK;
   }
-  const dim3 grid(static_cast<unsigned>(ebn_ceil_div(a.n_prob, ATT_WAVES))), block(64 * ATT_WAVES);
-  const size_t lds = static_cast<size_t>(ATT_WAVES) * 4 * L * sizeof(float);  // x STRIDE below
-  if (d == 16) hipLaunchKernelGGL((attn_mfma_bwd_kernel<16, 0>), grid, block, lds * Tile<16>::STRIDE, s, a);
-  else if (d == 20 && L == 30) hipLaunchKernelGGL((attn_mfma_bwd_kernel<20, 30>), grid, block, lds * Tile<20>::STRIDE, s, a);
-  else if (d == 20 && L == 20) hipLaunchKernelGGL((attn_mfma_bwd_kernel<20, 20>), grid, block, lds * Tile<20>::STRIDE, s, a);
-  else if (d == 20) hipLaunchKernelGGL((attn_mfma_bwd_kernel<20, 0>), grid, block, lds * Tile<20>::STRIDE, s, a);
-  else {
-    allow_lds(attn_mfma_bwd_kernel<32, 0>, lds * Tile<32>::STRIDE);
-    hipLaunchKernelGGL((attn_mfma_bwd_kernel<32, 0>), grid, block, lds * Tile<32>::STRIDE, s, a);
-  }
+  const size_t wb = static_cast<size_t>(ATT_WAVES) * sizeof(float);
+  if (d == 16) launch_waves(attn_mfma_bwd_kernel<16, 0>, wb * bwd_wave_floats<16>(L), a, s);
+  else if (d == 20 && L == 30) launch_waves(attn_mfma_bwd_kernel<20, 30>, wb * bwd_wave_floats<20>(L), a, s);
+  else if (d == 20 && L == 20) launch_waves(attn_mfma_bwd_kernel<20, 20>, wb * bwd_wave_floats<20>(L), a, s);
+  else if (d == 20) launch_waves(attn_mfma_bwd_kernel<20, 0>, wb * bwd_wave_floats<20>(L), a, s);
+  else launch_waves(attn_mfma_bwd_kernel<32, 0>, wb * bwd_wave_floats<32>(L), a, s);
   EBN_CHECK_LAUNCH();
   return EBN_OK;
 }
