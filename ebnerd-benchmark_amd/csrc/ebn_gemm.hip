@@ -21,6 +21,14 @@
 
 #include "ebn_common.h"
 
+// Buffer-load intrinsics bound by name (the __amdgpu_buffer_rsrc_t builtins make the HOST pass drop the launch stub of
+// a kernel that uses them).  Declared outside the anonymous namespace: they are external symbols of the compiler.
+typedef float ebn_f32x4 __attribute__((ext_vector_type(4)));
+typedef int ebn_i32x4 __attribute__((ext_vector_type(4)));
+__device__ ebn_f32x4 ebn_raw_buffer_load_x4(ebn_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+__device__ void ebn_raw_buffer_load_lds(ebn_i32x4 rsrc, __attribute__((address_space(3))) void* lds, int size, int voffset,
+                                        int soffset, int offset, int aux) __asm("llvm.amdgcn.raw.buffer.load.lds");
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -29,7 +37,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define EBN_GEMM_XCD 1
 #endif
 #ifndef EBN_GEMM_GLDS
-#define EBN_GEMM_GLDS 1  // direct global->LDS tile fetch when both operands are stored [K][mn] (the weight-gradient GEMMs)
+#define EBN_GEMM_GLDS 2  // direct global->LDS tile fetch, see GLDS_A / GLDS_B in the kernel
 #endif
 
 typedef float f32x4n __attribute__((ext_vector_type(4)));
@@ -38,7 +46,31 @@ __device__ __forceinline__ float4 gload4(const __attribute__((address_space(1)))
   const f32x4n t = *reinterpret_cast<const __attribute__((address_space(1))) f32x4n*>(p);
   return make_float4(t.x, t.y, t.z, t.w);
 }
+// Raw buffer resource over [base, base + 4 GB): buffer_load takes a scalar (SGPR) byte offset next to the lane's 32-bit
+// byte offset, so a slab loop advances ONE scalar per operand and carries no per-lane address.  (With plain pointers the
+// loop-strength-reduction pass turns base + lane offset back into a per-lane 64-bit pointer that is bumped on the
+// vector ALU every slab -- and on gfx950 the fp32 MFMA does not overlap vector-ALU work.)
+typedef ebn_i32x4 i32x4n;
+__device__ __forceinline__ i32x4n make_rsrc(const float* base) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+  i32x4n r;
+  r.x = static_cast<int>(static_cast<uint32_t>(a));
+  r.y = static_cast<int>(static_cast<uint32_t>(a >> 32) & 0xFFFFu);  // stride 0: raw buffer
+  r.z = -1;                                                            // 4 GB of records: no bounds use
+  r.w = 0x00020000;
+  return r;
+}
+__device__ __forceinline__ float4 bload4(i32x4n r, uint32_t lane_bytes, uint32_t slab_bytes) {
+  const f32x4n t = ebn_raw_buffer_load_x4(r, static_cast<int>(lane_bytes), static_cast<int>(slab_bytes), 0);
+  return make_float4(t.x, t.y, t.z, t.w);
+}
 
+#ifndef EBN_GEMM_WPE
+// Waves per SIMD the register allocation must allow (LDS admits three 41.5 KB workgroups per CU).  It also selects the
+// VGPR form of the MFMAs (accumulators in ordinary registers): without it the compiler picks the AGPR form and, around
+// the two-slab loop body, copies all 64 accumulators between the two register files every iteration.
+#define EBN_GEMM_WPE 3
+#endif
 constexpr int BK = 16;
 constexpr int PAD = 4;
 constexpr int GEMM_THREADS = 256;
@@ -135,7 +167,7 @@ struct GemmEpi {
 // SITE only labels the instantiation (0 = generic, 1 = the encoders' Q|K|V projection) so that per-kernel profiler
 // summaries separate the roofline kernel of bench.py from the other GEMM call sites of the same shape class.
 template <int BM, int BN, int WAVES_M, bool TA, bool TB, bool VEC, int SITE, int EPI = 0>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
+__global__ __launch_bounds__(GEMM_THREADS, EBN_GEMM_WPE) void gemm_f32_kernel(
     int64_t M, int64_t N, int64_t K, float alpha, const float* __restrict__ A, int64_t lda,
     const float* __restrict__ B, int64_t ldb, float beta, float* __restrict__ C, int64_t ldc,
     int64_t k_per_split, float* __restrict__ Cpart, GemmEpi epi) {
@@ -144,16 +176,23 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
   constexpr int WTN = BN / WAVES_N;
   constexpr int TM = WTM / 32;            // 32x32 MFMA tiles per wave along m / n
   constexpr int TN = WTN / 32;
-  // GLDS: both operands are stored [K][mn] -> a 16-deep slab is 16 contiguous row pieces per operand, which
-  // global_load_lds_dwordx4 (wave-uniform LDS base + lane x 16 B) can drop straight into an UNPADDED [k][mn] image:
-  // no staging registers, no ds_write pass.  (The pad only ever served the scalar stores of k-contiguous operands;
-  // the operand fetch reads 32 consecutive floats of one k row either way.)
-  constexpr bool GLDS = (EBN_GEMM_GLDS != 0) && TA && !TB && VEC;
-  constexpr int PADX = GLDS ? 0 : PAD;
-  constexpr int LDA_S = BM + PADX;
-  constexpr int LDB_S = BN + PADX;
-  using LA = TileLoader<BM, !TA, VEC, PADX>;
-  using LB = TileLoader<BN, TB, VEC, PADX>;
+  // GLDS: the 16-deep slab of an operand goes global -> LDS directly (buffer_load ... lds: wave-uniform LDS base + lane x
+  // 16 B), no staging registers, no ds_write pass:
+  //   * stored [K][mn]: 16 contiguous row pieces, dropped into an UNPADDED [k][mn] image (the pad only ever served the
+  //     scalar stores of the other layout; the operand fetch reads 32 consecutive floats of one k row either way);
+  //   * stored [mn][K]: the float4 image S4[mn][kq ^ ((mn >> 2) & 3)] is 64 contiguous bytes per row, so lane l of an
+  //     instruction fills chunk l and the XOR swizzle is applied to the SOURCE column it fetches -- the four lanes of a
+  //     row still read the row's 64 contiguous bytes, permuted.
+  // Used when B is stored [K][N] (NN: the projections; TN: the weight gradients).  With a k-contiguous B ([N][K], the NT
+  // input-gradient GEMMs) both operands stay on the register path: glds for A alone or for both measured slower there
+  // (profiles/r02_gemm_tuning.md).  EBN_GEMM_GLDS: 0 never, 1 TN only, 2 NN + TN, 3 every layout (tuning).
+  constexpr bool GLDS_A = VEC && ((EBN_GEMM_GLDS == 3) || (EBN_GEMM_GLDS == 2 && !TB) || (EBN_GEMM_GLDS == 1 && TA && !TB));
+  constexpr bool GLDS_B = GLDS_A;
+  constexpr int PADA = GLDS_A ? 0 : PAD, PADB = GLDS_B ? 0 : PAD;
+  constexpr int LDA_S = BM + PADA;
+  constexpr int LDB_S = BN + PADB;
+  using LA = TileLoader<BM, !TA, VEC, PADA>;
+  using LB = TileLoader<BN, TB, VEC, PADB>;
 
   // ONE __shared__ object: with two, hipcc cannot tell the glds destination from the buffer being read and waits
   // vmcnt(0) before the first ds_read of every slab (cdna_hip_programming.md, glds trap (a))
@@ -165,7 +204,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: LDS destinations of the glds fetch, wave tile origin
   const int wm = wave / WAVES_N;
   const int wn = wave % WAVES_N;
   // XCD-aware tile order: hardware deals consecutive workgroups round-robin to the 8 XCDs (private
@@ -210,11 +249,15 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
   // compiler loses track of their being GLOBAL pointers and emits flat_load -- which also counts on lgkmcnt, so every
   // s_waitcnt lgkmcnt(0) in front of the MFMAs (meant for the LDS operand reads) would wait for the prefetch of the next
   // slab as well and put the whole global-load latency on the MFMA critical path.
-  typedef const __attribute__((address_space(1))) float* gptr_t;
-  gptr_t pa[LA::PER_THREAD];
-  gptr_t pb[LB::PER_THREAD];
-  const int64_t step_a = TA ? BK * lda : BK;
-  const int64_t step_b = TB ? BK : BK * ldb;
+  // The source of a float4 is a buffer resource based at the tile's first row / column of this K split, a constant
+  // 32-bit lane offset and a scalar slab offset: the slab loop issues bare buffer_loads and one s_add per operand.
+  // (Offsets are BYTES in 32 bits: the launcher checks that 256 tile rows and the K range of an operand span < 4 GB.)
+  uint32_t oa[LA::PER_THREAD], ob[LB::PER_THREAD];
+  const i32x4n arsrc = make_rsrc(TA ? A + kbeg * lda + m0 : A + m0 * lda + kbeg);
+  const i32x4n brsrc = make_rsrc(TB ? B + n0 * ldb + kbeg : B + kbeg * ldb + n0);
+  const uint32_t step_a = static_cast<uint32_t>((TA ? BK * lda : BK) * 4);  // bytes per slab
+  const uint32_t step_b = static_cast<uint32_t>((TB ? BK : BK * ldb) * 4);
+  uint32_t sa = 0, sb = 0;                                                   // scalar slab offsets
   if (VEC) {
 #pragma unroll
     for (int i = 0; i < LA::PER_THREAD; ++i) {
@@ -222,11 +265,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
       if (!TA) {  // A is [M][K]
         int64_t row = m0 + v / (BK / 4);
         row = row < M ? row : M - 1;
-        pa[i] = (gptr_t)(A + row * lda + kbeg + (v % (BK / 4)) * 4);
+        oa[i] = static_cast<uint32_t>(((row - m0) * lda + (v % (BK / 4)) * 4) * 4);
       } else {  // A is [K][M]
         int64_t col = m0 + (v % (BM / 4)) * 4;
         col = col < M ? col : M - 4;
-        pa[i] = (gptr_t)(A + (kbeg + v / (BM / 4)) * lda + col);
+        oa[i] = static_cast<uint32_t>(((v / (BM / 4)) * lda + (col - m0)) * 4);
       }
     }
 #pragma unroll
@@ -235,64 +278,109 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
       if (TB) {  // B is [N][K]
         int64_t row = n0 + v / (BK / 4);
         row = row < N ? row : N - 1;
-        pb[i] = (gptr_t)(B + row * ldb + kbeg + (v % (BK / 4)) * 4);
+        ob[i] = static_cast<uint32_t>(((row - n0) * ldb + (v % (BK / 4)) * 4) * 4);
       } else {  // B is [K][N]
         int64_t col = n0 + (v % (BN / 4)) * 4;
         col = col < N ? col : N - 4;
-        pb[i] = (gptr_t)(B + (kbeg + v / (BN / 4)) * ldb + col);
+        ob[i] = static_cast<uint32_t>(((v / (BN / 4)) * ldb + (col - n0)) * 4);
       }
     }
   }
 
-  // ---- direct-to-LDS fetch (GLDS kernels): wave w issues IPW instructions per operand and slab; instruction q
-  // covers RPI consecutive k rows (64 lanes x 16 B = RPI rows of BMN floats)
-  constexpr int A_LPR = BM / 4, A_RPI = 64 / (A_LPR < 64 ? A_LPR : 64), A_IPW = (BK / A_RPI) / 4;
-  constexpr int B_LPR = BN / 4, B_RPI = 64 / (B_LPR < 64 ? B_LPR : 64), B_IPW = (BK / B_RPI) / 4;
-  static_assert(!GLDS || (BM <= 256 && BN <= 256 && A_IPW >= 1 && B_IPW >= 1), "glds tiling");
-  const float* ga[GLDS ? A_IPW : 1];
-  const float* gb[GLDS ? B_IPW : 1];
-  if (GLDS) {
+  // ---- direct-to-LDS fetch (GLDS kernels): wave w issues IPW instructions per operand and slab.  [K][mn] operands:
+  // instruction q covers RPI consecutive k rows (64 lanes x 16 B = RPI rows of BMN floats).  [mn][K] operands: instruction
+  // q covers the 16 rows (64 chunks of 16 B) number (q * 4 + w).
+  constexpr int A_LPR = BM / 4, A_RPI = 64 / (A_LPR < 64 ? A_LPR : 64), A_IPW = A_KC ? BM / 64 : (BK / A_RPI) / 4;
+  constexpr int B_LPR = BN / 4, B_RPI = 64 / (B_LPR < 64 ? B_LPR : 64), B_IPW = B_KC ? BN / 64 : (BK / B_RPI) / 4;
+  static_assert(BM <= 256 && BN <= 256 && A_IPW >= 1 && B_IPW >= 1, "glds tiling");
+  uint32_t gao[GLDS_A ? A_IPW : 1], gbo[GLDS_B ? B_IPW : 1];  // lane byte offsets into arsrc / brsrc
+  if (GLDS_A) {
 #pragma unroll
     for (int q = 0; q < A_IPW; ++q) {
-      const int krow = (wave * A_IPW + q) * A_RPI + lane / A_LPR;
-      int64_t col = m0 + (lane % A_LPR) * 4;
-      col = col < M ? col : M - 4;
-      ga[q] = A + (kbeg + krow) * lda + col;
-    }
-#pragma unroll
-    for (int q = 0; q < B_IPW; ++q) {
-      const int krow = (wave * B_IPW + q) * B_RPI + lane / B_LPR;
-      int64_t col = n0 + (lane % B_LPR) * 4;
-      col = col < N ? col : N - 4;
-      gb[q] = B + (kbeg + krow) * ldb + col;
+      if (A_KC) {
+        const int r = ((q * 4 + wave) * 64 + lane) >> 2, kq = (lane & 3) ^ ((r >> 2) & 3);
+        int64_t row = m0 + r;
+        row = row < M ? row : M - 1;
+        gao[q] = static_cast<uint32_t>(((row - m0) * lda + kq * 4) * 4);
+      } else {
+        const int krow = (wave * A_IPW + q) * A_RPI + lane / A_LPR;
+        int64_t col = m0 + (lane % A_LPR) * 4;
+        col = col < M ? col : M - 4;
+        gao[q] = static_cast<uint32_t>((krow * lda + (col - m0)) * 4);
+      }
     }
   }
-#define EBN_GLDS_SLAB(BUF)                                                                                          \
-  do {                                                                                                              \
-    _Pragma("unroll") for (int q = 0; q < A_IPW; ++q) {                                                             \
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ga[q],                        \
-                                       (__attribute__((address_space(3))) void*)(EBN_AS(BUF) + (wave * A_IPW + q) * A_RPI * BM), \
-                                       16, 0, 0);                                                                   \
-      ga[q] += BK * lda;                                                                                            \
-    }                                                                                                               \
-    _Pragma("unroll") for (int q = 0; q < B_IPW; ++q) {                                                             \
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gb[q],                        \
-                                       (__attribute__((address_space(3))) void*)(EBN_BS(BUF) + (wave * B_IPW + q) * B_RPI * BN), \
-                                       16, 0, 0);                                                                   \
-      gb[q] += BK * ldb;                                                                                            \
-    }                                                                                                               \
-  } while (0)
-
-#define EBN_LOAD_SLAB(KT)                                                                \
+  if (GLDS_B) {
+#pragma unroll
+    for (int q = 0; q < B_IPW; ++q) {
+      if (B_KC) {
+        const int r = ((q * 4 + wave) * 64 + lane) >> 2, kq = (lane & 3) ^ ((r >> 2) & 3);
+        int64_t row = n0 + r;
+        row = row < N ? row : N - 1;
+        gbo[q] = static_cast<uint32_t>(((row - n0) * ldb + kq * 4) * 4);
+      } else {
+        const int krow = (wave * B_IPW + q) * B_RPI + lane / B_LPR;
+        int64_t col = n0 + (lane % B_LPR) * 4;
+        col = col < N ? col : N - 4;
+        gbo[q] = static_cast<uint32_t>((krow * ldb + (col - n0)) * 4);
+      }
+    }
+  }
+  // LDS float offset of the 1 KB that instruction q of this wave fills
+#define EBN_GLDS_A_DST(Q) (A_KC ? ((Q) * 4 + wave) * 256 : (wave * A_IPW + (Q)) * A_RPI * BM)
+#define EBN_GLDS_B_DST(Q) (B_KC ? ((Q) * 4 + wave) * 256 : (wave * B_IPW + (Q)) * B_RPI * BN)
+  // Tail slab of a VEC kernel (K range not a multiple of BK): the same buffer loads, with the pieces at k >= kend replaced
+  // by zero -- a float4 is all-in or all-out (k-contiguous operands have K % 4 == 0; for the others a k row is in or out).
+  // An out-of-range piece reads offset 0 of the resource (always valid).  Costs a handful of VALU instructions, once.
+#define EBN_TAIL_PIECE(R, RSRC, OFF, SOFF, KREL)                                         \
   do {                                                                                   \
-  if (VEC && (KT) < nk_full) {                                                           \
+    const bool ok__ = (KREL) < krem__;                                                   \
+    const float4 t__ = bload4(RSRC, ok__ ? (OFF) + (SOFF) : 0u, 0u);                      \
+    (R).x = ok__ ? t__.x : 0.f; (R).y = ok__ ? t__.y : 0.f;                              \
+    (R).z = ok__ ? t__.z : 0.f; (R).w = ok__ ? t__.w : 0.f;                              \
+  } while (0)
+  // Fetch of a FULL slab of a VEC kernel: per operand straight to LDS buffer BUF (glds) or into registers (stored by
+  // EBN_STORE_FULL after the MFMAs).
+#define EBN_FETCH_FULL(BUF)                                                              \
+  do {                                                                                   \
+    if (GLDS_A) {                                                                        \
+      _Pragma("unroll") for (int q = 0; q < A_IPW; ++q)                                  \
+        ebn_raw_buffer_load_lds(arsrc, (__attribute__((address_space(3))) void*)(EBN_AS(BUF) + EBN_GLDS_A_DST(q)), \
+                                16, static_cast<int>(gao[q]), static_cast<int>(sa), 0, 0); \
+    } else {                                                                             \
+      _Pragma("unroll") for (int i = 0; i < LA::PER_THREAD; ++i) ra[i] = bload4(arsrc, oa[i], sa); \
+    }                                                                                    \
+    if (GLDS_B) {                                                                        \
+      _Pragma("unroll") for (int q = 0; q < B_IPW; ++q)                                  \
+        ebn_raw_buffer_load_lds(brsrc, (__attribute__((address_space(3))) void*)(EBN_BS(BUF) + EBN_GLDS_B_DST(q)), \
+                                16, static_cast<int>(gbo[q]), static_cast<int>(sb), 0, 0); \
+    } else {                                                                             \
+      _Pragma("unroll") for (int i = 0; i < LB::PER_THREAD; ++i) rb[i] = bload4(brsrc, ob[i], sb); \
+    }                                                                                    \
+    sa += step_a;                                                                        \
+    sb += step_b;                                                                        \
+  } while (0)
+#define EBN_STORE_FULL(BUF)                                                              \
+  do {                                                                                   \
+    if (!GLDS_A) {                                                                       \
+      _Pragma("unroll") for (int i = 0; i < LA::PER_THREAD; ++i) LA::store(EBN_AS(BUF), tid + i * GEMM_THREADS, ra[i]); \
+    }                                                                                    \
+    if (!GLDS_B) {                                                                       \
+      _Pragma("unroll") for (int i = 0; i < LB::PER_THREAD; ++i) LB::store(EBN_BS(BUF), tid + i * GEMM_THREADS, rb[i]); \
+    }                                                                                    \
+  } while (0)
+  // A partial last slab, and every slab of a non-VEC kernel: both operands through registers.
+#define EBN_FETCH_PART(KT)                                                               \
+  do {                                                                                   \
+  if (VEC) {                                                                             \
+    const int krem__ = static_cast<int>(kend - kbeg) - (KT) * BK;                        \
     _Pragma("unroll") for (int i = 0; i < LA::PER_THREAD; ++i) {                         \
-      ra[i] = gload4(pa[i]);                                                             \
-      pa[i] += step_a;                                                                   \
+      const int v__ = tid + i * GEMM_THREADS;                                            \
+      EBN_TAIL_PIECE(ra[i], arsrc, oa[i], sa, TA ? v__ / (BM / 4) : (v__ % (BK / 4)) * 4); \
     }                                                                                    \
     _Pragma("unroll") for (int i = 0; i < LB::PER_THREAD; ++i) {                         \
-      rb[i] = gload4(pb[i]);                                                             \
-      pb[i] += step_b;                                                                   \
+      const int v__ = tid + i * GEMM_THREADS;                                            \
+      EBN_TAIL_PIECE(rb[i], brsrc, ob[i], sb, TB ? (v__ % (BK / 4)) * 4 : v__ / (BN / 4)); \
     }                                                                                    \
   } else {                                                                               \
     const int64_t k0__ = kbeg + static_cast<int64_t>(KT) * BK;                           \
@@ -302,78 +390,109 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
         rb[i] = LB::load(B, ldb, n0, k0__, N, kend, tid + i * GEMM_THREADS);             \
   }                                                                                      \
   } while (0)
-#define EBN_STORE_SLAB(BUF)                                                                              \
-  {                                                                                                      \
+#define EBN_STORE_PART(BUF)                                                              \
+  do {                                                                                   \
     _Pragma("unroll") for (int i = 0; i < LA::PER_THREAD; ++i) LA::store(EBN_AS(BUF), tid + i * GEMM_THREADS, ra[i]); \
     _Pragma("unroll") for (int i = 0; i < LB::PER_THREAD; ++i) LB::store(EBN_BS(BUF), tid + i * GEMM_THREADS, rb[i]); \
-  }
+  } while (0)
 
   // Pipeline: LDS buffer `cur` holds slab kt; slab kt+1 is fetched into registers while slab kt is multiplied
   // and written to LDS[cur^1] afterwards; one barrier per slab.  Variants measured and rejected on MI355X
   // (profiles/r01_gemm_tuning.md): two-slab-deep prefetch, BK=32, S[k/4][mn][4] image with ds_read_b64, glds-filled
   // float4 image, in-kernel split-K fix-up, s_setprio around the MFMA cluster / per-workgroup static priority.
-  if (nk > 0) {
-    if (GLDS && nk_full > 0) {
-      EBN_GLDS_SLAB(0);
-    } else {
-      EBN_LOAD_SLAB(0);
-      EBN_STORE_SLAB(0);
-    }
+  // Two phases.  MAIN: the full slabs of a VEC kernel, two per loop iteration with the LDS buffer index a literal, and
+  // nothing but full-slab fetches inside (a partial-slab path merging into this loop makes the compiler wait vmcnt(0)
+  // before the first LDS read of every slab -- i.e. for the glds fetch it has just issued).  REST: a partial last slab,
+  // or every slab of a non-VEC kernel, through registers with a run-time buffer index.
+  const int nk_main = VEC ? nk_full : 0;
+  if (nk_main > 0) {
+    EBN_FETCH_FULL(0);
+    EBN_STORE_FULL(0);
+    __syncthreads();
   }
-  __syncthreads();
 
   const int kl = lane >> 5;
   const int il = lane & 31;
-  int cur = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    // next slab: straight into the other LDS buffer (GLDS; its readers passed the barrier of the previous
-    // iteration), or into registers while this one is multiplied
-    const bool via_lds = GLDS && (kt + 1 < nk_full);
-    if (via_lds) EBN_GLDS_SLAB(cur ^ 1);
-    else if (kt + 1 < nk) EBN_LOAD_SLAB(kt + 1);
-    // MFMA contraction index = (instruction, lane half); the slab's 16 k are assigned as
-    //   step 4j + w of half kl  <->  k = 8j + 4kl + w      (A and B agree, so any assignment is valid)
-    // which makes the four values a lane feeds to steps 4j..4j+3 one float4 of a k-contiguous operand.
-    const float* as = A_KC ? EBN_AS(cur) + (wm * WTM + il) * 16 : EBN_AS(cur) + (4 * kl) * LDA_S + wm * WTM + il;
-    const float* bs = B_KC ? EBN_BS(cur) + (wn * WTN + il) * 16 : EBN_BS(cur) + (4 * kl) * LDB_S + wn * WTN + il;
-    const int sw = (il >> 2) & 3;
-#pragma unroll
-    for (int j8 = 0; j8 < BK / 8; ++j8) {
-      float a[TM][4], b[TN][4];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        if (A_KC) {
-          const float4 t = *reinterpret_cast<const float4*>(as + i * 32 * 16 + (((2 * j8 + kl) ^ sw) * 4));
-          a[i][0] = t.x; a[i][1] = t.y; a[i][2] = t.z; a[i][3] = t.w;
-        } else {
-#pragma unroll
-          for (int w = 0; w < 4; ++w) a[i][w] = as[(8 * j8 + w) * LDA_S + i * 32];
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        if (B_KC) {
-          const float4 t = *reinterpret_cast<const float4*>(bs + j * 32 * 16 + (((2 * j8 + kl) ^ sw) * 4));
-          b[j][0] = t.x; b[j][1] = t.y; b[j][2] = t.z; b[j][3] = t.w;
-        } else {
-#pragma unroll
-          for (int w = 0; w < 4; ++w) b[j][w] = bs[(8 * j8 + w) * LDB_S + j * 32];
-        }
-      }
-#pragma unroll
-      for (int w = 0; w < 4; ++w)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][w], b[j][w], acc[i][j], 0, 0, 0);
-    }
-    if (!via_lds && kt + 1 < nk) EBN_STORE_SLAB(cur ^ 1);
-    __syncthreads();  // also drains the glds queue (vmcnt) -- the slab must have landed before anyone reads it
-    cur ^= 1;
+  // The MFMAs of one slab out of LDS buffer CUR.  MFMA contraction index = (instruction, lane half); the slab's 16 k are
+  // assigned as   step 4j + w of half kl  <->  k = 8j + 4kl + w      (A and B agree, so any assignment is valid)
+  // which makes the four values a lane feeds to steps 4j..4j+3 one float4 of a k-contiguous operand.
+#define EBN_MMA(CUR)  \
+  {  \
+    const float* as = A_KC ? EBN_AS((CUR)) + (wm * WTM + il) * 16 : EBN_AS((CUR)) + (4 * kl) * LDA_S + wm * WTM + il;  \
+    const float* bs = B_KC ? EBN_BS((CUR)) + (wn * WTN + il) * 16 : EBN_BS((CUR)) + (4 * kl) * LDB_S + wn * WTN + il;  \
+    const int sw = (il >> 2) & 3;  \
+_Pragma("unroll")  \
+    for (int j8 = 0; j8 < BK / 8; ++j8) {  \
+      float a[TM][4], b[TN][4];  \
+_Pragma("unroll")  \
+      for (int i = 0; i < TM; ++i) {  \
+        if (A_KC) {  \
+          const float4 t = *reinterpret_cast<const float4*>(as + i * 32 * 16 + (((2 * j8 + kl) ^ sw) * 4));  \
+          a[i][0] = t.x; a[i][1] = t.y; a[i][2] = t.z; a[i][3] = t.w;  \
+        } else {  \
+_Pragma("unroll")  \
+          for (int w = 0; w < 4; ++w) a[i][w] = as[(8 * j8 + w) * LDA_S + i * 32];  \
+        }  \
+      }  \
+_Pragma("unroll")  \
+      for (int j = 0; j < TN; ++j) {  \
+        if (B_KC) {  \
+          const float4 t = *reinterpret_cast<const float4*>(bs + j * 32 * 16 + (((2 * j8 + kl) ^ sw) * 4));  \
+          b[j][0] = t.x; b[j][1] = t.y; b[j][2] = t.z; b[j][3] = t.w;  \
+        } else {  \
+_Pragma("unroll")  \
+          for (int w = 0; w < 4; ++w) b[j][w] = bs[(8 * j8 + w) * LDB_S + j * 32];  \
+        }  \
+      }  \
+_Pragma("unroll")  \
+      for (int w = 0; w < 4; ++w)  \
+_Pragma("unroll")  \
+        for (int i = 0; i < TM; ++i)  \
+_Pragma("unroll")  \
+          for (int j = 0; j < TN; ++j)  \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][w], b[j][w], acc[i][j], 0, 0, 0);  \
+    }  \
   }
-#undef EBN_LOAD_SLAB
-#undef EBN_GLDS_SLAB
+  // MAIN: slab KT out of buffer CUR (a literal: every LDS address is a per-thread base register plus an immediate -- with a
+  // run-time buffer index the addresses were recomputed on the vector ALU every slab, a dozen VALU instructions that the
+  // MFMAs do not hide); the next full slab goes straight into the other buffer (glds; its readers passed the previous
+  // barrier) or into registers while this one is multiplied, and to LDS afterwards.  The barrier also drains the glds
+  // queue (vmcnt): the slab must have landed before anyone reads it.
+#define EBN_SLAB(CUR, KT)  \
+  {  \
+    const bool next__ = (KT) + 1 < nk_main;  \
+    if (next__) EBN_FETCH_FULL((CUR) ^ 1);  \
+    EBN_MMA(CUR)  \
+    if (next__) EBN_STORE_FULL((CUR) ^ 1);  \
+    __syncthreads();  \
+  }
+  for (int kt = 0; kt < nk_main; kt += 2) {
+    EBN_SLAB(0, kt);
+    if (kt + 1 < nk_main) EBN_SLAB(1, kt + 1);
+  }
+#undef EBN_SLAB
+  // REST
+  if (nk_main < nk) {
+    int cur = nk_main & 1;
+    EBN_FETCH_PART(nk_main);
+    EBN_STORE_PART(cur);
+    __syncthreads();
+    for (int kt = nk_main; kt < nk; ++kt) {
+      if (kt + 1 < nk) EBN_FETCH_PART(kt + 1);
+      EBN_MMA(cur)
+      if (kt + 1 < nk) EBN_STORE_PART(cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+#undef EBN_MMA
+#undef EBN_FETCH_FULL
+#undef EBN_FETCH_PART
+#undef EBN_STORE_FULL
+#undef EBN_STORE_PART
+#undef EBN_TAIL_PIECE
+#undef EBN_GLDS_A_DST
+#undef EBN_GLDS_B_DST
 #undef EBN_AS
 #undef EBN_BS
 #undef EBN_STORE_SLAB
