@@ -777,6 +777,171 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_small_kernel(int64_t M, int
   }
 }
 
+// The same tile for 16-byte-aligned operands (every call site of the hot path), rebuilt around what the step's small GEMMs
+// are bound by -- the latency of a slab's loads, four to nine times per workgroup -- and around the fact that VALU work
+// is not hidden by the fp32 MFMAs:
+//   * TWO slabs of loads in flight: slab kt+2 is requested before slab kt is multiplied, slab kt+1 (requested an
+//     iteration earlier) is written to LDS after it; the two register sets and the two LDS buffers alternate with literal
+//     indices (two slabs per loop iteration);
+//   * buffer loads with a constant 32-bit lane offset and a scalar slab offset: no per-slab address arithmetic;
+//   * only the partial last slab carries k masks.
+template <bool TA, bool TB>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_small_vec_kernel(int64_t M, int64_t N, int64_t K, float alpha,
+                                                                      const float* __restrict__ A, int64_t lda,
+                                                                      const float* __restrict__ B, int64_t ldb, float beta,
+                                                                      float* __restrict__ C, int64_t ldc, GemmEpi epi) {
+  extern __shared__ __attribute__((aligned(16))) float smem_small[];  // [2 buffers][A tile | B tile]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t m0 = static_cast<int64_t>(blockIdx.y) * SBM, n0 = static_cast<int64_t>(blockIdx.x) * SBN;
+  const int nk = static_cast<int>((K + SBK - 1) / SBK), nk_full = static_cast<int>(K / SBK);
+  constexpr int TILE = SBM * SLD;
+  constexpr bool A_KC = !TA, B_KC = TB;
+  const i32x4n arsrc = make_rsrc(A_KC ? A + m0 * lda : A + m0), brsrc = make_rsrc(B_KC ? B + n0 * ldb : B + n0);
+  const uint32_t step_a = static_cast<uint32_t>((A_KC ? SBK : SBK * lda) * 4), step_b = static_cast<uint32_t>((B_KC ? SBK : SBK * ldb) * 4);
+  uint32_t oa[SPT], ob[SPT];  // lane byte offsets of the SPT float4 a thread owns per operand and slab
+#pragma unroll
+  for (int i = 0; i < SPT; ++i) {
+    const int v = tid + i * GEMM_THREADS;
+    if (A_KC) {
+      int64_t r = m0 + v / (SBK / 4);
+      r = r < M ? r : M - 1;
+      oa[i] = static_cast<uint32_t>(((r - m0) * lda + (v % (SBK / 4)) * 4) * 4);
+    } else {
+      int64_t c = m0 + (v % (SBM / 4)) * 4;
+      c = c + 3 < M ? c : M - 4;
+      oa[i] = static_cast<uint32_t>(((v / (SBM / 4)) * lda + (c - m0)) * 4);
+    }
+    if (B_KC) {
+      int64_t r = n0 + v / (SBK / 4);
+      r = r < N ? r : N - 1;
+      ob[i] = static_cast<uint32_t>(((r - n0) * ldb + (v % (SBK / 4)) * 4) * 4);
+    } else {
+      int64_t c = n0 + (v % (SBN / 4)) * 4;
+      c = c + 3 < N ? c : N - 4;
+      ob[i] = static_cast<uint32_t>(((v / (SBN / 4)) * ldb + (c - n0)) * 4);
+    }
+  }
+  // FOUR accumulators, fed round-robin: a 16x16x4 MFMA that depends on the previous one issues only when that one has
+  // retired, and with one or two workgroups per CU there is no other wave to fill the gap -- a single chain of 32
+  // dependent MFMAs per slab ran at less than half the matrix rate.  (Deterministic: the order of the sums is fixed.)
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+  float4 ra[2][SPT], rb[2][SPT];
+  // slab KT -> register set SET; a piece at k >= K (partial last slab only) reads offset 0 and is replaced by zero
+#define EBN_SM_LOAD(SET, KT)                                                                              \
+  do {                                                                                                    \
+    const uint32_t sa__ = static_cast<uint32_t>(KT) * step_a, sb__ = static_cast<uint32_t>(KT) * step_b;  \
+    if ((KT) < nk_full) {                                                                                 \
+      _Pragma("unroll") for (int i = 0; i < SPT; ++i) ra[SET][i] = bload4(arsrc, oa[i], sa__);            \
+      _Pragma("unroll") for (int i = 0; i < SPT; ++i) rb[SET][i] = bload4(brsrc, ob[i], sb__);            \
+    } else {                                                                                              \
+      const int krem__ = static_cast<int>(K - static_cast<int64_t>(KT) * SBK);                            \
+      _Pragma("unroll") for (int i = 0; i < SPT; ++i) {                                                   \
+        const int v__ = tid + i * GEMM_THREADS;                                                           \
+        const bool oka__ = (A_KC ? (v__ % (SBK / 4)) * 4 : v__ / (SBM / 4)) < krem__;                     \
+        const bool okb__ = (B_KC ? (v__ % (SBK / 4)) * 4 : v__ / (SBN / 4)) < krem__;                     \
+        const float4 ta__ = bload4(arsrc, oka__ ? oa[i] + sa__ : 0u, 0u);                                 \
+        const float4 tb__ = bload4(brsrc, okb__ ? ob[i] + sb__ : 0u, 0u);                                 \
+        ra[SET][i] = make_float4(oka__ ? ta__.x : 0.f, oka__ ? ta__.y : 0.f, oka__ ? ta__.z : 0.f, oka__ ? ta__.w : 0.f); \
+        rb[SET][i] = make_float4(okb__ ? tb__.x : 0.f, okb__ ? tb__.y : 0.f, okb__ ? tb__.z : 0.f, okb__ ? tb__.w : 0.f); \
+      }                                                                                                   \
+    }                                                                                                     \
+  } while (0)
+#define EBN_SM_STORE(SET, BUF)                                            \
+  do {                                                                    \
+    small_store<A_KC>(smem_small + (BUF) * 2 * TILE, ra[SET], tid);       \
+    small_store<B_KC>(smem_small + (BUF) * 2 * TILE + TILE, rb[SET], tid); \
+  } while (0)
+  const int r16 = lane & 15, kq = lane >> 4;
+  // A full slab multiplies its four 32-deep groups with the operand reads of group g + 1 issued BEFORE the MFMAs of group g
+  // (explicit double buffer: left to itself the compiler reuses one register set and waits for every group's LDS reads
+  // in front of its MFMAs -- with one wave per SIMD nothing else covers that latency).  The partial last slab stops at its
+  // last non-empty group.
+#define EBN_SM_READ(SET, g)                                                     \
+  do {                                                                          \
+    fa__[SET][0] = *reinterpret_cast<const float4*>(ap__ + 32 * (g));           \
+    fa__[SET][1] = *reinterpret_cast<const float4*>(ap__ + 32 * (g) + 4);       \
+    fb__[SET][0] = *reinterpret_cast<const float4*>(bp__ + 32 * (g));           \
+    fb__[SET][1] = *reinterpret_cast<const float4*>(bp__ + 32 * (g) + 4);       \
+  } while (0)
+#define EBN_SM_MUL(SET)                                                                             \
+  do {                                                                                              \
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa__[SET][0].x, fb__[SET][0].x, acc0, 0, 0, 0);     \
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa__[SET][0].y, fb__[SET][0].y, acc1, 0, 0, 0);     \
+    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa__[SET][0].z, fb__[SET][0].z, acc2, 0, 0, 0);     \
+    acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa__[SET][0].w, fb__[SET][0].w, acc3, 0, 0, 0);     \
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa__[SET][1].x, fb__[SET][1].x, acc0, 0, 0, 0);     \
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa__[SET][1].y, fb__[SET][1].y, acc1, 0, 0, 0);     \
+    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa__[SET][1].z, fb__[SET][1].z, acc2, 0, 0, 0);     \
+    acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa__[SET][1].w, fb__[SET][1].w, acc3, 0, 0, 0);     \
+  } while (0)
+  // contraction index of MFMA step s in lane quarter kq: k = 32 g + 8 kq + s (the same for A and B)
+#define EBN_SM_MMA(BUF, KT)                                                                                         \
+  do {                                                                                                              \
+    const float* ap__ = smem_small + (BUF) * 2 * TILE + (wm * 16 + r16) * SLD + kq * 8;                             \
+    const float* bp__ = smem_small + (BUF) * 2 * TILE + TILE + (wn * 16 + r16) * SLD + kq * 8;                      \
+    float4 fa__[2][2], fb__[2][2];                                                                                  \
+    if ((KT) < nk_full) {                                                                                           \
+      EBN_SM_READ(0, 0);                                                                                            \
+      EBN_SM_READ(1, 1);                                                                                            \
+      __builtin_amdgcn_sched_barrier(0); /* keep the reads in front: the scheduler sinks them to their uses */     \
+      EBN_SM_MUL(0);                                                                                                \
+      __builtin_amdgcn_sched_barrier(0);                                                                            \
+      EBN_SM_READ(0, 2);                                                                                            \
+      __builtin_amdgcn_sched_barrier(0);                                                                            \
+      EBN_SM_MUL(1);                                                                                                \
+      __builtin_amdgcn_sched_barrier(0);                                                                            \
+      EBN_SM_READ(1, 3);                                                                                            \
+      __builtin_amdgcn_sched_barrier(0);                                                                            \
+      EBN_SM_MUL(0);                                                                                                \
+      EBN_SM_MUL(1);                                                                                                \
+    } else {                                                                                                        \
+      const int groups__ = static_cast<int>((K - static_cast<int64_t>(KT) * SBK + 31) / 32);                        \
+      for (int g = 0; g < groups__; ++g) {                                                                          \
+        EBN_SM_READ(0, g);                                                                                          \
+        EBN_SM_MUL(0);                                                                                              \
+      }                                                                                                             \
+    }                                                                                                               \
+  } while (0)
+  EBN_SM_LOAD(0, 0);
+  if (nk > 1) EBN_SM_LOAD(1, 1);
+  EBN_SM_STORE(0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; kt += 2) {
+    // slab kt is in LDS buffer 0, register set 1 holds slab kt + 1, set 0 is free
+    if (kt + 2 < nk) EBN_SM_LOAD(0, kt + 2);
+    EBN_SM_MMA(0, kt);
+    if (kt + 1 < nk) EBN_SM_STORE(1, 1);
+    __syncthreads();
+    if (kt + 1 >= nk) break;
+    // slab kt + 1 is in LDS buffer 1, register set 0 holds slab kt + 2, set 1 is free
+    if (kt + 3 < nk) EBN_SM_LOAD(1, kt + 3);
+    EBN_SM_MMA(1, kt + 1);
+    if (kt + 2 < nk) EBN_SM_STORE(0, 0);
+    __syncthreads();
+  }
+#undef EBN_SM_LOAD
+#undef EBN_SM_STORE
+#undef EBN_SM_MMA
+#undef EBN_SM_READ
+#undef EBN_SM_MUL
+  const f32x4 acc = (acc0 + acc1) + (acc2 + acc3);
+  // C/D map of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + r
+  const int64_t col = n0 + wn * 16 + r16;
+  if (col >= N) return;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t row = m0 + wm * 16 + 4 * kq + r;
+    if (row >= M) continue;
+    float v = alpha * acc[r];
+    if (beta != 0.f) v += beta * C[row * ldc + col];
+    if (epi.rs != nullptr)
+      v = fmaf(epi.rs[row], epi.cv[static_cast<int64_t>(static_cast<uint32_t>(row) / static_cast<uint32_t>(epi.L)) * epi.ldcv + col], v);
+    if (epi.bias != nullptr) v = fmaxf(v + epi.bias[col], 0.f);
+    C[row * ldc + col] = v;
+  }
+}
+
 int launch_gemm_small(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda,
                       const float* B, int64_t ldb, float beta, float* C, int64_t ldc, int vecA, int vecB, hipStream_t s,
                       GemmEpi epi) {
@@ -789,9 +954,20 @@ int launch_gemm_small(int transA, int transB, int64_t M, int64_t N, int64_t K, f
     if (attr__ != hipSuccess) return static_cast<int>(attr__);                                                            \
     hipLaunchKernelGGL((gemm_small_kernel<TA, TB, VA, VB>), grid, block, lds, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, epi); \
   } while (0)
+#define EBN_SMALL_VEC(TA, TB)                                                                                              \
+  do {                                                                                                                     \
+    static const hipError_t attr__ = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_small_vec_kernel<TA, TB>),    \
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)); \
+    if (attr__ != hipSuccess) return static_cast<int>(attr__);                                                            \
+    hipLaunchKernelGGL((gemm_small_vec_kernel<TA, TB>), grid, block, lds, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, epi); \
+  } while (0)
+  // 32-bit byte offsets inside a tile's resource: 32 rows (or K rows) x ld x 4 bytes
+  const bool fits32 = (K + SBK) * (transA ? lda : 1) * 4 + SBM * lda * 4 < (int64_t{1} << 31) &&
+                      (K + SBK) * (transB ? 1 : ldb) * 4 + SBN * ldb * 4 < (int64_t{1} << 31);
 #define EBN_SMALL(TA, TB)                              \
   do {                                                 \
-    if (vecA && vecB) EBN_SMALL_ONE(TA, TB, true, true); \
+    if (vecA && vecB && fits32) EBN_SMALL_VEC(TA, TB); \
+    else if (vecA && vecB) EBN_SMALL_ONE(TA, TB, true, true); \
     else EBN_SMALL_ONE(TA, TB, false, false);          \
   } while (0)
   if (!transA && !transB) EBN_SMALL(false, false);
@@ -799,6 +975,7 @@ int launch_gemm_small(int transA, int transB, int64_t M, int64_t N, int64_t K, f
   else if (transA && !transB) EBN_SMALL(true, false);
   else EBN_SMALL(true, true);
 #undef EBN_SMALL
+#undef EBN_SMALL_VEC
 #undef EBN_SMALL_ONE
   EBN_CHECK_LAUNCH();
   return EBN_OK;
