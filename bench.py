@@ -245,7 +245,7 @@ def bench_docvec(args, c, world, rank, device, sync, dfields):
         gather_bytes = n_rows * (4 + 2 * c["doc"] * 4)
         if "dense0" in kt:
             fl = 2.0 * n_rows * c["doc"] * c["units"][0]
-            line["roofline"] = {"kernel": f"gemm_small_vec_kernel<false, false> (Dense({c['units'][0]}, relu) over the {n_rows} document vectors of a "
+            line["roofline"] = {"kernel": f"gemm_small_vec_kernel<false, false, 32> (Dense({c['units'][0]}, relu) over the {n_rows} document vectors of a "
                                           f"step: {n_rows}x{c['units'][0]}x{c['doc']}; the largest kernel of a step that is launch/latency-bound as a whole: "
                                           "~0.19 GFLOP and 2.5 MB per step)", "bound": "mfma",
                                 "achieved": fl / kt["dense0"] / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -348,7 +348,7 @@ def main():
         bm, bn, sp = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
         _hip.call("ebn_gemm_plan", n_tok, 3 * E, c["D"], 0, ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(sp))
         gemm_name = (f"gemm_f32_kernel<{bm.value}, {bn.value}, {4 if bm.value == 256 else 2}, false, false, true, 1, 0>" if bm.value != 32
-                     else "gemm_small_vec_kernel<false, false>") + f" (ebn_gemm_plan: tile {bm.value}x{bn.value}, split-K {sp.value})"
+                     else "gemm_small_vec_kernel<false, false, 32>") + f" (ebn_gemm_plan: tile {bm.value}x{bn.value}, split-K {sp.value})"
         gather_bytes = n_tok * (4 + 2 * c["D"] * 4)  # id + row read + row write (materialising gather)
         traffic = {}
         tf = ROOT / "profiles" / "traffic.json"

@@ -785,41 +785,62 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_small_kernel(int64_t M, int
 //     indices (two slabs per loop iteration);
 //   * buffer loads with a constant 32-bit lane offset and a scalar slab offset: no per-slab address arithmetic;
 //   * only the partial last slab carries k masks.
-template <bool TA, bool TB>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_small_vec_kernel(int64_t M, int64_t N, int64_t K, float alpha,
+// T = 32: 256 threads, the tile of gemm_small_kernel.  (T = 64, a 64 x 64 tile of sixteen waves with half the operand
+// re-streaming, was measured and is not instantiated: the 14 DocVec shapes took 224 us instead of 125 us.)
+template <bool KC, int T>
+__device__ __forceinline__ void small_store_t(float* __restrict__ S, const float4 (&r)[SBK / T], int tid) {
+  constexpr int THREADS = T * T / 4;
+#pragma unroll
+  for (int i = 0; i < SBK / T; ++i) {
+    const int v = tid + i * THREADS;
+    if (KC) {
+      *reinterpret_cast<float4*>(&S[(v / (SBK / 4)) * SLD + (v % (SBK / 4)) * 4]) = r[i];
+    } else {  // k = v / (T/4), rows 4*(v % (T/4))..+3: transposed scalar stores
+      const int k = v / (T / 4), m4 = (v % (T / 4)) * 4;
+      S[(m4 + 0) * SLD + k] = r[i].x;
+      S[(m4 + 1) * SLD + k] = r[i].y;
+      S[(m4 + 2) * SLD + k] = r[i].z;
+      S[(m4 + 3) * SLD + k] = r[i].w;
+    }
+  }
+}
+
+template <bool TA, bool TB, int T>
+__global__ __launch_bounds__(T * T / 4) void gemm_small_vec_kernel(int64_t M, int64_t N, int64_t K, float alpha,
                                                                       const float* __restrict__ A, int64_t lda,
                                                                       const float* __restrict__ B, int64_t ldb, float beta,
                                                                       float* __restrict__ C, int64_t ldc, GemmEpi epi) {
   extern __shared__ __attribute__((aligned(16))) float smem_small[];  // [2 buffers][A tile | B tile]
+  constexpr int THREADS = T * T / 4, SPT = SBK / T, WPR = T / 16;  // float4 per thread, operand and slab; waves per tile row
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int64_t m0 = static_cast<int64_t>(blockIdx.y) * SBM, n0 = static_cast<int64_t>(blockIdx.x) * SBN;
+  const int wm = wave / WPR, wn = wave % WPR;
+  const int64_t m0 = static_cast<int64_t>(blockIdx.y) * T, n0 = static_cast<int64_t>(blockIdx.x) * T;
   const int nk = static_cast<int>((K + SBK - 1) / SBK), nk_full = static_cast<int>(K / SBK);
-  constexpr int TILE = SBM * SLD;
+  constexpr int TILE = T * SLD;
   constexpr bool A_KC = !TA, B_KC = TB;
   const i32x4n arsrc = make_rsrc(A_KC ? A + m0 * lda : A + m0), brsrc = make_rsrc(B_KC ? B + n0 * ldb : B + n0);
   const uint32_t step_a = static_cast<uint32_t>((A_KC ? SBK : SBK * lda) * 4), step_b = static_cast<uint32_t>((B_KC ? SBK : SBK * ldb) * 4);
   uint32_t oa[SPT], ob[SPT];  // lane byte offsets of the SPT float4 a thread owns per operand and slab
 #pragma unroll
   for (int i = 0; i < SPT; ++i) {
-    const int v = tid + i * GEMM_THREADS;
+    const int v = tid + i * THREADS;
     if (A_KC) {
       int64_t r = m0 + v / (SBK / 4);
       r = r < M ? r : M - 1;
       oa[i] = static_cast<uint32_t>(((r - m0) * lda + (v % (SBK / 4)) * 4) * 4);
     } else {
-      int64_t c = m0 + (v % (SBM / 4)) * 4;
+      int64_t c = m0 + (v % (T / 4)) * 4;
       c = c + 3 < M ? c : M - 4;
-      oa[i] = static_cast<uint32_t>(((v / (SBM / 4)) * lda + (c - m0)) * 4);
+      oa[i] = static_cast<uint32_t>(((v / (T / 4)) * lda + (c - m0)) * 4);
     }
     if (B_KC) {
       int64_t r = n0 + v / (SBK / 4);
       r = r < N ? r : N - 1;
       ob[i] = static_cast<uint32_t>(((r - n0) * ldb + (v % (SBK / 4)) * 4) * 4);
     } else {
-      int64_t c = n0 + (v % (SBN / 4)) * 4;
+      int64_t c = n0 + (v % (T / 4)) * 4;
       c = c + 3 < N ? c : N - 4;
-      ob[i] = static_cast<uint32_t>(((v / (SBN / 4)) * ldb + (c - n0)) * 4);
+      ob[i] = static_cast<uint32_t>(((v / (T / 4)) * ldb + (c - n0)) * 4);
     }
   }
   // FOUR accumulators, fed round-robin: a 16x16x4 MFMA that depends on the previous one issues only when that one has
@@ -837,9 +858,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_small_vec_kernel(int64_t M,
     } else {                                                                                              \
       const int krem__ = static_cast<int>(K - static_cast<int64_t>(KT) * SBK);                            \
       _Pragma("unroll") for (int i = 0; i < SPT; ++i) {                                                   \
-        const int v__ = tid + i * GEMM_THREADS;                                                           \
-        const bool oka__ = (A_KC ? (v__ % (SBK / 4)) * 4 : v__ / (SBM / 4)) < krem__;                     \
-        const bool okb__ = (B_KC ? (v__ % (SBK / 4)) * 4 : v__ / (SBN / 4)) < krem__;                     \
+        const int v__ = tid + i * THREADS;                                                           \
+        const bool oka__ = (A_KC ? (v__ % (SBK / 4)) * 4 : v__ / (T / 4)) < krem__;                     \
+        const bool okb__ = (B_KC ? (v__ % (SBK / 4)) * 4 : v__ / (T / 4)) < krem__;                     \
         const float4 ta__ = bload4(arsrc, oka__ ? oa[i] + sa__ : 0u, 0u);                                 \
         const float4 tb__ = bload4(brsrc, okb__ ? ob[i] + sb__ : 0u, 0u);                                 \
         ra[SET][i] = make_float4(oka__ ? ta__.x : 0.f, oka__ ? ta__.y : 0.f, oka__ ? ta__.z : 0.f, oka__ ? ta__.w : 0.f); \
@@ -849,8 +870,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_small_vec_kernel(int64_t M,
   } while (0)
 #define EBN_SM_STORE(SET, BUF)                                            \
   do {                                                                    \
-    small_store<A_KC>(smem_small + (BUF) * 2 * TILE, ra[SET], tid);       \
-    small_store<B_KC>(smem_small + (BUF) * 2 * TILE + TILE, rb[SET], tid); \
+    small_store_t<A_KC, T>(smem_small + (BUF) * 2 * TILE, ra[SET], tid);       \
+    small_store_t<B_KC, T>(smem_small + (BUF) * 2 * TILE + TILE, rb[SET], tid); \
   } while (0)
   const int r16 = lane & 15, kq = lane >> 4;
   // A full slab multiplies its four 32-deep groups with the operand reads of group g + 1 issued BEFORE the MFMAs of group g
@@ -954,16 +975,20 @@ int launch_gemm_small(int transA, int transB, int64_t M, int64_t N, int64_t K, f
     if (attr__ != hipSuccess) return static_cast<int>(attr__);                                                            \
     hipLaunchKernelGGL((gemm_small_kernel<TA, TB, VA, VB>), grid, block, lds, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, epi); \
   } while (0)
-#define EBN_SMALL_VEC(TA, TB)                                                                                              \
+#define EBN_SMALL_VEC_T(TA, TB, T)                                                                                         \
   do {                                                                                                                     \
-    static const hipError_t attr__ = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_small_vec_kernel<TA, TB>),    \
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)); \
+    constexpr size_t lds_t = static_cast<size_t>(2) * 2 * (T) * SLD * sizeof(float);                                       \
+    static const hipError_t attr__ = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_small_vec_kernel<TA, TB, T>), \
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_t)); \
     if (attr__ != hipSuccess) return static_cast<int>(attr__);                                                            \
-    hipLaunchKernelGGL((gemm_small_vec_kernel<TA, TB>), grid, block, lds, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, epi); \
+    const dim3 grid_t(static_cast<unsigned>(ebn_ceil_div(N, T)), static_cast<unsigned>(ebn_ceil_div(M, T)));               \
+    hipLaunchKernelGGL((gemm_small_vec_kernel<TA, TB, T>), grid_t, dim3((T) * (T) / 4), lds_t, s, M, N, K, alpha, A, lda, B, ldb, \
+                       beta, C, ldc, epi);                                                                                 \
   } while (0)
+#define EBN_SMALL_VEC(TA, TB) EBN_SMALL_VEC_T(TA, TB, 32)
   // 32-bit byte offsets inside a tile's resource: 32 rows (or K rows) x ld x 4 bytes
-  const bool fits32 = (K + SBK) * (transA ? lda : 1) * 4 + SBM * lda * 4 < (int64_t{1} << 31) &&
-                      (K + SBK) * (transB ? 1 : ldb) * 4 + SBN * ldb * 4 < (int64_t{1} << 31);
+  const bool fits32 = (K + SBK) * (transA ? lda : 1) * 4 + 64 * lda * 4 < (int64_t{1} << 31) &&
+                      (K + SBK) * (transB ? 1 : ldb) * 4 + 64 * ldb * 4 < (int64_t{1} << 31);
 #define EBN_SMALL(TA, TB)                              \
   do {                                                 \
     if (vecA && vecB && fits32) EBN_SMALL_VEC(TA, TB); \
@@ -976,6 +1001,7 @@ int launch_gemm_small(int transA, int transB, int64_t M, int64_t N, int64_t K, f
   else EBN_SMALL(true, true);
 #undef EBN_SMALL
 #undef EBN_SMALL_VEC
+#undef EBN_SMALL_VEC_T
 #undef EBN_SMALL_ONE
   EBN_CHECK_LAUNCH();
   return EBN_OK;
