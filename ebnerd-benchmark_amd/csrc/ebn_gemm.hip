@@ -416,6 +416,9 @@ __global__ __launch_bounds__(GEMM_THREADS, EBN_GEMM_WPE) void gemm_f32_kernel(
   // The MFMAs of one slab out of LDS buffer CUR.  MFMA contraction index = (instruction, lane half); the slab's 16 k are
   // assigned as   step 4j + w of half kl  <->  k = 8j + 4kl + w      (A and B agree, so any assignment is valid)
   // which makes the four values a lane feeds to steps 4j..4j+3 one float4 of a k-contiguous operand.
+  // (The k-contiguous images are read through FLOAT-typed loads -- the compiler still merges the four into one
+  // ds_read_b128 -- because a float4-typed LDS read next to the glds fetch of the other buffer makes it wait vmcnt(0), i.e.
+  // for the fetch it has just issued, in front of the first read of every slab: 436-442 -> 428 us on the projection.)
 #define EBN_MMA(CUR)  \
   {  \
     const float* as = A_KC ? EBN_AS((CUR)) + (wm * WTM + il) * 16 : EBN_AS((CUR)) + (4 * kl) * LDA_S + wm * WTM + il;  \
@@ -427,8 +430,8 @@ _Pragma("unroll")  \
 _Pragma("unroll")  \
       for (int i = 0; i < TM; ++i) {  \
         if (A_KC) {  \
-          const float4 t = *reinterpret_cast<const float4*>(as + i * 32 * 16 + (((2 * j8 + kl) ^ sw) * 4));  \
-          a[i][0] = t.x; a[i][1] = t.y; a[i][2] = t.z; a[i][3] = t.w;  \
+          const float* pa__ = as + i * 32 * 16 + (((2 * j8 + kl) ^ sw) * 4);  \
+          a[i][0] = pa__[0]; a[i][1] = pa__[1]; a[i][2] = pa__[2]; a[i][3] = pa__[3];  \
         } else {  \
 _Pragma("unroll")  \
           for (int w = 0; w < 4; ++w) a[i][w] = as[(8 * j8 + w) * LDA_S + i * 32];  \
@@ -437,8 +440,8 @@ _Pragma("unroll")  \
 _Pragma("unroll")  \
       for (int j = 0; j < TN; ++j) {  \
         if (B_KC) {  \
-          const float4 t = *reinterpret_cast<const float4*>(bs + j * 32 * 16 + (((2 * j8 + kl) ^ sw) * 4));  \
-          b[j][0] = t.x; b[j][1] = t.y; b[j][2] = t.z; b[j][3] = t.w;  \
+          const float* pb__ = bs + j * 32 * 16 + (((2 * j8 + kl) ^ sw) * 4);  \
+          b[j][0] = pb__[0]; b[j][1] = pb__[1]; b[j][2] = pb__[2]; b[j][3] = pb__[3];  \
         } else {  \
 _Pragma("unroll")  \
           for (int w = 0; w < 4; ++w) b[j][w] = bs[(8 * j8 + w) * LDB_S + j * 32];  \
