@@ -40,6 +40,20 @@ __device__ __forceinline__ float body(float seed) {
   return s;
 }
 
+// D: ONE accumulator -- every MFMA depends on the previous one (the shape of the attention kernels' 10- and 16-step chains)
+__global__ __launch_bounds__(512) void kdep(float* out, float seed) {
+  f32x16 acc;
+  for (int r = 0; r < 16; ++r) acc[r] = seed;
+  const float a = seed + 1.f, b = seed + 2.f;
+  for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+    for (int i = 0; i < MFMA_PER_ITER; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int r = 0; r < 16; ++r) s += acc[r];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(512) void k(float* out, float seed) {
   float s;
@@ -73,6 +87,23 @@ int main() {
   hipMalloc(&out, 256 * 512 * sizeof(float));
   const float m = run<0>(out, 256), v = run<1>(out, 256), s = run<2>(out, 256), x = run<3>(out, 512);
   const float m2 = run<0>(out, 512), v2 = run<1>(out, 512);
+  float d1, d2;
+  {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    for (int threads : {256, 512}) {
+      for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(kdep, dim3(256), dim3(threads), 0, 0, out, 1.0f);
+      hipEventRecord(e0);
+      for (int w = 0; w < 10; ++w) hipLaunchKernelGGL(kdep, dim3(256), dim3(threads), 0, 0, out, 1.0f);
+      hipEventRecord(e1);
+      hipEventSynchronize(e1);
+      float ms;
+      hipEventElapsedTime(&ms, e0, e1);
+      (threads == 256 ? d1 : d2) = ms / 10 * 1e3f;
+    }
+  }
+  printf("dependent chain (one accumulator): one wave per SIMD %.1f us, two waves per SIMD %.1f us\n", d1, d2);
   printf("one wave per SIMD:  M %.1f us   V %.1f us   same-wave M+V %.1f us  (sum %.1f, max %.1f)\n", m, v, s, m + v, m > v ? m : v);
   printf("two waves per SIMD: M|V split %.1f us   (M alone on 2 waves %.1f, V alone on 2 waves %.1f)\n", x, m2, v2);
   printf("expected M: %d MFMAs x 64 cycles = %.1f us at 2.4 GHz\n", ITERS * MFMA_PER_ITER, ITERS * MFMA_PER_ITER * 64 / 2400.0);
