@@ -1113,8 +1113,13 @@ static int gemm_dispatch(int32_t transA, int32_t transB, int64_t M, int64_t N, i
                          int64_t lda, const float* B, int64_t ldb, float beta, float* C, int64_t ldc, float* workspace,
                          int64_t workspace_floats, int32_t site, GemmEpi epi, hipStream_t s) {
   // contiguous-axis extent must be a multiple of 4 too (K for k-contiguous operands, M/N otherwise)
-  const int vecA = ((lda % 4) == 0 && ebn_aligned16(A) && ((transA ? M : K) % 4) == 0) ? 1 : 0;
-  const int vecB = ((ldb % 4) == 0 && ebn_aligned16(B) && ((transB ? K : N) % 4) == 0) ? 1 : 0;
+  // ... and the fast tile fetch addresses an operand tile with 32-bit BYTE offsets from the tile's origin: 256 tile rows
+  // (or the K range, for operands stored [K][mn]) times the leading dimension must stay below 4 GB
+  const bool spanA = (transA ? (K + 16) * lda + 256 : 256 * lda + K + 16) * 4 < (int64_t{1} << 32);
+  const bool spanB = (transB ? 256 * ldb + K + 16 : (K + 16) * ldb + 256) * 4 < (int64_t{1} << 32);
+  const int vecA = ((lda % 4) == 0 && ebn_aligned16(A) && ((transA ? M : K) % 4) == 0 && spanA) ? 1 : 0;
+  const int vecB = ((ldb % 4) == 0 && ebn_aligned16(B) && ((transB ? K : N) % 4) == 0 && spanB) ? 1 : 0;
+  if ((epi.bias != nullptr || epi.rs != nullptr) && !(vecA && vecB)) return EBN_ERR_UNSUPPORTED;  // epilogue kernels are VEC only
   const GemmPlan plan = gemm_plan(M, N, K, workspace ? workspace_floats : 0);
   const int splits = plan.splits;
   const int64_t kps = plan.kps;

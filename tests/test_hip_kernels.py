@@ -99,7 +99,9 @@ GEMM_SHAPES = [(1, 1, 1), (5, 7, 3), (64, 64, 16), (130, 70, 33), (257, 129, 300
                # shapes whose plan picks the 256x64 tile family (ragged M and N, split-K)
                (6000, 1200, 256), (5000, 300, 128), (1030, 1210, 3000),
                # split-K whose last K range ends in a partial slab (direct-to-LDS fetch for the full slabs, guarded loader for the tail)
-               (256, 256, 2004), (512, 64, 8200)]
+               (256, 256, 2004), (512, 64, 8200),
+               # the small-output kernel with two slabs of loads in flight: 6 full slabs; 3 full + a 16-wide tail; 5 full, ragged M
+               (800, 512, 768), (640, 1200, 400), (250, 768, 640)]
 
 
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
