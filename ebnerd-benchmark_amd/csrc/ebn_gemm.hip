@@ -37,7 +37,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define EBN_GEMM_XCD 1
 #endif
 #ifndef EBN_GEMM_GLDS
-#define EBN_GEMM_GLDS 2  // direct global->LDS tile fetch, see GLDS_A / GLDS_B in the kernel
+#define EBN_GEMM_GLDS 3  // direct global->LDS tile fetch, see GLDS_A / GLDS_B in the kernel
 #endif
 
 typedef float f32x4n __attribute__((ext_vector_type(4)));
@@ -183,9 +183,10 @@ __global__ __launch_bounds__(GEMM_THREADS, EBN_GEMM_WPE) void gemm_f32_kernel(
   //   * stored [mn][K]: the float4 image S4[mn][kq ^ ((mn >> 2) & 3)] is 64 contiguous bytes per row, so lane l of an
   //     instruction fills chunk l and the XOR swizzle is applied to the SOURCE column it fetches -- the four lanes of a
   //     row still read the row's 64 contiguous bytes, permuted.
-  // Used when B is stored [K][N] (NN: the projections; TN: the weight gradients).  With a k-contiguous B ([N][K], the NT
-  // input-gradient GEMMs) both operands stay on the register path: glds for A alone or for both measured slower there
-  // (profiles/r02_gemm_tuning.md).  EBN_GEMM_GLDS: 0 never, 1 TN only, 2 NN + TN, 3 every layout (tuning).
+  // Used for every layout of 16-byte-aligned operands.  (While the k-contiguous images were read through float4-typed
+  // loads the NT GEMMs lost with it -- the compiler then waits vmcnt(0) in front of the first LDS read of every slab --
+  // and were kept on the register path; with float-typed reads the NT input-gradient GEMM of c1 went 169 -> 156 us.)
+  // EBN_GEMM_GLDS: 0 never, 1 TN only, 2 NN + TN, 3 every layout (tuning).
   constexpr bool GLDS_A = VEC && ((EBN_GEMM_GLDS == 3) || (EBN_GEMM_GLDS == 2 && !TB) || (EBN_GEMM_GLDS == 1 && TA && !TB));
   constexpr bool GLDS_B = GLDS_A;
   constexpr int PADA = GLDS_A ? 0 : PAD, PADB = GLDS_B ? 0 : PAD;
