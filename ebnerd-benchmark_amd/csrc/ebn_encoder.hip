@@ -58,27 +58,29 @@ extern "C" int ebn_encoder_bwd_f32(const ebn_encoder_dims* dims, const ebn_encod
   EBN_TRY(ebn_attpool_bwd_pool_f32(a->Y, a->w, dout, nullptr, s->de, dims->n_seq, dims->L, E, stream));
   EBN_TRY(ebn_attpool_bwd_dpre_f32(a->U, p->q, s->de, g->dq, g->db, s->partials, R, A, accumulate, stream));
   // dW = Y^T . dpre ; dY = dpre . W^T + w (x) dout
-  EBN_TRY(ebn_gemm_f32_ws(1, 0, E, A, R, 1.0f, a->Y, E, a->U, A, beta, g->dW, A, s->gemm_ws, s->gemm_ws_floats, stream));
+  // (with the pooling term folded into the attention backward, dW and dY below are one call: ebn_dense_bwd_pair_f32)
   // The pooling term w (x) dout rides in the attention backward when its MFMA path takes the shape (it is added while dO
   // is staged: the GEMM needs no rank-1 epilogue); otherwise in the epilogue of the dpre.W^T GEMM.
   const bool fold = ebn_attn_bwd_pooled_supported(dims->L, dims->d) != 0 && (E % 4) == 0 && ebn_aligned16(dout) &&
                     ebn_aligned16(s->dY) && ebn_aligned16(a->QKV) && ebn_aligned16(s->dQKV);
   if (fold) {
-    EBN_TRY(ebn_gemm_f32_ws(0, 1, R, E, A, 1.0f, a->U, A, p->W, A, 0.0f, s->dY, E, s->gemm_ws, s->gemm_ws_floats, stream));
+    EBN_TRY(ebn_dense_bwd_pair_f32(R, E, A, a->Y, E, a->U, A, p->W, A, beta, g->dW, A, s->dY, E, s->gemm_ws, s->gemm_ws_floats,
+                                   stream));
     EBN_TRY(ebn_attn_bwd_pooled_f32(a->QKV, 3 * E, s->dY, E, a->w, dout, E, s->dQKV, 3 * E, dims->n_seq, dims->L, dims->h,
                                     dims->d, st, dims->drop_site, dims->drop_p, stream));
   } else {
+    EBN_TRY(ebn_gemm_f32_ws(1, 0, E, A, R, 1.0f, a->Y, E, a->U, A, beta, g->dW, A, s->gemm_ws, s->gemm_ws_floats, stream));
     EBN_TRY(ebn_gemm_f32_rank1(R, E, A, 1.0f, a->U, A, p->W, A, s->dY, E, a->w, dout, E, dims->L, s->gemm_ws,
                                s->gemm_ws_floats, stream));
     // self-attention core backward (re-derives the dropout mask of Y)
     EBN_TRY(ebn_attn_bwd_f32(a->QKV, 3 * E, s->dY, E, s->dQKV, 3 * E, dims->n_seq, dims->L, dims->h, dims->d, st, dims->drop_site,
                              dims->drop_p, stream));
   }
-  // dWqkv = X^T . dQKV ; dX = dQKV . Wqkv^T
+  // dWqkv = X^T . dQKV ; dX = dQKV . Wqkv^T  (one launch for the pair where both are small-output shapes: the user encoder)
+  if (dX != nullptr)
+    return ebn_dense_bwd_pair_f32(R, dims->Din, 3 * E, a->X, dims->Din, s->dQKV, 3 * E, p->Wqkv, 3 * E, beta, g->dWqkv, 3 * E, dX,
+                                  dims->Din, s->gemm_ws, s->gemm_ws_floats, stream);
   EBN_TRY(ebn_gemm_f32_ws(1, 0, dims->Din, 3 * E, R, 1.0f, a->X, dims->Din, s->dQKV, 3 * E, beta, g->dWqkv, 3 * E,
                           s->gemm_ws, s->gemm_ws_floats, stream));
-  if (dX != nullptr)
-    EBN_TRY(ebn_gemm_f32_ws(0, 1, R, dims->Din, 3 * E, 1.0f, s->dQKV, 3 * E, p->Wqkv, 3 * E, 0.0f, dX, dims->Din, s->gemm_ws,
-                            s->gemm_ws_floats, stream));
   return EBN_OK;
 }

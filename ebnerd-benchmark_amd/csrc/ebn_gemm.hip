@@ -810,15 +810,14 @@ __device__ __forceinline__ void small_store_t(float* __restrict__ S, const float
 }
 
 template <bool TA, bool TB, int T>
-__global__ __launch_bounds__(T * T / 4) void gemm_small_vec_kernel(int64_t M, int64_t N, int64_t K, float alpha,
-                                                                      const float* __restrict__ A, int64_t lda,
-                                                                      const float* __restrict__ B, int64_t ldb, float beta,
-                                                                      float* __restrict__ C, int64_t ldc, GemmEpi epi) {
+__device__ __forceinline__ void small_vec_body(int64_t M, int64_t N, int64_t K, float alpha, const float* __restrict__ A,
+                                               int64_t lda, const float* __restrict__ B, int64_t ldb, float beta,
+                                               float* __restrict__ C, int64_t ldc, GemmEpi epi, int64_t tile_x, int64_t tile_y) {
   extern __shared__ __attribute__((aligned(16))) float smem_small[];  // [2 buffers][A tile | B tile]
   constexpr int THREADS = T * T / 4, SPT = SBK / T, WPR = T / 16;  // float4 per thread, operand and slab; waves per tile row
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WPR, wn = wave % WPR;
-  const int64_t m0 = static_cast<int64_t>(blockIdx.y) * T, n0 = static_cast<int64_t>(blockIdx.x) * T;
+  const int64_t m0 = tile_y * T, n0 = tile_x * T;
   const int nk = static_cast<int>((K + SBK - 1) / SBK), nk_full = static_cast<int>(K / SBK);
   constexpr int TILE = T * SLD;
   constexpr bool A_KC = !TA, B_KC = TB;
@@ -965,6 +964,42 @@ __global__ __launch_bounds__(T * T / 4) void gemm_small_vec_kernel(int64_t M, in
     if (epi.bias != nullptr) v = fmaxf(v + epi.bias[col], 0.f);
     C[row * ldc + col] = v;
   }
+}
+
+template <bool TA, bool TB, int T>
+__global__ __launch_bounds__(T * T / 4) void gemm_small_vec_kernel(int64_t M, int64_t N, int64_t K, float alpha,
+                                                                      const float* __restrict__ A, int64_t lda,
+                                                                      const float* __restrict__ B, int64_t ldb, float beta,
+                                                                      float* __restrict__ C, int64_t ldc, GemmEpi epi) {
+  small_vec_body<TA, TB, T>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, epi, blockIdx.x, blockIdx.y);
+}
+
+// TWO independent small-output GEMMs in one launch: the weight gradient dW = X^T.dY (TN) and the input gradient
+// dX = dY.W^T (NT) of a Dense layer (or of the projections of the user encoder) read the same dY and do not depend on each
+// other.  Each fills half of the chip on its own (a few hundred 32x32 tiles for 256 CUs x 2 resident workgroups) and
+// costs a launch of the step's dependent chain; together they are one launch that fills it.
+struct SmallProblem {
+  int64_t M, N, K;
+  float alpha;
+  const float* A;
+  int64_t lda;
+  const float* B;
+  int64_t ldb;
+  float beta;
+  float* C;
+  int64_t ldc;
+  int32_t tiles_x, tiles;  // 32x32 tiles per row of tiles, and in total
+};
+
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_small_pair_kernel(SmallProblem p0, SmallProblem p1) {
+  const GemmEpi none{nullptr, nullptr, 0, 1, nullptr};
+  const int b = blockIdx.x;  // block-uniform branch: the workgroup runs one of the two bodies
+  if (b < p0.tiles)
+    small_vec_body<true, false, 32>(p0.M, p0.N, p0.K, p0.alpha, p0.A, p0.lda, p0.B, p0.ldb, p0.beta, p0.C, p0.ldc, none,
+                                    b % p0.tiles_x, b / p0.tiles_x);
+  else
+    small_vec_body<false, true, 32>(p1.M, p1.N, p1.K, p1.alpha, p1.A, p1.lda, p1.B, p1.ldb, p1.beta, p1.C, p1.ldc, none,
+                                    (b - p0.tiles) % p1.tiles_x, (b - p0.tiles) / p1.tiles_x);
 }
 
 int launch_gemm_small(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda,
@@ -1222,6 +1257,43 @@ extern "C" int ebn_gemm_f32_ws(int32_t transA, int32_t transB, int64_t M, int64_
                                ebn_stream_t stream) {
   return ebn_gemm_f32_site(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, workspace, workspace_floats, 0,
                            stream);
+}
+
+extern "C" int ebn_dense_bwd_pair_f32(int64_t R, int64_t K_in, int64_t N_out, const float* X, int64_t ldx, const float* dY,
+                                      int64_t lddy, const float* W, int64_t ldw, float beta_w, float* dW, int64_t lddw,
+                                      float* dX, int64_t lddx, float* workspace, int64_t workspace_floats,
+                                      ebn_stream_t stream) {
+  EBN_REQUIRE(R >= 0 && K_in >= 0 && N_out >= 0, EBN_ERR_BAD_ARG);
+  if (K_in == 0 || N_out == 0) return EBN_OK;
+  EBN_REQUIRE(X && dY && W && dW && dX, EBN_ERR_BAD_ARG);
+  EBN_REQUIRE(ldx >= K_in && lddy >= N_out && ldw >= N_out && lddw >= N_out && lddx >= K_in, EBN_ERR_BAD_ARG);
+  hipStream_t s = ebn_stream(stream);
+  // one launch when both GEMMs are small-output shapes with 16-byte-aligned operands; two launches otherwise
+  const bool aligned = (ldx % 4) == 0 && (lddy % 4) == 0 && (ldw % 4) == 0 && ebn_aligned16(X) && ebn_aligned16(dY) &&
+                       ebn_aligned16(W) && (K_in % 4) == 0 && (N_out % 4) == 0;
+  const int64_t span = (R + SBK) * (ldx > lddy ? ldx : lddy) * 4 + 64 * ((ldx > lddy ? ldx : lddy) > ldw ? (ldx > lddy ? ldx : lddy) : ldw) * 4;
+  const bool small = R > 0 && gemm_plan(K_in, N_out, R, workspace ? workspace_floats : 0).bm == 32 &&
+                     gemm_plan(R, K_in, N_out, workspace ? workspace_floats : 0).bm == 32 && forced_tile_bm() == 0;
+  if (aligned && small && span < (int64_t{1} << 31)) {
+    SmallProblem p0{K_in, N_out, R, 1.0f, X, ldx, dY, lddy, beta_w, dW, lddw, static_cast<int32_t>(ebn_ceil_div(N_out, SBN)), 0};
+    p0.tiles = p0.tiles_x * static_cast<int32_t>(ebn_ceil_div(K_in, SBM));
+    SmallProblem p1{R, K_in, N_out, 1.0f, dY, lddy, W, ldw, 0.0f, dX, lddx, static_cast<int32_t>(ebn_ceil_div(K_in, SBN)), 0};
+    p1.tiles = p1.tiles_x * static_cast<int32_t>(ebn_ceil_div(R, SBM));
+    constexpr size_t lds = static_cast<size_t>(2) * 2 * SBM * SLD * sizeof(float);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_small_pair_kernel),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    if (attr != hipSuccess) return static_cast<int>(attr);
+    hipLaunchKernelGGL(gemm_small_pair_kernel, dim3(static_cast<unsigned>(p0.tiles + p1.tiles)), dim3(GEMM_THREADS), lds, s, p0, p1);
+    EBN_CHECK_LAUNCH();
+    return EBN_OK;
+  }
+  const GemmEpi none{nullptr, nullptr, 0, 1, nullptr};
+  if (R == 0) {  // empty contraction: dW <- beta_w * dW, nothing to write for dX
+    return gemm_dispatch(1, 0, K_in, N_out, 0, 1.0f, X, ldx, dY, lddy, beta_w, dW, lddw, workspace, workspace_floats, 0, none, s);
+  }
+  const int rc = gemm_dispatch(1, 0, K_in, N_out, R, 1.0f, X, ldx, dY, lddy, beta_w, dW, lddw, workspace, workspace_floats, 0, none, s);
+  if (rc != EBN_OK) return rc;
+  return gemm_dispatch(0, 1, R, K_in, N_out, 1.0f, dY, lddy, W, ldw, 0.0f, dX, lddx, workspace, workspace_floats, 0, none, s);
 }
 
 extern "C" int ebn_gemm_f32(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K, float alpha,

@@ -124,12 +124,16 @@ class MLPStack:
                               ctypes.c_int64(r0 * u), S())
                 _hip.call("ebn_bias_relu_bwd_f32", _hip.ptr(b["R"][l]), _hip.ptr(dR), _hip.ptr(dR), _hip.ptr(self._g(f"d{l}_b")),
                           _hip.ptr(b["partials"]), N, u, 0, S())
-            self.gemm(1, 0, din, u, N, x_in, din, dR, u, 0.0, self._g(f"d{l}_W"), u, b["ws"])
-            if l:
-                self.gemm(0, 1, N, din, u, dR, u, self._pv(f"d{l}_W"), u, 0.0, b["dA"][l - 1], din, b["ws"])
-                dY = b["dA"][l - 1]
-            elif need_dx0:
-                self.gemm(0, 1, N, din, u, dR, u, self._pv(f"d{l}_W"), u, 0.0, b["dX0"], din, b["ws"])
+            if l or need_dx0:  # dW = X^T.dR and dX = dR.W^T: independent of each other, one launch for the pair
+                dx = b["dA"][l - 1] if l else b["dX0"]
+                ws = b["ws"]
+                _hip.call("ebn_dense_bwd_pair_f32", N, din, u, _hip.ptr(x_in), din, _hip.ptr(dR), u, _hip.ptr(self._pv(f"d{l}_W")), u,
+                          ctypes.c_float(0.0), _hip.ptr(self._g(f"d{l}_W")), u, _hip.ptr(dx), din,
+                          _hip.ptr(ws) if ws is not None else None, ws.numel() if ws is not None else 0, S())
+                if l:
+                    dY = dx
+            else:
+                self.gemm(1, 0, din, u, N, x_in, din, dR, u, 0.0, self._g(f"d{l}_W"), u, b["ws"])
         if self.l2 > 0 and self.units:
             # kernel_regularizer=l2(lambda) of every Dense kernel of the stack, after all dW are written: gW += 2*lambda*W
             # and loss += lambda*sum(W^2) -- one pass over the weights, two launches for the whole stack

@@ -170,6 +170,16 @@ int ebn_gemm_f32_rank1(int64_t M, int64_t N, int64_t K, float alpha, const float
                        int64_t ldb, float* C, int64_t ldc, const float* row_scale, const float* seq_rows,
                        int64_t ld_seq, int32_t L, float* workspace, int64_t workspace_floats, ebn_stream_t stream);
 
+/* Both gradient GEMMs of Y[R,N_out] = X[R,K_in] . W[K_in,N_out] (K.dot at layers.py:65,214,220,226; Dense at
+ * nrms_docvec.py:116,130 -- what tf.GradientTape emits for a MatMul):
+ *   dW[K_in,N_out] = X^T . dY + beta_w * dW          dX[R,K_in] = dY . W^T          (all row-major)
+ * They are independent of each other; when both are small-output shapes with 16-byte-aligned operands they run as ONE
+ * launch (each alone leaves half of the chip idle and costs a launch of the step's dependent chain), otherwise as two
+ * ebn_gemm_f32_ws calls.  dW, dX must not alias the inputs; workspace as for the larger of the two plain calls.        */
+int ebn_dense_bwd_pair_f32(int64_t R, int64_t K_in, int64_t N_out, const float* X, int64_t ldx, const float* dY,
+                           int64_t lddy, const float* W, int64_t ldw, float beta_w, float* dW, int64_t lddw, float* dX,
+                           int64_t lddx, float* workspace, int64_t workspace_floats, ebn_stream_t stream);
+
 /* C[M,N] = max(A[M,K] * B[K,N] + bias[n], 0): tf.keras.layers.Dense(units, activation="relu") forward
  * (nrms_docvec.py:116-119,130; nrms.py:143-146) in one pass -- bias and ReLU ride in the GEMM epilogue (or in its
  * split-K reduce) instead of a separate element-wise launch.  workspace as for ebn_gemm_f32_ws(0, 0, M, N, K).    */

@@ -150,6 +150,27 @@ def test_gemm_unaligned_pointers_take_the_scalar_path(hip):
     assert_close(host(C), A.astype(np.float64) @ B.astype(np.float64), rtol=2e-6, atol=2e-5, what="odd gemm")
 
 
+@pytest.mark.parametrize("R,K_in,N_out,beta", [(640, 400, 200, 0.0), (640, 400, 1200, 1.0), (800, 768, 512, 0.0), (250, 76, 36, 0.5),
+                                               (3000, 1200, 300, 0.0), (33, 30, 18, 1.0), (0, 64, 32, 1.0)])
+def test_dense_backward_pair_equals_the_two_gemms(hip, R, K_in, N_out, beta):
+    """ebn_dense_bwd_pair_f32: dW = X^T.dY + beta*dW and dX = dY.W^T, grouped into one launch for small-output aligned
+    shapes, two plain GEMMs otherwise (big, unaligned, empty) -- all against float64."""
+    rng = np.random.default_rng(R * 7 + K_in * 3 + N_out)
+    X = rng.standard_normal((R, K_in)).astype(np.float32)
+    dY = rng.standard_normal((R, N_out)).astype(np.float32)
+    W = rng.standard_normal((K_in, N_out)).astype(np.float32)
+    dW0 = rng.standard_normal((K_in, N_out)).astype(np.float32)
+    dW, dX = dev(dW0), torch.full((max(R, 1), K_in), float("nan"), device="cuda")
+    n = max(int(hip.lib().ebn_gemm_workspace_floats(K_in, N_out, max(R, 1))), int(hip.lib().ebn_gemm_workspace_floats(max(R, 1), K_in, N_out)), 1)
+    ws = torch.empty(n, device="cuda")
+    hip.call("ebn_dense_bwd_pair_f32", R, K_in, N_out, P(dev(X) if R else torch.zeros(1, device="cuda")), K_in,
+             P(dev(dY) if R else torch.zeros(1, device="cuda")), N_out, P(dev(W)), N_out, ctypes.c_float(beta), P(dW), N_out, P(dX), K_in,
+             P(ws), ws.numel(), S())
+    assert_close(host(dW), X.astype(np.float64).T @ dY.astype(np.float64) + beta * dW0, rtol=2e-6, atol=1e-5 + 3e-7 * max(R, 1), what="pair dW")
+    if R:
+        assert_close(host(dX)[:R], dY.astype(np.float64) @ W.astype(np.float64).T, rtol=2e-6, atol=1e-5 + 3e-7 * N_out, what="pair dX")
+
+
 # ---------------------------------------------------------------- a3/a6 attention core
 ATTN_CASES = [(4, 30, 20, 20), (3, 20, 20, 20), (2, 50, 16, 16), (5, 1, 2, 4), (2, 33, 3, 32), (3, 32, 2, 5),
               (1, 64, 2, 8),
