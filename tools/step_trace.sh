@@ -14,9 +14,10 @@ rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 # last step = from the last copy3/expand kernel to the last adam kernel
 names = [r["Kernel_Name"] for r in rows]
 ends = [i for i, n in enumerate(names) if "adam_keras" in n]
+starts = [i for i, n in enumerate(names) if "copy3_kernel" in n or "expand_titles" in n]
 last = ends[-1]
-prev = ends[-2]
-step = rows[prev + 1:last + 1]
+first = max(i for i in starts if i < last)
+step = rows[first:last + 1]
 t0 = int(step[0]["Start_Timestamp"])
 pe = None
 tot = 0
