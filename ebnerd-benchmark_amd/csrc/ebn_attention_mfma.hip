@@ -1,26 +1,25 @@
 // a3 / a6 fast path: the SelfAttention core (layers.py:231-252) for L <= 64 (one or 2 x 2 MFMA tiles), d in {16,20,32},
-// entirely on the matrix cores -- one 64-lane wave per (sequence, head), no workgroup barriers.
+// on the matrix cores -- one 64-lane wave per (sequence, head), no workgroup barriers.
 //
-// Memory side: the wave copies its L x d slices of Q, K, V (and dO) ONCE, as coalesced 16-byte loads, into a
-// wave-private LDS region (rows >= L zero-filled) and builds every MFMA operand form from there; results go back
-// through the same region and leave as coalesced 16-byte stores.  (Building the operand forms straight from global
-// memory touched every 128-byte line from 5-16 separate load instructions and thrashed the 32 KB vector L1.)
-//
-// Everything is a 32x32 exact-fp32 MFMA tile (v_mfma_f32_32x32x2_f32), zero-padded from L x L / L x d.
+// Everything is a 32x32 exact-fp32 MFMA tile (v_mfma_f32_32x32x2_f32), padded from L x L / L x d.
 // Two facts about that instruction drive the dataflow:
 //   * its contraction index is (step, lane-half); ANY mapping of the logical k to (step, half) is valid
 //     as long as A and B agree.  "Row-form" operands give half `hi` the k-range [hi*d/2, (hi+1)*d/2)
 //     of a row (contiguous 8-byte loads, no selects).
 //   * its result layout -- lane (n = lane&31, hi), register r <-> row crow(r,hi) = (r&3)+8(r>>2)+4hi --
 //     is exactly a B operand whose k is (r, hi): a result tile feeds the next product from registers.
-// Because the reference multiplies V by the TRANSPOSED attention matrix (O = P^T V, layers.py:249) the
-// product contracts over the softmax-row index i, so P is needed with i on registers (S = QK^T:
-// lane j, regs i); the softmax statistics (max_j, sum_j) are cheapest with j on registers
-// (T = KQ^T: lane i, regs j -> in-lane reduction + one cross-half swap).  Both tiles are computed
-// (same products, same order) and the per-row statistic c_i = max_i + log2(Z_i) moves between the two
-// layouts with ds_bpermute (__shfl).  Forward = 10+10+16 MFMAs, backward = 88 MFMAs per problem:
-// ~15 / ~37 us for the 16,000 (title, head) problems of a batch-32 step, vs 216 / 1300 us for the
-// LDS/VALU kernel it replaces (profiles/r01_a_*).
+// Because the reference multiplies V by the TRANSPOSED attention matrix (O = P^T V, layers.py:249) the product contracts
+// over the softmax-row index i, so P is needed with i on registers, while the softmax statistics (max_j, sum_j) are
+// cheapest with j on registers (T = K Q^T: lane i, regs j -> in-lane reductions + one cross-half swap).
+//
+// L <= 32 (the kernels of every BASELINE configuration's title level, and of history_size 20): T is computed ONCE, the
+// softmax is done in-lane, and the tile is TRANSPOSED through wave-private LDS into the other layout (tile_transpose).
+// Round 1 instead computed both layouts with swapped operands; on gfx950 the fp32 MFMA shares the vector ALU (it does not
+// overlap VALU work), so a recomputed tile is 640 ALU cycles where the LDS pipe does the same job on the side.  Forward
+// = 10 + 16 MFMAs, backward = 68.  Operands that are needed in row form only (Q, K forward; V backward) come straight
+// from global memory; the others are copied once, as coalesced 16-byte loads, into wave-private LDS; result tiles leave
+// from registers.  32 < L <= 64: the attn_mfma2_* kernels further down (2 x 2 tiles, both layouts computed, results staged
+// through LDS).
 #include "ebn_common.h"
 
 namespace {
