@@ -8,15 +8,17 @@
 // Block tile BM x BN x 16 (128x128 or 64x64 with the 4 waves as 2x2; 256x64 with the waves stacked 4x1), each wave
 // owning its share in 32x32 MFMA tiles.
 // LDS images of a 16-deep K slab, chosen per operand by how it is stored in memory:
-//   mn-contiguous ([K][mn]):  S[k][mn] -- one ds_write_b128 per fetched float4 (or, when BOTH operands are stored this
-//     way, global_load_lds_dwordx4 straight into an unpadded image: the weight-gradient GEMMs); operand fetch is a
-//     conflict-free ds_read_b32 of 32 consecutive floats of one k row;
-//   k-contiguous ([mn][K]):   S4[mn][kq ^ ((mn>>2)&3)] of float4 -- one ds_write_b128 per fetched float4 and one
-//     conflict-free ds_read_b128 per four MFMA steps.
+//   mn-contiguous ([K][mn]):  S[k][mn]; operand fetch is a conflict-free ds_read_b32 of 32 consecutive floats of one k row;
+//   k-contiguous ([mn][K]):   S4[mn][kq ^ ((mn>>2)&3)] of float4 -- one conflict-free ds_read_b128 per four MFMA steps.
+// Full slabs of 16-byte-aligned operands go global -> LDS directly (buffer_load_dwordx4 ... lds into an unpadded image; for
+// a k-contiguous operand the XOR swizzle is applied to the source column a lane fetches); a partial last slab and unaligned
+// operands go through registers (one ds_write_b128 per fetched float4).
 // The slab's 16 k are assigned to the MFMA's (step, lane half) as k = 8j + 4*half + w for step 4j + w, identically
-// for A and B, which is what makes a k-contiguous float4 feed four consecutive steps.  The next slab is prefetched
-// while the current one is multiplied (2 LDS buffers, one barrier per slab).  Skinny outputs (weight gradients:
-// M,N ~ 1e3, K ~ 2e4) use split-K with deterministic slab partials in the caller's workspace -- never atomics.
+// for A and B, which is what makes a k-contiguous float4 feed four consecutive steps.  The next slab is fetched
+// while the current one is multiplied (2 LDS buffers, one barrier per slab).  The slab loop carries NO vector-ALU work
+// (scalar slab offsets, literal LDS buffer indices): on gfx950 the fp32 MFMA does not overlap VALU instructions
+// (tools/microbench/mfma_valu_overlap.hip).  Skinny outputs (weight gradients: M,N ~ 1e3, K ~ 2e4) use split-K with
+// deterministic slab partials in the caller's workspace -- never atomics.
 #include <stdlib.h>
 
 #include "ebn_common.h"
