@@ -1126,6 +1126,10 @@ static GemmPlan gemm_plan(int64_t M, int64_t N, int64_t K, int64_t ws_floats) {
       const double lone = static_cast<double>(ebn_ceil_div(W, kTiles[t].resident)) * kTiles[t].ts_lone;
       double cost = static_cast<double>(kps / BK) * (full > lone ? full : lone) + 3.0;
       if (sp > 1) cost += 4.5 + static_cast<double>(sp + 1) * out_mb / 2.5;
+      // 64x64 tiles of a long split-K range: up to six co-resident workgroups per CU hide each other's per-slab fetch
+      // latency (300x1200x24000: split 16 instead of 8, 168 -> 154 us; at K = 52800 342 -> 334 us); short ranges do not
+      // repay the extra partials (400x200x24000: split 18 stays the best up to 54)
+      if (kTiles[t].bm == 64 && sp > 1 && kps / BK >= 64 && W <= 6) cost *= 1.0 - 0.01 * static_cast<double>(W);
       if (cost < best.cost) best = GemmPlan{kTiles[t].bm, kTiles[t].bn, static_cast<int>(sp), kps, cost};
     }
   }
