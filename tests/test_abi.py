@@ -61,6 +61,11 @@ def test_gemm_planner_is_a_pure_host_query_with_sane_plans():
     assert _plan(1024, 1200, 24000)[:2] == (256, 64) and _plan(1024, 1200, 24000)[2] > 1  # its weight gradient: split-K
     assert _plan(640, 1200, 400)[2] == 1  # user-encoder projection: one launch, a reduce would cost more than it saves
     assert _plan(800, 512, 768) == (32, 32, 1)  # DocVec Dense layer: 400 small workgroups instead of split-K + reduce
+    # the measured picks of profiles/r02_gemm_tuning.md: the small-output kernel wherever it applies (user encoder), the
+    # AttLayer2 shapes, the skinny weight gradient of a 300-wide table with a long K range (six workgroups per CU)
+    assert _plan(640, 1200, 400) == (32, 32, 1) and _plan(640, 400, 1200) == (32, 32, 1) and _plan(400, 1200, 640) == (32, 32, 1)
+    assert _plan(24000, 200, 400) == (64, 64, 1) and _plan(24000, 400, 200) == (128, 128, 1) and _plan(400, 200, 24000) == (64, 64, 18)
+    assert _plan(300, 1200, 24000) == (64, 64, 16) and _plan(24000, 300, 1200) == (256, 64, 1)
     assert _hip.lib().ebn_gemm_plan(-1, 1, 1, 0, None, None, None) == -1
 
 
