@@ -1103,12 +1103,16 @@ static GemmPlan gemm_plan(int64_t M, int64_t N, int64_t K, int64_t ws_floats) {
       double per_slab = static_cast<double>(W / 2) * 1.6 + static_cast<double>(W % 2) * 1.1;
       if (W >= 3) per_slab *= 1.3;
       const double cost = static_cast<double>(ebn_ceil_div(K > 0 ? K : 1, SBK)) * per_slab + 3.0;
-      best = GemmPlan{32, 32, 1, ebn_ceil_div(K > 0 ? K : 1, SBK) * SBK, cost};
-      // Taken whenever it applies: inside a training step (operands last touched a step ago, not re-read back to back as
-      // in the shape probe) the under-filled big tiles -- one workgroup on some CUs, one slab of loads in flight -- lose
-      // to it even where the probe has them level (640x1200x400: 23.5 us in the step for 64x64, 13.8 us in the probe;
-      // c2 step 1.355 -> 1.346 ms).  EBN_GEMM_FORCE_TILE = 64 | 128 | 256 still overrides.
-      if (forced_tile_bm() == 32 || forced_tile_bm() == 0) return best;
+      // Taken outright inside the MEASURED envelope (K <= 1536, at most three workgroups on the busiest CU: the user-encoder
+      // and DocVec shapes of c2 / c3 / c4): inside a training step (operands last touched a step ago, not re-read back to
+      // back as in the shape probe) the under-filled big tiles -- one workgroup on some CUs, one slab of loads in flight --
+      // lose to it even where the probe has them level (640x1200x400: 23.5 us in the step for 64x64, 13.8 us in the probe;
+      // c2 step 1.355 -> 1.346 ms).  OUTSIDE the envelope (K up to 4096, or a fourth workgroup per CU) nothing was measured:
+      // there it competes with the big tiles on modelled cost, with the same in-step bias (x 0.8) in its favour.
+      // EBN_GEMM_FORCE_TILE = 32 | 64 | 128 | 256 still overrides.
+      const bool measured = K <= 1536 && W <= 3;
+      best = GemmPlan{32, 32, 1, ebn_ceil_div(K > 0 ? K : 1, SBK) * SBK, (forced_tile_bm() == 32 || measured) ? cost : 0.8 * cost};
+      if (forced_tile_bm() == 32 || measured) return best;
     }
   }
   for (int t = 0; t < 3; ++t) {

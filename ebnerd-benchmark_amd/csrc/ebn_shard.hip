@@ -10,7 +10,8 @@
 //   inv[t]               = o*cap + j of token t                      (row of the received (W*cap, D) buffer)
 //   counts[o]            = number of distinct ids requested from owner o; counts[W] = 1 if any exceeded cap (overflow:
 //                          the excess ids were dropped -- the host must treat the step as failed); counts[W+1] = 1 if an
-//                          id was outside [0, V)
+//                          id was outside [0, V).  The two flags are STICKY: a plan call only ever raises them, the
+//                          caller clears them when it reads them (once per epoch, not per step)
 //
 // Dedup is sort-free: V is small next to HBM (250 002 rows -> a 1 MB int32 presence map), so tokens mark their id in a
 // direct-address map laid out by (owner, local row), a segmented prefix sum over the map numbers the present ids per
@@ -39,7 +40,7 @@ __device__ __forceinline__ int64_t shard_key(const ShardGeom& g, int64_t id, int
   return o * g.per + local;
 }
 
-// mark = 0, slot_rows = -1 (padding), counts = 0
+// mark = 0, slot_rows = -1 (padding), counts[0..world) = 0 (the two flag words behind them are left alone: sticky)
 __global__ __launch_bounds__(PLAN_THREADS) void shard_init_kernel(int32_t* __restrict__ mark, int64_t n_mark,
                                                                   int32_t* __restrict__ slot_rows, int64_t n_slot,
                                                                   int32_t* __restrict__ counts, int32_t n_counts) {
@@ -194,10 +195,10 @@ extern "C" int ebn_shard_plan_i32(const int32_t* ids, int64_t n_tok, int64_t V, 
   // (a kernel, not hipMemsetAsync: memset nodes of a captured hipGraph were seen to leave the tail of `counts` holding
   // garbage on later replays of the graph -- tests/test_multi_rank_gpu.py::test_two_rank_fit_keeps_ranks_in_lock_step)
   {
-    const int64_t n_init = static_cast<int64_t>(world) * g.per + static_cast<int64_t>(world) * cap + world + 2;
+    const int64_t n_init = static_cast<int64_t>(world) * g.per + static_cast<int64_t>(world) * cap + world;
     const unsigned init_grid = static_cast<unsigned>(ebn_ceil_div(n_init, PLAN_THREADS) < 2048 ? ebn_ceil_div(n_init, PLAN_THREADS) : 2048);
     hipLaunchKernelGGL(shard_init_kernel, dim3(init_grid), dim3(PLAN_THREADS), 0, s, mark, static_cast<int64_t>(world) * g.per,
-                       slot_rows, static_cast<int64_t>(world) * cap, counts, world + 2);
+                       slot_rows, static_cast<int64_t>(world) * cap, counts, world);
     EBN_CHECK_LAUNCH();
   }
   const unsigned tok_grid = static_cast<unsigned>(n_tok > 0 ? (ebn_ceil_div(n_tok, PLAN_THREADS) < 4096 ? ebn_ceil_div(n_tok, PLAN_THREADS) : 4096) : 1);

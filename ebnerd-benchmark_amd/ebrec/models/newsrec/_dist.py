@@ -4,8 +4,9 @@
 Two things shard:
   * impressions (data parallel): replicas all-reduce their flat gradient buckets once per step;
   * optionally the word-embedding table by ROWS (BASELINE.json config 5): rank r owns the contiguous
-    block [r*ceil(V/W), (r+1)*ceil(V/W)) (``partition="block"``) or the ids = r mod W (``"cyclic"``: tokenizer
-    ids are roughly frequency-ordered, a block split would make rank 0 the owner of most of a batch).
+    block [r*ceil(V/W), (r+1)*ceil(V/W)) (``partition="block"``) or the ids = r mod W (``"cyclic"``, the default of
+    the device-planned mode: tokenizer ids are roughly frequency-ordered, a block split would make rank 0 the owner of
+    most of a batch and overflow its request lists).
     A lookup is then
         dedup local token ids -> route each distinct id to its owner (all-to-all of row numbers)
         -> owners gather their rows (the HIP gather kernel on the local shard)
@@ -86,9 +87,13 @@ class PlannedBuffers:
 
 
 class ShardedTableExchange:
-    def __init__(self, V: int, D: int, group=None, mode: str = "alltoall", partition: str = "block", capacity_factor: float = 1.25):
+    def __init__(self, V: int, D: int, group=None, mode: str = "alltoall", partition: str | None = None, capacity_factor: float = 1.25):
         if mode not in ("alltoall", "alltoall_exact", "allgather"):
             raise ValueError(f"unknown exchange mode {mode}")
+        if partition is None:
+            # tokenizer ids are roughly frequency-ordered: under a block split rank 0 would own most of every batch and its
+            # request lists would overflow the default capacity, so the device-planned mode spreads ids round-robin by default
+            partition = "cyclic" if mode == "alltoall" else "block"
         if partition not in ("block", "cyclic"):
             raise ValueError(f"unknown table partition {partition}")
         if partition == "cyclic" and mode != "alltoall":
@@ -181,8 +186,14 @@ class ShardedTableExchange:
             fn()
 
     def check(self, b: PlannedBuffers, what="embedding table") -> None:
-        """One host read of the plan's flags (the engine calls this once per epoch, not per step)."""
-        c = b.counts.cpu().tolist()
+        """One host read of the plan's STICKY flags (the engine calls this once per epoch, not per step; the plan kernel
+        only ever raises them, this clears them).  A COLLECTIVE when world > 1: the flags are MAX-reduced over the group
+        first, so that either every rank raises or none does -- a rank raising alone would leave the others blocked in the
+        next step's all-to-all."""
+        flags = b.counts[self.world:].clone()
+        if self.world > 1:
+            dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.group)
+        c = b.counts[: self.world].cpu().tolist() + flags.cpu().tolist()
         b.counts[self.world:].zero_()
         if c[self.world + 1]:
             raise IndexError(f"token id out of range [0, {self.V}) for the {what} (plan counters {c})")

@@ -122,7 +122,7 @@ class NRMSEngine:
                  attention_hidden_dim: int, dropout: float, learning_rate: float, loss: str, seed=None,
                  train_embedding: bool = True, device=None, process_group=None, shard_table: bool = False,
                  shard_mode: str = "alltoall", deterministic: bool = True, units=None, l2: float = 0.0,
-                 shard_partition: str = "block", shard_capacity_factor: float = 1.25, table_grad_exchange: str = "auto"):
+                 shard_partition: str | None = None, shard_capacity_factor: float = 1.25, table_grad_exchange: str = "auto"):
         self.device = require_gpu() if device is None else torch.device(device)
         if loss not in LOSS_KIND:
             raise ValueError(f"this loss not defined {loss}")
@@ -277,6 +277,20 @@ class NRMSEngine:
         if not (self.world > 1 and self.train_embedding and self.exchange is None and self.deterministic and not self.keep_table_grad):
             return False
         return self.table_grad_exchange == "sparse" or (self.table_grad_exchange == "auto" and self.world * n_tok < self.V)
+
+    @property
+    def needs_equal_batches(self) -> bool:
+        """True when the step's collectives are sized by the local batch SHAPE, so every rank must run the same shape in
+        every step (fit() then leaves a shard's short last batch out): the row-sharded lookup's equal-split all-to-alls,
+        and the sparse table-gradient exchange of a replicated trainable table (all-gathers of n_tok ids / rows -- and
+        `_sparse_dp` itself decides by n_tok, so ranks with different shapes would not even pick the same collective).
+        The dense all-reduces are shape-independent."""
+        if self.world <= 1:
+            return False
+        if self.exchange is not None:
+            return True
+        return (self.train_embedding and self.deterministic and not self.keep_table_grad
+                and self.table_grad_exchange != "dense")
 
     @property
     def graph_capable(self) -> bool:
@@ -618,18 +632,24 @@ class NRMSEngine:
             raise ValueError(f"pred_input_title must be (B, C, {self.T}), got {tuple(pred.shape)}")
 
     def _check_oob(self):
+        """One host read of the device flags.  With world > 1 this is a COLLECTIVE (every rank must call it at the same point,
+        as fit()/evaluate() do once per epoch): the flags are MAX-reduced so that all ranks raise together -- a rank raising
+        alone would leave the others blocked in the next step's collectives."""
         if self._planned:  # the plan's own flags first: an overflowed exchange also shows up as zero rows in the gather
-            for b in self._bufs.values():
-                if hasattr(b, "xb"):
-                    try:
-                        self.exchange.check(b.xb)
-                    except Exception:
-                        self.oob_flag.zero_()
-                        raise
-        if int(self.oob_flag.item()) != 0:
+            for key in sorted(k for k, b in self._bufs.items() if hasattr(b, "xb")):
+                try:
+                    self.exchange.check(self._bufs[key].xb)
+                except Exception:
+                    self.oob_flag.zero_()
+                    raise
+        flags = torch.cat([self.oob_flag, self.range_flag])
+        if self.world > 1:
+            torch.distributed.all_reduce(flags, op=torch.distributed.ReduceOp.MAX, group=self.pg)
+        oob, rng_bad = (int(v) for v in flags.cpu().tolist())
+        if oob != 0:
             self.oob_flag.zero_()
             raise IndexError(f"token id out of range [0, {self.V}) for the embedding table")
-        if int(self.range_flag.item()) != 0:
+        if rng_bad != 0:
             self.range_flag.zero_()
             raise FloatingPointError("embedding gradient left the range of the deterministic fixed-point accumulator (|sum| >= 2^22 "
                                      "or NaN): the run has diverged; deterministic=False accumulates in fp32 instead")

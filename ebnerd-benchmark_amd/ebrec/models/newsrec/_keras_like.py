@@ -151,7 +151,9 @@ class TrainModel:
         self._engine.set_weights(weights)
 
     def save_weights(self, filepath, **_):
-        """Named tensors (SURVEY.md A.6 order) in a torch file at exactly `filepath`."""
+        """Named tensors (SURVEY.md A.6 order) in a torch file at exactly `filepath`.
+        With world > 1 this is a COLLECTIVE: every rank must call it (rank 0 writes; the others take part in the table
+        all-gather of a row-sharded engine and in the closing barrier).  Calling it on rank 0 only deadlocks."""
         rank, world, group = _dist_of(self._engine)
         # get_weights() is a collective when the table is row-sharded: every rank calls it, rank 0 writes the file
         state = {n: torch.from_numpy(np.ascontiguousarray(w)) for n, w in zip(self._names, self._engine.get_weights())}
@@ -188,9 +190,10 @@ class TrainModel:
         # data parallel: every step ends in a gradient all-reduce, so every rank must run the SAME number of steps per
         # epoch -- the shortest shard decides (the surplus batches of longer shards rotate in through the shuffle)
         n_batches = len(data)
-        if world > 1 and getattr(eng, "exchange", None) is not None:
-            # row-sharded table: the lookup's all-to-alls are sized by the batch SHAPE, which must therefore be the same on
-            # every rank in every step -- a shard's short last batch is left out (it is always the last index)
+        if world > 1 and getattr(eng, "needs_equal_batches", getattr(eng, "exchange", None) is not None):
+            # row-sharded table / sparse table-gradient exchange: the step's collectives are sized by the batch SHAPE, which
+            # must therefore be the same on every rank in every step -- a shard's short last batch is left out (it is always
+            # the last index).  Shards of unequal length would otherwise put one rank's short batch next to a full one.
             n_batches = _full_batches(data)
         n_steps = int(_allreduce_host([n_batches], eng, "min")[0]) if world > 1 else n_batches
         for cb in cbs:
@@ -249,6 +252,9 @@ class TrainModel:
         return hist
 
     def evaluate(self, x=None, y=None, batch_size=None, verbose=0, return_dict=False, **_):
+        """With world > 1 this is a COLLECTIVE: every rank evaluates ITS shard and must call this at the same point; loss,
+        AUC histograms and the device error flags are reduced over the group, so the result (and any raised error) is the
+        same on every rank.  For a rank-local evaluation build the model without a process group."""
         data = x if _is_loader(x) else _ArrayBatches(x, y, batch_size)
         eng = self._engine
         auc = StreamingAUC() if "auc" in self.metrics_names else None

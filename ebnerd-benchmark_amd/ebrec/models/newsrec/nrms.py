@@ -38,7 +38,7 @@ class NRMSModel:
     def __init__(self, hparams, word2vec_embedding: np.ndarray = None, word_emb_dim: int = 300,
                  vocab_size: int = 32000, seed: int = None, *, train_embedding: bool = True, device=None,
                  process_group=None, shard_table: bool = False, shard_mode: str = "alltoall",
-                 deterministic: bool = True, shard_partition: str = "block", shard_capacity_factor: float = 1.25,
+                 deterministic: bool = True, shard_partition: str | None = None, shard_capacity_factor: float = 1.25,
                  table_grad_exchange: str = "auto"):
         self.hparams = hparams
         self.seed = seed

@@ -107,7 +107,9 @@ int ebn_adam_keras_step_fixed_f32(float* theta, int64_t* acc, float* m, float* v
  *                         (what ebn_gather_rows_f32 / ebn_embedding_grad_scatter_f32 take as `ids` on the owner's side)
  *   inv[t]                o*cap + j of token t: its row in the received (world*cap, D) buffer; -1 for an id outside [0,V)
  *   counts[0..world)      distinct ids wanted from each owner;  counts[world] = 1 when a list overflowed `cap` (ids were
- *                         dropped: the caller must fail the step);  counts[world+1] = 1 when an id was out of range
+ *                         dropped: the caller must fail the step);  counts[world+1] = 1 when an id was out of range.
+ *                         The two flag words are STICKY (only ever raised here; the caller zeroes them before the first
+ *                         call and whenever it has read them), so one host read per epoch sees every step's overflow
  * `workspace`: ebn_shard_plan_workspace_ints(V, world) int32 of scratch.  Integer work only, deterministic.          */
 int64_t ebn_shard_plan_workspace_ints(int64_t V, int32_t world);
 int ebn_shard_plan_i32(const int32_t* ids, int64_t n_tok, int64_t V, int32_t world, int32_t cyclic, int64_t cap,

@@ -69,6 +69,23 @@ def test_gemm_planner_is_a_pure_host_query_with_sane_plans():
     assert _hip.lib().ebn_gemm_plan(-1, 1, 1, 0, None, None, None) == -1
 
 
+def test_gemm_planner_small_tile_choice_is_bounded_to_its_measured_envelope():
+    """Round-2 ADVICE: the 32x32 small-output kernel was returned unconditionally whenever tiles64 <= 256 and K <= 4096.
+    It is now taken outright only inside the envelope it was measured on (K <= 1536, at most three workgroups on the busiest
+    CU); outside it competes with the big tiles on modelled cost.  Edges: K = 1536 / 1537 / 4096 / 4097, tiles64 = 256 / 257."""
+    # inside the envelope: every step shape of c2 / c3 / c4 that used it keeps it
+    for shape in [(640, 1200, 400), (640, 400, 1200), (400, 1200, 640), (800, 512, 768), (640, 256, 200), (1600, 400, 1200)]:
+        assert _plan(*shape) == (32, 32, 1), shape
+    assert _plan(640, 1200, 1536) == (32, 32, 1)  # K edge of the envelope (W = 3)
+    # a fourth workgroup per CU at a long K is outside it: 1024 x 1024 (tiles64 = 256, W = 4) x 4096 -- whatever the model picks
+    # must be a valid plan, and a long, well-filled K range must not stay on the never-splitting small kernel
+    for shape in [(1024, 1024, 4096), (1024, 1024, 1537), (640, 1200, 1537), (640, 1200, 4096), (640, 1200, 4097), (1024, 1088, 1024)]:
+        bm, bn, sp = _plan(*shape)
+        assert (bm, bn) in ((128, 128), (64, 64), (256, 64), (32, 32)) and 1 <= sp <= 64 and (sp == 1 or bm != 32), shape
+    assert _plan(640, 1200, 4097)[0] != 32 and _plan(1024, 1088, 1024)[0] != 32  # K > 4096 / tiles64 = 272: never the small kernel
+    assert _plan(1024, 1024, 4096)[0] != 32  # modelled: 32 slabs x 4 workgroups per CU loses to 128x128 tiles with split-K
+
+
 def test_integration_doc_lists_exactly_the_exported_entry_points():
     """INTEGRATION.md's table of entry points by reference symbol stays in sync with the header."""
     import re

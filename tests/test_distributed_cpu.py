@@ -82,7 +82,7 @@ def torch_plan(ex, ids, n_tok, cap, ws, slot_rows, inv, counts):
     ids = ids[:n_tok].long()
     slot_rows.fill_(-1)
     inv[:n_tok] = -1
-    counts.zero_()
+    counts[:W].zero_()  # the two flag words behind the per-owner counts are sticky: only ever raised, the caller clears them
     ok = (ids >= 0) & (ids < V)
     if (~ok).any():
         counts[W + 1] = 1

@@ -101,7 +101,9 @@ GEMM_SHAPES = [(1, 1, 1), (5, 7, 3), (64, 64, 16), (130, 70, 33), (257, 129, 300
                # split-K whose last K range ends in a partial slab (direct-to-LDS fetch for the full slabs, guarded loader for the tail)
                (256, 256, 2004), (512, 64, 8200),
                # the small-output kernel with two slabs of loads in flight: 6 full slabs; 3 full + a 16-wide tail; 5 full, ragged M
-               (800, 512, 768), (640, 1200, 400), (250, 768, 640)]
+               (800, 512, 768), (640, 1200, 400), (250, 768, 640),
+               # the edges of the planner's small-tile envelope (K = 1536 | 1537, tiles64 = 256 at K = 4096)
+               (640, 1200, 1536), (640, 1200, 1537), (1024, 1024, 4096)]
 
 
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)

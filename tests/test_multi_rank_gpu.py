@@ -83,8 +83,9 @@ def test_shard_plan_kernel_is_the_reference_plan_bit_for_bit(hip, world, cyclic,
     slot = torch.empty(world * cap, dtype=torch.int32, device="cuda")
     inv = torch.full((max(n_tok, 1),), -7, dtype=torch.int32, device="cuda")
     counts = torch.full((world + 2,), -7, dtype=torch.int32, device="cuda")
+    counts[world:] = 0  # the caller owns the two sticky flag words: zeroed before the first plan, cleared when read
     hip.call("ebn_shard_plan_i32", P_(d_ids), n_tok, V, world, cyclic, cap, P_(ws), P_(slot), P_(inv), P_(counts), S_())
-    w_slot, w_inv, w_counts = torch.empty(world * cap, dtype=torch.int32), torch.full((max(n_tok, 1),), -7, dtype=torch.int32), torch.empty(world + 2, dtype=torch.int32)
+    w_slot, w_inv, w_counts = torch.empty(world * cap, dtype=torch.int32), torch.full((max(n_tok, 1),), -7, dtype=torch.int32), torch.zeros(world + 2, dtype=torch.int32)
     torch_plan(ex, torch.from_numpy(ids), n_tok, cap, None, w_slot, w_inv, w_counts)
     assert torch.equal(counts.cpu(), w_counts), (counts.cpu().tolist(), w_counts.tolist())
     assert torch.equal(slot.cpu(), w_slot)
@@ -92,6 +93,13 @@ def test_shard_plan_kernel_is_the_reference_plan_bit_for_bit(hip, world, cyclic,
     # replay on the same buffers (a captured graph does exactly this): the plan re-initialises everything it reads
     hip.call("ebn_shard_plan_i32", P_(d_ids), n_tok, V, world, cyclic, cap, P_(ws), P_(slot), P_(inv), P_(counts), S_())
     assert torch.equal(slot.cpu(), w_slot) and torch.equal(counts.cpu(), w_counts)
+    if n_tok > 100:
+        # the flags are sticky: a later, clean plan on the same buffers (the next step of an epoch) must not clear what an
+        # earlier step raised -- check() reads them once per epoch
+        flags = counts[world:].cpu().clone()
+        clean = torch.from_numpy(np.clip(ids, 0, V - 1)[:min(n_tok, cap)].copy()).cuda()
+        hip.call("ebn_shard_plan_i32", P_(clean), clean.numel(), V, world, cyclic, cap, P_(ws), P_(slot), P_(inv), P_(counts), S_())
+        assert flags[1] == 1 and torch.equal(counts[world:].cpu(), flags)
 
 
 @pytest.mark.parametrize("mode,partition,graph", [("alltoall", "block", False), ("alltoall", "cyclic", False), ("alltoall", "block", True),
@@ -228,7 +236,7 @@ def test_two_rank_row_sharded_table_step_equals_the_full_batch_oracle_step(hip, 
     _spawn(_dp_worker, 2, True, partition, graph, train_embedding, 20)
 
 
-def _fit_worker(rank, world, shard, tmpdir):
+def _fit_worker(rank, world, shard, tmpdir, table_grad_exchange="dense"):
     """model.fit under two ranks whose shards have DIFFERENT numbers of batches (and ragged last batches): same number of
     steps everywhere, all-reduced epoch logs -> identical callback decisions, identical replicas, one checkpoint file."""
     import torch.distributed as dist
@@ -240,8 +248,10 @@ def _fit_worker(rank, world, shard, tmpdir):
     rng = np.random.default_rng(5)
     emb = rng.standard_normal((V, D)).astype(np.float32)
     m = NRMSModel(hp, word2vec_embedding=emb, seed=3, train_embedding=True, shard_table=shard, shard_partition="cyclic",
-                  shard_capacity_factor=float(world), deterministic=not shard)
+                  shard_capacity_factor=float(world), deterministic=not shard, table_grad_exchange=table_grad_exchange)
     m._engine.enable_graphs()
+    equal = shard or table_grad_exchange != "dense"  # collectives sized by the batch shape: only full batches may run
+    assert m._engine.needs_equal_batches == equal
     n_rows = 70 if rank == 0 else 50  # batch 16: 5 batches (last one 6 rows) vs 4 batches (last one 2 rows)
     r2 = np.random.default_rng(100 + rank)
     his, pred, y = batch(r2, n_rows, hp.history_size, 5, hp.title_size, V)
@@ -253,7 +263,7 @@ def _fit_worker(rank, world, shard, tmpdir):
            ReduceLROnPlateau(monitor="val_auc", mode="max", factor=0.2, patience=1, min_lr=1e-6)]
     h = m.model.fit((his, pred), y.astype(np.float32), batch_size=16, epochs=3, verbose=0, callbacks=cbs,
                     validation_data=((vhis, vpred), vy.astype(np.float32)))
-    assert m._engine.read_state().step % (3 if shard else 4) == 0  # 4 steps per epoch (3 when only full batches may run)
+    assert m._engine.read_state().step % (3 if equal else 4) == 0  # 4 steps per epoch (3 when only full batches may run)
     hist = {k: [float(v) for v in vs] for k, vs in h.history.items()}
     parts = [None] * world
     dist.all_gather_object(parts, (hist, [w.tobytes() for w in m.model.get_weights()], float(m.model.optimizer.learning_rate)))
@@ -264,6 +274,9 @@ def _fit_worker(rank, world, shard, tmpdir):
     m.model.load_weights(ckpt)  # every rank can read rank 0's checkpoint
 
 
-@pytest.mark.parametrize("shard", [False, True])
-def test_two_rank_fit_keeps_ranks_in_lock_step(hip, shard, tmp_path):
-    _spawn(_fit_worker, 2, shard, str(tmp_path))
+@pytest.mark.parametrize("shard,table_grad_exchange", [(False, "dense"), (True, "dense"), (False, "sparse"), (False, "auto")])
+def test_two_rank_fit_keeps_ranks_in_lock_step(hip, shard, table_grad_exchange, tmp_path):
+    """Shards of UNEQUAL length (5 vs 4 batches, ragged last ones).  With the sparse table-gradient exchange the all-gathers
+    are sized by the local batch shape: a short last batch on one rank next to a full one on the other would hang or corrupt
+    memory (round-2 ADVICE, high) -- fit() runs only full batches then."""
+    _spawn(_fit_worker, 2, shard, str(tmp_path), table_grad_exchange)
