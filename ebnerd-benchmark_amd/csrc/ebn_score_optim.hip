@@ -6,6 +6,20 @@
 
 namespace {
 
+// loss_kind 2: binary cross-entropy on the CLIPPED SOFTMAX OUTPUTS (SURVEY.md A.5's reading of nrms.py:54,61-62 -- what
+// Keras' binary_crossentropy(from_logits=False) does when the tensor carries no cached logits) [KERAS-SEMANTICS]:
+//   p^ = clip(p, eps, 1 - eps);  l = -(y log(p^ + eps) + (1 - y) log(1 - p^ + eps)),  eps = K.epsilon() = 1e-7
+// Returns l and d(l)/d(p) (zero where the clip is active: clip_by_value passes no gradient outside its range).
+constexpr float EBN_KERAS_EPS = 1e-7f;
+__device__ __forceinline__ float bce_probs(float p, float y, float* dldp) {
+  const float lo = EBN_KERAS_EPS, hi = 1.0f - EBN_KERAS_EPS;
+  const bool in_range = p >= lo && p <= hi;
+  const float pc = fminf(fmaxf(p, lo), hi);
+  const float a = pc + EBN_KERAS_EPS, b = 1.0f - pc + EBN_KERAS_EPS;
+  *dldp = in_range ? (-(y / a) + (1.0f - y) / b) : 0.f;
+  return -(y * logf(a) + (1.0f - y) * logf(b));
+}
+
 // one 4-wave workgroup per impression b: the waves take candidates round-robin, wave 0 finishes the activation
 __global__ __launch_bounds__(256) void score_fwd_kernel(const float* __restrict__ cand,
                                                        const float* __restrict__ user,
@@ -77,7 +91,7 @@ __global__ __launch_bounds__(64) void score_loss_bwd_kernel(const float* __restr
       sm[c] = (expf(logp) * ysum - y[c]) * inv_batch;
     }
     loss = ebn_wave_sum(loss) * inv_batch;
-  } else {
+  } else if (loss_kind == 1) {
     // sigmoid CE on the logits, mean over (b,c): max(s,0) - s*y + log1p(exp(-|s|))
     const float invbc = inv_batch / static_cast<float>(C);
     for (int c = lane; c < C; c += 64) {
@@ -85,6 +99,26 @@ __global__ __launch_bounds__(64) void score_loss_bwd_kernel(const float* __restr
       loss += fmaxf(x, 0.f) - x * y[c] + log1pf(expf(-fabsf(x)));
       sm[c] = (1.0f / (1.0f + expf(-x)) - y[c]) * invbc;
     }
+    loss = ebn_wave_sum(loss) * invbc;
+  } else {
+    // BCE on the clipped softmax outputs, mean over (b,c); ds = p * (dl/dp - sum_k p_k dl/dp_k)  (softmax backward)
+    const float invbc = inv_batch / static_cast<float>(C);
+    float mx = -INFINITY;
+    for (int c = lane; c < C; c += 64) mx = fmaxf(mx, s[c]);
+    mx = ebn_wave_max(mx);
+    float se = 0.f;
+    for (int c = lane; c < C; c += 64) se += expf(s[c] - mx);
+    se = ebn_wave_sum(se);
+    float dot = 0.f;
+    for (int c = lane; c < C; c += 64) {
+      const float p = expf(s[c] - mx) / se;
+      float dldp;
+      loss += bce_probs(p, y[c], &dldp);
+      sm[c] = dldp;
+      dot = fmaf(p, dldp, dot);
+    }
+    dot = ebn_wave_sum(dot);
+    for (int c = lane; c < C; c += 64) sm[c] = (expf(s[c] - mx) / se) * (sm[c] - dot) * invbc;
     loss = ebn_wave_sum(loss) * invbc;
   }
   if (lane == 0) loss_rows[b] = loss;
@@ -135,24 +169,32 @@ __global__ __launch_bounds__(256) void score_loss_train_kernel(
     for (int c = lane; c < C; c += 64) se += expf(sm[c] - mx);
     se = ebn_wave_sum(se);
     const float lse = mx + logf(se);
-    float loss = 0.f;
+    float loss = 0.f, dot = 0.f;
+    const float invbc = inv_batch / static_cast<float>(C);
     for (int c = lane; c < C; c += 64) {
       const float sc = sm[c];
       scores[b * C + c] = sc;
-      probs[b * C + c] = expf(sc - mx) / se;
+      const float p = expf(sc - mx) / se;
+      probs[b * C + c] = p;
       float ds;
       if (loss_kind == 0) {
         const float logp = sc - lse;
         loss -= y[c] * logp;
         ds = (expf(logp) * ysum - y[c]) * inv_batch;
-      } else {
-        const float invbc = inv_batch / static_cast<float>(C);
+      } else if (loss_kind == 1) {
         loss += fmaxf(sc, 0.f) - sc * y[c] + log1pf(expf(-fabsf(sc)));
         ds = (1.0f / (1.0f + expf(-sc)) - y[c]) * invbc;
+      } else {  // BCE on the clipped softmax outputs: ds needs sum_k p_k dl/dp_k first
+        loss += bce_probs(p, y[c], &ds);
+        dot = fmaf(p, ds, dot);
       }
       sm[C + c] = ds;
     }
-    loss = ebn_wave_sum(loss) * (loss_kind == 0 ? inv_batch : inv_batch / static_cast<float>(C));
+    if (loss_kind == 2) {
+      dot = ebn_wave_sum(dot);
+      for (int c = lane; c < C; c += 64) sm[C + c] = (expf(sm[c] - mx) / se) * (sm[C + c] - dot) * invbc;
+    }
+    loss = ebn_wave_sum(loss) * (loss_kind == 0 ? inv_batch : invbc);
     if (lane == 0) loss_rows[b] = loss;
   }
   __syncthreads();
@@ -312,7 +354,7 @@ extern "C" int ebn_score_loss_bwd_f32(const float* cand, const float* user, cons
                                       ebn_stream_t stream) {
   EBN_REQUIRE(cand && user && scores && labels && loss_rows && dcand && duser, EBN_ERR_BAD_ARG);
   EBN_REQUIRE(B >= 0 && C > 0 && E > 0, EBN_ERR_BAD_ARG);
-  EBN_REQUIRE(C <= 8192 && (loss_kind == 0 || loss_kind == 1), EBN_ERR_UNSUPPORTED);
+  EBN_REQUIRE(C <= 8192 && loss_kind >= 0 && loss_kind <= 2, EBN_ERR_UNSUPPORTED);
   if (B == 0) return EBN_OK;
   hipLaunchKernelGGL(score_loss_bwd_kernel, dim3(static_cast<unsigned>(B)), dim3(64), C * sizeof(float),
                      ebn_stream(stream), cand, user, scores, labels, loss_rows, dcand, duser, C, E, loss_kind,
@@ -327,7 +369,7 @@ extern "C" int ebn_score_loss_train_f32(const float* cand, const float* user, co
                                         ebn_stream_t stream) {
   EBN_REQUIRE(cand && user && labels && scores && probs && loss_rows && loss_out && dcand && duser, EBN_ERR_BAD_ARG);
   EBN_REQUIRE(B >= 0 && C > 0 && E > 0, EBN_ERR_BAD_ARG);
-  EBN_REQUIRE(C <= 8192 && (loss_kind == 0 || loss_kind == 1), EBN_ERR_UNSUPPORTED);
+  EBN_REQUIRE(C <= 8192 && loss_kind >= 0 && loss_kind <= 2, EBN_ERR_UNSUPPORTED);
   if (B == 0) return EBN_OK;
   hipLaunchKernelGGL(score_loss_train_kernel, dim3(static_cast<unsigned>(B)), dim3(256), 2 * C * sizeof(float),
                      ebn_stream(stream), cand, user, labels, scores, probs, loss_rows, dcand, duser, C, E, loss_kind,

@@ -28,6 +28,17 @@ BETA1, BETA2, ADAM_EPS = 0.9, 0.999, 1e-7  # tf.keras.optimizers.Adam defaults (
 _ALIGN = 64  # floats; keeps every parameter 256-byte aligned inside the flat buffer
 
 LOSS_KIND = {"cross_entropy_loss": 0, "log_loss": 1}
+BCE_ON = ("logits", "probs")
+
+
+def loss_kind_of(loss: str, bce_on: str) -> int:
+    """C-ABI loss_kind: 0 categorical CE on the softmax logits; 1 log_loss as sigmoid-CE on the logits Keras caches on the
+    output of Activation("softmax") (bce_on="logits", the default); 2 log_loss as BCE on the clipped softmax outputs
+    (bce_on="probs", SURVEY.md A.5's reading).  Which of the two TF 2.12-2.15 runs at nrms.py:54,61-62 is settled by the TF
+    dump (tools/dump_tf_golden.py); until then both are implemented and tested, and switching is this one argument."""
+    if bce_on not in BCE_ON:
+        raise ValueError(f"bce_on must be one of {BCE_ON}, got {bce_on}")
+    return 0 if loss == "cross_entropy_loss" else (1 if bce_on == "logits" else 2)
 
 
 def require_gpu() -> torch.device:
@@ -59,7 +70,7 @@ def eval_loss_from_news(eng, news_all: torch.Tensor, his_idx, pred_idx, y):
     rows, junk_c, junk_u = torch.empty(B, device=eng.device), torch.empty(B * C, E, device=eng.device), torch.empty(B, E, device=eng.device)
     loss = torch.empty(1, device=eng.device)
     _hip.call("ebn_score_loss_bwd_f32", _hip.ptr(cand), _hip.ptr(user), _hip.ptr(scores), _hip.ptr(labels), _hip.ptr(rows),
-              _hip.ptr(junk_c), _hip.ptr(junk_u), B, C, E, LOSS_KIND[eng.loss], ctypes.c_float(1.0 / B), S())
+              _hip.ptr(junk_c), _hip.ptr(junk_u), B, C, E, eng.loss_kind, ctypes.c_float(1.0 / B), S())
     _hip.call("ebn_sum_f32", _hip.ptr(rows), B, ctypes.c_float(1.0), _hip.ptr(loss), 0, S())
     return loss, probs
 
@@ -122,10 +133,13 @@ class NRMSEngine:
                  attention_hidden_dim: int, dropout: float, learning_rate: float, loss: str, seed=None,
                  train_embedding: bool = True, device=None, process_group=None, shard_table: bool = False,
                  shard_mode: str = "alltoall", deterministic: bool = True, units=None, l2: float = 0.0,
-                 shard_partition: str | None = None, shard_capacity_factor: float = 1.25, table_grad_exchange: str = "auto"):
+                 shard_partition: str | None = None, shard_capacity_factor: float = 1.25, table_grad_exchange: str = "auto",
+                 bce_on: str = "logits"):
         self.device = require_gpu() if device is None else torch.device(device)
         if loss not in LOSS_KIND:
             raise ValueError(f"this loss not defined {loss}")
+        loss_kind_of(loss, bce_on)
+        self.bce_on = bce_on
         self.T, self.H = int(title_size), int(history_size)
         self.h, self.d, self.A = int(head_num), int(head_dim), int(attention_hidden_dim)
         self.E = self.h * self.d
@@ -184,6 +198,10 @@ class NRMSEngine:
         self.world = 1
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
+
+    @property
+    def loss_kind(self) -> int:
+        return loss_kind_of(self.loss, self.bce_on)
 
     # ------------------------------------------------------------------ parameters
     def _init_weights(self, seed):
@@ -614,7 +632,7 @@ class NRMSEngine:
         loss = torch.empty(1, device=self.device)
         _hip.call("ebn_score_loss_bwd_f32", _hip.ptr(nb.out[B * self.H:]), _hip.ptr(ub.out), _hip.ptr(scores),
                   _hip.ptr(labels), _hip.ptr(rows), _hip.ptr(junk_c), _hip.ptr(junk_u), B, C, self.E,
-                  LOSS_KIND[self.loss], ctypes.c_float(1.0 / B), _hip.stream_handle())
+                  self.loss_kind, ctypes.c_float(1.0 / B), _hip.stream_handle())
         _hip.call("ebn_sum_f32", _hip.ptr(rows), B, ctypes.c_float(1.0), _hip.ptr(loss), 0, _hip.stream_handle())
         return loss, probs
 
@@ -866,7 +884,7 @@ class NRMSEngine:
         # scorer + compiled loss + their backward into the representations + the batch loss: one launch
         _hip.call("ebn_score_loss_train_f32", _hip.ptr(cand), _hip.ptr(ub.out), _hip.ptr(nb.labels), _hip.ptr(nb.scores),
                   _hip.ptr(nb.probs), _hip.ptr(ub.loss_rows), _hip.ptr(self.loss_dev), _hip.ptr(dcand), _hip.ptr(ub.duser), B, C, E,
-                  LOSS_KIND[self.loss], ctypes.c_float(1.0 / B), S())
+                  self.loss_kind, ctypes.c_float(1.0 / B), S())
         # ---- backward
         self._encoder_bwd("u", ub, B, nb.out, ub.duser, nb.dNE)  # writes dNE[:B*H]
         self._encoder_bwd("n", nb, N, nb.X, nb.dNE, nb.dX, B * H)

@@ -17,16 +17,19 @@ import torch
 
 from ebrec import _hip
 
-from ._engine import ADAM_EPS, BETA1, BETA2, LOSS_KIND, EncoderBuffers, FlatParams, glorot_uniform_np, require_gpu
+from ._engine import ADAM_EPS, BETA1, BETA2, LOSS_KIND, loss_kind_of, EncoderBuffers, FlatParams, glorot_uniform_np, require_gpu
 from ._mlp import MLPStack
 
 
 class DocVecEngine:
     def __init__(self, doc_dim: int, units, history_size: int, head_num: int, head_dim: int, attention_hidden_dim: int,
-                 dropout: float, learning_rate: float, loss: str, l2: float, seed=None, device=None, process_group=None):
+                 dropout: float, learning_rate: float, loss: str, l2: float, seed=None, device=None, process_group=None,
+                 bce_on: str = "logits"):
         self.device = require_gpu() if device is None else torch.device(device)
         if loss not in LOSS_KIND:
             raise ValueError(f"this loss not defined {loss}")
+        loss_kind_of(loss, bce_on)
+        self.bce_on = bce_on
         self.Din, self.units, self.H = int(doc_dim), [int(u) for u in (units or [])], int(history_size)
         self.h, self.d, self.A = int(head_num), int(head_dim), int(attention_hidden_dim)
         self.E = self.h * self.d
@@ -50,6 +53,10 @@ class DocVecEngine:
         self.world = 1
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
+
+    @property
+    def loss_kind(self) -> int:
+        return loss_kind_of(self.loss, self.bce_on)
 
     # ------------------------------------------------------------------ parameters
     def _init_weights(self, seed):
@@ -232,7 +239,7 @@ class DocVecEngine:
         rows, jc, ju = torch.empty(B, device=self.device), torch.empty(B * C, self.E, device=self.device), torch.empty(B, self.E, device=self.device)
         loss = torch.empty(1, device=self.device)
         _hip.call("ebn_score_loss_bwd_f32", _hip.ptr(mb["NE"][B * self.H:]), _hip.ptr(ub.out), _hip.ptr(scores), _hip.ptr(labels),
-                  _hip.ptr(rows), _hip.ptr(jc), _hip.ptr(ju), B, C, self.E, LOSS_KIND[self.loss], ctypes.c_float(1.0 / B), _hip.stream_handle())
+                  _hip.ptr(rows), _hip.ptr(jc), _hip.ptr(ju), B, C, self.E, self.loss_kind, ctypes.c_float(1.0 / B), _hip.stream_handle())
         _hip.call("ebn_sum_f32", _hip.ptr(rows), B, ctypes.c_float(1.0), _hip.ptr(loss), 0, _hip.stream_handle())
         return loss, probs
 
@@ -364,7 +371,7 @@ class DocVecEngine:
         cand = mb["NE"][n_hist:]
         _hip.call("ebn_score_loss_train_f32", _hip.ptr(cand), _hip.ptr(ub.out), _hip.ptr(mb["labels"]), _hip.ptr(mb["scores"]),
                   _hip.ptr(mb["probs"]), _hip.ptr(ub.loss_rows), _hip.ptr(self.loss_dev), _hip.ptr(mb["dNE"][n_hist:]), _hip.ptr(ub.duser),
-                  B, C, E, LOSS_KIND[self.loss], ctypes.c_float(1.0 / B), S())
+                  B, C, E, self.loss_kind, ctypes.c_float(1.0 / B), S())
         g = self.params.g
         grads = _hip.EncoderGrads(g("u_Wqkv").data_ptr(), g("u_W").data_ptr(), g("u_b").data_ptr(), g("u_q").data_ptr())
         scratch = _hip.EncoderScratch(ub.dY.data_ptr(), ub.dQKV.data_ptr(), ub.de.data_ptr(), ub.partials.data_ptr(),

@@ -22,7 +22,7 @@ from ._keras_like import EncoderModel, ScorerModel, TrainModel, dedup_rows
 
 
 class NRMSDocVec:
-    def __init__(self, hparams, seed: int = None, *, device=None, process_group=None):
+    def __init__(self, hparams, seed: int = None, *, device=None, process_group=None, bce_on: str = "logits"):
         self.hparams = hparams
         self.seed = seed
         if seed is not None:
@@ -33,7 +33,7 @@ class NRMSDocVec:
         self._engine = DocVecEngine(
             hparams.title_size, hparams.newsencoder_units_per_layer, hparams.history_size, hparams.head_num,
             hparams.head_dim, hparams.attention_hidden_dim, hparams.dropout, hparams.learning_rate, hparams.loss,
-            hparams.newsencoder_l2_regularization, seed=seed, device=device, process_group=process_group)
+            hparams.newsencoder_l2_regularization, seed=seed, device=device, process_group=process_group, bce_on=bce_on)
         self.model, self.scorer = self._build_graph()
 
     def _get_loss(self, loss: str):

@@ -274,8 +274,10 @@ int ebn_encoder_bwd_f32(const ebn_encoder_dims* dims, const ebn_encoder_params* 
  * scores[b,c] = cand[b,c,:].user[b,:]; probs = softmax_c (mode 0) or sigmoid (mode 1). */
 int ebn_score_fwd_f32(const float* cand, const float* user, float* scores, float* probs,
                       int64_t B, int32_t C, int32_t E, int32_t mode, ebn_stream_t stream);
-/* loss_kind 0: categorical CE on the softmax logits; 1: sigmoid CE on the same logits
- * ([KERAS-SEMANTICS] _keras_logits path).  Writes loss_rows[b] (already divided so that
+/* loss_kind 0: categorical CE on the softmax logits; 1: log_loss as sigmoid CE on the same logits
+ * ([KERAS-SEMANTICS] _keras_logits path); 2: log_loss as binary CE on the softmax OUTPUTS clipped to
+ * [1e-7, 1-1e-7], -(y log(p^+1e-7) + (1-y) log(1-p^+1e-7)) (SURVEY.md A.5's reading of nrms.py:54,61-62; Keras
+ * binary_crossentropy(from_logits=False) on a tensor without cached logits).  Writes loss_rows[b] (already divided so that
  * sum_b loss_rows = batch loss), dscores, dcand[b,c,:], duser[b,:].                   */
 int ebn_score_loss_bwd_f32(const float* cand, const float* user, const float* scores,
                            const float* labels, float* loss_rows, float* dcand, float* duser,

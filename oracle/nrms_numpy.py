@@ -383,7 +383,11 @@ def scorer_forward(his, pred_one, P, h, d):
 
 
 # A.5 losses [KERAS-SEMANTICS, unverified]: both Keras cross-entropies recover
-# the cached logits of the softmax Activation (output._keras_logits).
+# the cached logits of the softmax Activation (output._keras_logits).  For
+# log_loss the OTHER reading -- SURVEY.md A.5: binary cross-entropy on the
+# clipped softmax outputs, what Keras' backend.binary_crossentropy does for a
+# tensor without cached logits -- is kind="log_loss_probs"; the TF dump
+# (tools/dump_tf_golden.py) decides between the two.
 def loss_fwd_bwd(s, y, kind="cross_entropy_loss"):
     """Returns (loss, dL/ds).  nrms.py:56-67."""
     y = np.asarray(y, dtype=s.dtype)
@@ -398,6 +402,16 @@ def loss_fwd_bwd(s, y, kind="cross_entropy_loss"):
     if kind == "log_loss":  # binary_crossentropy -> sigmoid CE on the logits
         L = (np.maximum(s, 0) - s * y + np.log1p(np.exp(-np.abs(s)))).mean()
         ds = (sigmoid(s) - y) / (B * C)
+        return L, ds
+    if kind == "log_loss_probs":  # binary_crossentropy(from_logits=False) on the softmax outputs (nrms.py:54,61-62 per SURVEY A.5)
+        # Keras 2.12-2.15 backend.binary_crossentropy: output = clip(output, eps, 1-eps);
+        # bce = -(target*log(output+eps) + (1-target)*log(1-output+eps)); mean over the last axis, then over the batch
+        eps = s.dtype.type(EPS_KERAS)
+        p = softmax_rows(s)
+        pc = np.clip(p, eps, 1 - eps)
+        L = -(y * np.log(pc + eps) + (1 - y) * np.log(1 - pc + eps)).mean()
+        dLdp = np.where((p >= eps) & (p <= 1 - eps), -(y / (pc + eps)) + (1 - y) / (1 - pc + eps), 0.0) / (B * C)
+        ds = p * (dLdp - (p * dLdp).sum(-1, keepdims=True))  # softmax backward
         return L, ds
     raise ValueError(f"this loss not defined {kind}")
 

@@ -73,6 +73,10 @@ def loss_from_scores(s, y, kind="cross_entropy_loss"):
         return -(y * torch.log_softmax(s, -1)).sum(-1).mean()
     if kind == "log_loss":
         return torch.nn.functional.binary_cross_entropy_with_logits(s, y)
+    if kind == "log_loss_probs":  # SURVEY.md A.5's reading: Keras backend.binary_crossentropy on the clipped softmax outputs
+        eps = 1e-7
+        p = torch.softmax(s, -1).clamp(eps, 1 - eps)
+        return -(y * torch.log(p + eps) + (1 - y) * torch.log(1 - p + eps)).mean()
     raise ValueError(f"this loss not defined {kind}")
 
 

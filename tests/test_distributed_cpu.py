@@ -172,13 +172,26 @@ def _planned_overflow_worker(rank, world):
     from ebrec.models.newsrec._dist import PlannedBuffers
 
     V, D, n_tok = 100000, 4, 4096
-    ex = ShardedTableExchange(V, D, capacity_factor=1.0)
+    ids = torch.arange(n_tok, dtype=torch.int32)  # every id distinct and low: frequency-ordered tokenizer ids look like this
+    # the DEFAULT partition of the device-planned mode is cyclic: low ids spread over the owners, nothing overflows
+    ex_default = ShardedTableExchange(V, D, capacity_factor=1.0)
+    assert ex_default.partition == "cyclic" and ShardedTableExchange(V, D, mode="alltoall_exact").partition == "block"
+    bd = PlannedBuffers(ex_default, n_tok, "cpu", need_grad=False, ws_ints=1)
+    ex_default.planned_lookup(ids, n_tok, bd, lambda *a: torch_plan(ex_default, *a), lambda rows, out: out.zero_())
+    ex_default.check(bd)
+    # block split: all of them are owned by rank 0: 4096 > capacity 2048
+    ex = ShardedTableExchange(V, D, partition="block", capacity_factor=1.0)
     assert ex.capacity(n_tok) == 2048
-    ids = torch.arange(n_tok, dtype=torch.int32)  # every id distinct and owned by rank 0: 4096 > capacity 2048
     b = PlannedBuffers(ex, n_tok, "cpu", need_grad=False, ws_ints=1)
-    ex.planned_lookup(ids, n_tok, b, lambda *a: torch_plan(ex, *a), lambda rows, out: out.zero_())
+    first = ids if rank == 0 else ids % 1000  # rank 1's own requests fit (1000 distinct rows)
+    ex.planned_lookup(first, n_tok, b, lambda *a: torch_plan(ex, *a), lambda rows, out: out.zero_())
+    # the flags are STICKY: a later clean step (ids that fit) must not hide the overflow from the once-per-epoch check,
+    # and check() is a collective -- rank 1 only ever sees clean steps here, yet must raise together with rank 0
+    clean = torch.arange(1000, dtype=torch.int32) * 7
+    ex.planned_lookup(clean, 1000, b, lambda *a: torch_plan(ex, *a), lambda rows, out: out.zero_())
     with pytest.raises(RuntimeError, match="overflowed"):
         ex.check(b)
+    ex.check(b)  # cleared by the read
     ids[5] = V  # out of range beats overflow
     ex.planned_lookup(ids, n_tok, b, lambda *a: torch_plan(ex, *a), lambda rows, out: out.zero_())
     with pytest.raises(IndexError):

@@ -1,0 +1,182 @@
+"""Oracle parity at BASELINE.json's FULL configuration sizes (gpu-marked): one whole training step of c2 (the headline
+config), three steps of c1 including the dense Adam sweep over the trainable table, one step of c3 (NRMSDocVec) --
+loss, every dense gradient and the post-Adam weights against oracle/nrms_numpy.py in float64 on identical inputs.
+
+The small-shape tests pin the arithmetic; these pin what only appears at size: the 24000 x 1200 x 1024 projection GEMM
+and its 24000-deep weight-gradient contraction (tile families, split-K slabs, operand layouts the small shapes never
+pick), 16 000 attention problems per launch, index arithmetic past 2^24 elements, the dropout stream over 24.6 M elements.
+
+The oracle never needs the whole 250002 x 1024 table in float64: a frozen table only ever contributes the rows a batch
+looks up, so the test hands the oracle the COMPACTED vocabulary (the distinct ids of the batch, renumbered) -- the same
+arithmetic on ~0.2 GB instead of 2 GB.  One float64 forward + backward at c2 is ~240 GFLOP of numpy matmul: seconds.
+
+Reference: nrms.py:161-210 (the training graph), nrms_docvec.py:99-188.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nrms_numpy as on
+from tests.hip_testutil import assert_close
+from tests.test_nrms_model import batch, make_hp, weight_list
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_dense_grads(eng, g, rtol=1e-4):
+    for pre in ("n", "u"):
+        want = np.concatenate([g[f"{pre}_WQ"], g[f"{pre}_WK"], g[f"{pre}_WV"]], 1)
+        assert_close(eng.params.g(f"{pre}_Wqkv").cpu().numpy(), want, rtol=rtol, atol=1e-6 + rtol * np.abs(want).max(), what=f"{pre} dWqkv")
+        for nm in ("W", "b", "q"):
+            want = g[f"{pre}_{nm}"].reshape(eng.params.shapes[f"{pre}_{nm}"])
+            assert_close(eng.params.g(f"{pre}_{nm}").cpu().numpy(), want, rtol=rtol, atol=1e-6 + rtol * np.abs(want).max(), what=f"{pre} d{nm}")
+
+
+def _dense_weights(eng):
+    """the 12 dense arrays in on.PARAM_ORDER[1:] order, without copying a 1 GB table to the host"""
+    E, out = eng.E, {}
+    for pre in ("n", "u"):
+        w = eng.params.view(f"{pre}_Wqkv").cpu().numpy()
+        out[f"{pre}_WQ"], out[f"{pre}_WK"], out[f"{pre}_WV"] = w[:, :E], w[:, E:2 * E], w[:, 2 * E:]
+        out[f"{pre}_W"] = eng.params.view(f"{pre}_W").cpu().numpy()
+        out[f"{pre}_b"] = eng.params.view(f"{pre}_b").cpu().numpy()
+        out[f"{pre}_q"] = eng.params.view(f"{pre}_q").cpu().numpy().reshape(-1, 1)
+    return out
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_c2_full_size_training_step_matches_the_oracle(hip, graph):
+    """configs[1] as bench.py runs it: V = 250002, D = 1024, B = 32, H = 20, C = 5, T = 30, heads 20 x 20, dropout 0.2, frozen
+    table.  graph=True replays the captured hipGraph (the launch path of the timed region) -- second step, fresh keys."""
+    from ebrec.models.newsrec import NRMSModel
+
+    V, D, B, C, seed, lr = 250002, 1024, 32, 5, 7, 1e-3
+    hp = make_hp(dropout=0.2, learning_rate=lr)
+    rng = np.random.default_rng(2024)
+    table = rng.standard_normal((V, D), dtype=np.float32) * np.float32(0.05)
+    P = on.random_nrms_params(1, D, hp.head_num, hp.head_dim, hp.attention_hidden_dim, seed=21)
+    m = NRMSModel(hp, word2vec_embedding=table, seed=seed, train_embedding=False)
+    m.from_keras_weight_list([table] + weight_list(P)[1:])
+    eng = m._engine
+    if graph:
+        eng.enable_graphs()
+    P = {k: v.astype(np.float32).astype(np.float64) for k, v in P.items()}
+    P0 = {k: v.copy() for k, v in P.items()}
+    mom = {k: (np.zeros_like(v), np.zeros_like(v)) for k, v in P.items()}
+    for t in range(1, 3 if graph else 2):
+        his, pred, y = batch(rng, B, hp.history_size, C, hp.title_size, V)
+        uniq, inv = np.unique(np.concatenate([his.reshape(-1), pred.reshape(-1)]), return_inverse=True)
+        P["emb"] = table[uniq].astype(np.float64)  # the compacted vocabulary: only looked-up rows matter to a frozen table
+        his_c, pred_c = inv[: his.size].reshape(his.shape), inv[his.size:].reshape(pred.shape)
+        if t == 1 and not graph:  # inference-mode forward at full size first (north_star: scores to 1e-4; here 1e-5)
+            probs, _, _ = on.nrms_forward(his_c, pred_c, P, hp.head_num, hp.head_dim)
+            assert_close(m.model.predict((his, pred)), probs, rtol=0, atol=1e-5, what="c2 full-size click probabilities")
+        L, _, g = on.nrms_loss_and_grads(his_c, pred_c, y, P, hp.head_num, hp.head_dim, "cross_entropy_loss", on.Drop(0.2, seed, t),
+                                         need_emb_grad=False)
+        got_L = float(m.train_step(his, pred, y).item())
+        assert abs(got_L - L) <= 2e-5 * max(1.0, abs(L)), (t, got_L, L)
+        _check_dense_grads(eng, g)
+        for k in on.PARAM_ORDER[1:]:
+            on.adam_keras_step(P[k], g[k], mom[k][0], mom[k][1], t, lr=lr)
+    got = _dense_weights(eng)
+    for k in on.PARAM_ORDER[1:]:
+        step = np.abs(P[k] - P0[k])
+        assert_close(got[k].reshape(P[k].shape), P[k], rtol=0, atol=2e-5 + 0.02 * float(step.max()), what=f"c2 weights {k} after Adam")
+    eng.check_oob()
+    assert torch.equal(eng.table[uniq[:64]].cpu(), torch.from_numpy(table[uniq[:64]]))  # frozen
+
+
+@pytest.mark.parametrize("loss", ["cross_entropy_loss", "log_loss"])
+def test_c1_full_size_three_steps_with_the_dense_table_sweep(hip, loss):
+    """configs[0] at bench size: 32000 x 300 TRAINABLE table, B = 32, dropout 0.2, 3 steps.  Keras' Adam decays the
+    moments of every row each step (dense sweep): rows untouched by a batch still move after step 1 -- the whole
+    32000 x 300 table is compared."""
+    from ebrec.models.newsrec import NRMSModel
+
+    V, D, B, C, seed, lr = 32000, 300, 32, 5, 11, 1e-3
+    hp = make_hp(dropout=0.2, learning_rate=lr, loss=loss)
+    rng = np.random.default_rng(31)
+    P = on.random_nrms_params(V, D, hp.head_num, hp.head_dim, hp.attention_hidden_dim, seed=5)
+    m = NRMSModel(hp, word2vec_embedding=P["emb"], seed=seed).from_keras_weight_list(weight_list(P))
+    eng = m._engine
+    eng.enable_graphs()
+    P = {k: v.astype(np.float32).astype(np.float64) for k, v in P.items()}
+    P0 = {k: v.copy() for k, v in P.items()}
+    mom = {k: (np.zeros_like(v), np.zeros_like(v)) for k, v in P.items()}
+    touched = np.zeros(V, bool)
+    for t in range(1, 4):
+        his, pred, y = batch(rng, B, hp.history_size, C, hp.title_size, V)
+        touched[his.reshape(-1)] = True
+        touched[pred.reshape(-1)] = True
+        L, _, g = on.nrms_loss_and_grads(his, pred, y, P, hp.head_num, hp.head_dim, loss, on.Drop(0.2, seed, t))
+        got_L = float(m.train_step(his, pred, y).item())
+        assert abs(got_L - L) <= 2e-5 * max(1.0, abs(L)), (t, got_L, L)
+        if t == 1:
+            _check_dense_grads(eng, g)
+        for k in P:
+            on.adam_keras_step(P[k], g[k], mom[k][0], mom[k][1], t, lr=lr)
+    eng.check_oob()
+    got = dict(zip(on.PARAM_ORDER, m.model.get_weights()))
+    for k in on.PARAM_ORDER:
+        step = np.abs(P[k] - P0[k])
+        assert_close(got[k].reshape(P[k].shape), P[k], rtol=0, atol=2e-5 + 0.02 * float(step.max()), what=f"c1 weights {k} after 3 steps")
+    # rows no batch looked up never saw a gradient: with zero moments the dense sweep must leave them bit-identical
+    assert (~touched).sum() > 0
+    assert np.array_equal(got["emb"][~touched], P0["emb"][~touched].astype(np.float32))
+
+
+def test_c3_full_size_docvec_step_matches_the_oracle(hip):
+    """configs[2] at bench size: 125542 x 768 document vectors resident in HBM, MLP 512-512-512 -> 256 (16 heads x 16),
+    B = 32, batches given as article-row numbers and gathered on the device; dropout 0.2, l2 1e-4."""
+    from ebrec.models.newsrec import NRMSDocVec
+    from tests.test_docvec_model import make_hp as docvec_hp, oracle_params, weight_list as docvec_weights
+
+    n_art, B, C, seed, lr = 125542, 32, 5, 9, 1e-3
+    hp = docvec_hp(learning_rate=lr)
+    P = oracle_params(hp, 4)
+    m = NRMSDocVec(hp, seed=seed)
+    m.model.set_weights(docvec_weights(P))
+    eng = m._engine
+    rng = np.random.default_rng(77)
+    matrix = rng.standard_normal((n_art, hp.title_size), dtype=np.float32)
+    matrix[0] = 0
+    eng.set_article_matrix(matrix)
+    eng.enable_graphs()
+    units = P["units"]
+    P0 = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in P.items()}
+    mom = {}
+    for t in range(1, 3):  # two steps: the second one is a replay of the captured graph and sees the moved BatchNorm statistics
+        hi, pi = rng.integers(0, n_art, (B, hp.history_size)), rng.integers(0, n_art, (B, C))
+        hi[rng.random(hi.shape) < 0.1] = 0  # padded history slots = the zero "unknown" vector
+        y = np.eye(C, dtype=np.float32)[rng.integers(0, C, B)]
+        L, _, g, stats = on.docvec_loss_and_grads(matrix[hi].astype(np.float64), matrix[pi].astype(np.float64), y, P, hp.head_num, hp.head_dim,
+                                                  l2=hp.newsencoder_l2_regularization, training=True, drop=on.Drop(0.2, seed, t))
+        got = float(eng.train_step(hi, pi, y, indexed=True).item())
+        assert abs(got - L) <= 3e-5 * max(1.0, abs(L)), (t, got, L)
+        if t == 1:
+            names = [f"d{l}_{s}" for l in range(len(units)) for s in ("W", "b")] + [f"bn{l}_{s}" for l in range(len(units)) for s in ("g", "b")] + \
+                ["out_W", "out_b", "u_W", "u_b", "u_q"]
+            for k in names:
+                want = g[k].reshape(eng.params.shapes[k])
+                assert_close(eng.params.g(k).cpu().numpy(), want, rtol=2e-4, atol=1e-6 + 2e-4 * np.abs(want).max(), what=f"c3 d{k}")
+            want = np.concatenate([g["u_WQ"], g["u_WK"], g["u_WV"]], 1)
+            assert_close(eng.params.g("u_Wqkv").cpu().numpy(), want, rtol=2e-4, atol=1e-6 + 2e-4 * np.abs(want).max(), what="c3 du_Wqkv")
+        on.bn_update_moving(P, stats)
+        for l in range(len(units)):
+            assert_close(eng.bn_mean[l].cpu().numpy(), P[f"bn{l}_mean"], rtol=1e-5, atol=1e-6, what=f"c3 moving mean {l} step {t}")
+            assert_close(eng.bn_var[l].cpu().numpy(), P[f"bn{l}_var"], rtol=1e-5, atol=1e-6, what=f"c3 moving var {l} step {t}")
+        for k in g:  # Keras-form Adam on every trainable array (the moving statistics are not trainable)
+            if k not in mom:
+                mom[k] = (np.zeros_like(P[k]), np.zeros_like(P[k]))
+            P[k] = P[k].copy()
+            on.adam_keras_step(P[k], g[k].reshape(P[k].shape), mom[k][0], mom[k][1], t, lr=lr)
+    keys = []
+    for l in range(len(units)):
+        keys += [f"d{l}_W", f"d{l}_b", f"bn{l}_g", f"bn{l}_b", f"bn{l}_mean", f"bn{l}_var"]
+    keys += ["out_W", "out_b", "u_WQ", "u_WK", "u_WV", "u_W", "u_b", "u_q"]
+    for k, a in zip(keys, m.model.get_weights()):
+        if "mean" in k or "var" in k:
+            continue  # compared above, step by step
+        step = np.abs(P[k] - P0[k])
+        assert_close(a.reshape(P[k].shape), P[k], rtol=0, atol=2e-5 + 0.02 * float(step.max()), what=f"c3 weights {k} after 2 steps")
+    eng.check_oob()

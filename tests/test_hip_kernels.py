@@ -443,7 +443,10 @@ def test_score_forward_softmax_and_sigmoid(hip, B, C, E):
         assert_close(host(pr), want, rtol=3e-5, atol=1e-7, what=f"probs mode {mode}")
 
 
-@pytest.mark.parametrize("kind", ["cross_entropy_loss", "log_loss"])
+LOSS_KINDS = {"cross_entropy_loss": 0, "log_loss": 1, "log_loss_probs": 2}  # the C ABI's loss_kind per oracle loss name
+
+
+@pytest.mark.parametrize("kind", list(LOSS_KINDS))
 @pytest.mark.parametrize("B,C,E", [(32, 5, 400), (4, 9, 20)])
 def test_loss_and_backward_into_representations(hip, kind, B, C, E):
     rng = np.random.default_rng(43)
@@ -459,7 +462,7 @@ def test_loss_and_backward_into_representations(hip, kind, B, C, E):
     dc = torch.empty(B, C, E, device="cuda")
     du = torch.empty(B, E, device="cuda")
     hip.call("ebn_score_loss_bwd_f32", P(dev(cand)), P(dev(user)), P(dev(s)), P(dev(y)), P(rows), P(dc), P(du), B, C, E,
-             0 if kind == "cross_entropy_loss" else 1, ctypes.c_float(1.0 / B), S())
+             LOSS_KINDS[kind], ctypes.c_float(1.0 / B), S())
     assert abs(host(rows).sum() - L) <= 3e-6 * max(1, abs(L))
     assert_close(host(dc), dcand, rtol=3e-5, atol=1e-7, what="dcand")
     assert_close(host(du), duser, rtol=3e-5, atol=1e-7, what="duser")
@@ -468,7 +471,7 @@ def test_loss_and_backward_into_representations(hip, kind, B, C, E):
     assert abs(float(tot.item()) - L) <= 3e-6 * max(1, abs(L))
 
 
-@pytest.mark.parametrize("kind", ["cross_entropy_loss", "log_loss"])
+@pytest.mark.parametrize("kind", list(LOSS_KINDS))
 @pytest.mark.parametrize("B,C,E", [(32, 5, 400), (64, 5, 256), (3, 64, 20), (1, 1, 8), (300, 5, 400), (4, 70, 16)])
 def test_fused_train_scorer_equals_the_three_kernels_and_the_oracle(hip, kind, B, C, E):
     """ebn_score_loss_train_f32: scorer + loss + backward in one launch (+ the batch-loss reduction) -- bitwise the separate
@@ -478,7 +481,7 @@ def test_fused_train_scorer_equals_the_three_kernels_and_the_oracle(hip, kind, B
     user = (rng.standard_normal((B, E)) * 0.4).astype(np.float32)
     y = np.zeros((B, C), np.float32)
     y[np.arange(B), rng.integers(0, C, B)] = 1
-    lk = 0 if kind == "cross_entropy_loss" else 1
+    lk = LOSS_KINDS[kind]
     f = lambda *shape: torch.empty(*shape, device="cuda")
     sc0, pr0, rows0, dc0, du0, tot0 = f(B, C), f(B, C), f(B), f(B, C, E), f(B, E), torch.zeros(1, device="cuda")
     hip.call("ebn_score_fwd_f32", P(dev(cand)), P(dev(user)), P(sc0), P(pr0), B, C, E, 0, S())

@@ -140,3 +140,18 @@ def test_missing_library_raises(monkeypatch, tmp_path):
     monkeypatch.delenv("EBNERD_HIP_LIB")
     monkeypatch.setattr(binding, "_lib", None)
     assert binding.lib() is not None
+
+
+def test_bce_default_is_the_one_the_tf_golden_tests_expect():
+    """tests/test_tf_golden.py flips DEFAULT_BCE_ON and the engines' default together."""
+    import inspect
+
+    from ebrec.models.newsrec._engine import NRMSEngine, loss_kind_of
+    from ebrec.models.newsrec._engine_docvec import DocVecEngine
+    from tests.test_tf_golden import DEFAULT_BCE_ON
+
+    for cls in (NRMSEngine, DocVecEngine):
+        assert inspect.signature(cls.__init__).parameters["bce_on"].default == DEFAULT_BCE_ON
+    assert [loss_kind_of("cross_entropy_loss", "probs"), loss_kind_of("log_loss", "logits"), loss_kind_of("log_loss", "probs")] == [0, 1, 2]
+    with pytest.raises(ValueError):
+        loss_kind_of("log_loss", "sigmoid")

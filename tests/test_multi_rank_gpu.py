@@ -1,7 +1,8 @@
 """BASELINE.json configs[3] (data parallel, H=50) and configs[4] (row-sharded table) on the GPU box (gpu-marked).
 
 The box has ONE GPU, and RCCL refuses two ranks on one device, so the multi-rank tests run the REAL engine (HIP kernels
-through the C ABI, hipGraph segments, the engine's own collectives) with two processes sharing cuda:0 over gloo.  What
+through the C ABI, hipGraph segments, the engine's own collectives) with two -- and, for the rank counts BASELINE.json
+names, eight -- processes sharing cuda:0 over gloo.  What
 is compared is arithmetic, not transport: the averaged update of the ranks must equal the single-process full-batch
 step of the float64 oracle.  The 8-GPU RCCL run itself is the driver's (bench.py --gpus 8).
 """
@@ -145,7 +146,16 @@ def _spawn(fn, world, *args):
     import torch.multiprocessing as mp
 
     port = _free_port()
-    mp.spawn(_entry, args=(world, port, fn, args), nprocs=world, join=True)
+    # every rank also runs the float64 oracle on the GLOBAL batch: keep `world` BLAS pools from oversubscribing the host
+    old = os.environ.get("OMP_NUM_THREADS")
+    os.environ["OMP_NUM_THREADS"] = str(max(1, (os.cpu_count() or 8) // world))
+    try:
+        mp.spawn(_entry, args=(world, port, fn, args), nprocs=world, join=True)
+    finally:
+        if old is None:
+            os.environ.pop("OMP_NUM_THREADS", None)
+        else:
+            os.environ["OMP_NUM_THREADS"] = old
 
 
 def _entry(rank, world, port, fn, args):
@@ -234,6 +244,23 @@ def test_two_rank_row_sharded_table_step_equals_the_full_batch_oracle_step(hip, 
     """configs[4]: table rows split over two ranks, device-planned lookups, equal-split all-to-alls between the captured
     kernel segments, row gradients routed to their owners (never all-reduced)."""
     _spawn(_dp_worker, 2, True, partition, graph, train_embedding, 20)
+
+
+# ---------------------------------------------------------------- world = 8 on the one GPU (BASELINE configs[3] / configs[4] rank count)
+@pytest.mark.parametrize("table_grad_exchange", ["dense", "sparse"])
+def test_eight_rank_c4_data_parallel_step_equals_the_full_batch_oracle_step(hip, table_grad_exchange):
+    """configs[3] with its real rank count: 8 processes over gloo on cuda:0, history_size = 50, trainable table, hipGraph
+    segments on; the dense all-reduce of the table gradient and the sparse (id, gradient row) all-gather with 8 slabs.
+    Every rank must end on the float64 oracle's weights after 3 steps on the GLOBAL batch (reduced V)."""
+    _spawn(_dp_worker, 8, False, "block", True, True, 50, table_grad_exchange)
+
+
+@pytest.mark.parametrize("partition,train_embedding", [("block", True), ("cyclic", True), ("cyclic", False)])
+def test_eight_rank_c5_row_sharded_table_step_equals_the_full_batch_oracle_step(hip, partition, train_embedding):
+    """configs[4] with its real rank count: the table's rows split 8 ways (block and cyclic ownership; V = 600 is not a
+    multiple of 8 for neither), capacity() at W = 8, the 8-way equal-split all-to-all buffer offsets inside captured graph
+    segments, row gradients routed to 8 owners."""
+    _spawn(_dp_worker, 8, True, partition, True, train_embedding, 20)
 
 
 def _fit_worker(rank, world, shard, tmpdir, table_grad_exchange="dense"):

@@ -103,12 +103,16 @@ def test_scorer_on_eval_loader_layout_dedups_but_keeps_row_order(nrms):
     assert_close(got, want, rtol=0, atol=1e-5, what="ragged scorer")
 
 
-@pytest.mark.parametrize("loss", ["cross_entropy_loss", "log_loss"])
+@pytest.mark.parametrize("loss", ["cross_entropy_loss", "log_loss", "log_loss_probs"])
 @pytest.mark.parametrize("p", [0.0, 0.2])
 def test_training_steps_follow_the_oracle_trajectory(nrms, loss, p):
     """3 optimizer steps: loss values and every updated tensor vs float64 oracle + Keras-form Adam,
-    with the shared counter-based dropout stream (training-mode parity)."""
-    hp = make_hp(loss=loss, dropout=p, learning_rate=1e-3)
+    with the shared counter-based dropout stream (training-mode parity).  "log_loss_probs" = hparams.loss "log_loss" with
+    bce_on="probs": binary cross-entropy on the clipped softmax outputs, the hedge next to the logits form."""
+    hp = make_hp(loss="log_loss" if loss == "log_loss_probs" else loss, dropout=p, learning_rate=1e-3)
+    if loss == "log_loss_probs":
+        nrms_cls = nrms
+        nrms = lambda *a, **k: nrms_cls(*a, bce_on="probs", **k)
     V, D, seed = 400, 300, 11
     rng = np.random.default_rng(7)
     P = on.random_nrms_params(V, D, hp.head_num, hp.head_dim, hp.attention_hidden_dim, seed=5)

@@ -183,6 +183,39 @@ def test_losses_follow_keras_logits_path():
         on.loss_fwd_bwd(s, y, "mse")
 
 
+def test_log_loss_on_clipped_probabilities_is_the_other_keras_reading():
+    """binary_crossentropy on the softmax OUTPUTS (clip to [1e-7, 1-1e-7], +1e-7 inside the logs) -- kept next
+    to the logits reading until the TF dump decides.  Value by hand, gradient against torch autograd and finite differences,
+    and the clip passes no gradient where it is active."""
+    import torch
+    from oracle import nrms_torch as ot
+
+    rng = np.random.default_rng(3)
+    s = rng.standard_normal((6, 5)) * 2
+    y = np.eye(5)[rng.integers(0, 5, 6)]
+    L, ds = on.loss_fwd_bwd(s, y, "log_loss_probs")
+    p = on.softmax_rows(s)
+    assert L == pytest.approx(float(-(y * np.log(p + 1e-7) + (1 - y) * np.log(1 - p + 1e-7)).mean()), rel=1e-12)
+    ts = torch.tensor(s, dtype=torch.float64, requires_grad=True)
+    Lt = ot.loss_from_scores(ts, torch.tensor(y), "log_loss_probs")
+    Lt.backward()
+    assert float(Lt) == pytest.approx(L, rel=1e-12)
+    np.testing.assert_allclose(ds, ts.grad.numpy(), rtol=1e-9, atol=1e-14)
+    num = np.zeros_like(s)
+    for i in np.ndindex(*s.shape):
+        sp, sm = s.copy(), s.copy()
+        sp[i] += 1e-6
+        sm[i] -= 1e-6
+        num[i] = (on.loss_fwd_bwd(sp, y, "log_loss_probs")[0] - on.loss_fwd_bwd(sm, y, "log_loss_probs")[0]) / 2e-6
+    np.testing.assert_allclose(ds, num, rtol=1e-6, atol=1e-9)
+    # the two readings are different functions (this is what the TF dump decides between)
+    assert abs(L - on.loss_fwd_bwd(s, y, "log_loss")[0]) > 1e-2
+    # saturated row: p = (1, 0, 0) to within 1e-7 -> every element sits on the clip, the gradient vanishes
+    s_sat = np.array([[60.0, 0.0, 0.0]])
+    L_sat, ds_sat = on.loss_fwd_bwd(s_sat, np.array([[0.0, 1.0, 0.0]]), "log_loss_probs")
+    assert np.all(ds_sat == 0) and L_sat == pytest.approx(-(np.log(2e-7) + np.log(2e-7) + np.log(1.0)) / 3, rel=1e-6)
+
+
 # ---------------- NRMSDocVec ---------------------------------------------------------------------------
 def test_docvec_golden_and_batchnorm_call_site_statistics():
     z = np.load(GOLD / "docvec_oracle_small.npz")

@@ -58,21 +58,50 @@ def test_oracle_matches_tensorflow_forward():
     np.testing.assert_allclose(ne, z["newsencoder"], atol=TOL, rtol=0)
 
 
+DEFAULT_BCE_ON = "logits"  # must equal NRMSEngine's default `bce_on`; the test below says when to flip both
+
+
+def _bce_reading(z, P, h, d):
+    """Which of the two implemented readings of `log_loss` (nrms.py:54,61-62) TensorFlow's evaluate() agrees with:
+    "logits" (sigmoid-CE on the softmax's cached logits) or "probs" (BCE on the clipped softmax outputs)."""
+    _, s, _ = on.nrms_forward(z["his"], z["pred"], P, h, d)
+    want = float(np.ravel(z["loss_log_loss"])[0])
+    err = {"logits": abs(on.loss_fwd_bwd(s, z["y"], "log_loss")[0] - want), "probs": abs(on.loss_fwd_bwd(s, z["y"], "log_loss_probs")[0] - want)}
+    return min(err, key=err.get), err
+
+
+@needs_gold
+def test_tensorflow_decides_the_log_loss_reading_and_the_default_follows_it():
+    """Both readings are implemented end to end (oracle kind "log_loss" / "log_loss_probs", C-ABI loss_kind 1 / 2, model
+    argument bce_on).  Exactly one must match TF; if it is not the default, flip `bce_on` in _engine.py and DEFAULT_BCE_ON."""
+    z, P, h, d = _load()
+    if "loss_log_loss" not in z.files:
+        pytest.skip("golden file predates the widened dump")
+    which, err = _bce_reading(z, P, h, d)
+    assert err[which] < TOL and max(err.values()) > TOL, err
+    assert which == DEFAULT_BCE_ON, f"TensorFlow runs log_loss on the {which}: make bce_on='{which}' the default"
+
+
 @needs_gold
 @pytest.mark.parametrize("loss", ["cross_entropy_loss", "log_loss"])
 def test_oracle_matches_tensorflow_losses_and_three_adam_steps(loss):
     """Pins every [KERAS-SEMANTICS] choice of training: the compiled loss (log_loss is where SURVEY A.5 and the oracle
-    disagree on paper), the gradient of the batch mean, Adam's sqrt(v)+eps placement and the dense decay of untouched rows."""
+    disagree on paper -- the reading TF agrees with is used from here on), the gradient of the batch mean, Adam's
+    sqrt(v)+eps placement and the dense decay of untouched rows."""
     z, P, h, d = _load()
     if f"loss_{loss}" not in z.files:
         pytest.skip("golden file predates the widened dump")
+    if loss == "log_loss" and _bce_reading(z, P, h, d)[0] == "probs":
+        loss_kind = "log_loss_probs"
+    else:
+        loss_kind = loss
     _, s, _ = on.nrms_forward(z["his"], z["pred"], P, h, d)
-    L, _ = on.loss_fwd_bwd(s, z["y"], loss)
+    L, _ = on.loss_fwd_bwd(s, z["y"], loss_kind)
     assert abs(L - float(np.ravel(z[f"loss_{loss}"])[0])) < TOL
     mom = {k: (np.zeros_like(v), np.zeros_like(v)) for k, v in P.items()}
     lr = float(z["learning_rate"])
     for t in range(1, 4):
-        Lt, _, g = on.nrms_loss_and_grads(z["his"], z["pred"], z["y"], P, h, d, loss, None)
+        Lt, _, g = on.nrms_loss_and_grads(z["his"], z["pred"], z["y"], P, h, d, loss_kind, None)
         assert abs(Lt - float(z[f"train3_losses_{loss}"][t - 1])) < TOL, (t, Lt)
         for k in P:
             on.adam_keras_step(P[k], g[k], mom[k][0], mom[k][1], t, lr=lr)
@@ -149,7 +178,8 @@ def test_hip_path_matches_tensorflow_training_steps(hip, loss):
     if f"train3_losses_{loss}" not in z.files:
         pytest.skip("golden file predates the widened dump")
     hp = type("hp", (hparams_nrms,), dict(loss=loss, dropout=0.0, learning_rate=float(z["learning_rate"])))
-    m = NRMSModel(hp, word2vec_embedding=P["emb"], seed=42).from_keras_weight_list([z[f"w{i:02d}"] for i in range(13)])
+    bce_on = _bce_reading(z, P, h, d)[0] if "loss_log_loss" in z.files else DEFAULT_BCE_ON  # the reading TF agrees with
+    m = NRMSModel(hp, word2vec_embedding=P["emb"], seed=42, bce_on=bce_on).from_keras_weight_list([z[f"w{i:02d}"] for i in range(13)])
     for t in range(3):
         got = float(m.train_step(z["his"], z["pred"], z["y"]).item())
         assert abs(got - float(z[f"train3_losses_{loss}"][t])) < TOL, (t, got)
