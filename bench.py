@@ -21,8 +21,15 @@ Extra objects on the JSON line:
                   arguments: 10 launches captured into a hipGraph (the launch path of the timed region), HIP events
                   on the launch stream around 5 replays
   roofline_gather the title-embedding gather (HBM-bound) the metric string names, same method
+  roofline_step   the WHOLE step against the exact-fp32 MFMA peak: exact matmul FLOPs of one step / the step's time
   cpu_baseline    oracle/nrms_torch.py (fp32 torch-eager port of the reference math; the reference's
-                  TF path cannot run here) timed on the host cores over a bounded sample
+                  TF path cannot run here) timed on the host cores: 20 timed steps after 5 warm-ups
+
+Every figure on the line is measured in this run or labelled static:  the kernel NAMES and the HBM `traffic` of the two
+roofline kernels come from three short rocprofv3 passes (--kernel-trace --stats; --pmc FETCH_SIZE; --pmc WRITE_SIZE -- each
+counter in its own pass, corrected as MI355X_MICROARCH.md section HBM prescribes) over `bench.py --kernel-probe`, a
+subprocess that launches exactly those two kernels on the step's shapes.  When rocprofv3 is missing or this process is
+itself being profiled, the line says `"traffic_source": "static: profiles/traffic.json ..."` instead.
 """
 from __future__ import annotations
 
@@ -89,8 +96,9 @@ def synthetic_batches(c, n, seed, device):
     return out
 
 
-def cpu_baseline(c, seconds=15.0):
-    """fp32 torch-eager port of the reference train step on the host cores (bounded sample)."""
+def cpu_baseline(c, steps=20, warmup=5, max_seconds=150.0):
+    """fp32 torch-eager port of the reference train step on the host cores: SURVEY.md 8(d)'s protocol -- `warmup` untimed
+    steps, then `steps` timed ones (median) -- cut short only if the timed part would pass `max_seconds` (said so in `sample`)."""
     from oracle.nrms_torch import CpuNRMSTrainer
 
     rng = np.random.default_rng(123)
@@ -113,23 +121,45 @@ def cpu_baseline(c, seconds=15.0):
         return his, pred, y
     # torch's default intra-op pool = the physical cores.  set_num_threads(os.cpu_count()) (all SMT siblings, 256 on the GPU
     # box) was measured 11x SLOWER on this eager workload (29 s vs 2.5 s per step), so the default is kept and reported.
-    tr.step(*batch())  # warm-up (thread pool, allocator, first-touch of the table)
+    for _ in range(warmup):  # thread pool, allocator, first touch of the table
+        tr.step(*batch())
     times = []
     t0 = time.perf_counter()
-    while True:
+    while len(times) < steps:
         t1 = time.perf_counter()
         tr.step(*batch())
         times.append(time.perf_counter() - t1)
-        el = time.perf_counter() - t0
-        if (el >= seconds and len(times) >= 3) or len(times) >= 200:
+        if time.perf_counter() - t0 >= max_seconds and len(times) >= 3:
             break
+    el = time.perf_counter() - t0
     n, med = len(times), float(np.median(times))
+    cut = "" if n == steps else f" (cut from {steps} steps at the {max_seconds:.0f} s cap)"
     return {"value": c["B"] / med, "unit": "impressions/s", "cores": int(torch.get_num_threads()), "kind": "port",
-            "sample": f"median of {n} train steps of batch {c['B']} ({c['H']}+{c['C']} titles x {c['T']} tokens, table {c['V']}x{c['D']}"
-                      f"{' frozen' if not c['train_embedding'] else ' trainable'}) after 1 warm-up step, {el:.1f}s of CPU work "
-                      f"(bounded to ~{seconds:.0f}s by the bench contract, hence fewer than 20 steps when a step takes >{seconds / 20:.2f}s; "
-                      f"step min/max {min(times) * 1e3:.0f}/{max(times) * 1e3:.0f} ms), oracle/nrms_torch.py fp32 eager, "
-                      f"{torch.get_num_threads()} intra-op threads of {os.cpu_count()} logical CPUs"}
+            "timed_steps": n, "warmup_steps": warmup,
+            "sample": f"median of {n} timed train steps{cut} of batch {c['B']} ({c['H']}+{c['C']} titles x {c['T']} tokens, table {c['V']}x{c['D']}"
+                      f"{' frozen' if not c['train_embedding'] else ' trainable'}) after {warmup} warm-up steps, {el:.1f}s of CPU work "
+                      f"(step min/max {min(times) * 1e3:.0f}/{max(times) * 1e3:.0f} ms), oracle/nrms_torch.py fp32 eager, "
+                      f"{torch.get_num_threads()} intra-op threads of {os.cpu_count()} logical CPUs (torch's default = the physical cores; "
+                      f"all {os.cpu_count()} SMT threads measured 11x slower)"}
+
+
+def step_flops(c):
+    """Exact matmul FLOPs (2 per multiply-add) of ONE training step at per-GPU batch B -- every GEMM and attention
+    contraction of forward and backward, nothing else (elementwise work, softmaxes, the optimizer are not counted)."""
+    B, H, C, T, D, h, d, A = c["B"], c["H"], c["C"], c["T"], c["D"], c["h"], c["d"], c["A"]
+    E, N = h * d, B * (H + C)
+    n_tok, n_his = N * T, B * H
+    f = 0.0
+    # news encoder: Q|K|V projection fwd + weight gradient (+ input gradient when the table trains)
+    f += 2.0 * n_tok * D * 3 * E * (3 if c["train_embedding"] else 2)
+    f += N * h * (4.0 + 8.0) * T * T * d          # attention core: fwd QK^T, P^T V; bwd dV, dP, dQ, dK
+    f += 3 * 2.0 * n_tok * E * A                  # AttLayer2: fwd, dW, d(input)
+    # user encoder: the same on B sequences of H news vectors (input gradient always needed)
+    f += 3 * 2.0 * n_his * E * 3 * E
+    f += B * h * (4.0 + 8.0) * H * H * d
+    f += 3 * 2.0 * n_his * E * A
+    f += 3 * 2.0 * B * C * E                      # scorer fwd, d(cand), d(user)
+    return f
 
 
 def timed_repeats(step_fn, args, sync, world, device):
@@ -186,6 +216,70 @@ def time_kernel(fns, sync, reps=10, replays=5):
     e1.record()
     sync()
     return e0.elapsed_time(e1) / (reps * replays) * 1e-3
+
+
+def being_profiled() -> bool:
+    return any(k.startswith(("ROCP_", "ROCPROF", "ROCPROFILER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+
+
+def probe_kernels(config, batch):
+    """Kernel names and HBM traffic of the two roofline kernels, observed IN THIS RUN: three rocprofv3 passes over
+    `bench.py --kernel-probe` (a subprocess that builds the same engine and launches the Q|K|V projection and the gather
+    eagerly on the step's buffers): (1) --kernel-trace --stats -> the names as the profiler sees them, (2) --pmc FETCH_SIZE
+    and (3) --pmc WRITE_SIZE -> per-launch fabric traffic = (2 x FETCH_SIZE + WRITE_SIZE) KiB (each counter in its own pass;
+    FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM: gfx950 tallies the 128-B requests of 16-B/lane loads at 64 B).
+    Returns None when rocprofv3 is unavailable or this process is itself under a profiler."""
+    import csv
+    import shutil
+    import tempfile
+
+    exe = shutil.which("rocprofv3")
+    if exe is None or being_profiled():
+        return None
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="ebn_probe_", dir=os.environ.get("TMPDIR", "/tmp"))
+    probe = [sys.executable, str(Path(__file__).resolve()), "--kernel-probe", "--config", config] + (["--batch", str(batch)] if batch else [])
+    env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
+    try:
+        for tag, flags in (("stats", ["--kernel-trace", "--stats"]), ("fetch", ["--pmc", "FETCH_SIZE", "--kernel-trace"]),
+                           ("write", ["--pmc", "WRITE_SIZE", "--kernel-trace"])):
+            r = subprocess.run([exe] + flags + ["--output-format", "csv", "-d", f"{tmp}/{tag}", "-o", "p", "--"] + probe,
+                               cwd=tmp, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+            if r.returncode != 0:
+                return None
+        pick = lambda name: "gather" if "gather_rows" in name else ("qkv_gemm" if "gemm" in name else None)
+        stats = next(Path(tmp, "stats").rglob("*kernel_stats.csv"))
+        for row in csv.DictReader(open(stats)):
+            k = pick(row["Name"])
+            if k and k not in out:
+                out[k] = {"name": row["Name"], "probe_calls": int(row["Calls"]), "probe_avg_us": float(row["AverageNs"]) * 1e-3}
+        for tag, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+            acc = {}
+            for row in csv.DictReader(open(next(Path(tmp, tag).rglob("*counter_collection.csv")))):
+                k = pick(row["Kernel_Name"])
+                if k and row["Counter_Name"] == counter:
+                    acc.setdefault(k, []).append(float(row["Counter_Value"]))
+            for k, v in acc.items():
+                out.setdefault(k, {})[counter + "_KiB"] = sum(v) / len(v)
+        for k, v in out.items():
+            if "FETCH_SIZE_KiB" in v and "WRITE_SIZE_KiB" in v:
+                v["traffic"] = (2.0 * v["FETCH_SIZE_KiB"] + v["WRITE_SIZE_KiB"]) * 1024.0
+        return out
+    except Exception:  # a profiler that cannot run here must not take the benchmark down: fall back to the static labels
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def static_traffic(config):
+    tf = ROOT / "profiles" / "traffic.json"
+    if not tf.exists():
+        return {}, None
+    blob = json.loads(tf.read_text())
+    tags = [k for k in blob.get("_detail", {}) if k.endswith("_" + config)]
+    src = f"static: profiles/traffic.json entry '{tags[-1]}'" if tags else "static: profiles/traffic.json"
+    return blob.get(config, {}), src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run, file dated " + \
+        time.strftime("%Y-%m-%d", time.gmtime(tf.stat().st_mtime)) + "; NOT measured in this run)"
 
 
 def timing_fields(times, args, world, per_gpu_batch):
@@ -279,8 +373,11 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch kernel by kernel instead of hipGraph replay")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-steps", type=int, default=20, help="timed steps of the CPU baseline (after 5 warm-ups; SURVEY.md 8d)")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel roofline timing (counter-collection passes)")
+    ap.add_argument("--no-probe", action="store_true", help="skip the rocprofv3 passes behind roofline.kernel / roofline.traffic (labelled static then)")
+    ap.add_argument("--kernel-probe", action="store_true", help="internal: launch the two roofline kernels a few times on the step's "
+                                                                "buffers and exit (what probe_kernels() wraps rocprofv3 around)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -330,6 +427,16 @@ def main():
     eng = model._engine
     batches = synthetic_batches(c, 8, 123 + rank, device)
 
+    if args.kernel_probe:
+        # the two roofline kernels, eagerly, on the step's own buffers: 4 launches each (the gather over 4 different id sets)
+        eng.train_step(*batches[0])  # allocates the step's buffers and fills X with gathered rows
+        rk = eng.roofline_kernels(c["B"], c["C"])
+        for h_, p_, _ in batches[:4]:
+            rk["gather"](torch.cat([h_.reshape(-1), p_.reshape(-1)]).contiguous())()
+            rk["qkv_gemm"]()
+        sync()
+        return
+
     eng.enable_graphs(not args.no_graph)
     times = timed_repeats(lambda k: eng.train_step(*batches[k % len(batches)]), args, sync, world, device)
     # Kernel-level rooflines: the Q|K|V projection GEMM and the embedding gather of THIS step (same buffers, same
@@ -340,6 +447,7 @@ def main():
     if not args.no_roofline:
         kt = {"qkv_gemm": time_kernel(rk["qkv_gemm"], sync), "gather": time_kernel([rk["gather"](ids) for ids in id_sets], sync)}
     loss = float(eng.loss_dev.item())
+    eng.check_oob()  # sticky device flags of the whole run (ids out of range, exchange overflow, accumulator range): raise, don't report
 
     if rank == 0:
         n_tok = c["B"] * (c["H"] + c["C"]) * c["T"]
@@ -350,10 +458,17 @@ def main():
         gemm_name = (f"gemm_f32_kernel<{bm.value}, {bn.value}, {4 if bm.value == 256 else 2}, false, false, true, 1, 0>" if bm.value != 32
                      else "gemm_small_vec_kernel<false, false, 32>") + f" (ebn_gemm_plan: tile {bm.value}x{bn.value}, split-K {sp.value})"
         gather_bytes = n_tok * (4 + 2 * c["D"] * 4)  # id + row read + row write (materialising gather)
-        traffic = {}
-        tf = ROOT / "profiles" / "traffic.json"
-        if tf.exists():
-            traffic = json.loads(tf.read_text()).get(args.config, {})
+        probed = None if (args.no_probe or args.no_roofline or world > 1) else probe_kernels(args.config, args.batch)
+        if probed and "traffic" in probed.get("qkv_gemm", {}) and "traffic" in probed.get("gather", {}):
+            traffic = {k: v["traffic"] for k, v in probed.items()}
+            traffic_source = ("measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over "
+                              "`bench.py --kernel-probe`, (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch")
+            name_source = "observed in this run: rocprofv3 --kernel-trace --stats over `bench.py --kernel-probe`"
+            gemm_name, gather_name = probed["qkv_gemm"]["name"], probed["gather"]["name"]
+        else:
+            traffic, traffic_source = static_traffic(args.config)
+            name_source = "static: the template instantiation ebn_gemm_plan selects for this shape (not observed in a trace of this run)"
+            gather_name = "gather_rows_vec4_kernel"
         cfg_idx = {"c1": 0, "c2": 1, "c4": 3, "c5": 4, "c5h50": 4}[args.config]
         table_kind = "trainable" if c["train_embedding"] else "frozen lookup"
         if sharded:
@@ -370,17 +485,25 @@ def main():
                        "global_batch": world * c["B"], "per_gpu_batch": c["B"], "parallelism": f"dp{world}",
                        "final_loss": loss},
         }
+        fl_step = step_flops(c)
+        line["roofline_step"] = {"what": "the whole training step against the exact-fp32 MFMA peak: exact matmul FLOPs of one step "
+                                         "(every GEMM and attention contraction, forward and backward) / ms_per_step",
+                                 "bound": "mfma", "achieved": fl_step / (line["ms_per_step"] * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
+                                 "unit": "TFLOP/s", "frac": fl_step / (line["ms_per_step"] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                                 "algorithmic_flops_per_step": fl_step}
         if kt is not None:
             line.update({
-            "roofline": {"kernel": gemm_name + " (news-encoder Q|K|V projection, fwd)", "bound": "mfma",
+            "roofline": {"kernel": gemm_name, "role": "news-encoder Q|K|V projection, forward (the time-dominant kernel)",
+                         "kernel_name_source": name_source, "bound": "mfma",
                          "achieved": gemm_flops / kt["qkv_gemm"] / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": gemm_flops / kt["qkv_gemm"] / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                         "traffic": traffic.get("qkv_gemm"), "avg_launch_us": kt["qkv_gemm"] * 1e6,
+                         "traffic": traffic.get("qkv_gemm"), "traffic_source": traffic_source, "avg_launch_us": kt["qkv_gemm"] * 1e6,
                          "algorithmic_flops_per_launch": gemm_flops},
-            "roofline_gather": {"kernel": "gather_rows_vec4_kernel (title-token embedding gather + dropout)", "bound": "hbm",
+            "roofline_gather": {"kernel": gather_name, "role": "title-token embedding gather + dropout", "kernel_name_source": name_source,
+                                "bound": "hbm",
                                 "achieved": gather_bytes / kt["gather"] / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": gather_bytes / kt["gather"] / 1e9 / HBM_PEAK_GBS,
-                                "traffic": traffic.get("gather"), "avg_launch_us": kt["gather"] * 1e6,
+                                "traffic": traffic.get("gather"), "traffic_source": traffic_source, "avg_launch_us": kt["gather"] * 1e6,
                                 "algorithmic_bytes_per_launch": gather_bytes}})
         line.update(dfields)
         if sharded:
@@ -388,7 +511,7 @@ def main():
         if world > 1:
             line["allreduce_bytes_per_step"] = eng.allreduce_bytes(c["B"] * (c["H"] + c["C"]) * c["T"])
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(c, args.cpu_seconds)
+            line["cpu_baseline"] = cpu_baseline(c, steps=args.cpu_steps)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -55,7 +55,7 @@ def eval_loss_from_news(eng, news_all: torch.Tensor, his_idx, pred_idx, y):
     Returns (loss[1], probs (B,C)) device tensors."""
     his_idx, pred_idx = np.asarray(his_idx), np.asarray(pred_idx)
     B, C = his_idx.shape[0], pred_idx.shape[1]
-    H, E = eng.H, eng.E
+    H, E = his_idx.shape[1], eng.E
     idx = torch.from_numpy(np.ascontiguousarray(np.concatenate([his_idx.reshape(-1), pred_idx.reshape(-1)]), dtype=np.int32)).to(eng.device)
     NE = torch.empty(B * (H + C), E, device=eng.device)
     S = _hip.stream_handle
@@ -359,11 +359,15 @@ class NRMSEngine:
             self._graphs.clear()  # captured graphs hold raw pointers into the old buffers
         return b
 
-    def _user_bufs(self, B, train):
-        key = ("user", train)
+    def _user_bufs(self, B, train, H=None):
+        """H: history length of an INFERENCE pass that differs from hparams.history_size (the reference's history-length sweep,
+        ebnerd_nrms_doc_hist.py:270-300, scores one trained model on histories truncated to 1..50); training always runs
+        hparams.history_size."""
+        H = self.H if H is None else int(H)
+        key = ("user", train) if H == self.H else ("user", train, H)
         b = self._bufs.get(key)
         if b is None or b.n_seq < B:
-            b = EncoderBuffers(B, self.H, self.E, self.E, self.A, self.device, own_input=False, need_dx=False)
+            b = EncoderBuffers(B, H, self.E, self.E, self.A, self.device, own_input=False, need_dx=False)
             self._bufs[key] = b
             self._graphs.clear()
         return b
@@ -586,18 +590,19 @@ class NRMSEngine:
         return out
 
     def encode_users_from_news(self, NEh: torch.Tensor) -> torch.Tensor:
-        """user encoder on already-encoded history (B,H,E) -> (B,E)  (nrms.py:108-111)."""
-        B = NEh.shape[0]
-        X = NEh.reshape(B * self.H, self.E).contiguous()
-        b = self._user_bufs(B, False)
+        """user encoder on already-encoded history (B,H,E) -> (B,E)  (nrms.py:108-111).  H is taken from the input: the
+        layers have no weight that depends on it (layers.py:200-254, 55-81)."""
+        B, H = NEh.shape[0], NEh.shape[1]
+        X = NEh.reshape(B * H, self.E).contiguous()
+        b = self._user_bufs(B, False, H)
         self._encoder_fwd("u", b, B, X, False)
         return b.out[:B].clone()
 
     def encode_users(self, his) -> torch.Tensor:
         his = his if isinstance(his, torch.Tensor) else np.asarray(his)
-        B = his.shape[0]
-        NEh = self.encode_news(his.reshape(B * self.H, self.T))
-        return self.encode_users_from_news(NEh.view(B, self.H, self.E))
+        B, H = his.shape[0], his.shape[1]
+        NEh = self.encode_news(his.reshape(B * H, self.T))
+        return self.encode_users_from_news(NEh.view(B, H, self.E))
 
     def forward(self, his, pred, mode="softmax"):
         """(B,H,T),(B,C,T) ids -> (probs (B,C), scores (B,C)) device tensors, inference mode."""

@@ -127,14 +127,19 @@ class DocVecEngine:
             self._graphs.clear()  # captured graphs hold raw pointers into the old buffers (an eval pass may grow them)
         return b
 
-    def _user_bufs(self, B):
-        b = self._bufs.get("user")
+    def _user_bufs(self, B, H=None):
+        """H: history length of an INFERENCE pass that differs from hparams.history_size (the history-length sweep of
+        ebnerd_nrms_doc_hist.py:270-300); training always runs hparams.history_size."""
+        H = self.H if H is None else int(H)
+        key = "user" if H == self.H else ("user", H)
+        b = self._bufs.get(key)
         if b is None or b.n_seq < B:
-            b = EncoderBuffers(B, self.H, self.E, self.E, self.A, self.device, own_input=False, need_dx=False)
+            b = EncoderBuffers(B, H, self.E, self.E, self.A, self.device, own_input=False, need_dx=False)
             b.duser = torch.empty(B, self.E, device=self.device)
             b.loss_rows = torch.empty(B, device=self.device)
-            self._bufs["user"] = b
-            self._graphs.clear()
+            self._bufs[key] = b
+            if H == self.H:
+                self._graphs.clear()
         return b
 
     # ------------------------------------------------------------------ kernels
@@ -170,7 +175,7 @@ class DocVecEngine:
 
     def _enc(self, ub, B, X, dims_only=False):
         pv = self.params.view
-        dims = _hip.EncoderDims(B, self.H, self.E, self.h, self.d, self.A, -1, 0.0)
+        dims = _hip.EncoderDims(B, ub.L, self.E, self.h, self.d, self.A, -1, 0.0)
         params = _hip.EncoderParams(pv("u_Wqkv").data_ptr(), pv("u_W").data_ptr(), pv("u_b").data_ptr(), pv("u_q").data_ptr())
         acts = _hip.EncoderActs(X.data_ptr(), ub.QKV.data_ptr(), ub.Y.data_ptr(), ub.U.data_ptr(), ub.w.data_ptr(), ub.out.data_ptr())
         return dims, params, acts
@@ -204,17 +209,17 @@ class DocVecEngine:
         return out
 
     def encode_users_from_news(self, NEh: torch.Tensor) -> torch.Tensor:
-        B = NEh.shape[0]
-        ub = self._user_bufs(B)
-        X = NEh.reshape(B * self.H, self.E).contiguous()
+        B, H = NEh.shape[0], NEh.shape[1]  # H from the input: no weight of the user encoder depends on it
+        ub = self._user_bufs(B, H)
+        X = NEh.reshape(B * H, self.E).contiguous()
         dims, params, acts = self._enc(ub, B, X)
         _hip.call("ebn_encoder_fwd_f32", ctypes.byref(dims), ctypes.byref(params), ctypes.byref(acts), ctypes.byref(self._fwd_scratch(ub)), None, _hip.stream_handle())
         return ub.out[:B].clone()
 
     def encode_users(self, his) -> torch.Tensor:
         his = np.asarray(his, dtype=np.float32) if not isinstance(his, torch.Tensor) else his
-        B = his.shape[0]
-        return self.encode_users_from_news(self.encode_news(his.reshape(B * self.H, self.Din)).view(B, self.H, self.E))
+        B, H = his.shape[0], his.shape[1]
+        return self.encode_users_from_news(self.encode_news(his.reshape(B * H, self.Din)).view(B, H, self.E))
 
     def forward(self, his, pred, mode="softmax"):
         his = his if isinstance(his, torch.Tensor) else np.asarray(his)

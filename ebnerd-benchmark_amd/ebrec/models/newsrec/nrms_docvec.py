@@ -85,11 +85,11 @@ class NRMSDocVec:
         eng = self._engine
         dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(eng.device)
         hi = dev(np.asarray(his_idx).reshape(-1))
-        b = len(his_idx)
-        NEh = torch.empty(b * eng.H, eng.E, device=eng.device)
-        _hip.call("ebn_gather_rows_f32", _hip.ptr(hi), _hip.ptr(news_all), _hip.ptr(NEh), b * eng.H, eng.E, news_all.shape[0],
+        b, H = len(his_idx), np.asarray(his_idx).shape[1]  # H from the batch: the history-length sweep scores truncated histories
+        NEh = torch.empty(b * H, eng.E, device=eng.device)
+        _hip.call("ebn_gather_rows_f32", _hip.ptr(hi), _hip.ptr(news_all), _hip.ptr(NEh), b * H, eng.E, news_all.shape[0],
                   None, -1, ctypes.c_float(0.0), None, _hip.stream_handle())
-        user = eng.encode_users_from_news(NEh.view(b, eng.H, eng.E))
+        user = eng.encode_users_from_news(NEh.view(b, H, eng.E))
         return eng.pair_scores(user, news_all, dev(rows), dev(cand_idx), sigmoid=True)
 
     def train_step(self, his, pred, y):

@@ -94,8 +94,11 @@ def main(argv=None):
     return run(args, hparams, build_model, article_mapping, NRMSModel.__name__)
 
 
-def run(args, hparams, build_model, article_mapping, MODEL_NAME):
-    """Everything after the article representation is built: shared by the NRMS and NRMSDocVec drivers."""
+def run(args, hparams, build_model, article_mapping, MODEL_NAME, after_validation=None):
+    """Everything after the article representation is built: shared by the NRMS and NRMSDocVec drivers.
+    after_validation(model, ctx): when given, it runs after training + the held-out-day metrics INSTEAD of the test-set
+    prediction, and its result is returned next to the history and the metrics (the history-length sweep of
+    ebnerd_nrms_doc_hist.py ends that way: reference lines 250-300 have no test-set part)."""
     import torch
 
     rank, world = 0, int(os.environ.get("WORLD_SIZE", "1"))
@@ -179,6 +182,11 @@ def run(args, hparams, build_model, article_mapping, MODEL_NAME):
     if rank == 0:
         print(metrics)
         write_json_file(metrics.evaluations, ARTIFACT_DIR / "validation_metrics.json")
+
+    if after_validation is not None:
+        ctx = dict(args=args, PATH=PATH, DATASPLIT=DATASPLIT, SEED=SEED, COLUMNS=COLUMNS, ARTIFACT_DIR=ARTIFACT_DIR,
+                   article_mapping=article_mapping, rank=rank, world=world)
+        return hist, metrics.evaluations, after_validation(model, ctx)
 
     # Test prediction is rank 0's job.  With a row-sharded table every lookup is a collective, so the other ranks run
     # the same frames alongside (identical call sequence) and simply do not write; with a replicated table they leave.

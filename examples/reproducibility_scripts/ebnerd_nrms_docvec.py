@@ -18,8 +18,8 @@ from ebrec.models.newsrec.model_config import hparams_nrms_docvec  # noqa: E402
 from ebrec.utils._articles import create_article_id_to_value_mapping  # noqa: E402
 
 
-def main(argv=None):
-    args = get_args(argv, docvec=True)
+def prepare(args):
+    """Document-vector mapping and hparams from the command line (shared with ebnerd_nrms_doc_hist.py)."""
     PATH = Path(args.data_path).expanduser()
     df_vec = pd.read_parquet(PATH / args.document_embeddings)
     vec_col = [c for c in df_vec.columns if c != "article_id"][0]
@@ -32,6 +32,12 @@ def main(argv=None):
     hparams.optimizer, hparams.loss, hparams.dropout, hparams.learning_rate = args.optimizer, args.loss, args.dropout, args.learning_rate
     hparams.newsencoder_units_per_layer = args.newsencoder_units_per_layer
     hparams.newsencoder_l2_regularization = args.newsencoder_l2_regularization
+    return hparams, article_mapping
+
+
+def main(argv=None):
+    args = get_args(argv, docvec=True)
+    hparams, article_mapping = prepare(args)
     return ebnerd_nrms.run(args, hparams, lambda: NRMSDocVec(hparams=hparams, seed=42), article_mapping, NRMSDocVec.__name__)
 
 

@@ -13,7 +13,7 @@ ROOT = Path(__file__).resolve().parents[1]
 @pytest.mark.parametrize("cfg", ["c2", "c3"])
 def test_bench_line_carries_the_contract_fields(cfg):
     out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--config", cfg, "--steps", "3", "--warmup", "1", "--repeats", "2",
-                          "--cpu-seconds", "2"], capture_output=True, text=True, timeout=600, cwd=str(ROOT))
+                          "--cpu-steps", "3"], capture_output=True, text=True, timeout=900, cwd=str(ROOT))
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
@@ -31,4 +31,17 @@ def test_bench_line_carries_the_contract_fields(cfg):
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     if cfg == "c2":  # the driver's configuration: the CPU port of the same step is timed beside it
         c = d["cpu_baseline"]
-        assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
+        assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1 and c["sample"] and c["timed_steps"] == 3
+        # every figure is measured in the run or says it is static: kernel names and traffic come from rocprofv3 passes over
+        # `bench.py --kernel-probe` when rocprofv3 can run, from profiles/traffic.json (labelled) otherwise
+        for key in ("roofline", "roofline_gather"):
+            rr = d[key]
+            assert rr["kernel_name_source"].startswith(("observed in this run", "static:")) and rr["traffic_source"].startswith(("measured in this run", "static:"))
+            if rr["traffic_source"].startswith("measured"):
+                assert rr["kernel_name_source"].startswith("observed") and "(" in rr["kernel"]  # a demangled signature from the trace
+                alg = rr.get("algorithmic_bytes_per_launch")
+                if alg:  # the gather's corrected counter traffic equals its known byte count (calibration of the x2 rule)
+                    assert abs(rr["traffic"] - alg) < 0.02 * alg, (rr["traffic"], alg)
+        st = d["roofline_step"]
+        assert st["bound"] == "mfma" and abs(st["frac"] - st["achieved"] / st["peak"]) < 1e-9 and 0 < st["frac"] < d["roofline"]["frac"]
+        assert abs(st["achieved"] * 1e12 - st["algorithmic_flops_per_step"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * st["achieved"] * 1e12

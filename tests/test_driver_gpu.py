@@ -51,3 +51,29 @@ def test_ebnerd_nrms_docvec_driver_end_to_end(hip, tmp_path):
                                              "--learning_rate", "1e-3", "--dump_dir", str(dump)])
     assert "val_auc" in hist.history and 0.0 <= metrics["auc"] <= 1.0
     assert len(list(dump.rglob("NRMSDocVec-123-ebnerd_demo.zip"))) == 1
+
+
+def test_ebnerd_nrms_doc_hist_driver_sweeps_the_history_length(hip, tmp_path):
+    """ebnerd_nrms_doc_hist.py:250-300: train one NRMSDocVec, then AUC of the long-history validation users on histories cut
+    to each size of the reference's `pairs` -- one model (history_size 20) scoring H = 1 ... 50."""
+    import json
+
+    sys.path.insert(0, str(ROOT / "tools"))
+    sys.path.insert(0, str(ROOT / "examples" / "reproducibility_scripts"))
+    import ebnerd_nrms_doc_hist
+    from make_synthetic_ebnerd import make
+
+    data = make(tmp_path / "data", split="ebnerd_demo", n_impressions=400, n_users=40, n_articles=300, seed=3, doc_dim=48)
+    dump = tmp_path / "out"
+    hist, metrics, sweep = ebnerd_nrms_doc_hist.main(["--data_path", str(data), "--datasplit", "ebnerd_demo", "--epochs", "2",
+                                                      "--newsencoder_units_per_layer", "32", "32", "--head_num", "4", "--head_dim", "8",
+                                                      "--learning_rate", "1e-3", "--dump_dir", str(dump), "--filter_min_history", "12"])
+    assert "val_auc" in hist.history and 0.0 <= metrics["auc"] <= 1.0
+    assert list(sweep) == [h for h, _ in ebnerd_nrms_doc_hist.PAIRS] and all(0.0 <= a <= 1.0 for a in sweep.values())
+    assert len(set(sweep.values())) > 1  # the history length matters to the scores
+    files = list(dump.rglob("auc_history_length.json"))
+    assert len(files) == 1 and {int(k): v for k, v in json.loads(files[0].read_text()).items()} == sweep
+    assert not list(dump.rglob("*.zip"))  # the sweep replaces the test-set prediction
+    with pytest.raises(ValueError, match="filter_min_history"):
+        ebnerd_nrms_doc_hist.main(["--data_path", str(data), "--datasplit", "ebnerd_demo", "--epochs", "1", "--newsencoder_units_per_layer", "32",
+                                   "--head_num", "4", "--head_dim", "8", "--dump_dir", str(dump), "--filter_min_history", "1000"])

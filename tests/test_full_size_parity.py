@@ -153,23 +153,31 @@ def test_c3_full_size_docvec_step_matches_the_oracle(hip):
                                                   l2=hp.newsencoder_l2_regularization, training=True, drop=on.Drop(0.2, seed, t))
         got = float(eng.train_step(hi, pi, y, indexed=True).item())
         assert abs(got - L) <= 3e-5 * max(1.0, abs(L)), (t, got, L)
-        if t == 1:
-            names = [f"d{l}_{s}" for l in range(len(units)) for s in ("W", "b")] + [f"bn{l}_{s}" for l in range(len(units)) for s in ("g", "b")] + \
-                ["out_W", "out_b", "u_W", "u_b", "u_q"]
-            for k in names:
-                want = g[k].reshape(eng.params.shapes[k])
-                assert_close(eng.params.g(k).cpu().numpy(), want, rtol=2e-4, atol=1e-6 + 2e-4 * np.abs(want).max(), what=f"c3 d{k}")
-            want = np.concatenate([g["u_WQ"], g["u_WK"], g["u_WV"]], 1)
-            assert_close(eng.params.g("u_Wqkv").cpu().numpy(), want, rtol=2e-4, atol=1e-6 + 2e-4 * np.abs(want).max(), what="c3 du_Wqkv")
+        # every trainable gradient against the oracle's, both steps (the engine's weights follow the oracle's to ~1e-6, below)
+        names = [f"d{l}_{s}" for l in range(len(units)) for s in ("W", "b")] + [f"bn{l}_{s}" for l in range(len(units)) for s in ("g", "b")] + \
+            ["out_W", "out_b", "u_W", "u_b", "u_q"]
+        g_eng = {}
+        for k in names:
+            want = g[k].reshape(eng.params.shapes[k])
+            g_eng[k] = eng.params.g(k).cpu().numpy().astype(np.float64)
+            assert_close(g_eng[k], want, rtol=2e-4, atol=1e-6 + 2e-4 * np.abs(want).max(), what=f"c3 d{k} step {t}")
+        want = np.concatenate([g["u_WQ"], g["u_WK"], g["u_WV"]], 1)
+        gq = eng.params.g("u_Wqkv").cpu().numpy().astype(np.float64)
+        assert_close(gq, want, rtol=2e-4, atol=1e-6 + 2e-4 * np.abs(want).max(), what=f"c3 du_Wqkv step {t}")
+        E = eng.E
+        g_eng["u_WQ"], g_eng["u_WK"], g_eng["u_WV"] = gq[:, :E], gq[:, E:2 * E], gq[:, 2 * E:]
         on.bn_update_moving(P, stats)
         for l in range(len(units)):
             assert_close(eng.bn_mean[l].cpu().numpy(), P[f"bn{l}_mean"], rtol=1e-5, atol=1e-6, what=f"c3 moving mean {l} step {t}")
             assert_close(eng.bn_var[l].cpu().numpy(), P[f"bn{l}_var"], rtol=1e-5, atol=1e-6, what=f"c3 moving var {l} step {t}")
-        for k in g:  # Keras-form Adam on every trainable array (the moving statistics are not trainable)
+        # Keras-form Adam on every trainable array, fed the ENGINE's (fp32) gradient: Adam's m / (sqrt(v) + eps) turns the
+        # fp32-vs-fp64 noise of a gradient element that nearly cancels (data term against the l2 term) into an O(lr) difference of
+        # the update, which says nothing about either side -- gradient parity is asserted above, Adam parity here, each tightly
+        for k in g:
             if k not in mom:
                 mom[k] = (np.zeros_like(P[k]), np.zeros_like(P[k]))
             P[k] = P[k].copy()
-            on.adam_keras_step(P[k], g[k].reshape(P[k].shape), mom[k][0], mom[k][1], t, lr=lr)
+            on.adam_keras_step(P[k], g_eng[k].reshape(P[k].shape), mom[k][0], mom[k][1], t, lr=lr)
     keys = []
     for l in range(len(units)):
         keys += [f"d{l}_W", f"d{l}_b", f"bn{l}_g", f"bn{l}_b", f"bn{l}_mean", f"bn{l}_var"]
@@ -177,6 +185,6 @@ def test_c3_full_size_docvec_step_matches_the_oracle(hip):
     for k, a in zip(keys, m.model.get_weights()):
         if "mean" in k or "var" in k:
             continue  # compared above, step by step
-        step = np.abs(P[k] - P0[k])
-        assert_close(a.reshape(P[k].shape), P[k], rtol=0, atol=2e-5 + 0.02 * float(step.max()), what=f"c3 weights {k} after 2 steps")
+        assert_close(a.reshape(P[k].shape), P[k], rtol=0, atol=1e-6, what=f"c3 weights {k} after 2 Adam steps")
+        assert np.abs(P[k] - P0[k]).max() > 0.5 * lr  # ... and they did move
     eng.check_oob()

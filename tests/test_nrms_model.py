@@ -85,6 +85,33 @@ def test_forward_matches_oracle_on_identical_weights(nrms, cfg):
     assert_close(ue, want_u, rtol=1e-5, atol=1e-5, what="userencoder")
 
 
+def test_one_model_scores_every_history_length_from_1_to_50(nrms):
+    """The reference's history-length sweep (ebnerd_nrms_doc_hist.py:270-300) feeds ONE trained model histories truncated to
+    1 ... 50 entries: no weight of the user encoder depends on H (layers.py:200-254, 55-81), so scorer / userencoder take H
+    from the batch.  Every L = 1 ... 50 of the news-level attention kernels (one MFMA tile up to 32, 2x2 tiles beyond)
+    against the float64 oracle."""
+    hp = make_hp()  # history_size = 20: the length the model would have been trained with
+    V, D = 300, 64
+    rng = np.random.default_rng(15)
+    P = on.random_nrms_params(V, D, hp.head_num, hp.head_dim, hp.attention_hidden_dim, seed=12)
+    m = nrms(hp, word2vec_embedding=P["emb"]).from_keras_weight_list(weight_list(P))
+    for H in range(1, 51):
+        B = 3 if H > 8 else 5
+        his = rng.integers(0, V, (B, H, hp.title_size))
+        if H > 2:
+            his[0, : H // 2] = 0  # left padding of a short history
+        one = rng.integers(0, V, (B, 1, hp.title_size))
+        want = on.scorer_forward(his, one, P, hp.head_num, hp.head_dim)
+        assert_close(m.scorer.predict((his, one)), want, rtol=0, atol=1e-5, what=f"scorer at history length {H}")
+        if H in (1, 7, 33, 50):
+            NEh, _ = on.news_encoder_fwd(his.reshape(-1, hp.title_size), P, hp.head_num, hp.head_dim)
+            want_u, _ = on.user_encoder_from_news_fwd(NEh.reshape(B, H, -1), P, hp.head_num, hp.head_dim)
+            assert_close(m.userencoder.predict(his), want_u, rtol=1e-5, atol=1e-5, what=f"userencoder at history length {H}")
+    # training keeps hparams.history_size
+    with pytest.raises(ValueError):
+        m.train_step(rng.integers(0, V, (2, 7, hp.title_size)), rng.integers(0, V, (2, 5, hp.title_size)), np.eye(5)[[0, 1]])
+
+
 def test_scorer_on_eval_loader_layout_dedups_but_keeps_row_order(nrms):
     """dataloader.py:99-107 layout: history repeated per candidate, pred (sum C_i, 1, T)."""
     hp = make_hp()
