@@ -464,8 +464,10 @@ def test_loss_and_backward_into_representations(hip, kind, B, C, E):
     hip.call("ebn_score_loss_bwd_f32", P(dev(cand)), P(dev(user)), P(dev(s)), P(dev(y)), P(rows), P(dc), P(du), B, C, E,
              LOSS_KINDS[kind], ctypes.c_float(1.0 / B), S())
     assert abs(host(rows).sum() - L) <= 3e-6 * max(1, abs(L))
-    assert_close(host(dc), dcand, rtol=3e-5, atol=1e-7, what="dcand")
-    assert_close(host(du), duser, rtol=3e-5, atol=1e-7, what="duser")
+    # (the clipped-probabilities form differentiates through the softmax: ds = p (dl/dp - sum_k p_k dl/dp_k) cancels in fp32)
+    atol = 5e-7 if kind == "log_loss_probs" else 1e-7
+    assert_close(host(dc), dcand, rtol=3e-5, atol=atol, what="dcand")
+    assert_close(host(du), duser, rtol=3e-5, atol=atol, what="duser")
     tot = torch.zeros(1, device="cuda")
     hip.call("ebn_sum_f32", P(rows), B, ctypes.c_float(1.0), P(tot), 0, S())
     assert abs(float(tot.item()) - L) <= 3e-6 * max(1, abs(L))
