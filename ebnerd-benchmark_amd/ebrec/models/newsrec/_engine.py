@@ -195,6 +195,7 @@ class NRMSEngine:
         self.range_flag = torch.zeros(1, dtype=torch.int32, device=self.device)  # fixed-point gradient accumulator left its range
         self.loss_dev = torch.zeros(1, device=self.device)
         self.use_graph = False  # capture the per-shape kernel sequence into hipGraphs (enable_graphs())
+        self.fuse_user_head = True  # False: the per-impression head of a step as its six separate launches (validation)
         self.world = 1
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
@@ -810,6 +811,7 @@ class NRMSEngine:
         if not hasattr(ub, "duser"):
             ub.duser = torch.empty(ub.n_seq, E, device=self.device)
             ub.loss_rows = torch.empty(ub.n_seq, device=self.device)
+            ub.head_partials = torch.empty(max(int(_hip.lib().ebn_user_head_partials_len(ub.n_seq, self.A)), 1), device=self.device)
         return nb, ub
 
     def _capture(self, B, C, advanced=False):
@@ -884,14 +886,20 @@ class NRMSEngine:
         st = _hip.ptr(self.state)
         # ---- forward
         self._news_forward(nb, N, True, B * H, looked_up=True)
-        self._encoder_fwd("u", ub, B, nb.out, True)  # history encodings are the first B*H rows
         cand, dcand = nb.out[B * H:], nb.dNE[B * H:]
-        # scorer + compiled loss + their backward into the representations + the batch loss: one launch
-        _hip.call("ebn_score_loss_train_f32", _hip.ptr(cand), _hip.ptr(ub.out), _hip.ptr(nb.labels), _hip.ptr(nb.scores),
-                  _hip.ptr(nb.probs), _hip.ptr(ub.loss_rows), _hip.ptr(self.loss_dev), _hip.ptr(dcand), _hip.ptr(ub.duser), B, C, E,
-                  self.loss_kind, ctypes.c_float(1.0 / B), S())
-        # ---- backward
-        self._encoder_bwd("u", ub, B, nb.out, ub.duser, nb.dNE)  # writes dNE[:B*H]
+        # user encoder (its input: the first B*H rows of the news vectors, no copy) + scorer + compiled loss, forward and
+        # backward, as one stage call: the per-impression middle of it is ONE launch where it fits (ebn_user_head_train_f32);
+        # writes the batch loss, d(cand) and d(history news vectors) = dNE[:B*H]
+        dims, params, acts = self._enc_structs("u", ub, B, nb.out, -1, 0.0)
+        g = self.params.g
+        grads = _hip.EncoderGrads(g("u_Wqkv").data_ptr(), g("u_W").data_ptr(), g("u_b").data_ptr(), g("u_q").data_ptr())
+        scratch = _hip.EncoderScratch(ub.dY.data_ptr(), ub.dQKV.data_ptr(), ub.de.data_ptr(), ub.partials.data_ptr(),
+                                      ub.ws.data_ptr(), ub.ws.numel())
+        _hip.call("ebn_user_stage_train_f32", ctypes.byref(dims), ctypes.byref(params), ctypes.byref(acts), _hip.ptr(cand),
+                  _hip.ptr(nb.labels), _hip.ptr(nb.scores), _hip.ptr(nb.probs), _hip.ptr(ub.loss_rows), _hip.ptr(self.loss_dev),
+                  _hip.ptr(dcand), _hip.ptr(ub.duser), ctypes.byref(grads), ctypes.byref(scratch),
+                  _hip.ptr(ub.head_partials) if self.fuse_user_head else None, _hip.ptr(nb.dNE), C, self.loss_kind,
+                  ctypes.c_float(1.0 / B), st, S())
         self._encoder_bwd("n", nb, N, nb.X, nb.dNE, nb.dX, B * H)
         if self.train_embedding and not self._planned and not sparse_table_grads:
             if self.exchange is not None or not self.deterministic:

@@ -270,6 +270,19 @@ int ebn_encoder_bwd_f32(const ebn_encoder_dims* dims, const ebn_encoder_params* 
                         float* dX, int32_t accumulate, const ebn_step_state* st,
                         ebn_stream_t stream);
 
+/* The user encoder and the scorer of a TRAINING step in one call: ebn_encoder_fwd_f32 on the B sequences of L news vectors
+ * (nrms.py:108-111), Dot + softmax + compiled loss (nrms.py:201-202, 56-67) against cand [B*C, E] / labels [B*C], and the
+ * backward of both into dcand [B*C, E], dX [B*L, Din] (the history news vectors) and the user encoder's weight gradients
+ * (overwritten).  When ebn_user_head_supported(L, C, E, A) and ebn_attn_bwd_pooled_supported(L, d) hold and
+ * `head_partials` (ebn_user_head_partials_len(B, A) floats) is given, everything between the two GEMM groups is
+ * ebn_user_head_train_f32 -- one launch instead of six; otherwise ebn_encoder_fwd_f32 + ebn_score_loss_train_f32 +
+ * ebn_encoder_bwd_f32 run as they are.  a->out receives the user vectors, duser [B, E] their gradient.              */
+int ebn_user_stage_train_f32(const ebn_encoder_dims* dims, const ebn_encoder_params* p, const ebn_encoder_acts* a,
+                             const float* cand, const float* labels, float* scores, float* probs, float* loss_rows,
+                             float* loss_out, float* dcand, float* duser, const ebn_encoder_grads* g,
+                             const ebn_encoder_scratch* s, float* head_partials, float* dX, int32_t C, int32_t loss_kind,
+                             float inv_batch, const ebn_step_state* st, ebn_stream_t stream);
+
 /* ---- a8/a9  Dot + softmax/sigmoid + loss (nrms.py:201-205, 56-67) ------------------
  * scores[b,c] = cand[b,c,:].user[b,:]; probs = softmax_c (mode 0) or sigmoid (mode 1). */
 int ebn_score_fwd_f32(const float* cand, const float* user, float* scores, float* probs,
@@ -288,6 +301,25 @@ int ebn_score_loss_bwd_f32(const float* cand, const float* user, const float* sc
 int ebn_score_loss_train_f32(const float* cand, const float* user, const float* labels, float* scores, float* probs,
                              float* loss_rows, float* loss_out, float* dcand, float* duser, int64_t B, int32_t C,
                              int32_t E, int32_t loss_kind, float inv_batch, ebn_stream_t stream);
+/* The head of a TRAINING step in one launch (+ a small fixed-order reduction): everything between the user encoder's two
+ * GEMM groups, all of it local to one impression --
+ *   user AttLayer2 after its x.W matmul: U <- tanh(U + b), w = exp(U.q) / (sum + 1e-7), user = sum_l w_l X_l (layers.py:65-81)
+ *   -> scores = cand . user, probs = softmax (nrms.py:201-202) -> compiled loss and d(scores) (nrms.py:56-67; loss_kind as above)
+ *   -> dcand = ds (x) user, duser = sum_c ds_c cand_c -> AttLayer2 backward: de = w (dw - sum w dw), dw_l = duser . X_l,
+ *      U <- d(pre-tanh) = de q (1 - tanh^2), dq = sum de tanh, db = sum d(pre-tanh)
+ * i.e. ebn_attpool_fwd_f32 + ebn_score_loss_train_f32 + ebn_attpool_bwd_pool_f32 + ebn_attpool_bwd_dpre_f32 of the USER
+ * encoder (same formulas; six links of the step's dependent launch chain become two).  One workgroup per impression keeps
+ * its L x A, L x E and C x E rows in LDS: ebn_user_head_supported(L, C, E, A) says whether they fit (E, A multiples of 4;
+ * history_size 50 at E = 400, A = 200 does).  U [B*L, A], X [B*L, E], cand / dcand [B*C, E], labels / scores / probs [B*C],
+ * w / de [B*L], user / duser [B, E], loss_rows [B], loss_out [1] = sum(loss_rows), dq / db [A] (overwritten),
+ * partials: ebn_user_head_partials_len(B, A) floats of scratch.  16-byte aligned pointers.                              */
+int ebn_user_head_supported(int32_t L, int32_t C, int32_t E, int32_t A);
+int64_t ebn_user_head_partials_len(int64_t B, int32_t A);
+int ebn_user_head_train_f32(float* U, const float* b, const float* q, const float* X, const float* cand, const float* labels,
+                            float* w, float* user, float* scores, float* probs, float* loss_rows, float* loss_out,
+                            float* dcand, float* duser, float* de, float* dq, float* db, float* partials, int64_t B,
+                            int32_t L, int32_t C, int32_t E, int32_t A, int32_t loss_kind, float inv_batch,
+                            ebn_stream_t stream);
 /* Streaming AUC of compile(metrics=["AUC"]) (ebnerd_nrms.py:244-248; tf.keras.metrics.AUC defaults): every (label,
  * prediction) pair of a batch goes into pos_hist / neg_hist [n_thresholds + 1] at bucket = number of thresholds strictly
  * below the prediction (`thresholds`: ascending float64 on the device).  Integer atomics: order-independent.           */

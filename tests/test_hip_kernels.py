@@ -499,6 +499,81 @@ def test_fused_train_scorer_equals_the_three_kernels_and_the_oracle(hip, kind, B
     assert abs(float(tot.item()) - L) <= 3e-6 * max(1, abs(L)) and abs(float(tot.item()) - float(tot0.item())) <= 1e-6 * max(1, abs(L))
 
 
+@pytest.mark.parametrize("kind", list(LOSS_KINDS))
+@pytest.mark.parametrize("B,L,C,E,A", [(32, 20, 5, 400, 200), (3, 50, 5, 400, 200), (5, 7, 9, 20, 12), (2, 1, 1, 8, 4), (64, 20, 5, 256, 200)])
+def test_user_head_is_the_six_kernels_it_replaces(hip, kind, B, L, C, E, A):
+    """ebn_user_head_train_f32: user AttLayer2 after its matmul -> scorer -> loss -> their backward up to d(pre-tanh), one
+    workgroup per impression out of LDS.  Against the float64 oracle (layers.py:65-81, nrms.py:201-202, 56-67) AND against the
+    separate kernels it replaces (attpool_fwd, score_loss_train, attpool_bwd_pool, attpool_bwd_dpre) on the same inputs."""
+    assert hip.lib().ebn_user_head_supported(L, C, E, A) == 1
+    rng = np.random.default_rng(B * 1000 + L * 10 + C)
+    Upre = (rng.standard_normal((B * L, A)) * 0.7).astype(np.float32)
+    bb = (rng.standard_normal(A) * 0.2).astype(np.float32)
+    q = (rng.standard_normal(A) * 0.3).astype(np.float32)
+    X = (rng.standard_normal((B * L, E)) * 0.5).astype(np.float32)
+    cand = (rng.standard_normal((B * C, E)) * 0.4).astype(np.float32)
+    y = np.zeros((B, C), np.float32)
+    y[np.arange(B), rng.integers(0, C, B)] = 1
+    # ---- oracle, float64
+    U64, X64, c64 = Upre.astype(np.float64).reshape(B, L, A), X.astype(np.float64).reshape(B, L, E), cand.astype(np.float64).reshape(B, C, E)
+    t = np.tanh(U64 + bb)
+    a_ = np.exp(t @ q.astype(np.float64))
+    w = a_ / (a_.sum(-1, keepdims=True) + 1e-7)
+    user = (w[..., None] * X64).sum(1)
+    sc = np.einsum("bce,be->bc", c64, user)
+    Lw, ds = on.loss_fwd_bwd(sc, y.astype(np.float64), kind)
+    dcand = ds[..., None] * user[:, None, :]
+    duser = np.einsum("bc,bce->be", ds, c64)
+    dw = np.einsum("ble,be->bl", X64, duser)
+    de = w * (dw - (w * dw).sum(-1, keepdims=True))
+    dpre = de[..., None] * q * (1 - t * t)
+    dq, db = (de[..., None] * t).sum((0, 1)), dpre.sum((0, 1))
+    # ---- fused head
+    f = lambda *shape: torch.full(shape, 7.0, device="cuda")
+    U = dev(Upre)
+    o = dict(w=f(B * L), user=f(B, E), scores=f(B * C), probs=f(B * C), rows=f(B), loss=f(1), dcand=f(B * C, E), duser=f(B, E), de=f(B * L),
+             dq=f(A), db=f(A), part=f(int(hip.lib().ebn_user_head_partials_len(B, A))))
+    hip.call("ebn_user_head_train_f32", P(U), P(dev(bb)), P(dev(q)), P(dev(X)), P(dev(cand)), P(dev(y)), P(o["w"]), P(o["user"]), P(o["scores"]),
+             P(o["probs"]), P(o["rows"]), P(o["loss"]), P(o["dcand"]), P(o["duser"]), P(o["de"]), P(o["dq"]), P(o["db"]), P(o["part"]),
+             B, L, C, E, A, LOSS_KINDS[kind], ctypes.c_float(1.0 / B), S())
+    tol = dict(rtol=3e-5, atol=5e-7)
+    assert_close(host(o["w"]).reshape(B, L), w, rtol=2e-5, atol=1e-7, what="w")
+    assert_close(host(o["user"]), user, what="user", **tol)
+    assert_close(host(o["scores"]).reshape(B, C), sc, rtol=3e-5, atol=3e-6, what="scores")
+    assert_close(host(o["probs"]).reshape(B, C), on.softmax_rows(sc), rtol=5e-5, atol=1e-7, what="probs")
+    assert abs(float(o["loss"].item()) - Lw) <= 5e-6 * max(1, abs(Lw)) and abs(host(o["rows"]).sum() - Lw) <= 5e-6 * max(1, abs(Lw))
+    g_tol = dict(rtol=1e-4, atol=2e-6 if kind == "log_loss_probs" else 1e-6)
+    assert_close(host(o["dcand"]).reshape(B, C, E), dcand, what="dcand", **g_tol)
+    assert_close(host(o["duser"]), duser, what="duser", **g_tol)
+    assert_close(host(o["de"]).reshape(B, L), de, rtol=1e-4, atol=1e-6 + 1e-4 * np.abs(de).max(), what="de")
+    assert_close(host(U).reshape(B, L, A), dpre, rtol=1e-4, atol=1e-7 + 1e-4 * np.abs(dpre).max(), what="d(pre-tanh) written over U")
+    assert_close(host(o["dq"]), dq, rtol=1e-4, atol=1e-6 + 1e-4 * np.abs(dq).max(), what="dq")
+    assert_close(host(o["db"]), db, rtol=1e-4, atol=1e-6 + 1e-4 * np.abs(db).max(), what="db")
+    # ---- the separate kernels on the same inputs: same values to fp32 summation-order noise
+    U2, w2, out2 = dev(Upre), f(B * L), f(B, E)
+    hip.call("ebn_attpool_fwd_f32", P(U2), P(dev(bb)), P(dev(q)), P(dev(X)), P(out2), P(w2), B, L, E, A, S())
+    sc2, pr2, rows2, tot2, dc2, du2 = f(B * C), f(B * C), f(B), f(1), f(B * C, E), f(B, E)
+    hip.call("ebn_score_loss_train_f32", P(dev(cand)), P(out2), P(dev(y)), P(sc2), P(pr2), P(rows2), P(tot2), P(dc2), P(du2), B, C, E,
+             LOSS_KINDS[kind], ctypes.c_float(1.0 / B), S())
+    de2, dq2, db2 = f(B * L), f(A), f(A)
+    part2 = f(int(hip.lib().ebn_attpool_partials_len(B * L, A)))
+    hip.call("ebn_attpool_bwd_pool_f32", P(dev(X)), P(w2), P(du2), None, P(de2), B, L, E, S())
+    hip.call("ebn_attpool_bwd_dpre_f32", P(U2), P(dev(q)), P(de2), P(dq2), P(db2), P(part2), B * L, A, 0, S())
+    for got, ref, what in ((o["w"], w2, "w"), (o["user"], out2, "user"), (o["scores"], sc2, "scores"), (o["probs"], pr2, "probs"),
+                           (o["dcand"], dc2, "dcand"), (o["duser"], du2, "duser"), (o["de"], de2, "de"), (U, U2, "dpre"), (o["dq"], dq2, "dq"),
+                           (o["db"], db2, "db")):
+        r = host(ref)
+        assert_close(host(got), r, rtol=2e-4, atol=2e-6 + 2e-5 * np.abs(r).max(), what=f"fused head vs separate kernels: {what}")
+    assert abs(float(o["loss"].item()) - float(tot2.item())) <= 2e-6 * max(1, abs(Lw))
+
+
+def test_user_head_supported_says_what_fits_one_workgroup(hip):
+    sup = hip.lib().ebn_user_head_supported
+    assert sup(20, 5, 400, 200) == 1 and sup(50, 5, 400, 200) == 1  # history_size 20 and 50 at the reference's sizes
+    assert sup(100, 5, 400, 200) == 0  # 100 x (400 + 200) floats do not fit 160 KB: the stage runs its separate kernels
+    assert sup(20, 5, 402, 200) == 0 and sup(20, 5, 400, 202) == 0 and sup(0, 5, 400, 200) == 0
+
+
 def test_pair_score_ragged(hip):
     rng = np.random.default_rng(47)
     nu, nn, E, n_pairs = 7, 13, 400, 101

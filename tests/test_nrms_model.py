@@ -162,6 +162,32 @@ def test_training_steps_follow_the_oracle_trajectory(nrms, loss, p):
         assert_close(got[k].reshape(P[k].shape), P[k], rtol=0, atol=2e-5 + 0.02 * float(step.max()), what=f"weights {k} after 3 steps")
 
 
+@pytest.mark.parametrize("H", [20, 50, 100])
+def test_fused_user_head_step_equals_the_step_with_separate_kernels(nrms, H):
+    """The stage call runs the per-impression head of a step as ONE launch where it fits (H = 20, 50) and as its separate
+    kernels otherwise (H = 100: 100 x 600 floats exceed a workgroup's LDS) -- and `fuse_user_head = False` forces the latter.
+    Loss and every gradient buffer of the two forms agree to fp32 summation-order noise."""
+    hp = make_hp(history_size=H, dropout=0.2)
+    V, D, seed = 300, 64, 4
+    rng = np.random.default_rng(21)
+    P = on.random_nrms_params(V, D, hp.head_num, hp.head_dim, hp.attention_hidden_dim, seed=9)
+    his, pred, y = batch(rng, 5, H, 5, hp.title_size, V)
+    out = []
+    for fuse in (True, False):
+        m = nrms(hp, word2vec_embedding=P["emb"], seed=seed).from_keras_weight_list(weight_list(P))
+        m._engine.fuse_user_head = fuse
+        m._engine.keep_table_grad = True
+        loss = float(m.train_step(his, pred, y).item())
+        out.append((loss, m._engine.params.grad.cpu().numpy().astype(np.float64), m._engine.table_grad.cpu().numpy().astype(np.float64)))
+    (l0, g0, t0), (l1, g1, t1) = out
+    assert abs(l0 - l1) <= 2e-6 * max(1.0, abs(l1))
+    assert_close(g0, g1, rtol=1e-4, atol=1e-7 + 2e-5 * np.abs(g1).max(), what="dense gradients, fused vs separate")
+    assert_close(t0, t1, rtol=1e-4, atol=1e-7 + 2e-5 * np.abs(t1).max(), what="table gradient, fused vs separate")
+    L, _, g = on.nrms_loss_and_grads(his, pred, y, {k: v.astype(np.float32).astype(np.float64) for k, v in P.items()}, hp.head_num, hp.head_dim,
+                                     "cross_entropy_loss", on.Drop(0.2, seed, 1))
+    assert abs(l0 - L) <= 2e-5 * max(1.0, abs(L))
+
+
 def test_gradients_match_oracle_directly(nrms):
     """Backward parity without the optimizer in the way: raw gradient buffers after one step."""
     hp = make_hp(dropout=0.2)
