@@ -232,6 +232,148 @@ class DocVecEngine:
         n_hist, n_cand = self._upload(mb, his, pred)
         self._news_forward(mb, n_hist, n_cand, False)
         dims, params, acts = self._enc(ub, B, mb["NE"])
+        _hip.call("ebn_encoder_fwd_f32", ctypes.byref(dims), ctypes.byref(params), ctypes.byref(acts), ctypes.byref(self._fwd_scratch(ub)), None, _hip.stream_handle())
+        scores, probs = torch.empty(B, C, device=self.device), torch.empty(B, C, device=self.device)
+        _hip.call("ebn_score_fwd_f32", _hip.ptr(mb["NE"][n_hist:]), _hip.ptr(ub.out), _hip.ptr(scores), _hip.ptr(probs), B, C,
+                  self.E, 0 if mode == "softmax" else 1, _hip.stream_handle())
+        return probs, scores
+
+    def eval_loss(self, his, pred, y):
+        probs, scores = self.forward(his, pred)
+        B, C = scores.shape
+        labels = torch.as_tensor(np.asarray(y, dtype=np.float32)).to(self.device).reshape(B, C).contiguous()
+        mb, ub = self._mlp_bufs(B * (self.H + C)), self._user_bufs(B)
+        rows, jc, ju = torch.empty(B, device=self.device), torch.empty(B * C, self.E, device=self.device), torch.empty(B, self.E, device=self.device)
+        loss = torch.empty(1, device=self.device)
+        _hip.call("ebn_score_loss_bwd_f32", _hip.ptr(mb["NE"][B * self.H:]), _hip.ptr(ub.out), _hip.ptr(scores), _hip.ptr(labels),
+                  _hip.ptr(rows), _hip.ptr(jc), _hip.ptr(ju), B, C, self.E, self.loss_kind, ctypes.c_float(1.0 / B), _hip.stream_handle())
+        _hip.call("ebn_sum_f32", _hip.ptr(rows), B, ctypes.c_float(1.0), _hip.ptr(loss), 0, _hip.stream_handle())
+        return loss, probs
+
+    def pair_scores(self, user, news, u_idx, n_idx, sigmoid=True):
+        n = u_idx.numel()
+        out = torch.empty(n, device=self.device)
+        _hip.call("ebn_pair_score_f32", _hip.ptr(user), _hip.ptr(news), _hip.ptr(u_idx), _hip.ptr(n_idx), _hip.ptr(out), n,
+                  self.E, 1 if sigmoid else 0, _hip.stream_handle())
+        return out
+
+    def enable_graphs(self, flag=True):
+        """Capture the per-(B, C) kernel sequence of a train step into a hipGraph (the DocVec step is ~70 small
+        launches: launch-bound without it)."""
+        self.use_graph = bool(flag)
+        if not flag:
+            self._graphs = {}
+        return self
+
+    def set_article_matrix(self, matrix) -> None:
+        """Keep the loader's (n_articles+1, Din) document-vector matrix in HBM (386 MB for the 125 542 EB-NeRD
+        articles x 768); batches can then be article-row numbers, gathered on the device by the embedding-gather
+        kernel (``train_step(..., indexed=True)``)."""
+        m = np.asarray(matrix)
+        if m.ndim != 2 or m.shape[1] != self.Din or not np.issubdtype(m.dtype, np.floating):
+            raise ValueError(f"article matrix must be float (n_articles+1, {self.Din}), got {m.dtype} {m.shape}")
+        self.article_matrix = torch.from_numpy(np.ascontiguousarray(m.astype(np.float32))).to(self.device)
+        self._article_matrix_src = matrix
+        self._oob = torch.zeros(1, dtype=torch.int32, device=self.device)
+
+    def _stage_indexed(self, mb, his_idx, pred_idx, y=None):
+        """Article-row numbers -> mb["art_idx"], then the document vectors are gathered on the device.  Returns y, or None
+        when the labels were copied along (device-resident batch in the step's dtypes: one copy launch for all three)."""
+        n = his_idx.shape[0] * (self.H + pred_idx.shape[1])
+        if "art_idx" not in mb:
+            mb["art_idx"] = torch.empty(mb["N"], dtype=torch.int32, device=self.device)
+        same_dev = lambda t: t.is_cuda and (self.device.index is None or t.device.index == self.device.index)
+        ok = lambda t, dt: isinstance(t, torch.Tensor) and same_dev(t) and t.dtype == dt and t.is_contiguous()
+        if ok(his_idx, torch.int32) and ok(pred_idx, torch.int32) and ok(y, torch.float32):
+            nh = his_idx.numel()
+            _hip.call("ebn_copy3_advance", _hip.ptr(his_idx), _hip.ptr(mb["art_idx"]), nh * 4, _hip.ptr(pred_idx), _hip.ptr(mb["art_idx"][nh:]),
+                      pred_idx.numel() * 4, _hip.ptr(y), _hip.ptr(mb["labels"]), y.numel() * 4, _hip.ptr(self.state), BETA1, BETA2,
+                      _hip.stream_handle())
+            y, self._advanced = None, True  # the step-state advance rode in the staging launch
+        elif not isinstance(his_idx, torch.Tensor) and not isinstance(pred_idx, torch.Tensor) and y is not None and not isinstance(y, torch.Tensor):
+            # host batch (what the loaders hand over): ONE asynchronous copy out of a pinned, double-buffered staging area; the
+            # kernel that unpacks it also advances the step state -- the host never waits for the GPU
+            B, C = his_idx.shape[0], pred_idx.shape[1]
+            n_lab, tot = B * C, n + B * C
+            st = getattr(self, "_host_stage", None)
+            if st is None or st["pinned"][0].numel() < tot:
+                st = self._host_stage = {"pinned": [torch.empty(2 * tot, dtype=torch.int32).pin_memory() for _ in range(2)],
+                                         "dev": torch.empty(2 * tot, dtype=torch.int32, device=self.device), "ev": [None, None], "k": 0}
+            k = st["k"] = st["k"] ^ 1
+            if st["ev"][k] is not None:
+                st["ev"][k].synchronize()
+            hs = st["pinned"][k].numpy()
+            nh = B * self.H
+            hs[:nh] = np.asarray(his_idx).reshape(-1)
+            hs[nh:n] = np.asarray(pred_idx).reshape(-1)
+            hs[n:tot].view(np.float32)[:] = np.asarray(y, dtype=np.float32).reshape(-1)
+            st["dev"][:tot].copy_(st["pinned"][k][:tot], non_blocking=True)
+            st["ev"][k] = torch.cuda.Event()
+            st["ev"][k].record()
+            _hip.call("ebn_copy3_advance", _hip.ptr(st["dev"]), _hip.ptr(mb["art_idx"]), n * 4, None, None, 0, _hip.ptr(st["dev"][n:]),
+                      _hip.ptr(mb["labels"]), n_lab * 4, _hip.ptr(self.state), BETA1, BETA2, _hip.stream_handle())
+            y, self._advanced = None, True
+        else:
+            off = 0
+            for a in (his_idx, pred_idx):
+                t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(a).reshape(-1).astype(np.int32, copy=False)))
+                t = t.reshape(-1)
+                mb["art_idx"][off: off + t.numel()].copy_(t.to(device=self.device, dtype=torch.int32), non_blocking=True)
+                off += t.numel()
+        _hip.call("ebn_gather_rows_f32", _hip.ptr(mb["art_idx"]), _hip.ptr(self.article_matrix), _hip.ptr(mb["X0"]), n, self.Din,
+                  self.article_matrix.shape[0], None, -1, ctypes.c_float(0.0), _hip.ptr(self._oob), _hip.stream_handle())
+        return y
+
+    def train_step(self, his, pred, y, return_probs=False, indexed=False):
+        his = his if isinstance(his, torch.Tensor) else np.asarray(his)
+        pred = pred if isinstance(pred, torch.Tensor) else np.asarray(pred)
+        if not indexed:
+            self._check_shapes(his, pred)
+        elif his.ndim != 2 or his.shape[1] != self.H or pred.ndim != 2 or pred.shape[0] != his.shape[0]:
+            raise ValueError(f"indexed batches must be (B, {self.H}) and (B, C), got {tuple(his.shape)} {tuple(pred.shape)}")
+        B, C = his.shape[0], pred.shape[1]
+        mb, ub = self._mlp_bufs(B * (self.H + C)), self._user_bufs(B)  # (re)allocation clears the captured graphs
+        self._advanced = False
+        if indexed:
+            y = self._stage_indexed(mb, his, pred, y)
+        else:
+            self._upload(mb, his, pred)
+        if y is not None:
+            labels = (y if isinstance(y, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(y, dtype=np.float32))))
+            mb["labels"][: B * C].copy_(labels.reshape(-1).to(device=self.device, dtype=torch.float32))
+        if self.use_graph:
+            # graph(forward + backward) -> gradient all-reduce over RCCL (eager, data-parallel only) -> graph(Adam)
+            adv = self._advanced
+            g = self._graphs.get((B, C, adv))
+            if g is None:
+                torch.cuda.synchronize()
+                g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g1, capture_error_mode="thread_local"):
+                    self._fwd_bwd_kernels(B, C, adv)
+                with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode="thread_local"):
+                    self._optimizer_kernels()
+                g = self._graphs[(B, C, adv)] = (g1, g2)
+            g[0].replay()
+            self._allreduce_grads()
+            g[1].replay()
+        else:
+            self._fwd_bwd_kernels(B, C, self._advanced)
+            self._allreduce_grads()
+            self._optimizer_kernels()
+        if return_probs:
+            return self.loss_dev, mb["probs"][: B * C].view(B, C), mb["labels"][: B * C].view(B, C)
+        return self.loss_dev
+
+    def _fwd_bwd_kernels(self, B, C, advanced=False):
+        E = self.E
+        S = _hip.stream_handle
+        mb, ub = self._mlp_bufs(B * (self.H + C)), self._user_bufs(B)
+        n_hist, n_cand = B * self.H, B * C
+        st = _hip.ptr(self.state)
+        if not advanced:
+            _hip.call("ebn_step_advance", st, BETA1, BETA2, S())
+        self._news_forward(mb, n_hist, n_cand, True)
+        dims, params, acts = self._enc(ub, B, mb["NE"])
         cand = mb["NE"][n_hist:]
         g = self.params.g
         grads = _hip.EncoderGrads(g("u_Wqkv").data_ptr(), g("u_W").data_ptr(), g("u_b").data_ptr(), g("u_q").data_ptr())
