@@ -15,7 +15,7 @@
 
 namespace {
 
-constexpr int HEAD_THREADS = 256;
+constexpr int HEAD_THREADS = 1024;  // 16 waves: every phase is short and latency-bound, the workgroup has its CU to itself
 constexpr float HEAD_KERAS_EPS = 1e-7f;  // K.epsilon(), layers.py:75-77
 
 struct HeadArgs {
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(HEAD_THREADS) void user_head_train_kernel(HeadArgs 
     const float4* Xg = reinterpret_cast<const float4*>(a.X + bi * L * E);
     const float4* Cg = reinterpret_cast<const float4*>(a.cand + bi * C * E);
     const float4* bg = reinterpret_cast<const float4*>(a.b);
-    constexpr int NB = 8;
+    constexpr int NB = 2;  // float4 loads per thread in flight per batch (1024 threads: 32 KB per batch)
     for (int base = 0; base < L * E4; base += HEAD_THREADS * NB) {
       float4 v[NB];
 #pragma unroll
