@@ -55,6 +55,7 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: exact-fp32 MFMA = vector peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (16x the exact-fp32 rate)
 
 CONFIGS = {
     # name: (V, D, H, C, T, h, d, A, train_embedding, per-GPU batch)
@@ -222,7 +223,7 @@ def being_profiled() -> bool:
     return any(k.startswith(("ROCP_", "ROCPROF", "ROCPROFILER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
 
 
-def probe_kernels(config, batch):
+def probe_kernels(config, batch, precision="exact"):
     """Kernel names and HBM traffic of the two roofline kernels, observed IN THIS RUN: three rocprofv3 passes over
     `bench.py --kernel-probe` (a subprocess that builds the same engine and launches the Q|K|V projection and the gather
     eagerly on the step's buffers): (1) --kernel-trace --stats -> the names as the profiler sees them, (2) --pmc FETCH_SIZE
@@ -238,7 +239,8 @@ def probe_kernels(config, batch):
         return None
     out = {}
     tmp = tempfile.mkdtemp(prefix="ebn_probe_", dir=os.environ.get("TMPDIR", "/tmp"))
-    probe = [sys.executable, str(Path(__file__).resolve()), "--kernel-probe", "--config", config] + (["--batch", str(batch)] if batch else [])
+    probe = [sys.executable, str(Path(__file__).resolve()), "--kernel-probe", "--config", config, "--precision", precision] + \
+        (["--batch", str(batch)] if batch else [])
     env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
     try:
         for tag, flags in (("stats", ["--kernel-trace", "--stats"]), ("fetch", ["--pmc", "FETCH_SIZE", "--kernel-trace"]),
@@ -376,6 +378,10 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=20, help="timed steps of the CPU baseline (after 5 warm-ups; SURVEY.md 8d)")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel roofline timing (counter-collection passes)")
     ap.add_argument("--no-probe", action="store_true", help="skip the rocprofv3 passes behind roofline.kernel / roofline.traffic (labelled static then)")
+    ap.add_argument("--precision", default="exact", choices=["exact", "split"],
+                    help="exact: every matmul on the exact-fp32 MFMA kernels (the headline). split: the news encoder's projection GEMMs as "
+                         "bf16x6 split products on the bf16 matrix pipe -- fp32-accurate (three bf16 planes per operand, six cross products, "
+                         "fp32 accumulate), an opt-in second precision with its own line")
     ap.add_argument("--kernel-probe", action="store_true", help="internal: launch the two roofline kernels a few times on the step's "
                                                                 "buffers and exit (what probe_kernels() wraps rocprofv3 around)")
     args = ap.parse_args()
@@ -422,7 +428,7 @@ def main():
     rng = np.random.default_rng(42)  # identical weights on every rank (data-parallel replicas)
     table = (rng.standard_normal((c["V"], c["D"]), dtype=np.float32) * 0.02) if not c["train_embedding"] else None
     model = NRMSModel(make_hparams(c), word2vec_embedding=table, word_emb_dim=c["D"], vocab_size=c["V"], seed=42,
-                      train_embedding=c["train_embedding"], device=device, shard_table=sharded)
+                      train_embedding=c["train_embedding"], device=device, shard_table=sharded, precision=args.precision)
     del table
     eng = model._engine
     batches = synthetic_batches(c, 8, 123 + rank, device)
@@ -458,7 +464,7 @@ def main():
         gemm_name = (f"gemm_f32_kernel<{bm.value}, {bn.value}, {4 if bm.value == 256 else 2}, false, false, true, 1, 0>" if bm.value != 32
                      else "gemm_small_vec_kernel<false, false, 32>") + f" (ebn_gemm_plan: tile {bm.value}x{bn.value}, split-K {sp.value})"
         gather_bytes = n_tok * (4 + 2 * c["D"] * 4)  # id + row read + row write (materialising gather)
-        probed = None if (args.no_probe or args.no_roofline or world > 1) else probe_kernels(args.config, args.batch)
+        probed = None if (args.no_probe or args.no_roofline or world > 1) else probe_kernels(args.config, args.batch, args.precision)
         if probed and "traffic" in probed.get("qkv_gemm", {}) and "traffic" in probed.get("gather", {}):
             traffic = {k: v["traffic"] for k, v in probed.items()}
             traffic_source = ("measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over "
@@ -477,7 +483,8 @@ def main():
             "metric": "training impressions/sec", **timing_fields(times, args, world, c["B"]), "unit": "impressions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "launch": "eager" if (args.no_graph or not eng.graph_capable) else "hipGraph replay",
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.precision == "exact" else "f32 (bf16x6 split, fp32 accumulate)", "data": "synthetic",
             "config": {"workload": f"NRMS train step, BASELINE.json configs[{cfg_idx}] "
                                    f"({args.config}): table {c['V']}x{c['D']} {table_kind}, "
                                    f"history_size={c['H']} npratio={c['C'] - 1} title_len={c['T']} head={c['h']}x{c['d']} "
@@ -485,13 +492,32 @@ def main():
                        "global_batch": world * c["B"], "per_gpu_batch": c["B"], "parallelism": f"dp{world}",
                        "final_loss": loss},
         }
+        if args.precision == "split":
+            line["precision_note"] = ("OPT-IN second precision, not the headline: the news encoder's projection GEMMs (forward Q|K|V and its "
+                                      "weight gradient) split every fp32 operand exactly into three bf16 values and keep the six leading cross "
+                                      "products (v_mfma_f32_32x32x16_bf16, fp32 accumulate); dropped terms < 2^-23 per product; every other kernel "
+                                      "is the exact-fp32 one.  Same tolerances as the exact path in tests/test_hip_kernels.py")
         fl_step = step_flops(c)
         line["roofline_step"] = {"what": "the whole training step against the exact-fp32 MFMA peak: exact matmul FLOPs of one step "
                                          "(every GEMM and attention contraction, forward and backward) / ms_per_step",
                                  "bound": "mfma", "achieved": fl_step / (line["ms_per_step"] * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
                                  "unit": "TFLOP/s", "frac": fl_step / (line["ms_per_step"] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
                                  "algorithmic_flops_per_step": fl_step}
-        if kt is not None:
+        if kt is not None and args.precision == "split":
+            # the projection as the step runs it: two split passes + the bf16x6 GEMM (six bf16 MFMA products per fp32 product)
+            line["roofline"] = {"kernel": gemm_name, "role": "news-encoder Q|K|V projection, forward, as split passes + bf16x6 GEMM "
+                                "(timed together: three launches)", "kernel_name_source": name_source, "bound": "mfma",
+                                "achieved": 6.0 * gemm_flops / kt["qkv_gemm"] / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": 6.0 * gemm_flops / kt["qkv_gemm"] / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                                "fp32_equivalent_tflops": gemm_flops / kt["qkv_gemm"] / 1e12, "traffic": traffic.get("qkv_gemm"),
+                                "traffic_source": traffic_source, "avg_launch_us": kt["qkv_gemm"] * 1e6,
+                                "algorithmic_flops_per_launch": 6.0 * gemm_flops}
+            line["roofline_gather"] = {"kernel": gather_name, "role": "title-token embedding gather + dropout", "kernel_name_source": name_source,
+                                       "bound": "hbm", "achieved": gather_bytes / kt["gather"] / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": gather_bytes / kt["gather"] / 1e9 / HBM_PEAK_GBS, "traffic": traffic.get("gather"),
+                                       "traffic_source": traffic_source, "avg_launch_us": kt["gather"] * 1e6,
+                                       "algorithmic_bytes_per_launch": gather_bytes}
+        elif kt is not None:
             line.update({
             "roofline": {"kernel": gemm_name, "role": "news-encoder Q|K|V projection, forward (the time-dominant kernel)",
                          "kernel_name_source": name_source, "bound": "mfma",

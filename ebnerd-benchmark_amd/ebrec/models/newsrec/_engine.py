@@ -134,8 +134,12 @@ class NRMSEngine:
                  train_embedding: bool = True, device=None, process_group=None, shard_table: bool = False,
                  shard_mode: str = "alltoall", deterministic: bool = True, units=None, l2: float = 0.0,
                  shard_partition: str | None = None, shard_capacity_factor: float = 1.25, table_grad_exchange: str = "auto",
-                 bce_on: str = "logits"):
+                 bce_on: str = "logits", precision: str = "exact"):
         self.device = require_gpu() if device is None else torch.device(device)
+        if precision not in ("exact", "split"):
+            raise ValueError(f"precision must be 'exact' (fp32 MFMA, the default) or 'split' (bf16x6 split on the bf16 matrix pipe, "
+                             f"fp32-accurate, fp32 accumulate), got {precision}")
+        self.precision = precision
         if loss not in LOSS_KIND:
             raise ValueError(f"this loss not defined {loss}")
         loss_kind_of(loss, bce_on)
@@ -388,6 +392,8 @@ class NRMSEngine:
         st = _hip.ptr(self.state) if train else None
         if pre == "n" and self.mlp is not None:
             return self._news_encoder_fwd_mlp(b, n_seq, X, train, n_seq if n_first is None else n_first)
+        if pre == "n" and self.precision == "split":
+            return self._news_encoder_fwd_split(b, n_seq, X, st, site, p)
         dims, params, acts = self._enc_structs(pre, b, n_seq, X, site, p)
         _hip.call("ebn_encoder_fwd_f32", ctypes.byref(dims), ctypes.byref(params), ctypes.byref(acts),
                   ctypes.byref(self._fwd_scratch(b)), st, _hip.stream_handle())
@@ -432,6 +438,59 @@ class NRMSEngine:
             _hip.call("ebn_gemm_f32_ws", 0, 1, R, b.Din, 3 * E, one, _hip.ptr(b.dQKV), 3 * E, _hip.ptr(pv("n_Wqkv")), 3 * E, zero,
                       _hip.ptr(dX), b.Din, ws, wsn, S())
 
+    # ---- precision = "split": the news encoder's two (three, with a trainable table) big projection GEMMs run as bf16x6 split
+    # products on the bf16 matrix pipe (ebn_gemm_f32_prec, precision 1); everything else is the same kernels in the same
+    # order as ebn_encoder_fwd_f32 / ebn_encoder_bwd_f32 (csrc/ebn_encoder.hip)
+    def _split_ws(self, b):
+        if getattr(b, "split_ws", None) is None:
+            f = _hip.lib().ebn_gemm_prec_workspace_bytes
+            R, E3, D = b.R, 3 * b.E, b.Din
+            nbytes = max(int(f(R, E3, D, 1)), int(f(D, E3, R, 1)), int(f(R, D, E3, 1)) if b.dX is not None else 0)
+            b.split_ws = torch.empty(nbytes // 4 + 64, device=self.device)
+            b.split_ws_bytes = nbytes
+        return b.split_ws
+
+    def _gemm_prec(self, b, tA, tB, M, N, K, A, lda, Bm, ldb, C, ldc):
+        ws = self._split_ws(b)
+        _hip.call("ebn_gemm_f32_prec", tA, tB, M, N, K, ctypes.c_float(1.0), _hip.ptr(A), lda, _hip.ptr(Bm), ldb, ctypes.c_float(0.0),
+                  _hip.ptr(C), ldc, _hip.ptr(ws), b.split_ws_bytes, 1, _hip.stream_handle())
+
+    def _news_encoder_fwd_split(self, b, n_seq, X, st, site, p):
+        S, E, A, T = _hip.stream_handle, self.E, self.A, b.L
+        R = n_seq * T
+        pv = self.params.view
+        self._gemm_prec(b, 0, 0, R, 3 * E, b.Din, X, b.Din, pv("n_Wqkv"), 3 * E, b.QKV, 3 * E)      # layers.py:214,220,226
+        _hip.call("ebn_attn_fwd_f32", _hip.ptr(b.QKV), 3 * E, _hip.ptr(b.Y), E, n_seq, T, self.h, self.d, st, site, ctypes.c_float(p), S())
+        _hip.call("ebn_gemm_f32_ws", 0, 0, R, A, E, ctypes.c_float(1.0), _hip.ptr(b.Y), E, _hip.ptr(pv("n_W")), A, ctypes.c_float(0.0),
+                  _hip.ptr(b.U), A, _hip.ptr(b.ws), b.ws.numel(), S())
+        _hip.call("ebn_attpool_fwd_f32", _hip.ptr(b.U), _hip.ptr(pv("n_b")), _hip.ptr(pv("n_q")), _hip.ptr(b.Y), _hip.ptr(b.out),
+                  _hip.ptr(b.w), n_seq, T, E, A, S())
+
+    def _news_encoder_bwd_split(self, b, n_seq, X, dout, dX, site, p):
+        S, E, A, T = _hip.stream_handle, self.E, self.A, b.L
+        R = n_seq * T
+        pv, g = self.params.view, self.params.g
+        ws, wsn = _hip.ptr(b.ws), b.ws.numel()
+        one, zero = ctypes.c_float(1.0), ctypes.c_float(0.0)
+        st = _hip.ptr(self.state)
+        _hip.call("ebn_attpool_bwd_pool_f32", _hip.ptr(b.Y), _hip.ptr(b.w), _hip.ptr(dout), None, _hip.ptr(b.de), n_seq, T, E, S())
+        _hip.call("ebn_attpool_bwd_dpre_f32", _hip.ptr(b.U), _hip.ptr(pv("n_q")), _hip.ptr(b.de), _hip.ptr(g("n_q")), _hip.ptr(g("n_b")),
+                  _hip.ptr(b.partials), R, A, 0, S())
+        if int(_hip.lib().ebn_attn_bwd_pooled_supported(T, self.d)) != 0 and E % 4 == 0:
+            _hip.call("ebn_dense_bwd_pair_f32", R, E, A, _hip.ptr(b.Y), E, _hip.ptr(b.U), A, _hip.ptr(pv("n_W")), A, zero, _hip.ptr(g("n_W")), A,
+                      _hip.ptr(b.dY), E, ws, wsn, S())
+            _hip.call("ebn_attn_bwd_pooled_f32", _hip.ptr(b.QKV), 3 * E, _hip.ptr(b.dY), E, _hip.ptr(b.w), _hip.ptr(dout), E, _hip.ptr(b.dQKV), 3 * E,
+                      n_seq, T, self.h, self.d, st, site, ctypes.c_float(p), S())
+        else:
+            _hip.call("ebn_gemm_f32_ws", 1, 0, E, A, R, one, _hip.ptr(b.Y), E, _hip.ptr(b.U), A, zero, _hip.ptr(g("n_W")), A, ws, wsn, S())
+            _hip.call("ebn_gemm_f32_rank1", R, E, A, one, _hip.ptr(b.U), A, _hip.ptr(pv("n_W")), A, _hip.ptr(b.dY), E, _hip.ptr(b.w), _hip.ptr(dout), E,
+                      T, ws, wsn, S())
+            _hip.call("ebn_attn_bwd_f32", _hip.ptr(b.QKV), 3 * E, _hip.ptr(b.dY), E, _hip.ptr(b.dQKV), 3 * E, n_seq, T, self.h, self.d, st, site,
+                      ctypes.c_float(p), S())
+        self._gemm_prec(b, 1, 0, b.Din, 3 * E, R, X, b.Din, b.dQKV, 3 * E, g("n_Wqkv"), 3 * E)        # dWqkv = X^T . dQKV
+        if dX is not None:
+            self._gemm_prec(b, 0, 1, R, b.Din, 3 * E, b.dQKV, 3 * E, pv("n_Wqkv"), 3 * E, dX, b.Din)  # dX = dQKV . Wqkv^T
+
     def roofline_kernels(self, B, C):
         """Launchers of single kernels of the training step at batch shape (B, C), on the step's own buffers and arguments
         (bench.py captures them into hipGraphs and times them with HIP events on the launch stream): "qkv_gemm" = zero-
@@ -445,6 +504,8 @@ class NRMSEngine:
         st = _hip.ptr(self.state)
 
         def qkv_gemm():
+            if self.precision == "split":  # the two split passes + the bf16x6 GEMM, as the step runs them
+                return self._gemm_prec(nb, 0, 0, R, 3 * E, nb.Din, nb.X, nb.Din, pv("n_Wqkv"), 3 * E, nb.QKV, 3 * E)
             _hip.call("ebn_gemm_f32_site", 0, 0, R, 3 * E, nb.Din, ctypes.c_float(1.0), _hip.ptr(nb.X), nb.Din,
                       _hip.ptr(pv("n_Wqkv")), 3 * E, ctypes.c_float(0.0), _hip.ptr(nb.QKV), 3 * E, _hip.ptr(nb.ws), nb.ws.numel(), 1, S())
 
@@ -467,6 +528,8 @@ class NRMSEngine:
         if pre == "n" and self.mlp is not None:
             return self._news_encoder_bwd_mlp(b, n_seq, X, dout, dX, n_seq if n_first is None else n_first)
         site, p = (1, self.p) if (pre == "n" and self.p > 0) else (-1, 0.0)
+        if pre == "n" and self.precision == "split":
+            return self._news_encoder_bwd_split(b, n_seq, X, dout, dX, site, p)
         dims, params, acts = self._enc_structs(pre, b, n_seq, X, site, p)
         g = self.params.g
         grads = _hip.EncoderGrads(g(f"{pre}_Wqkv").data_ptr(), g(f"{pre}_W").data_ptr(), g(f"{pre}_b").data_ptr(),

@@ -39,7 +39,7 @@ class NRMSModel:
                  vocab_size: int = 32000, seed: int = None, *, train_embedding: bool = True, device=None,
                  process_group=None, shard_table: bool = False, shard_mode: str = "alltoall",
                  deterministic: bool = True, shard_partition: str | None = None, shard_capacity_factor: float = 1.25,
-                 table_grad_exchange: str = "auto", bce_on: str = "logits"):
+                 table_grad_exchange: str = "auto", bce_on: str = "logits", precision: str = "exact"):
         self.hparams = hparams
         self.seed = seed
         if seed is not None:
@@ -59,7 +59,7 @@ class NRMSModel:
             seed=seed, train_embedding=train_embedding, device=device, process_group=process_group,
             shard_table=shard_table, shard_mode=shard_mode, deterministic=deterministic,
             shard_partition=shard_partition, shard_capacity_factor=shard_capacity_factor,
-            table_grad_exchange=table_grad_exchange, bce_on=bce_on,
+            table_grad_exchange=table_grad_exchange, bce_on=bce_on, precision=precision,
             units=getattr(hparams, "newsencoder_units_per_layer", None),
             l2=getattr(hparams, "newsencoder_l2_regularization", 0.0))
         self.model, self.scorer = self._build_graph()

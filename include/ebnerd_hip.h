@@ -98,6 +98,22 @@ int ebn_adam_keras_step_fixed_f32(float* theta, int64_t* acc, float* m, float* v
                                   double beta1, double beta2, double eps, float grad_scale, int32_t* range_flag,
                                   ebn_stream_t stream);
 
+/* ---- an OPT-IN second precision of the projection matmuls (layers.py:214-226 and their weight gradient): fp32-accurate
+ * GEMM on the bf16 matrix pipe.  Each fp32 operand element is split exactly into three bf16 values (8 + 8 + 8 significand
+ * bits) and the product keeps the six leading cross terms, each a bf16 MFMA with fp32 accumulation; the dropped terms are
+ * below 2^-23 of |a.b| per product, i.e. below the rounding of the fp32 accumulation itself.  Same argument meaning as
+ * ebn_gemm_f32 (all four layouts, alpha / beta, leading dimensions); `workspace`: ebn_gemm_split_workspace_bytes(M, N, K) bytes,
+ * 16-byte aligned (the bf16 planes of both operands + deterministic split-K partials).  The exact-fp32 kernels stay the default
+ * everywhere; ebn_gemm_f32_prec selects by `precision` (0 = exact fp32, 1 = bf16x6 split).                               */
+int64_t ebn_gemm_split_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int ebn_gemm_f32_split(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K, float alpha, const float* A,
+                       int64_t lda, const float* B, int64_t ldb, float beta, float* C, int64_t ldc, void* workspace,
+                       int64_t workspace_bytes, ebn_stream_t stream);
+int64_t ebn_gemm_prec_workspace_bytes(int64_t M, int64_t N, int64_t K, int32_t precision);
+int ebn_gemm_f32_prec(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K, float alpha, const float* A,
+                      int64_t lda, const float* B, int64_t ldb, float beta, float* C, int64_t ldc, void* workspace,
+                      int64_t workspace_bytes, int32_t precision, ebn_stream_t stream);
+
 /* ---- row-sharded Embedding (BASELINE.json configs[4]; no reference counterpart: nrms.py:125-134 keeps one table on
  * one device) -- device-side plan of a lookup into a table whose rows are split over `world` ranks (rank o owns the
  * block [o*per, (o+1)*per), per = ceil(V/world); or, cyclic != 0, the ids = o mod world).  Dedups the n_tok local ids

@@ -127,6 +127,56 @@ def test_gemm_all_layouts(hip, M, N, K, tA, tB):
         assert_close(host(C), want, rtol=2e-6, atol=1e-5 + 3e-7 * K, what=f"gemm {M}x{N}x{K} tA={tA} tB={tB} a={alpha} b={beta} ws={use_ws}")
 
 
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+@pytest.mark.parametrize("tA,tB", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_split_precision_gemm_holds_the_exact_path_tolerances(hip, M, N, K, tA, tB):
+    """ebn_gemm_f32_prec(precision = 1): every fp32 operand element split exactly into three bf16 values, six bf16 MFMA
+    products with fp32 accumulation.  The SAME shapes, layouts, alpha / beta cases and tolerances (rtol 2e-6 against float64)
+    as test_gemm_all_layouts asserts for the exact-fp32 kernels -- an opt-in precision that is not a reduced one."""
+    rng = np.random.default_rng(M * 131 + N * 17 + K)
+    A = rng.standard_normal((K, M) if tA else (M, K)).astype(np.float32)
+    B = rng.standard_normal((N, K) if tB else (K, N)).astype(np.float32)
+    C0 = rng.standard_normal((M, N)).astype(np.float32)
+    ref = (A.T if tA else A).astype(np.float64) @ (B.T if tB else B).astype(np.float64)
+    nbytes = int(hip.lib().ebn_gemm_prec_workspace_bytes(M, N, K, 1))
+    ws = torch.empty(nbytes // 4 + 64, device="cuda")
+    for alpha, beta in ((1.0, 0.0), (0.5, 1.0), (2.0, -0.5)):
+        C = dev(C0)
+        hip.call("ebn_gemm_f32_prec", tA, tB, M, N, K, ctypes.c_float(alpha), P(dev(A)), A.shape[1], P(dev(B)), B.shape[1], ctypes.c_float(beta),
+                 P(C), N, P(ws), nbytes, 1, S())
+        assert_close(host(C), alpha * ref + beta * C0, rtol=2e-6, atol=1e-5 + 3e-7 * K, what=f"split gemm {M}x{N}x{K} tA={tA} tB={tB} a={alpha} b={beta}")
+    # precision 0 through the same entry point is the exact path, bit for bit
+    C1, C2 = dev(C0), dev(C0)
+    n0 = int(hip.lib().ebn_gemm_prec_workspace_bytes(M, N, K, 0))
+    ws0 = torch.empty(max(n0 // 4, 1), device="cuda")
+    hip.call("ebn_gemm_f32_prec", tA, tB, M, N, K, ctypes.c_float(1.0), P(dev(A)), A.shape[1], P(dev(B)), B.shape[1], ctypes.c_float(0.0), P(C1), N,
+             P(ws0), n0, 0, S())
+    gemm(tA, tB, M, N, K, 1.0, dev(A), A.shape[1], dev(B), B.shape[1], 0.0, C2, N, ws0)
+    assert torch.equal(C1, C2)
+
+
+def test_split_precision_is_fp32_accurate_not_bf16_accurate(hip):
+    """The six-product split against the exact-fp32 kernel on the projection's contraction length: the two differ from float64
+    by the same order (fp32 accumulation noise); a plain bf16 product would be off by ~3e-3 relative.  Asymmetric operands with
+    padded leading dimensions (an operand or output swap cannot hide), ragged M / N / K (zero padding of the planes)."""
+    M, N, K = 777, 333, 1030
+    rng = np.random.default_rng(3)
+    A = (rng.standard_normal((M, K + 6)) * np.exp(rng.standard_normal((M, 1)))).astype(np.float32)  # rows of very different scale
+    B = rng.standard_normal((K, N + 2)).astype(np.float32)
+    ref = A[:, :K].astype(np.float64) @ B[:, :N].astype(np.float64)
+    nbytes = int(hip.lib().ebn_gemm_prec_workspace_bytes(M, N, K, 1))
+    ws = torch.empty(nbytes // 4 + 64, device="cuda")
+    Cs, Ce = torch.full((M, N + 3), 9.0, device="cuda"), torch.full((M, N + 3), 9.0, device="cuda")
+    hip.call("ebn_gemm_f32_prec", 0, 0, M, N, K, ctypes.c_float(1.0), P(dev(A)), K + 6, P(dev(B)), N + 2, ctypes.c_float(0.0), P(Cs), N + 3, P(ws), nbytes, 1, S())
+    gemm(0, 0, M, N, K, 1.0, dev(A), K + 6, dev(B), N + 2, 0.0, Ce, N + 3)
+    assert torch.all(Cs[:, N:] == 9.0)  # the padding columns of C are untouched
+    scale = np.abs(A[:, :K]).astype(np.float64) @ np.abs(B[:, :N]).astype(np.float64)  # sum |a||b| per output: the error scale
+    err_s = np.abs(host(Cs)[:, :N] - ref) / scale
+    err_e = np.abs(host(Ce)[:, :N] - ref) / scale
+    assert err_s.max() < 3e-7 and err_e.max() < 3e-7, (err_s.max(), err_e.max())  # both: a few fp32 ulps of the error scale
+    assert err_s.max() < 4 * err_e.max() + 1e-8  # ... and of the same order
+
+
 def test_gemm_is_asymmetric_safe_and_respects_ld(hip):
     """A = I against an asymmetric B, with padded leading dimensions (catches C^T / operand swaps)."""
     M = N = K = 96

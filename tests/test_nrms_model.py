@@ -188,6 +188,46 @@ def test_fused_user_head_step_equals_the_step_with_separate_kernels(nrms, H):
     assert abs(l0 - L) <= 2e-5 * max(1.0, abs(L))
 
 
+@pytest.mark.parametrize("train_embedding", [False, True])
+def test_split_precision_model_holds_the_exact_model_tolerances(nrms, train_embedding):
+    """NRMSModel(precision="split"): the news encoder's projection GEMMs as bf16x6 split products on the bf16 matrix pipe.
+    The SAME assertions as the exact path: forward probabilities to 1e-5 of the float64 oracle (10x inside north_star's 1e-4),
+    loss / gradients / three-step Adam trajectory to the tolerances of test_training_steps_follow_the_oracle_trajectory."""
+    hp = make_hp(dropout=0.2, learning_rate=1e-3)
+    V, D, seed = 400, 300, 11
+    rng = np.random.default_rng(8)
+    P = on.random_nrms_params(V, D, hp.head_num, hp.head_dim, hp.attention_hidden_dim, seed=5)
+    m = nrms(hp, word2vec_embedding=P["emb"], seed=seed, precision="split", train_embedding=train_embedding).from_keras_weight_list(weight_list(P))
+    assert m._engine.precision == "split"
+    P = {k: v.astype(np.float32).astype(np.float64) for k, v in P.items()}
+    P0 = {k: v.copy() for k, v in P.items()}
+    his, pred, y = batch(rng, 7, hp.history_size, 5, hp.title_size, V)
+    probs, _, _ = on.nrms_forward(his, pred, P, hp.head_num, hp.head_dim)
+    assert_close(m.model.predict((his, pred)), probs, rtol=0, atol=1e-5, what="split precision: click probabilities")
+    mom = {k: (np.zeros_like(v), np.zeros_like(v)) for k, v in P.items()}
+    m._engine.keep_table_grad = True
+    for t in range(1, 4):
+        his, pred, y = batch(rng, 8, hp.history_size, 5, hp.title_size, V)
+        L, _, g = on.nrms_loss_and_grads(his, pred, y, P, hp.head_num, hp.head_dim, "cross_entropy_loss", on.Drop(0.2, seed, t))
+        got_L = float(m.train_step(his, pred, y).item())
+        assert abs(got_L - L) <= 2e-5 * max(1.0, abs(L)), (t, got_L, L)
+        if t == 1:
+            want = np.concatenate([g["n_WQ"], g["n_WK"], g["n_WV"]], 1)
+            assert_close(m._engine.params.g("n_Wqkv").cpu().numpy(), want, rtol=1e-4, atol=1e-6 + 1e-4 * np.abs(want).max(), what="split precision: dWqkv")
+            if train_embedding:
+                assert_close(m._engine.table_grad.cpu().numpy(), g["emb"], rtol=1e-4, atol=1e-6 + 1e-4 * np.abs(g["emb"]).max(), what="split precision: dEmb")
+        for k in P:
+            if k == "emb" and not train_embedding:
+                continue
+            on.adam_keras_step(P[k], g[k], mom[k][0], mom[k][1], t, lr=1e-3)
+    got = dict(zip(on.PARAM_ORDER, m.model.get_weights()))
+    for k in on.PARAM_ORDER:
+        step = np.abs(P[k] - P0[k])
+        assert_close(got[k].reshape(P[k].shape), P[k], rtol=0, atol=2e-5 + 0.02 * float(step.max()), what=f"split precision: weights {k} after 3 steps")
+    with pytest.raises(ValueError):
+        nrms(hp, word_emb_dim=16, vocab_size=50, precision="bf16")
+
+
 def test_gradients_match_oracle_directly(nrms):
     """Backward parity without the optimizer in the way: raw gradient buffers after one step."""
     hp = make_hp(dropout=0.2)
