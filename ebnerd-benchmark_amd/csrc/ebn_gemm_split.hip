@@ -17,6 +17,8 @@
 //   gemm_bf16x6_kernel    C[M,N] = A . B^T on those planes, block tile 256 x 128 x 16, 4 waves as 2 x 2 (wave tile 128 x 64 =
 //                         4 x 2 MFMA tiles, 48 MFMAs per slab), double-buffered LDS (2 x 36 KB: two workgroups per CU), one
 //                         barrier per slab, XCD-aware tile order, deterministic split-K through slab partials.
+#include <stdlib.h>
+
 #include "ebn_common.h"
 
 typedef float ebn_f32x4s __attribute__((ext_vector_type(4)));
@@ -33,11 +35,15 @@ typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 constexpr int SP_BM = 256, SP_BN = 128, SP_BK = 16;
 constexpr int SP_THREADS = 256;
 
-// round-to-nearest-even bf16 of a finite fp32 (the operands of a training step are finite; NaN/Inf propagate as bf16 NaN/Inf
-// through the first plane and poison the product as they would in fp32)
+// round-to-nearest-even bf16 of an fp32: the hardware conversion of gfx950 (v_cvt_pk_bf16_f32)
 __device__ __forceinline__ uint32_t bf16_rne_bits(float x) {
+#ifdef EBN_SPLIT_SW_RNE  // tuning: integer rounding instead of the conversion instruction
   const uint32_t u = __float_as_uint(x);
   return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+#else
+  const __bf16 h = static_cast<__bf16>(x);
+  return static_cast<uint32_t>(__builtin_bit_cast(unsigned short, h));
+#endif
 }
 __device__ __forceinline__ void split3(float x, uint16_t& p0, uint16_t& p1, uint16_t& p2) {
   const uint32_t b0 = bf16_rne_bits(x);
@@ -105,9 +111,8 @@ __device__ __forceinline__ ebn_i32x4s make_rsrc_s(const void* base) {
 }
 
 // C[M,N] (+ split-K partials) = A . B^T, A planes [3][Kp/8][a_rows][8], B planes [3][Kp/8][b_rows][8] (a_rows, b_rows multiples of
-// the tile, Kp a multiple of 16).  `ws` is the base of the buffer holding BOTH plane sets (one buffer resource, byte offsets
-// a_off / b_off; everything below 4 GB from `ws`).
-__global__ __launch_bounds__(SP_THREADS, 2) void gemm_bf16x6_kernel(const uint16_t* __restrict__ ws, uint32_t a_off, uint32_t b_off,
+// 256, Kp a multiple of 16; each plane set below 4 GB: 32-bit byte offsets inside its buffer resource).
+__global__ __launch_bounds__(SP_THREADS, 2) void gemm_bf16x6_kernel(const uint16_t* __restrict__ Apl, const uint16_t* __restrict__ Bpl,
                                                                     uint32_t a_rows, uint32_t b_rows, uint32_t Kp, int64_t M,
                                                                     int64_t N, float* __restrict__ C, int64_t ldc,
                                                                     int32_t slabs_per_split, float* __restrict__ Cpart) {
@@ -139,7 +144,7 @@ __global__ __launch_bounds__(SP_THREADS, 2) void gemm_bf16x6_kernel(const uint16
   // ---- tile fetch: per slab 24 KB of A (3 planes x 2 octets x 256 rows x 16 B) and 12 KB of B, as 36 wave instructions of 1 KB
   // (64 rows x 16 B, contiguous in memory AND in LDS); wave w issues A pieces 6w..6w+5 and B pieces 3w..3w+2.
   // Byte offset of a piece inside the buffer resource = operand offset + (plane * plane_bytes) + ((2 s + octet) * rows + row0) * 16.
-  const ebn_i32x4s rsrc = make_rsrc_s(ws);
+  const ebn_i32x4s arsrc = make_rsrc_s(Apl), brsrc = make_rsrc_s(Bpl);
   const uint32_t a_plane_b = (Kp / 8) * a_rows * 16u, b_plane_b = (Kp / 8) * b_rows * 16u;
   const uint32_t a_slab_b = 2u * a_rows * 16u, b_slab_b = 2u * b_rows * 16u;  // bytes per 16-deep slab (two octets)
   uint32_t a_src[6], b_src[3];  // scalar: piece base at slab 0 of this split
@@ -147,14 +152,14 @@ __global__ __launch_bounds__(SP_THREADS, 2) void gemm_bf16x6_kernel(const uint16
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
     const int q = wave * 6 + j, p = q >> 3, oct = (q >> 2) & 1, chunk = q & 3;
-    a_src[j] = a_off + static_cast<uint32_t>(p) * a_plane_b + (static_cast<uint32_t>(oct) * a_rows + static_cast<uint32_t>(m0) + chunk * 64u) * 16u +
+    a_src[j] = static_cast<uint32_t>(p) * a_plane_b + (static_cast<uint32_t>(oct) * a_rows + static_cast<uint32_t>(m0) + chunk * 64u) * 16u +
                static_cast<uint32_t>(s_beg) * a_slab_b;
     a_dst[j] = ((p * 2 + oct) * BM + chunk * 64) * 8;
   }
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
     const int q = wave * 3 + j, p = q >> 2, oct = (q >> 1) & 1, chunk = q & 1;
-    b_src[j] = b_off + static_cast<uint32_t>(p) * b_plane_b + (static_cast<uint32_t>(oct) * b_rows + static_cast<uint32_t>(n0) + chunk * 64u) * 16u +
+    b_src[j] = static_cast<uint32_t>(p) * b_plane_b + (static_cast<uint32_t>(oct) * b_rows + static_cast<uint32_t>(n0) + chunk * 64u) * 16u +
                static_cast<uint32_t>(s_beg) * b_slab_b;
     b_dst[j] = A_ELEMS + ((p * 2 + oct) * BN + chunk * 64) * 8;
   }
@@ -163,10 +168,10 @@ __global__ __launch_bounds__(SP_THREADS, 2) void gemm_bf16x6_kernel(const uint16
 #define SP_FETCH(BUFI)                                                                                                   \
   do {                                                                                                                   \
     _Pragma("unroll") for (int j = 0; j < 6; ++j)                                                                        \
-      ebn_raw_buffer_load_lds_s(rsrc, (__attribute__((address_space(3))) void*)(smem + (BUFI) * BUF + a_dst[j]), 16, lane_b, \
+      ebn_raw_buffer_load_lds_s(arsrc, (__attribute__((address_space(3))) void*)(smem + (BUFI) * BUF + a_dst[j]), 16, lane_b, \
                                 static_cast<int>(a_src[j] + sa), 0, 0);                                                  \
     _Pragma("unroll") for (int j = 0; j < 3; ++j)                                                                        \
-      ebn_raw_buffer_load_lds_s(rsrc, (__attribute__((address_space(3))) void*)(smem + (BUFI) * BUF + b_dst[j]), 16, lane_b, \
+      ebn_raw_buffer_load_lds_s(brsrc, (__attribute__((address_space(3))) void*)(smem + (BUFI) * BUF + b_dst[j]), 16, lane_b, \
                                 static_cast<int>(b_src[j] + sb), 0, 0);                                                  \
     sa += a_slab_b;                                                                                                      \
     sb += b_slab_b;                                                                                                      \
@@ -266,22 +271,220 @@ __global__ __launch_bounds__(256) void scale_inplace_kernel(float* __restrict__ 
   }
 }
 
+// Gather + dropout + split in one pass (the training step's embedding lookup in split precision): token r's row is
+// table[ids[r]] with the inverted-dropout mask of flat element index r*D + c (the stream of ebn_gather_rows_f32, bit for
+// bit), and the result goes out as bf16 planes in BOTH orientations the two projection GEMMs contract over --
+//   outN: rows = tokens, contraction = embedding columns   (A operand of Q|K|V = X.Wqkv)
+//   outT: rows = embedding columns, contraction = tokens   (A operand of dWqkv = X^T.dQKV)
+// -- instead of the fp32 X nothing else reads.  One workgroup per 64 tokens x 64 columns; every table-row piece is a
+// contiguous 256 bytes.
+__global__ __launch_bounds__(256) void gather_split_planes_kernel(const int32_t* __restrict__ ids, const float* __restrict__ table,
+                                                                  int64_t R, int64_t D, int64_t V, const uint32_t* __restrict__ key_ptr,
+                                                                  uint32_t thresh, float scale, int32_t* __restrict__ oob_flag,
+                                                                  uint16_t* __restrict__ outN, int64_t n_rows_p, int64_t n_Kp,
+                                                                  uint16_t* __restrict__ outT, int64_t t_rows_p, int64_t t_Kp) {
+  __shared__ float tile[64][65];  // [token][column]
+  const int tid = threadIdx.x;
+  const int64_t r0 = static_cast<int64_t>(blockIdx.x) * 64, c0 = static_cast<int64_t>(blockIdx.y) * 64;
+  const bool do_drop = key_ptr != nullptr;
+  const uint32_t key = do_drop ? *key_ptr : 0u;
+  int64_t id[16];
+  bool bad = false;
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {  // ids first, then the rows: all loads unconditional with clamped addresses
+    const int64_t r = r0 + it * 4 + (tid >> 6);
+    id[it] = ids[r < R ? r : 0];
+  }
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const int a = it * 4 + (tid >> 6), c = tid & 63;
+    const int64_t r = r0 + a, col = c0 + c;
+    const bool in_range = id[it] >= 0 && id[it] < V;
+    const bool ok = r < R && col < D;
+    bad |= (r < R) && !in_range;
+    float v = table[(ok && in_range) ? id[it] * D + col : 0];
+    v = (ok && in_range) ? v : 0.f;
+    if (do_drop) v = ebn_dropout_keep(key, static_cast<uint64_t>(r) * static_cast<uint64_t>(D) + static_cast<uint64_t>(col), thresh) ? v * scale : 0.f;
+    tile[a][c] = v;
+  }
+  if (bad && oob_flag != nullptr) *oob_flag = 1;
+  __syncthreads();
+  const int64_t n_plane = (n_Kp / 8) * n_rows_p * 8, t_plane = (t_Kp / 8) * t_rows_p * 8;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int o = it * 4 + (tid >> 6), l = tid & 63;
+    // N orientation: item (column octet o, token l)
+    if (r0 + l < n_rows_p && c0 + o * 8 < n_Kp) {
+      u16x8 v0, v1, v2;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        uint16_t p0, p1, p2;
+        split3(tile[l][o * 8 + e], p0, p1, p2);
+        v0[e] = p0;
+        v1[e] = p1;
+        v2[e] = p2;
+      }
+      const int64_t off = (((c0 >> 3) + o) * n_rows_p + r0 + l) * 8;
+      *reinterpret_cast<u16x8*>(outN + off) = v0;
+      *reinterpret_cast<u16x8*>(outN + n_plane + off) = v1;
+      *reinterpret_cast<u16x8*>(outN + 2 * n_plane + off) = v2;
+    }
+    // T orientation: item (token octet o, column l)
+    if (c0 + l < t_rows_p && r0 + o * 8 < t_Kp) {
+      u16x8 v0, v1, v2;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        uint16_t p0, p1, p2;
+        split3(tile[o * 8 + e][l], p0, p1, p2);
+        v0[e] = p0;
+        v1[e] = p1;
+        v2[e] = p2;
+      }
+      const int64_t off = (((r0 >> 3) + o) * t_rows_p + c0 + l) * 8;
+      *reinterpret_cast<u16x8*>(outT + off) = v0;
+      *reinterpret_cast<u16x8*>(outT + t_plane + off) = v1;
+      *reinterpret_cast<u16x8*>(outT + 2 * t_plane + off) = v2;
+    }
+  }
+}
+
+// TRANS split without a transpose through LDS: the source [K][rows] is row-contiguous along `rows`, and the plane layout
+// [K/8][rows][8] wants, per octet of 8 source rows, every column's 8 values as one 16-byte chunk -- consecutive columns are
+// consecutive chunks.  One workgroup per octet: thread c reads its column's 8 values (8 loads in flight, each wave-coalesced
+// along the row) and writes three 16-byte chunks; a wave writes 1 KB contiguous per plane.  Whole source rows are read in
+// order, so rows that are not 128-byte multiples apart (ld = 1200) cost nothing extra -- the 64 x 64-tile kernel read them as
+// 256-byte pieces that straddle three lines instead of two (4.0 instead of 6.0 TB/s).
+__global__ __launch_bounds__(256) void split_planes_t_rows_kernel(const float* __restrict__ src, int64_t ld, int64_t rows, int64_t K,
+                                                                  uint16_t* __restrict__ out, int64_t rows_p, int64_t Kp) {
+  const int64_t k0 = static_cast<int64_t>(blockIdx.x) * 8;
+  const int64_t plane = (Kp / 8) * rows_p * 8;
+  for (int64_t c = threadIdx.x; c < rows_p; c += 256) {
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const bool ok = c < rows && k0 + e < K;
+      const float v = src[ok ? (k0 + e) * ld + c : 0];
+      x[e] = ok ? v : 0.f;
+    }
+    u16x8 v0, v1, v2;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      uint16_t p0, p1, p2;
+      split3(x[e], p0, p1, p2);
+      v0[e] = p0;
+      v1[e] = p1;
+      v2[e] = p2;
+    }
+    const int64_t off = ((k0 >> 3) * rows_p + c) * 8;
+    *reinterpret_cast<u16x8*>(out + off) = v0;
+    *reinterpret_cast<u16x8*>(out + plane + off) = v1;
+    *reinterpret_cast<u16x8*>(out + 2 * plane + off) = v2;
+  }
+}
+
+// Gather + dropout + split, whole table rows at a time (D % 4 == 0, 16-byte aligned table): one workgroup per 16 tokens x up
+// to GS_CHUNK columns.  Loads are the fp32 gather's: 16-byte vectors, consecutive lanes on consecutive vectors of a row (a
+// wave reads 1 KB contiguous of one table row, all of a thread's loads in flight).  The 64 x 64-tile kernel above reads every
+// 4 KB table row as sixteen 256-byte pieces from sixteen workgroups at different times -- random 256-byte reads run at half
+// the HBM rate of random 4 KB reads.  LDS tile [16][GS_CHUNK + 4] fp32 (the +4 makes both read patterns conflict-free).
+constexpr int GS_TOK = 16, GS_CHUNK = 1024, GS_PITCH = GS_CHUNK + 4;
+__global__ __launch_bounds__(256) void gather_split_rows_kernel(const int32_t* __restrict__ ids, const float4* __restrict__ table,
+                                                                int64_t R, int64_t D, int64_t V, const uint32_t* __restrict__ key_ptr,
+                                                                uint32_t thresh, float scale, int32_t* __restrict__ oob_flag,
+                                                                uint16_t* __restrict__ outN, int64_t n_rows_p, int64_t n_Kp,
+                                                                uint16_t* __restrict__ outT, int64_t t_rows_p, int64_t t_Kp) {
+  extern __shared__ __attribute__((aligned(16))) float gs_tile[];  // [GS_TOK][GS_PITCH]
+  const int tid = threadIdx.x;
+  const int64_t r0 = static_cast<int64_t>(blockIdx.x) * GS_TOK, c0 = static_cast<int64_t>(blockIdx.y) * GS_CHUNK;
+  const bool do_drop = key_ptr != nullptr;
+  const uint32_t key = do_drop ? *key_ptr : 0u;
+  const int64_t vpr = D >> 2;  // float4 per table row
+  // ---- gather: item (token t, vector v4 of the chunk): GS_TOK * GS_CHUNK / 4 = 4096 items, 16 per thread
+  constexpr int ITEMS = GS_TOK * GS_CHUNK / 4 / 256;
+  int64_t id[ITEMS];
+  bool bad = false;
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    const int t = (it * 256 + tid) / (GS_CHUNK / 4);
+    id[it] = ids[r0 + t < R ? r0 + t : 0];
+  }
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    const int item = it * 256 + tid, t = item / (GS_CHUNK / 4), v4 = item % (GS_CHUNK / 4);
+    const int64_t r = r0 + t, col = c0 + v4 * 4;
+    const bool in_range = id[it] >= 0 && id[it] < V;
+    const bool ok = r < R && col < D;
+    bad |= (r < R) && !in_range;
+    float4 v = table[(ok && in_range) ? id[it] * vpr + (col >> 2) : 0];
+    if (!(ok && in_range)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (do_drop) {
+      const uint64_t pair0 = (static_cast<uint64_t>(r) * static_cast<uint64_t>(D) + static_cast<uint64_t>(col)) >> 1;  // D % 4 == 0: even
+      const uint32_t h0 = ebn_dropout_pair_hash(key, pair0), h1 = ebn_dropout_pair_hash(key, pair0 + 1);
+      v.x = ((h0 & 0xFFFFu) >= thresh) ? v.x * scale : 0.f;
+      v.y = ((h0 >> 16) >= thresh) ? v.y * scale : 0.f;
+      v.z = ((h1 & 0xFFFFu) >= thresh) ? v.z * scale : 0.f;
+      v.w = ((h1 >> 16) >= thresh) ? v.w * scale : 0.f;
+    }
+    *reinterpret_cast<float4*>(gs_tile + t * GS_PITCH + v4 * 4) = v;
+  }
+  if (bad && oob_flag != nullptr) *oob_flag = 1;
+  __syncthreads();
+  const int64_t n_plane = (n_Kp / 8) * n_rows_p * 8, t_plane = (t_Kp / 8) * t_rows_p * 8;
+  // ---- T orientation (rows = columns, contraction = tokens): item (token octet o of 2, column c): a wave writes 1 KB contiguous
+#pragma unroll
+  for (int it = 0; it < 2 * GS_CHUNK / 256; ++it) {
+    const int item = it * 256 + tid, o = item / GS_CHUNK, c = item % GS_CHUNK;
+    if (c0 + c >= t_rows_p || r0 + o * 8 >= t_Kp) continue;
+    u16x8 v0, v1, v2;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      uint16_t p0, p1, p2;
+      split3(gs_tile[(o * 8 + e) * GS_PITCH + c], p0, p1, p2);
+      v0[e] = p0;
+      v1[e] = p1;
+      v2[e] = p2;
+    }
+    const int64_t off = (((r0 >> 3) + o) * t_rows_p + c0 + c) * 8;
+    *reinterpret_cast<u16x8*>(outT + off) = v0;
+    *reinterpret_cast<u16x8*>(outT + t_plane + off) = v1;
+    *reinterpret_cast<u16x8*>(outT + 2 * t_plane + off) = v2;
+  }
+  // ---- N orientation (rows = tokens, contraction = columns): item (column octet oc, token t): 16 tokens x 16 B = 256 B runs
+#pragma unroll
+  for (int it = 0; it < GS_TOK * (GS_CHUNK / 8) / 256; ++it) {
+    const int item = it * 256 + tid, t = item % GS_TOK, oc = item / GS_TOK;
+    if (r0 + t >= n_rows_p || c0 + oc * 8 >= n_Kp) continue;
+    const float4 lo = *reinterpret_cast<const float4*>(gs_tile + t * GS_PITCH + oc * 8);
+    const float4 hi = *reinterpret_cast<const float4*>(gs_tile + t * GS_PITCH + oc * 8 + 4);
+    const float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    u16x8 v0, v1, v2;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      uint16_t p0, p1, p2;
+      split3(x[e], p0, p1, p2);
+      v0[e] = p0;
+      v1[e] = p1;
+      v2[e] = p2;
+    }
+    const int64_t off = (((c0 >> 3) + oc) * n_rows_p + r0 + t) * 8;
+    *reinterpret_cast<u16x8*>(outN + off) = v0;
+    *reinterpret_cast<u16x8*>(outN + n_plane + off) = v1;
+    *reinterpret_cast<u16x8*>(outN + 2 * n_plane + off) = v2;
+  }
+}
+
+constexpr int64_t SP_ROW_PAD = 256;  // plane sets pad their rows to the larger tile edge, whichever operand they become
+int64_t pad_rows(int64_t rows) { return ebn_ceil_div(rows > 0 ? rows : 1, SP_ROW_PAD) * SP_ROW_PAD; }
+int64_t pad_k(int64_t K) { return ebn_ceil_div(K > 0 ? K : 1, SP_BK) * SP_BK; }
+
 struct SplitPlan {
-  int64_t a_rows, b_rows, Kp;  // padded extents of the plane sets
-  int64_t a_bytes, b_bytes;    // bytes of each plane set (three planes)
   int splits;
   int slabs_per_split;
-  int64_t part_floats;         // split-K partials
 };
 
 SplitPlan split_plan(int64_t M, int64_t N, int64_t K) {
   SplitPlan p;
-  p.a_rows = ebn_ceil_div(M, SP_BM) * SP_BM;
-  p.b_rows = ebn_ceil_div(N, SP_BN) * SP_BN;
-  p.Kp = ebn_ceil_div(K > 0 ? K : 1, SP_BK) * SP_BK;
-  p.a_bytes = 3 * p.a_rows * p.Kp * 2;
-  p.b_bytes = 3 * p.b_rows * p.Kp * 2;
-  const int64_t tiles = (p.a_rows / SP_BM) * (p.b_rows / SP_BN), slabs = p.Kp / SP_BK;
+  const int64_t tiles = (pad_rows(M) / SP_BM) * ebn_ceil_div(N, SP_BN), slabs = pad_k(K) / SP_BK;
   // fill the chip (512 resident workgroups: two per CU) when the output alone has too few tiles, keeping >= 32 slabs per split
   int64_t splits = 1;
   if (tiles < 384) {
@@ -292,55 +495,81 @@ SplitPlan split_plan(int64_t M, int64_t N, int64_t K) {
   }
   p.slabs_per_split = static_cast<int>(ebn_ceil_div(slabs, splits));
   p.splits = static_cast<int>(ebn_ceil_div(slabs, p.slabs_per_split));
-  p.part_floats = static_cast<int64_t>(p.splits) * M * N;  // (one slice when K is not split: the beta != 0 combine reads it)
   return p;
 }
 
 }  // namespace
 
-// bytes of workspace ebn_gemm_f32_split needs for (M, N, K): both operands' bf16 planes and the split-K partials
-extern "C" int64_t ebn_gemm_split_workspace_bytes(int64_t M, int64_t N, int64_t K) {
-  if (M <= 0 || N <= 0 || K < 0) return 0;
-  const SplitPlan p = split_plan(M, N, K);
-  return p.a_bytes + p.b_bytes + p.part_floats * 4 + 256;
+extern "C" int64_t ebn_planes_bytes(int64_t rows, int64_t K) { return 3 * pad_rows(rows) * pad_k(K) * 2; }
+
+extern "C" int ebn_split_planes_f32(const float* src, int64_t ld, int64_t rows, int64_t K, int32_t trans, void* planes,
+                                    ebn_stream_t stream) {
+  EBN_REQUIRE(src && planes && rows > 0 && K > 0 && ld >= (trans ? rows : K), EBN_ERR_BAD_ARG);
+  EBN_REQUIRE(ebn_aligned16(planes), EBN_ERR_ALIGN);
+  const int64_t rows_p = pad_rows(rows), Kp = pad_k(K);
+  const dim3 grid(static_cast<unsigned>(rows_p / 64), static_cast<unsigned>(ebn_ceil_div(Kp, 64)));
+  if (!trans) hipLaunchKernelGGL((split_planes_kernel<false>), grid, dim3(256), 0, ebn_stream(stream), src, ld, rows, K,
+                                 static_cast<uint16_t*>(planes), rows_p, Kp);
+  else if (getenv("EBN_SPLIT_T_TILE") != nullptr)  // tuning: the 64 x 64-tile transpose through LDS
+    hipLaunchKernelGGL((split_planes_kernel<true>), grid, dim3(256), 0, ebn_stream(stream), src, ld, rows, K,
+                       static_cast<uint16_t*>(planes), rows_p, Kp);
+  else
+    hipLaunchKernelGGL(split_planes_t_rows_kernel, dim3(static_cast<unsigned>(Kp / 8)), dim3(256), 0, ebn_stream(stream), src, ld, rows, K,
+                       static_cast<uint16_t*>(planes), rows_p, Kp);
+  EBN_CHECK_LAUNCH();
+  return EBN_OK;
 }
 
-extern "C" int ebn_gemm_f32_split(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K, float alpha, const float* A,
-                                  int64_t lda, const float* B, int64_t ldb, float beta, float* C, int64_t ldc, void* workspace,
-                                  int64_t workspace_bytes, ebn_stream_t stream) {
+extern "C" int ebn_gather_split_planes_f32(const int32_t* ids, const float* table, int64_t n_rows, int32_t D, int64_t V,
+                                           const ebn_step_state* st, int32_t site, float drop_p, int32_t* oob_flag, void* planes_n,
+                                           void* planes_t, ebn_stream_t stream) {
+  EBN_REQUIRE(ids && table && planes_n && planes_t && n_rows > 0 && D > 0 && V > 0, EBN_ERR_BAD_ARG);
+  EBN_REQUIRE(ebn_aligned16(planes_n) && ebn_aligned16(planes_t), EBN_ERR_ALIGN);
+  const EbnDrop d = ebn_make_drop(st, site, drop_p);
+  const int64_t n_rows_p = pad_rows(n_rows), n_Kp = pad_k(D), t_rows_p = pad_rows(D), t_Kp = pad_k(n_rows);
+  const int64_t tok_ext = n_rows_p > t_Kp ? n_rows_p : t_Kp, col_ext = t_rows_p > n_Kp ? t_rows_p : n_Kp;
+  if ((D % 4) == 0 && ebn_aligned16(table) && getenv("EBN_GATHER_SPLIT_TILE") == nullptr) {  // whole table rows at a time
+    constexpr size_t lds = static_cast<size_t>(GS_TOK) * GS_PITCH * sizeof(float);  // 65,792 bytes: above the 64 KB default limit
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_split_rows_kernel),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    if (attr != hipSuccess) return static_cast<int>(attr);
+    const dim3 grid_r(static_cast<unsigned>(ebn_ceil_div(tok_ext, GS_TOK)), static_cast<unsigned>(ebn_ceil_div(col_ext, GS_CHUNK)));
+    hipLaunchKernelGGL(gather_split_rows_kernel, grid_r, dim3(256), lds, ebn_stream(stream), ids, reinterpret_cast<const float4*>(table), n_rows,
+                       static_cast<int64_t>(D), V, d.key_ptr, d.thresh, d.scale, oob_flag, static_cast<uint16_t*>(planes_n), n_rows_p, n_Kp,
+                       static_cast<uint16_t*>(planes_t), t_rows_p, t_Kp);
+    EBN_CHECK_LAUNCH();
+    return EBN_OK;
+  }
+  const dim3 grid(static_cast<unsigned>(ebn_ceil_div(tok_ext, 64)), static_cast<unsigned>(ebn_ceil_div(col_ext, 64)));
+  hipLaunchKernelGGL(gather_split_planes_kernel, grid, dim3(256), 0, ebn_stream(stream), ids, table, n_rows, static_cast<int64_t>(D), V,
+                     d.key_ptr, d.thresh, d.scale, oob_flag, static_cast<uint16_t*>(planes_n), n_rows_p, n_Kp,
+                     static_cast<uint16_t*>(planes_t), t_rows_p, t_Kp);
+  EBN_CHECK_LAUNCH();
+  return EBN_OK;
+}
+
+extern "C" int64_t ebn_gemm_planes_workspace_floats(int64_t M, int64_t N, int64_t K) {
+  if (M <= 0 || N <= 0 || K < 0) return 0;
+  return static_cast<int64_t>(split_plan(M, N, K).splits) * M * N;  // (one slice when K is not split: the beta != 0 combine reads it)
+}
+
+extern "C" int ebn_gemm_planes_f32(const void* a_planes, int64_t M, const void* b_planes, int64_t N, int64_t K, float alpha, float beta,
+                                   float* C, int64_t ldc, float* workspace, int64_t workspace_floats, ebn_stream_t stream) {
   EBN_REQUIRE(M >= 0 && N >= 0 && K >= 0, EBN_ERR_BAD_ARG);
   if (M == 0 || N == 0) return EBN_OK;
-  EBN_REQUIRE(A && B && C && workspace, EBN_ERR_BAD_ARG);
-  EBN_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, EBN_ERR_BAD_ARG);
-  EBN_REQUIRE(ebn_aligned16(workspace), EBN_ERR_ALIGN);
+  EBN_REQUIRE(a_planes && b_planes && C && ldc >= N, EBN_ERR_BAD_ARG);
+  EBN_REQUIRE(ebn_aligned16(a_planes) && ebn_aligned16(b_planes), EBN_ERR_ALIGN);
+  EBN_REQUIRE(ebn_planes_bytes(M, K) < (int64_t{1} << 32) && ebn_planes_bytes(N, K) < (int64_t{1} << 32), EBN_ERR_UNSUPPORTED);
   const SplitPlan p = split_plan(M, N, K);
-  EBN_REQUIRE(workspace_bytes >= ebn_gemm_split_workspace_bytes(M, N, K), EBN_ERR_BAD_ARG);
-  EBN_REQUIRE(p.a_bytes + p.b_bytes < (int64_t{1} << 32) && M * N < (int64_t{1} << 40), EBN_ERR_UNSUPPORTED);  // 32-bit byte offsets
   hipStream_t s = ebn_stream(stream);
-  uint16_t* Ap = static_cast<uint16_t*>(workspace);
-  uint16_t* Bp = Ap + p.a_bytes / 2;
-  float* part = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + ((p.a_bytes + p.b_bytes + 255) / 256) * 256);
-  // operand A as rows = m, contraction = k: source is [M][K] (transA = 0) or [K][M] (transA = 1)
-  {
-    const dim3 grid(static_cast<unsigned>(p.a_rows / 64), static_cast<unsigned>(ebn_ceil_div(p.Kp, 64)));
-    if (!transA) hipLaunchKernelGGL((split_planes_kernel<false>), grid, dim3(256), 0, s, A, lda, M, K, Ap, p.a_rows, p.Kp);
-    else hipLaunchKernelGGL((split_planes_kernel<true>), grid, dim3(256), 0, s, A, lda, M, K, Ap, p.a_rows, p.Kp);
-    EBN_CHECK_LAUNCH();
-  }
-  // operand B as rows = n, contraction = k: source is [K][N] (transB = 0: transposed on the way) or [N][K] (transB = 1)
-  {
-    const dim3 grid(static_cast<unsigned>(p.b_rows / 64), static_cast<unsigned>(ebn_ceil_div(p.Kp, 64)));
-    if (transB) hipLaunchKernelGGL((split_planes_kernel<false>), grid, dim3(256), 0, s, B, ldb, N, K, Bp, p.b_rows, p.Kp);
-    else hipLaunchKernelGGL((split_planes_kernel<true>), grid, dim3(256), 0, s, B, ldb, N, K, Bp, p.b_rows, p.Kp);
-    EBN_CHECK_LAUNCH();
-  }
+  const uint16_t* Ap = static_cast<const uint16_t*>(a_planes);
+  const uint16_t* Bp = static_cast<const uint16_t*>(b_planes);
+  const uint32_t a_rows = static_cast<uint32_t>(pad_rows(M)), b_rows = static_cast<uint32_t>(pad_rows(N)), Kp = static_cast<uint32_t>(pad_k(K));
   const bool direct = p.splits == 1 && beta == 0.f;  // the GEMM writes C itself; alpha applied afterwards when != 1
-  const dim3 grid(static_cast<unsigned>(p.b_rows / SP_BN), static_cast<unsigned>(p.a_rows / SP_BM), static_cast<unsigned>(direct ? 1 : p.splits));
-  float* partials = direct ? nullptr : part;
+  EBN_REQUIRE(direct || (workspace && workspace_floats >= static_cast<int64_t>(p.splits) * M * N), EBN_ERR_BAD_ARG);
+  const dim3 grid(static_cast<unsigned>(ebn_ceil_div(N, SP_BN)), static_cast<unsigned>(a_rows / SP_BM), static_cast<unsigned>(direct ? 1 : p.splits));
   if (direct) {
-    hipLaunchKernelGGL(gemm_bf16x6_kernel, grid, dim3(SP_THREADS), 0, s, Ap, 0u, static_cast<uint32_t>(p.a_bytes),
-                       static_cast<uint32_t>(p.a_rows), static_cast<uint32_t>(p.b_rows), static_cast<uint32_t>(p.Kp), M, N, C, ldc,
-                       p.slabs_per_split, partials);
+    hipLaunchKernelGGL(gemm_bf16x6_kernel, grid, dim3(SP_THREADS), 0, s, Ap, Bp, a_rows, b_rows, Kp, M, N, C, ldc, p.slabs_per_split, nullptr);
     EBN_CHECK_LAUNCH();
     if (alpha != 1.0f) {
       int64_t g = ebn_ceil_div(M * N, 256);
@@ -351,22 +580,48 @@ extern "C" int ebn_gemm_f32_split(int32_t transA, int32_t transB, int64_t M, int
     return EBN_OK;
   }
   // split-K, or beta != 0: every z-slice writes a partial, a fixed-order combine finishes
-  if (p.splits == 1) {
-    // beta != 0 without a K split: the kernel treats gridDim.z == 1 as "write C", so C is pointed at the partial buffer (ld = N)
-    hipLaunchKernelGGL(gemm_bf16x6_kernel, grid, dim3(SP_THREADS), 0, s, Ap, 0u, static_cast<uint32_t>(p.a_bytes),
-                       static_cast<uint32_t>(p.a_rows), static_cast<uint32_t>(p.b_rows), static_cast<uint32_t>(p.Kp), M, N, part, N,
-                       p.slabs_per_split, nullptr);
-  } else {
-    hipLaunchKernelGGL(gemm_bf16x6_kernel, grid, dim3(SP_THREADS), 0, s, Ap, 0u, static_cast<uint32_t>(p.a_bytes),
-                       static_cast<uint32_t>(p.a_rows), static_cast<uint32_t>(p.b_rows), static_cast<uint32_t>(p.Kp), M, N, C, ldc,
-                       p.slabs_per_split, part);
-  }
+  if (p.splits == 1)  // the kernel treats gridDim.z == 1 as "write C": C is pointed at the partial buffer (ld = N)
+    hipLaunchKernelGGL(gemm_bf16x6_kernel, grid, dim3(SP_THREADS), 0, s, Ap, Bp, a_rows, b_rows, Kp, M, N, workspace, N, p.slabs_per_split, nullptr);
+  else
+    hipLaunchKernelGGL(gemm_bf16x6_kernel, grid, dim3(SP_THREADS), 0, s, Ap, Bp, a_rows, b_rows, Kp, M, N, C, ldc, p.slabs_per_split, workspace);
   EBN_CHECK_LAUNCH();
   int64_t g = ebn_ceil_div(M * N, 256);
   if (g > 4096) g = 4096;
-  hipLaunchKernelGGL(split_reduce_kernel, dim3(static_cast<unsigned>(g)), dim3(256), 0, s, part, p.splits, M, N, alpha, beta, C, ldc);
+  hipLaunchKernelGGL(split_reduce_kernel, dim3(static_cast<unsigned>(g)), dim3(256), 0, s, workspace, p.splits, M, N, alpha, beta, C, ldc);
   EBN_CHECK_LAUNCH();
   return EBN_OK;
+}
+
+// bytes of workspace ebn_gemm_f32_split needs for (M, N, K): both operands' bf16 planes and the split-K partials
+extern "C" int64_t ebn_gemm_split_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  if (M <= 0 || N <= 0 || K < 0) return 0;
+  return ebn_planes_bytes(M, K) + ebn_planes_bytes(N, K) + ebn_gemm_planes_workspace_floats(M, N, K) * 4 + 256;
+}
+
+extern "C" int ebn_gemm_f32_split(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K, float alpha, const float* A,
+                                  int64_t lda, const float* B, int64_t ldb, float beta, float* C, int64_t ldc, void* workspace,
+                                  int64_t workspace_bytes, ebn_stream_t stream) {
+  EBN_REQUIRE(M >= 0 && N >= 0 && K >= 0, EBN_ERR_BAD_ARG);
+  if (M == 0 || N == 0) return EBN_OK;
+  EBN_REQUIRE(A && B && C && workspace, EBN_ERR_BAD_ARG);
+  EBN_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, EBN_ERR_BAD_ARG);
+  EBN_REQUIRE(ebn_aligned16(workspace), EBN_ERR_ALIGN);
+  EBN_REQUIRE(workspace_bytes >= ebn_gemm_split_workspace_bytes(M, N, K), EBN_ERR_BAD_ARG);
+  if (K == 0) {  // empty contraction: C <- beta * C (the plane kernels need K > 0)
+    return ebn_gemm_f32_ws(transA, transB, M, N, 0, alpha, A, lda, B, ldb, beta, C, ldc, nullptr, 0, stream);
+  }
+  char* base = static_cast<char*>(workspace);
+  const int64_t a_bytes = ebn_planes_bytes(M, K), b_bytes = ebn_planes_bytes(N, K);
+  void* Ap = base;
+  void* Bp = base + a_bytes;
+  float* part = reinterpret_cast<float*>(base + ((a_bytes + b_bytes + 255) / 256) * 256);
+  // operand A as rows = m, contraction = k: the source is [M][K] (transA = 0) or [K][M] (transA = 1: transposed on the way);
+  // operand B as rows = n: the source is [N][K] (transB = 1) or [K][N] (transB = 0: transposed on the way)
+  int rc = ebn_split_planes_f32(A, lda, M, K, transA ? 1 : 0, Ap, stream);
+  if (rc != EBN_OK) return rc;
+  rc = ebn_split_planes_f32(B, ldb, N, K, transB ? 0 : 1, Bp, stream);
+  if (rc != EBN_OK) return rc;
+  return ebn_gemm_planes_f32(Ap, M, Bp, N, K, alpha, beta, C, ldc, part, ebn_gemm_planes_workspace_floats(M, N, K), stream);
 }
 
 // One entry point for both precisions of the projection GEMM: precision 0 = the exact-fp32 MFMA kernels (bitwise an fp32 fma

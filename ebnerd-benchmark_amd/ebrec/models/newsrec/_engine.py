@@ -450,16 +450,40 @@ class NRMSEngine:
             b.split_ws_bytes = nbytes
         return b.split_ws
 
+    def _split_bufs(self, b):
+        """Plane sets of a training step in split precision (allocated once per buffer set): X in both orientations (written by
+        the gather), Wqkv^T and dQKV^T (split passes), and the split-K partials of the weight-gradient GEMM."""
+        sb = getattr(b, "split_bufs", None)
+        if sb is None:
+            L = _hip.lib()
+            R, E3, D = b.R, 3 * b.E, b.Din
+            u8 = lambda n: torch.empty(int(n) + 64, dtype=torch.uint8, device=self.device)
+            sb = b.split_bufs = {"XN": u8(L.ebn_planes_bytes(R, D)), "XT": u8(L.ebn_planes_bytes(D, R)), "Wp": u8(L.ebn_planes_bytes(E3, D)),
+                                 "dQp": u8(L.ebn_planes_bytes(E3, R)),
+                                 "part": torch.empty(max(int(L.ebn_gemm_planes_workspace_floats(D, E3, R)), int(L.ebn_gemm_planes_workspace_floats(R, E3, D)), 1),
+                                                     device=self.device)}
+        return sb
+
     def _gemm_prec(self, b, tA, tB, M, N, K, A, lda, Bm, ldb, C, ldc):
         ws = self._split_ws(b)
         _hip.call("ebn_gemm_f32_prec", tA, tB, M, N, K, ctypes.c_float(1.0), _hip.ptr(A), lda, _hip.ptr(Bm), ldb, ctypes.c_float(0.0),
                   _hip.ptr(C), ldc, _hip.ptr(ws), b.split_ws_bytes, 1, _hip.stream_handle())
 
+    def _news_encoder_fwd_split_gemm(self, b, R):
+        S, E = _hip.stream_handle, self.E
+        sb = self._split_bufs(b)
+        _hip.call("ebn_split_planes_f32", _hip.ptr(self.params.view("n_Wqkv")), 3 * E, 3 * E, b.Din, 1, _hip.ptr(sb["Wp"]), S())
+        _hip.call("ebn_gemm_planes_f32", _hip.ptr(sb["XN"]), R, _hip.ptr(sb["Wp"]), 3 * E, b.Din, ctypes.c_float(1.0), ctypes.c_float(0.0),
+                  _hip.ptr(b.QKV), 3 * E, _hip.ptr(sb["part"]), sb["part"].numel(), S())
+
     def _news_encoder_fwd_split(self, b, n_seq, X, st, site, p):
         S, E, A, T = _hip.stream_handle, self.E, self.A, b.L
         R = n_seq * T
         pv = self.params.view
-        self._gemm_prec(b, 0, 0, R, 3 * E, b.Din, X, b.Din, pv("n_Wqkv"), 3 * E, b.QKV, 3 * E)      # layers.py:214,220,226
+        if getattr(b, "planes_rows", -1) == R:   # layers.py:214,220,226 on the planes the gather wrote
+            self._news_encoder_fwd_split_gemm(b, R)
+        else:
+            self._gemm_prec(b, 0, 0, R, 3 * E, b.Din, X, b.Din, pv("n_Wqkv"), 3 * E, b.QKV, 3 * E)
         _hip.call("ebn_attn_fwd_f32", _hip.ptr(b.QKV), 3 * E, _hip.ptr(b.Y), E, n_seq, T, self.h, self.d, st, site, ctypes.c_float(p), S())
         _hip.call("ebn_gemm_f32_ws", 0, 0, R, A, E, ctypes.c_float(1.0), _hip.ptr(b.Y), E, _hip.ptr(pv("n_W")), A, ctypes.c_float(0.0),
                   _hip.ptr(b.U), A, _hip.ptr(b.ws), b.ws.numel(), S())
@@ -487,7 +511,13 @@ class NRMSEngine:
                       T, ws, wsn, S())
             _hip.call("ebn_attn_bwd_f32", _hip.ptr(b.QKV), 3 * E, _hip.ptr(b.dY), E, _hip.ptr(b.dQKV), 3 * E, n_seq, T, self.h, self.d, st, site,
                       ctypes.c_float(p), S())
-        self._gemm_prec(b, 1, 0, b.Din, 3 * E, R, X, b.Din, b.dQKV, 3 * E, g("n_Wqkv"), 3 * E)        # dWqkv = X^T . dQKV
+        if getattr(b, "planes_rows", -1) == R:  # dWqkv = X^T . dQKV on the transposed planes the gather wrote
+            sb = self._split_bufs(b)
+            _hip.call("ebn_split_planes_f32", _hip.ptr(b.dQKV), 3 * E, 3 * E, R, 1, _hip.ptr(sb["dQp"]), S())
+            _hip.call("ebn_gemm_planes_f32", _hip.ptr(sb["XT"]), b.Din, _hip.ptr(sb["dQp"]), 3 * E, R, one, zero, _hip.ptr(g("n_Wqkv")), 3 * E,
+                      _hip.ptr(sb["part"]), sb["part"].numel(), S())
+        else:
+            self._gemm_prec(b, 1, 0, b.Din, 3 * E, R, X, b.Din, b.dQKV, 3 * E, g("n_Wqkv"), 3 * E)
         if dX is not None:
             self._gemm_prec(b, 0, 1, R, b.Din, 3 * E, b.dQKV, 3 * E, pv("n_Wqkv"), 3 * E, dX, b.Din)  # dX = dQKV . Wqkv^T
 
@@ -504,8 +534,9 @@ class NRMSEngine:
         st = _hip.ptr(self.state)
 
         def qkv_gemm():
-            if self.precision == "split":  # the two split passes + the bf16x6 GEMM, as the step runs them
-                return self._gemm_prec(nb, 0, 0, R, 3 * E, nb.Din, nb.X, nb.Din, pv("n_Wqkv"), 3 * E, nb.QKV, 3 * E)
+            if self.precision == "split":  # as the step runs it: the weight split pass + the bf16x6 GEMM on the gather's planes
+                nb.planes_rows = R  # (a training step has filled them)
+                return self._news_encoder_fwd_split_gemm(nb, R)
             _hip.call("ebn_gemm_f32_site", 0, 0, R, 3 * E, nb.Din, ctypes.c_float(1.0), _hip.ptr(nb.X), nb.Din,
                       _hip.ptr(pv("n_Wqkv")), 3 * E, ctypes.c_float(0.0), _hip.ptr(nb.QKV), 3 * E, _hip.ptr(nb.ws), nb.ws.numel(), 1, S())
 
@@ -517,8 +548,7 @@ class NRMSEngine:
             src = ids if table_rows == self.V else torch.remainder(ids, table_rows).to(torch.int32)
 
             def gather():
-                _hip.call("ebn_gather_rows_f32", _hip.ptr(src), _hip.ptr(self.table), _hip.ptr(nb.X), R, self.D, table_rows, st, site,
-                          ctypes.c_float(p), _hip.ptr(self.oob_flag), S())
+                self._gather_tokens(nb, src, self.table, table_rows, R, st, site, p, True)
 
             return gather
 
@@ -574,22 +604,31 @@ class NRMSEngine:
                 for _kind, fn in self._lookup_segments(b, N):
                     fn()
             xb = b.xb
-            _hip.call("ebn_gather_rows_f32", _hip.ptr(xb.inv), _hip.ptr(xb.rows), _hip.ptr(b.X), n_tok, self.D,
-                      self.exchange.world * self.exchange.capacity(n_tok), st, site, ctypes.c_float(p), _hip.ptr(self.oob_flag),
-                      _hip.stream_handle())
+            self._gather_tokens(b, xb.inv, xb.rows, self.exchange.world * self.exchange.capacity(n_tok), n_tok, st, site, p, train)
             return self._encoder_fwd("n", b, N, b.X, train, n_first)
         if self.exchange is not None:
             # validation forms (host-planned, eager only): route the distinct ids to their owners, fetch the rows over
             # RCCL, then expand them to token order (ids = positions in the unique list) with dropout fused
             b.plan = self.exchange.plan(b.ids[: n_tok])
             b.rows_uniq = self.exchange.lookup(b.plan, self._local_gather)
-            _hip.call("ebn_gather_rows_f32", _hip.ptr(b.plan.inv), _hip.ptr(b.rows_uniq), _hip.ptr(b.X), n_tok,
-                      self.D, b.rows_uniq.shape[0], st, site, ctypes.c_float(p), _hip.ptr(self.oob_flag),
-                      _hip.stream_handle())
+            self._gather_tokens(b, b.plan.inv, b.rows_uniq, b.rows_uniq.shape[0], n_tok, st, site, p, train)
             return self._encoder_fwd("n", b, N, b.X, train, n_first)
-        _hip.call("ebn_gather_rows_f32", _hip.ptr(b.ids), _hip.ptr(self.table), _hip.ptr(b.X), n_tok, self.D,
-                  self.V, st, site, ctypes.c_float(p), _hip.ptr(self.oob_flag), _hip.stream_handle())
+        self._gather_tokens(b, b.ids, self.table, self.V, n_tok, st, site, p, train)
         self._encoder_fwd("n", b, N, b.X, train, n_first)
+
+    def _gather_tokens(self, b, ids, table, table_rows, n_tok, st, site, p, train):
+        """a1: the title-token embedding gather (+ dropout) of n_tok tokens.  Exact precision: fp32 rows into b.X.  Split
+        precision, training step: the rows go out as bf16 planes in the two orientations the projection GEMMs contract over
+        (b.XN: tokens x D, b.XT: D x tokens) -- nothing else reads the fp32 X, so it is not written at all."""
+        if self.precision == "split" and train and self.mlp is None and n_tok <= b.R:
+            sb = self._split_bufs(b)
+            _hip.call("ebn_gather_split_planes_f32", _hip.ptr(ids), _hip.ptr(table), n_tok, self.D, table_rows, st, site, ctypes.c_float(p),
+                      _hip.ptr(self.oob_flag), _hip.ptr(sb["XN"]), _hip.ptr(sb["XT"]), _hip.stream_handle())
+            b.planes_rows = n_tok
+            return
+        b.planes_rows = -1
+        _hip.call("ebn_gather_rows_f32", _hip.ptr(ids), _hip.ptr(table), _hip.ptr(b.X), n_tok, self.D, table_rows, st, site,
+                  ctypes.c_float(p), _hip.ptr(self.oob_flag), _hip.stream_handle())
 
     # ---- device-planned row-sharded lookup, as ("k" kernels | "c" collective, fn) segments -------------------------
     def _lookup_segments(self, b, N):

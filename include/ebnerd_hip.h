@@ -109,6 +109,25 @@ int64_t ebn_gemm_split_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int ebn_gemm_f32_split(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K, float alpha, const float* A,
                        int64_t lda, const float* B, int64_t ldb, float beta, float* C, int64_t ldc, void* workspace,
                        int64_t workspace_bytes, ebn_stream_t stream);
+/* The pieces ebn_gemm_f32_split is made of, for callers that keep an operand's planes across calls or have a producer write
+ * them directly.  A plane set = the three bf16 planes of one operand as [plane][K/8][rows][8] (rows padded to 256, K to 16,
+ * zero-filled: ebn_planes_bytes(rows, K) bytes, 16-byte aligned) -- `rows` is the operand's non-contracted extent (M or N).
+ *   ebn_split_planes_f32         src fp32 row-major [rows][K] (trans = 0) or [K][rows] (trans = 1, transposed on the way)
+ *   ebn_gather_split_planes_f32  the training step's Embedding + Dropout (nrms.py:125-136) in split precision: token r's row
+ *                                table[ids[r]] with the dropout stream of ebn_gather_rows_f32 (same mask bit for bit), written as
+ *                                planes in BOTH orientations -- planes_n (rows = tokens, K = D: the A operand of X.Wqkv) and
+ *                                planes_t (rows = D, K = tokens: the A operand of X^T.dQKV) -- instead of the fp32 X
+ *   ebn_gemm_planes_f32          C[M,N] = alpha * A.B^T + beta * C from two plane sets (A: rows M, B: rows N, same K);
+ *                                workspace: ebn_gemm_planes_workspace_floats(M, N, K) floats (deterministic split-K partials) */
+int64_t ebn_planes_bytes(int64_t rows, int64_t K);
+int ebn_split_planes_f32(const float* src, int64_t ld, int64_t rows, int64_t K, int32_t trans, void* planes,
+                         ebn_stream_t stream);
+int ebn_gather_split_planes_f32(const int32_t* ids, const float* table, int64_t n_rows, int32_t D, int64_t V,
+                                const ebn_step_state* st, int32_t site, float drop_p, int32_t* oob_flag, void* planes_n,
+                                void* planes_t, ebn_stream_t stream);
+int64_t ebn_gemm_planes_workspace_floats(int64_t M, int64_t N, int64_t K);
+int ebn_gemm_planes_f32(const void* a_planes, int64_t M, const void* b_planes, int64_t N, int64_t K, float alpha, float beta,
+                        float* C, int64_t ldc, float* workspace, int64_t workspace_floats, ebn_stream_t stream);
 int64_t ebn_gemm_prec_workspace_bytes(int64_t M, int64_t N, int64_t K, int32_t precision);
 int ebn_gemm_f32_prec(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K, float alpha, const float* A,
                       int64_t lda, const float* B, int64_t ldb, float beta, float* C, int64_t ldc, void* workspace,

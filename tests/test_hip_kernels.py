@@ -930,3 +930,45 @@ def test_streaming_auc_histogram_kernel_equals_the_numpy_accumulation(hip):
     assert np.array_equal(got._dev[1].cpu().numpy().astype(np.float64), ref.pos_hist)
     assert np.array_equal(got._dev[2].cpu().numpy().astype(np.float64), ref.neg_hist)
     assert got.result() == ref.result()
+
+
+@pytest.mark.parametrize("R,D,V,p", [(24000, 1024, 5000, 0.2), (700, 300, 97, 0.0), (130, 36, 50, 0.5), (130, 37, 50, 0.5), (333, 2052, 40, 0.2)])
+def test_gather_split_planes_is_the_gather_then_the_split(hip, R, D, V, p):
+    """ebn_gather_split_planes_f32 (Embedding + Dropout of a training step in split precision): the planes it writes are, bit for
+    bit, the planes ebn_split_planes_f32 makes of ebn_gather_rows_f32's output (same rows, same dropout mask) in both
+    orientations -- and the two projection products computed from them equal the generic split GEMM on the fp32 rows."""
+    rng = np.random.default_rng(R + D)
+    table = rng.standard_normal((V, D)).astype(np.float32)
+    ids = rng.integers(0, V, R).astype(np.int32)
+    ids[:5] = 0
+    st = make_state(seed=3, step=2)
+    L = hip.lib()
+    d_ids, d_tab = torch.from_numpy(ids).cuda(), dev(table)
+    X = torch.empty(R, D, device="cuda")
+    hip.call("ebn_gather_rows_f32", P(d_ids), P(d_tab), P(X), R, D, V, P(st), 0, ctypes.c_float(p), None, S())
+    X += 0.0  # (the scalar gather of an odd D writes a dropped negative element as -0.0, x * 0; the planes carry +0.0)
+    u8 = lambda n: torch.zeros(int(n), dtype=torch.uint8, device="cuda")
+    refN, refT = u8(L.ebn_planes_bytes(R, D)), u8(L.ebn_planes_bytes(D, R))
+    hip.call("ebn_split_planes_f32", P(X), D, R, D, 0, P(refN), S())
+    hip.call("ebn_split_planes_f32", P(X), D, D, R, 1, P(refT), S())
+    gotN, gotT = u8(L.ebn_planes_bytes(R, D)) + 7, u8(L.ebn_planes_bytes(D, R)) + 7  # poisoned: the kernel must write the zero padding too
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    hip.call("ebn_gather_split_planes_f32", P(d_ids), P(d_tab), R, D, V, P(st), 0, ctypes.c_float(p), P(flag), P(gotN), P(gotT), S())
+    assert torch.equal(gotN, refN) and torch.equal(gotT, refT) and int(flag.item()) == 0
+    # the planes are an exact three-way split: plane0 + plane1 + plane2 == the fp32 value (checked through a product with the identity-like W)
+    E3 = 48
+    W = rng.standard_normal((D, E3)).astype(np.float32)
+    dQ = rng.standard_normal((R, E3)).astype(np.float32)
+    Wp, dQp = u8(L.ebn_planes_bytes(E3, D)), u8(L.ebn_planes_bytes(E3, R))
+    hip.call("ebn_split_planes_f32", P(dev(W)), E3, E3, D, 1, P(Wp), S())
+    hip.call("ebn_split_planes_f32", P(dev(dQ)), E3, E3, R, 1, P(dQp), S())
+    part = torch.empty(max(int(L.ebn_gemm_planes_workspace_floats(D, E3, R)), int(L.ebn_gemm_planes_workspace_floats(R, E3, D)), 1), device="cuda")
+    QKV, dW = torch.empty(R, E3, device="cuda"), torch.empty(D, E3, device="cuda")
+    hip.call("ebn_gemm_planes_f32", P(gotN), R, P(Wp), E3, D, ctypes.c_float(1.0), ctypes.c_float(0.0), P(QKV), E3, P(part), part.numel(), S())
+    hip.call("ebn_gemm_planes_f32", P(gotT), D, P(dQp), E3, R, ctypes.c_float(1.0), ctypes.c_float(0.0), P(dW), E3, P(part), part.numel(), S())
+    X64 = host(X)
+    assert_close(host(QKV), X64 @ W.astype(np.float64), rtol=2e-6, atol=1e-5 + 3e-7 * D, what="X.W from the gather's planes")
+    assert_close(host(dW), X64.T @ dQ.astype(np.float64), rtol=2e-6, atol=1e-5 + 3e-7 * R, what="X^T.dQ from the gather's transposed planes")
+    ids[7] = V  # an id outside the table raises the flag, like the fp32 gather
+    hip.call("ebn_gather_split_planes_f32", P(torch.from_numpy(ids).cuda()), P(d_tab), R, D, V, P(st), 0, ctypes.c_float(p), P(flag), P(gotN), P(gotT), S())
+    assert int(flag.item()) == 1

@@ -51,3 +51,39 @@ for name, tA, tB, M, Nn, K, A, B in [("fwd  QKV = X.W", 0, 0, R, N, D, X, W), ("
     ref = (A.t() if tA else A).double() @ B.double()
     for nm, C in (("exact", C0), ("split", C1)):
         print(f"      {nm}: max abs err vs fp64 {float((C.double() - ref).abs().max()):.3e}  (|ref| max {float(ref.abs().max()):.1f})")
+
+# the split passes on their own: X (both orientations in one pass, with the gather; or one orientation from fp32), dQKV^T, W^T
+L = _hip.lib()
+u8 = lambda n: torch.empty(int(n) + 64, dtype=torch.uint8, device="cuda")
+V = 250002
+table = torch.randn(V, D, device="cuda", generator=g)
+ids = [torch.randint(0, V, (R,), device="cuda", generator=g, dtype=torch.int32) for _ in range(5)]
+XN, XT, dQp, Wp = u8(L.ebn_planes_bytes(R, D)), u8(L.ebn_planes_bytes(D, R)), u8(L.ebn_planes_bytes(N, R)), u8(L.ebn_planes_bytes(N, D))
+st = _hip.StepState()
+st.step, st.seed = 3, 7
+for s_ in range(_hip.binding.EBN_N_SITES):
+    st.drop_key[s_] = 0x9E3779B9 * (s_ + 1) & 0xFFFFFFFF
+st_dev = torch.frombuffer(bytearray(bytes(st)), dtype=torch.uint8).cuda()
+k = [0]
+
+
+def gather_split():
+    k[0] = (k[0] + 1) % 5
+    _hip.call("ebn_gather_split_planes_f32", P(ids[k[0]]), P(table), R, D, V, P(st_dev), 0, ctypes.c_float(0.2), None, P(XN), P(XT), S())
+
+
+def gather_f32():
+    k[0] = (k[0] + 1) % 5
+    _hip.call("ebn_gather_rows_f32", P(ids[k[0]]), P(table), P(X), R, D, V, P(st_dev), 0, ctypes.c_float(0.2), None, S())
+
+
+t = timed(gather_f32)
+print(f"gather fp32 (+dropout)            {t:8.1f} us  {R * (4 + 2 * D * 4) / t / 1e3:7.1f} GB/s")
+t = timed(gather_split)
+print(f"gather + split, both orientations {t:8.1f} us  {(R * D * 4 + L.ebn_planes_bytes(R, D) + L.ebn_planes_bytes(D, R)) / t / 1e3:7.1f} GB/s")
+t = timed(lambda: _hip.call("ebn_split_planes_f32", P(X), D, R, D, 0, P(XN), S()))
+print(f"split X  [R][D] -> planes         {t:8.1f} us  {(R * D * 4 + L.ebn_planes_bytes(R, D)) / t / 1e3:7.1f} GB/s")
+t = timed(lambda: _hip.call("ebn_split_planes_f32", P(dQ), N, N, R, 1, P(dQp), S()))
+print(f"split dQKV^T [R][3E] -> planes    {t:8.1f} us  {(R * N * 4 + L.ebn_planes_bytes(N, R)) / t / 1e3:7.1f} GB/s")
+t = timed(lambda: _hip.call("ebn_split_planes_f32", P(W), N, N, D, 1, P(Wp), S()))
+print(f"split W^T [D][3E] -> planes       {t:8.1f} us")
