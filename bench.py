@@ -196,7 +196,9 @@ def time_kernel(fns, sync, reps=10, replays=5):
     fns[0]()
     sync()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g, capture_error_mode="thread_local"):  # (the RCCL watchdog thread may poll events meanwhile)
+    from ebrec import _hip
+
+    with _hip.capture(g):  # (thread_local error mode: the RCCL watchdog thread may poll events meanwhile; GC held off)
         for i in range(reps):
             fns[i % len(fns)]()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

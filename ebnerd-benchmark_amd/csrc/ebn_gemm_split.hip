@@ -387,7 +387,11 @@ __global__ __launch_bounds__(256) void split_planes_t_rows_kernel(const float* _
 // wave reads 1 KB contiguous of one table row, all of a thread's loads in flight).  The 64 x 64-tile kernel above reads every
 // 4 KB table row as sixteen 256-byte pieces from sixteen workgroups at different times -- random 256-byte reads run at half
 // the HBM rate of random 4 KB reads.  LDS tile [16][GS_CHUNK + 4] fp32 (the +4 makes both read patterns conflict-free).
-constexpr int GS_TOK = 16, GS_CHUNK = 1024, GS_PITCH = GS_CHUNK + 4;
+#ifndef EBN_GS_TOK
+#define EBN_GS_TOK 16
+#define EBN_GS_CHUNK 1024
+#endif
+constexpr int GS_TOK = EBN_GS_TOK, GS_CHUNK = EBN_GS_CHUNK, GS_PITCH = GS_CHUNK + 4;  // (tuning: 16 x 1024 | 32 x 512 | 64 x 256)
 __global__ __launch_bounds__(256) void gather_split_rows_kernel(const int32_t* __restrict__ ids, const float4* __restrict__ table,
                                                                 int64_t R, int64_t D, int64_t V, const uint32_t* __restrict__ key_ptr,
                                                                 uint32_t thresh, float scale, int32_t* __restrict__ oob_flag,
@@ -432,7 +436,7 @@ __global__ __launch_bounds__(256) void gather_split_rows_kernel(const int32_t* _
   const int64_t n_plane = (n_Kp / 8) * n_rows_p * 8, t_plane = (t_Kp / 8) * t_rows_p * 8;
   // ---- T orientation (rows = columns, contraction = tokens): item (token octet o of 2, column c): a wave writes 1 KB contiguous
 #pragma unroll
-  for (int it = 0; it < 2 * GS_CHUNK / 256; ++it) {
+  for (int it = 0; it < (GS_TOK / 8) * GS_CHUNK / 256; ++it) {
     const int item = it * 256 + tid, o = item / GS_CHUNK, c = item % GS_CHUNK;
     if (c0 + c >= t_rows_p || r0 + o * 8 >= t_Kp) continue;
     u16x8 v0, v1, v2;

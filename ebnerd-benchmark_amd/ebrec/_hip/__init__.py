@@ -7,5 +7,5 @@ builds it) or no GPU is visible, callers get a RuntimeError.
 """
 from .binding import (  # noqa: F401
     EncoderActs, EncoderDims, EncoderGrads, EncoderParams, EncoderScratch, HipError,
-    StepState, call, declared_functions, header_path, lib, library_path, ptr, stream_handle,
+    StepState, call, capture, declared_functions, header_path, lib, library_path, ptr, stream_handle,
 )

@@ -127,6 +127,42 @@ def stream_handle():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class capture:
+    """``with capture(graph, pool=None):`` -- torch.cuda.graph(...) in thread_local error mode (the RCCL watchdog thread of
+    torch.distributed polls events while this thread captures; in the default "global" mode any such call from another thread
+    invalidates the capture) with Python's cyclic garbage collector held off for the duration: a collection that happens to run
+    inside the capture can destroy an old CUDAGraph / event / cached block of an earlier model, and the runtime aborts the
+    process on such a call from a capturing thread (seen as "Fatal Python error: Aborted ... Garbage-collecting")."""
+
+    def __init__(self, graph, pool=None):
+        import torch
+
+        self._cm = torch.cuda.graph(graph, pool=pool, capture_error_mode="thread_local")
+        self._gc = False
+
+    def __enter__(self):
+        import gc
+
+        gc.collect()
+        self._gc = gc.isenabled()
+        gc.disable()
+        try:
+            return self._cm.__enter__()
+        except BaseException:
+            if self._gc:
+                gc.enable()
+            raise
+
+    def __exit__(self, *exc):
+        import gc
+
+        try:
+            return self._cm.__exit__(*exc)
+        finally:
+            if self._gc:
+                gc.enable()
+
+
 def call(name: str, *args):
     """Invoke an int-returning entry point; raise HipError on a non-zero code."""
     handle = lib()

@@ -929,9 +929,7 @@ class NRMSEngine:
             while j < len(segs) and segs[j][0] == "k":
                 j += 1
             g = torch.cuda.CUDAGraph()
-            # thread_local: the RCCL watchdog thread of torch.distributed polls events while this thread captures -- in the default
-            # "global" mode any such call from another thread invalidates the capture
-            with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
+            with _hip.capture(g, pool=pool):  # (thread_local error mode, garbage collector held off: see _hip.capture)
                 for _kind, fn in segs[i:j]:
                     fn()
             pool = pool or g.pool()

@@ -348,9 +348,9 @@ class DocVecEngine:
             if g is None:
                 torch.cuda.synchronize()
                 g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g1, capture_error_mode="thread_local"):
+                with _hip.capture(g1):
                     self._fwd_bwd_kernels(B, C, adv)
-                with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode="thread_local"):
+                with _hip.capture(g2, pool=g1.pool()):
                     self._optimizer_kernels()
                 g = self._graphs[(B, C, adv)] = (g1, g2)
             g[0].replay()
