@@ -455,6 +455,20 @@ def main():
     if not args.no_roofline:
         kt = {"qkv_gemm": time_kernel(rk["qkv_gemm"], sync), "gather": time_kernel([rk["gather"](ids) for ids in id_sets], sync)}
     loss = float(eng.loss_dev.item())
+    comm = None
+    if world > 1:
+        # what the collectives cost the step: the same steps timed again with every collective skipped (the results of those
+        # steps are wrong and thrown away; all ranks skip together) -- exposed = with - without, after whatever the overlap hid
+        eng.skip_collectives = True
+        if eng.exchange is not None:
+            eng.exchange.skip = True
+        t_no = timed_repeats(lambda k: eng.train_step(*batches[k % len(batches)]), argparse.Namespace(warmup=2, repeats=max(args.repeats, 3), steps=args.steps),
+                             sync, world, device)
+        eng.skip_collectives = False
+        if eng.exchange is not None:
+            eng.exchange.skip = False
+        ms_no = float(np.median([t / args.steps * 1e3 for t in t_no]))
+        comm = {"ms_per_step_without_collectives": ms_no, "overlap": bool(eng.overlap_collectives)}
     eng.check_oob()  # sticky device flags of the whole run (ids out of range, exchange overflow, accumulator range): raise, don't report
 
     if rank == 0:
@@ -538,6 +552,11 @@ def main():
             line["exchange"] = eng.exchange.stats()
         if world > 1:
             line["allreduce_bytes_per_step"] = eng.allreduce_bytes(c["B"] * (c["H"] + c["C"]) * c["T"])
+            line["comm_exposed_us"] = (line["ms_per_step"] - comm["ms_per_step_without_collectives"]) * 1e3
+            line["comm"] = {**comm, "note": "comm_exposed_us = ms_per_step - the same steps with every collective skipped (measured after the timed "
+                                            "region, same graphs).  Dense gradients travel as two buckets started asynchronously under the rest of the "
+                                            "backward (everything-but-dWqkv under the attention backward + dWqkv GEMM; dWqkv under the dX GEMM and the "
+                                            "table-gradient accumulation when the table trains)"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(c, steps=args.cpu_steps)
         print(json.dumps(line), flush=True)

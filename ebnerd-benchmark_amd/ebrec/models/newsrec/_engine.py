@@ -200,6 +200,9 @@ class NRMSEngine:
         self.loss_dev = torch.zeros(1, device=self.device)
         self.use_graph = False  # capture the per-shape kernel sequence into hipGraphs (enable_graphs())
         self.fuse_user_head = True  # False: the per-impression head of a step as its six separate launches (validation)
+        self.overlap_collectives = True  # multi-rank: start the dense-gradient buckets under the rest of the backward (see _segments)
+        self.skip_collectives = False    # bench.py only: time the step without its collectives (-> comm_exposed_us); results are wrong
+        self._pending = []
         self.world = 1
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
@@ -491,35 +494,67 @@ class NRMSEngine:
                   _hip.ptr(b.w), n_seq, T, E, A, S())
 
     def _news_encoder_bwd_split(self, b, n_seq, X, dout, dX, site, p):
+        self._news_bwd_p1(b, n_seq, dout)
+        self._news_bwd_p2(b, n_seq, X, dout, site, p)
+        if dX is not None:
+            self._news_bwd_p3(b, n_seq, dX)
+
+    # The news encoder's backward as three runs of kernels -- the kernels of ebn_encoder_bwd_f32 (csrc/ebn_encoder.hip) in its
+    # order, cut where a multi-rank step can start a collective on what has just been written:
+    #   p1  AttLayer2 backward: de; dq, db, d(pre-tanh); dW = Y^T.dpre | dY = dpre.W^T           -> every dense gradient but dWqkv
+    #   p2  self-attention core backward (pooling term folded in where supported); dWqkv = X^T.dQKV   -> the last dense gradient
+    #   p3  dX = dQKV.Wqkv^T (trainable table only)
+    def _news_bwd_p1(self, b, n_seq, dout):
         S, E, A, T = _hip.stream_handle, self.E, self.A, b.L
         R = n_seq * T
         pv, g = self.params.view, self.params.g
         ws, wsn = _hip.ptr(b.ws), b.ws.numel()
         one, zero = ctypes.c_float(1.0), ctypes.c_float(0.0)
-        st = _hip.ptr(self.state)
         _hip.call("ebn_attpool_bwd_pool_f32", _hip.ptr(b.Y), _hip.ptr(b.w), _hip.ptr(dout), None, _hip.ptr(b.de), n_seq, T, E, S())
         _hip.call("ebn_attpool_bwd_dpre_f32", _hip.ptr(b.U), _hip.ptr(pv("n_q")), _hip.ptr(b.de), _hip.ptr(g("n_q")), _hip.ptr(g("n_b")),
                   _hip.ptr(b.partials), R, A, 0, S())
-        if int(_hip.lib().ebn_attn_bwd_pooled_supported(T, self.d)) != 0 and E % 4 == 0:
+        if self._fold_pooling(T):
             _hip.call("ebn_dense_bwd_pair_f32", R, E, A, _hip.ptr(b.Y), E, _hip.ptr(b.U), A, _hip.ptr(pv("n_W")), A, zero, _hip.ptr(g("n_W")), A,
                       _hip.ptr(b.dY), E, ws, wsn, S())
-            _hip.call("ebn_attn_bwd_pooled_f32", _hip.ptr(b.QKV), 3 * E, _hip.ptr(b.dY), E, _hip.ptr(b.w), _hip.ptr(dout), E, _hip.ptr(b.dQKV), 3 * E,
-                      n_seq, T, self.h, self.d, st, site, ctypes.c_float(p), S())
         else:
             _hip.call("ebn_gemm_f32_ws", 1, 0, E, A, R, one, _hip.ptr(b.Y), E, _hip.ptr(b.U), A, zero, _hip.ptr(g("n_W")), A, ws, wsn, S())
             _hip.call("ebn_gemm_f32_rank1", R, E, A, one, _hip.ptr(b.U), A, _hip.ptr(pv("n_W")), A, _hip.ptr(b.dY), E, _hip.ptr(b.w), _hip.ptr(dout), E,
                       T, ws, wsn, S())
+
+    def _fold_pooling(self, T) -> bool:
+        return int(_hip.lib().ebn_attn_bwd_pooled_supported(T, self.d)) != 0 and self.E % 4 == 0
+
+    def _news_bwd_p2(self, b, n_seq, X, dout, site, p):
+        S, E, T = _hip.stream_handle, self.E, b.L
+        R = n_seq * T
+        g = self.params.g
+        st = _hip.ptr(self.state)
+        one, zero = ctypes.c_float(1.0), ctypes.c_float(0.0)
+        if self._fold_pooling(T):
+            _hip.call("ebn_attn_bwd_pooled_f32", _hip.ptr(b.QKV), 3 * E, _hip.ptr(b.dY), E, _hip.ptr(b.w), _hip.ptr(dout), E, _hip.ptr(b.dQKV), 3 * E,
+                      n_seq, T, self.h, self.d, st, site, ctypes.c_float(p), S())
+        else:
             _hip.call("ebn_attn_bwd_f32", _hip.ptr(b.QKV), 3 * E, _hip.ptr(b.dY), E, _hip.ptr(b.dQKV), 3 * E, n_seq, T, self.h, self.d, st, site,
                       ctypes.c_float(p), S())
-        if getattr(b, "planes_rows", -1) == R:  # dWqkv = X^T . dQKV on the transposed planes the gather wrote
+        if self.precision != "split":                       # dWqkv = X^T . dQKV
+            _hip.call("ebn_gemm_f32_ws", 1, 0, b.Din, 3 * E, R, one, _hip.ptr(X), b.Din, _hip.ptr(b.dQKV), 3 * E, zero, _hip.ptr(g("n_Wqkv")), 3 * E,
+                      _hip.ptr(b.ws), b.ws.numel(), S())
+        elif getattr(b, "planes_rows", -1) == R:            # ... on the transposed planes the gather wrote
             sb = self._split_bufs(b)
             _hip.call("ebn_split_planes_f32", _hip.ptr(b.dQKV), 3 * E, 3 * E, R, 1, _hip.ptr(sb["dQp"]), S())
             _hip.call("ebn_gemm_planes_f32", _hip.ptr(sb["XT"]), b.Din, _hip.ptr(sb["dQp"]), 3 * E, R, one, zero, _hip.ptr(g("n_Wqkv")), 3 * E,
                       _hip.ptr(sb["part"]), sb["part"].numel(), S())
         else:
             self._gemm_prec(b, 1, 0, b.Din, 3 * E, R, X, b.Din, b.dQKV, 3 * E, g("n_Wqkv"), 3 * E)
-        if dX is not None:
-            self._gemm_prec(b, 0, 1, R, b.Din, 3 * E, b.dQKV, 3 * E, pv("n_Wqkv"), 3 * E, dX, b.Din)  # dX = dQKV . Wqkv^T
+
+    def _news_bwd_p3(self, b, n_seq, dX):
+        E, R = self.E, n_seq * b.L
+        pv = self.params.view
+        if self.precision != "split":                       # dX = dQKV . Wqkv^T
+            _hip.call("ebn_gemm_f32_ws", 0, 1, R, b.Din, 3 * E, ctypes.c_float(1.0), _hip.ptr(b.dQKV), 3 * E, _hip.ptr(pv("n_Wqkv")), 3 * E,
+                      ctypes.c_float(0.0), _hip.ptr(dX), b.Din, _hip.ptr(b.ws), b.ws.numel(), _hip.stream_handle())
+        else:
+            self._gemm_prec(b, 0, 1, R, b.Din, 3 * E, b.dQKV, 3 * E, pv("n_Wqkv"), 3 * E, dX, b.Din)
 
     def roofline_kernels(self, B, C):
         """Launchers of single kernels of the training step at batch shape (B, C), on the step's own buffers and arguments
@@ -921,7 +956,7 @@ class NRMSEngine:
         torch.cuda.synchronize()
         segs, run, pool, i = self._segments(B, C, advanced), [], None, 0
         while i < len(segs):
-            if segs[i][0] == "c":
+            if segs[i][0] != "k":  # "c" | "a" | "w": collectives (and the wait for them) stay eager launches between the replays
                 run.append(segs[i][1])
                 i += 1
                 continue
@@ -940,7 +975,15 @@ class NRMSEngine:
         return run
 
     def _segments(self, B, C, advanced=False):
-        """One training step as an ordered list of ("k" = kernels only | "c" = collective, fn)."""
+        """One training step as an ordered list of (kind, fn): "k" = kernels only (captured into hipGraphs), "c" = collective the
+        step waits for, "a" = collective started asynchronously (RCCL runs it on its own stream after everything enqueued so far;
+        the following kernels do not wait), "w" = wait for every started collective.
+
+        Multi-rank data parallel: the dense gradients travel as TWO buckets in the order the backward finishes them -- A = every
+        dense gradient but dWqkv (complete after the news AttLayer2 backward) starts under the attention-core backward and the
+        dWqkv GEMM; B = dWqkv starts under the dX GEMM and the table-gradient accumulation of a trainable table (with a frozen
+        table nothing is left to hide it under).  The buckets are the same two calls whether or not anything overlaps, so the
+        overlapped step is bit-identical to the serial one."""
         N = B * (self.H + C)
         nb, _ub = self._train_bufs(B, C)
         multi = self.world > 1
@@ -948,15 +991,44 @@ class NRMSEngine:
         if self._planned:
             segs += self._lookup_segments(nb, N)
         sparse = self._sparse_dp(N * self.T)
-        segs.append(("k", lambda: self._fwd_bwd_kernels(B, C, sparse)))
-        if self._planned and self.train_embedding:
-            segs += self._table_grad_segments(nb, N)
-        if multi:
-            segs.append(("c", lambda: self._allreduce_grads(dense_table=not sparse)))
-        if sparse:
-            segs += self._sparse_table_grad_segments(nb, N)
+        if multi and self.mlp is None and self.overlap_collectives:
+            cut = self.params.offsets["n_W"]  # n_Wqkv is the first parameter of the flat buffer: bucket B = grad[:cut], A = grad[cut:]
+            segs.append(("k", lambda: self._fwd_bwd_kernels(B, C, sparse, part="a")))
+            segs.append(("a", lambda: self._allreduce_async(self.params.grad[cut:])))
+            segs.append(("k", lambda: self._fwd_bwd_kernels(B, C, sparse, part="b")))
+            segs.append(("a", lambda: self._allreduce_async(self.params.grad[:cut])))
+            if self.train_embedding:
+                segs.append(("k", lambda: self._fwd_bwd_kernels(B, C, sparse, part="c")))
+            if self._planned and self.train_embedding:
+                segs += self._table_grad_segments(nb, N)
+            if self.train_embedding and self.exchange is None and not sparse:
+                segs.append(("c", lambda: self._allreduce_table_grad()))
+            if sparse:
+                segs += self._sparse_table_grad_segments(nb, N)
+            segs.append(("w", self._wait_collectives))
+        else:
+            segs.append(("k", lambda: self._fwd_bwd_kernels(B, C, sparse)))
+            if self._planned and self.train_embedding:
+                segs += self._table_grad_segments(nb, N)
+            if multi:
+                segs.append(("c", lambda: self._allreduce_grads(dense_table=not sparse)))
+            if sparse:
+                segs += self._sparse_table_grad_segments(nb, N)
         segs.append(("k", lambda: self._optimizer_kernels(from_acc=self._adam_from_acc or sparse)))
         return segs
+
+    def _allreduce_async(self, t):
+        if self.world > 1 and not self.skip_collectives:
+            self._pending.append(torch.distributed.all_reduce(t, group=self.pg, async_op=True))
+
+    def _wait_collectives(self):
+        for w in self._pending:
+            w.wait()  # RCCL: the compute stream waits for the collective's stream (no host block); gloo: the host waits
+        self._pending = []
+
+    def _allreduce_table_grad(self):
+        if self.world > 1 and not self.skip_collectives:
+            torch.distributed.all_reduce(self.table_grad, group=self.pg)
 
     def _sparse_table_grad_segments(self, nb, N):
         n_tok, W = N * self.T, self.world
@@ -967,6 +1039,8 @@ class NRMSEngine:
         site, p = (0, self.p) if self.p > 0 else (-1, 0.0)
 
         def gather():
+            if self.skip_collectives:
+                return
             torch.distributed.all_gather_into_tensor(ids_all, nb.ids[:n_tok], group=self.pg)
             torch.distributed.all_gather_into_tensor(dX_all, nb.dX[:n_tok], group=self.pg)
 
@@ -978,11 +1052,32 @@ class NRMSEngine:
 
         return [("c", gather), ("k", accumulate)]
 
-    def _fwd_bwd_kernels(self, B, C, sparse_table_grads=False):
+    def _fwd_bwd_kernels(self, B, C, sparse_table_grads=False, part="all"):
+        """part: "all" = the whole forward + backward (one rank: the stage calls run the news backward as one C call);
+        "a" | "b" | "c" = the same kernels cut in three for a multi-rank step (see _segments): a = forward, user stage, news
+        AttLayer2 backward; b = attention-core backward + dWqkv; c = dX + the table-gradient accumulation."""
         H, E = self.H, self.E
         N = B * (H + C)
         S = _hip.stream_handle
         nb, ub = self._train_bufs(B, C)
+        st = _hip.ptr(self.state)
+        site1, p1 = (1, self.p) if self.p > 0 else (-1, 0.0)
+        if part == "b":
+            return self._news_bwd_p2(nb, N, nb.X, nb.dNE, site1, p1)
+        if part in ("all", "a"):
+            self._fwd_user_stage_kernels(B, C, nb, ub)
+        if part == "a":
+            return self._news_bwd_p1(nb, N, nb.dNE)
+        if part == "all":
+            self._encoder_bwd("n", nb, N, nb.X, nb.dNE, nb.dX, B * H)
+        elif nb.dX is not None:  # part "c"
+            self._news_bwd_p3(nb, N, nb.dX)
+        self._table_grad_kernels(nb, N, sparse_table_grads)
+
+    def _fwd_user_stage_kernels(self, B, C, nb, ub):
+        H, E = self.H, self.E
+        N = B * (H + C)
+        S = _hip.stream_handle
         st = _hip.ptr(self.state)
         # ---- forward
         self._news_forward(nb, N, True, B * H, looked_up=True)
@@ -1000,7 +1095,10 @@ class NRMSEngine:
                   _hip.ptr(dcand), _hip.ptr(ub.duser), ctypes.byref(grads), ctypes.byref(scratch),
                   _hip.ptr(ub.head_partials) if self.fuse_user_head else None, _hip.ptr(nb.dNE), C, self.loss_kind,
                   ctypes.c_float(1.0 / B), st, S())
-        self._encoder_bwd("n", nb, N, nb.X, nb.dNE, nb.dX, B * H)
+
+    def _table_grad_kernels(self, nb, N, sparse_table_grads):
+        S = _hip.stream_handle
+        st = _hip.ptr(self.state)
         if self.train_embedding and not self._planned and not sparse_table_grads:
             if self.exchange is not None or not self.deterministic:
                 self.table_grad.zero_()
@@ -1022,9 +1120,13 @@ class NRMSEngine:
                           N * self.T, self.D, self.V, st, site, ctypes.c_float(p), S())
 
     def _allreduce_grads(self, dense_table=True):
-        """Data-parallel gradient all-reduce over RCCL (SUM; the 1/world is folded into Adam)."""
-        if self.world > 1:
-            torch.distributed.all_reduce(self.params.grad, group=self.pg)
+        """Data-parallel gradient all-reduce over RCCL (SUM; the 1/world is folded into Adam).  Two buckets, cut where the
+        overlapped form cuts them (same collectives on the same buffers -> bit-identical results either way)."""
+        if self.world > 1 and not self.skip_collectives:
+            cut = self.params.offsets.get("n_W", 0)
+            torch.distributed.all_reduce(self.params.grad[cut:], group=self.pg)
+            if cut:
+                torch.distributed.all_reduce(self.params.grad[:cut], group=self.pg)
             # (a sharded table's gradients already sit at their owner; the sparse exchange all-gathers token rows instead)
             if self.train_embedding and self.exchange is None and dense_table:
                 torch.distributed.all_reduce(self.table_grad, group=self.pg)

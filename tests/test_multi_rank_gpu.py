@@ -246,6 +246,44 @@ def test_two_rank_row_sharded_table_step_equals_the_full_batch_oracle_step(hip, 
     _spawn(_dp_worker, 2, True, partition, graph, train_embedding, 20)
 
 
+def _overlap_worker(rank, world, H, train_embedding, graph, exchange):
+    """The step with the dense-gradient buckets started under the rest of the backward against the step that waits for each
+    collective where it is issued: same kernels, same two buckets -> bit-identical losses and replicas."""
+    from ebrec.models.newsrec import NRMSModel
+
+    hp = make_hp(history_size=H, dropout=0.2, learning_rate=1e-3)
+    V, D, seed, B, C = 600, 64, 5, 3, 5
+    rng = np.random.default_rng(91)
+    emb = rng.standard_normal((V, D)).astype(np.float32)
+    ms = []
+    for overlap in (True, False):
+        m = NRMSModel(hp, word2vec_embedding=emb, seed=seed, train_embedding=train_embedding, table_grad_exchange=exchange)
+        m._engine.overlap_collectives = overlap
+        if graph:
+            m._engine.enable_graphs()
+        ms.append(m)
+    kinds = [k for k, _ in ms[0]._engine._segments(B, C)]
+    assert kinds.count("a") == 2 and "w" in kinds and [k for k, _ in ms[1]._engine._segments(B, C)].count("a") == 0
+    for t in range(3):
+        his, pred, y = batch(np.random.default_rng(1000 * t + rank), B, H, C, hp.title_size, V)
+        l0, l1 = (float(m.train_step(his, pred, y).item()) for m in ms)
+        assert l0 == l1, (rank, t, l0, l1)
+    for a, b in zip(ms[0].model.get_weights(), ms[1].model.get_weights()):
+        assert np.array_equal(a, b)
+    import torch.distributed as dist
+
+    mine = [w.tobytes() for w in ms[0].model.get_weights()]
+    parts = [None] * world
+    dist.all_gather_object(parts, mine)
+    assert all(p == parts[0] for p in parts)  # identical replicas on every rank
+
+
+@pytest.mark.parametrize("world,H,train_embedding,graph,exchange", [(2, 20, False, True, "auto"), (2, 20, True, True, "dense"), (2, 50, True, False, "sparse"),
+                                                                    (8, 20, True, True, "dense")])
+def test_overlapped_gradient_buckets_are_bit_identical_to_the_serial_step(hip, world, H, train_embedding, graph, exchange):
+    _spawn(_overlap_worker, world, H, train_embedding, graph, exchange)
+
+
 # ---------------------------------------------------------------- world = 8 on the one GPU (BASELINE configs[3] / configs[4] rank count)
 @pytest.mark.parametrize("table_grad_exchange", ["dense", "sparse"])
 def test_eight_rank_c4_data_parallel_step_equals_the_full_batch_oracle_step(hip, table_grad_exchange):
