@@ -9,7 +9,7 @@ import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 G, P = ROOT / "gpurun_out" / tag, ROOT / "profiles"
 
 
@@ -57,9 +57,15 @@ for c in ("c1", "c2", "c3", "c4", "c5", "c5h50"):
         line = last_json(src) if src.exists() else None
         if line is None:
             continue
-        if c == "c2" and "roofline" in line:  # the run itself read the previous round's traffic.json
-            line["roofline"]["traffic"], line["roofline_gather"]["traffic"] = traffic["qkv_gemm"], traffic["gather"]
         (P / f"{tag}_bench_{c}{kind}_1gpu.json").write_text(json.dumps(line) + "\n")
+for kind in ("", "_under_rocprof"):  # the opt-in split precision
+    src = G / f"bench_c2_split{kind}.json"
+    line = last_json(src) if src.exists() else None
+    if line:
+        (P / f"{tag}_bench_c2_split_precision{kind}_1gpu.json").write_text(json.dumps(line) + "\n")
+st = find(G / "stats_c2_split", "kernel_stats.csv") if (G / "stats_c2_split").exists() else None
+if st:
+    shutil.copy(st, P / f"{tag}_kernel_stats_bench_c2_split_precision.csv")
 for c in ("c2", "c4", "c5"):
     src = G / f"bench_{c}_2ranks_gloo.json"
     line = last_json(src) if src.exists() else None
