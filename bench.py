@@ -251,7 +251,7 @@ def probe_kernels(config, batch, precision="exact"):
                                cwd=tmp, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
             if r.returncode != 0:
                 return None
-        pick = lambda name: "gather" if "gather_rows" in name else ("qkv_gemm" if "gemm" in name else None)
+        pick = lambda name: "gather" if "gather" in name else ("qkv_gemm" if "gemm" in name else None)
         stats = next(Path(tmp, "stats").rglob("*kernel_stats.csv"))
         for row in csv.DictReader(open(stats)):
             k = pick(row["Name"])
@@ -519,6 +519,10 @@ def main():
                                  "bound": "mfma", "achieved": fl_step / (line["ms_per_step"] * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
                                  "unit": "TFLOP/s", "frac": fl_step / (line["ms_per_step"] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
                                  "algorithmic_flops_per_step": fl_step}
+        if args.precision == "split":  # part of the step runs on the bf16 pipe: a fraction of the fp32 peak would mean nothing
+            line["roofline_step"].update({"what": "fp32-equivalent matmul rate of the whole step (exact matmul FLOPs of one step / ms_per_step); the "
+                                                  "projection GEMMs execute 6 bf16 MFMA products per fp32 product on the bf16 pipe, so no single peak applies",
+                                          "peak": None, "frac": None})
         if kt is not None and args.precision == "split":
             # the projection as the step runs it: two split passes + the bf16x6 GEMM (six bf16 MFMA products per fp32 product)
             line["roofline"] = {"kernel": gemm_name, "role": "news-encoder Q|K|V projection, forward, as split passes + bf16x6 GEMM "
