@@ -55,6 +55,31 @@ assert parts[0][0] == [[1, 0]]
 # a second capture while the communicator (and its watchdog thread) is alive
 eng.train_step(his[:2], pred[:2], y[:2])
 torch.cuda.synchronize()
+# the multi-rank STEP itself on RCCL: the engine is told it has two ranks (the group still has one, so every collective is an
+# identity), which makes it run the overlapped form -- graph | async all-reduce of bucket A (a slice of the flat gradient
+# buffer) | graph | async all-reduce of bucket B | graph | table-gradient all-reduce | wait | graph(Adam) -- eager and replayed,
+# then again with the collectives skipped as bench.py's comm_exposed_us measurement does
+for frozen in (False, True):
+    m2 = NRMSModel(hp, word2vec_embedding=emb, seed=1, device=dev, train_embedding=not frozen, table_grad_exchange="dense")
+    e2 = m2._engine
+    e2.world = 2
+    kinds = [k for k, _ in e2._segments(4, 5)]
+    assert kinds.count("a") == 2 and "w" in kinds, kinds
+    ref = NRMSModel(hp, word2vec_embedding=emb, seed=1, device=dev, train_embedding=not frozen)
+    ref._engine.world = 2  # same 1/world gradient scale, serial collectives
+    ref._engine.overlap_collectives = False
+    for graphs in (False, True):
+        e2.enable_graphs(graphs); ref._engine.enable_graphs(graphs)
+        for _ in range(3):
+            l2 = float(e2.train_step(his, pred, y).item()); lr = float(ref._engine.train_step(his, pred, y).item())
+            assert l2 == lr, (frozen, graphs, l2, lr)
+    for a_, b_ in zip(m2.model.get_weights(), ref.model.get_weights()):
+        assert np.array_equal(a_, b_)
+    e2.skip_collectives = True
+    e2.train_step(his, pred, y)
+    e2.skip_collectives = False
+    e2.check_oob()
+torch.cuda.synchronize()
 dist.destroy_process_group()
 print("RCCL_SINGLE_RANK_OK", float(eng.loss_dev.item()))
 '''
