@@ -512,9 +512,10 @@ extern "C" int ebn_split_planes_f32(const float* src, int64_t ld, int64_t rows, 
   EBN_REQUIRE(ebn_aligned16(planes), EBN_ERR_ALIGN);
   const int64_t rows_p = pad_rows(rows), Kp = pad_k(K);
   const dim3 grid(static_cast<unsigned>(rows_p / 64), static_cast<unsigned>(ebn_ceil_div(Kp, 64)));
+  static const bool split_t_tile = getenv("EBN_SPLIT_T_TILE") != nullptr;  // read once (tuning switch)
   if (!trans) hipLaunchKernelGGL((split_planes_kernel<false>), grid, dim3(256), 0, ebn_stream(stream), src, ld, rows, K,
                                  static_cast<uint16_t*>(planes), rows_p, Kp);
-  else if (getenv("EBN_SPLIT_T_TILE") != nullptr)  // tuning: the 64 x 64-tile transpose through LDS
+  else if (split_t_tile)  // tuning: the 64 x 64-tile transpose through LDS
     hipLaunchKernelGGL((split_planes_kernel<true>), grid, dim3(256), 0, ebn_stream(stream), src, ld, rows, K,
                        static_cast<uint16_t*>(planes), rows_p, Kp);
   else
@@ -532,7 +533,8 @@ extern "C" int ebn_gather_split_planes_f32(const int32_t* ids, const float* tabl
   const EbnDrop d = ebn_make_drop(st, site, drop_p);
   const int64_t n_rows_p = pad_rows(n_rows), n_Kp = pad_k(D), t_rows_p = pad_rows(D), t_Kp = pad_k(n_rows);
   const int64_t tok_ext = n_rows_p > t_Kp ? n_rows_p : t_Kp, col_ext = t_rows_p > n_Kp ? t_rows_p : n_Kp;
-  if ((D % 4) == 0 && ebn_aligned16(table) && getenv("EBN_GATHER_SPLIT_TILE") == nullptr) {  // whole table rows at a time
+  static const bool gather_tile = getenv("EBN_GATHER_SPLIT_TILE") != nullptr;  // read once (tuning: the 64 x 64-tile kernel)
+  if ((D % 4) == 0 && ebn_aligned16(table) && !gather_tile) {  // whole table rows at a time
     constexpr size_t lds = static_cast<size_t>(GS_TOK) * GS_PITCH * sizeof(float);  // 65,792 bytes: above the 64 KB default limit
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_split_rows_kernel),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));

@@ -333,13 +333,10 @@ extern "C" int ebn_user_head_train_f32(float* U, const float* b, const float* q,
   if (B == 0) return EBN_OK;
   hipStream_t s = ebn_stream(stream);
   const size_t lds = head_lds_bytes(L, C, E, A);
-  static size_t lds_set = 0;  // raise the dynamic-LDS limit once per size class (above the 64 KB default for long histories)
-  if (lds > 64 * 1024 && lds > lds_set) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&user_head_train_kernel),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    if (e != hipSuccess) return static_cast<int>(e);
-    lds_set = 150 * 1024;
-  }
+  // the dynamic-LDS limit is raised once, to the most ebn_user_head_supported admits (above the 64 KB default: long histories)
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&user_head_train_kernel),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+  if (attr != hipSuccess) return static_cast<int>(attr);
   HeadArgs a{U, b, q, X, cand, labels, w, user, scores, probs, loss_rows, dcand, duser, de, partials, L, C, E, A, loss_kind, inv_batch};
   hipLaunchKernelGGL(user_head_train_kernel, dim3(static_cast<unsigned>(B)), dim3(HEAD_THREADS), lds, s, a);
   EBN_CHECK_LAUNCH();

@@ -42,6 +42,8 @@ def test_bench_line_carries_the_contract_fields(cfg):
                 alg = rr.get("algorithmic_bytes_per_launch")
                 if alg:  # the gather's corrected counter traffic equals its known byte count (calibration of the x2 rule)
                     assert abs(rr["traffic"] - alg) < 0.02 * alg, (rr["traffic"], alg)
+        fl = d["fit_loop"]  # the host loop + loader keep up with the device step (the timed region itself replays staged batches)
+        assert fl["steps"] == 100 and fl["value"] > 0.8 * d["value"] and abs(fl["frac_of_value"] - fl["value"] / d["value"]) < 1e-9
         st = d["roofline_step"]
         assert st["bound"] == "mfma" and abs(st["frac"] - st["achieved"] / st["peak"]) < 1e-9 and 0 < st["frac"] < d["roofline"]["frac"]
         assert abs(st["achieved"] * 1e12 - st["algorithmic_flops_per_step"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * st["achieved"] * 1e12

@@ -17,7 +17,7 @@ done
 # the opt-in second precision (bf16x6 split projections): its own line, next to an exact line from the same box
 python bench.py --config c2 --steps 20 --warmup 5 --no-cpu-baseline --precision split > $out/bench_c2_split.json 2> $out/bench_c2_split.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_c2_split -o c2_split -- \
-  python bench.py --config c2 --steps 20 --warmup 5 --no-cpu-baseline --no-probe --precision split > $out/bench_c2_split_under_rocprof.json 2> $out/rocprof_c2_split.err
+  python bench.py --config c2 --steps 20 --warmup 5 --no-cpu-baseline --no-probe --no-fit-loop --precision split > $out/bench_c2_split_under_rocprof.json 2> $out/rocprof_c2_split.err
 rm -f $out/stats_c2_split/*kernel_trace.csv $out/stats_c2_split/*agent_info.csv
 # two ranks sharing the one GPU over gloo: functional dry run of the multi-rank paths (not a scaling number)
 for c in c2 c4 c5; do
@@ -26,19 +26,19 @@ done
 # per-kernel statistics of the same bench command, per config
 for c in c2 c1 c3 c4 c5; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$c -o $c -- \
-    python bench.py --config $c --steps 20 --warmup 5 --no-cpu-baseline --no-probe > $out/bench_${c}_under_rocprof.json 2> $out/rocprof_$c.err
+    python bench.py --config $c --steps 20 --warmup 5 --no-cpu-baseline --no-probe --no-fit-loop > $out/bench_${c}_under_rocprof.json 2> $out/rocprof_$c.err
   rm -f $out/stats_$c/*kernel_trace.csv $out/stats_$c/*agent_info.csv
 done
 # HBM traffic counters (c2): separate --pmc passes, kernel by kernel (no graphs: counters are per dispatch)
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_$c -o b -- \
-    python bench.py --no-graph --no-roofline --no-probe --no-cpu-baseline --steps 10 --warmup 2 --repeats 1 > /dev/null 2> $out/pmc_$c.err
+    python bench.py --no-graph --no-roofline --no-probe --no-fit-loop --no-cpu-baseline --steps 10 --warmup 2 --repeats 1 > /dev/null 2> $out/pmc_$c.err
   rm -f $out/pmc_$c/*kernel_trace.csv $out/pmc_$c/*agent_info.csv
 done
 rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/pmc_mfma_a -o b -- \
-  python bench.py --no-graph --no-roofline --no-probe --no-cpu-baseline --steps 10 --warmup 2 --repeats 1 > /dev/null 2> $out/pmc_mfma_a.err
+  python bench.py --no-graph --no-roofline --no-probe --no-fit-loop --no-cpu-baseline --steps 10 --warmup 2 --repeats 1 > /dev/null 2> $out/pmc_mfma_a.err
 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $out/pmc_mfma_b -o b -- \
-  python bench.py --no-graph --no-roofline --no-probe --no-cpu-baseline --steps 10 --warmup 2 --repeats 1 > /dev/null 2> $out/pmc_mfma_b.err
+  python bench.py --no-graph --no-roofline --no-probe --no-fit-loop --no-cpu-baseline --steps 10 --warmup 2 --repeats 1 > /dev/null 2> $out/pmc_mfma_b.err
 rm -f $out/pmc_mfma_*/*kernel_trace.csv $out/pmc_mfma_*/*agent_info.csv
 bash tools/trace_kernel.sh c2 "256, 64, 4, false, false, true, 1" > $out/gemm_launch_trace.txt 2>&1
 cat $out/pytest_gpu.log
