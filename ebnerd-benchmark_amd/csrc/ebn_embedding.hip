@@ -196,6 +196,122 @@ __global__ __launch_bounds__(256) void adam_keras_fixed_kernel(float* __restrict
   if (bad && range_flag != nullptr) *range_flag = 1;
 }
 
+// ---- the same deterministic accumulation WITHOUT a 64-bit atomic per gradient element: counting sort of the tokens by id
+// (histogram -> exclusive scan -> bucket fill), then a segmented reduction over the sorted positions in which every table
+// row that lies wholly inside a thread's run of positions is added with plain loads / stores by its one owner; only the rows
+// that straddle a run boundary (a hot row such as token 0 of padded titles spans many runs) use the integer atomics.  The sums
+// are 2^40-scaled integers either way, so the result is bit-identical to scatter_add_rows_fixed_kernel.
+// workspace (int32): count[V] | cursor[V] | offset[V] | total[1] | perm[n_tok] | sid[n_tok]; count and cursor are zero on
+// entry and are left zero (first use: the caller zeroes them once).
+__global__ __launch_bounds__(256) void seg_count_kernel(const int32_t* __restrict__ ids, int64_t n_tok, int64_t V, int32_t* __restrict__ count) {
+  for (int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; t < n_tok; t += static_cast<int64_t>(gridDim.x) * 256) {
+    const int64_t id = ids[t];
+    if (id >= 0 && id < V) atomicAdd(&count[id], 1);
+  }
+}
+
+// one workgroup: offset = exclusive scan of count (count is re-zeroed), total[0] = number of in-range tokens
+__global__ __launch_bounds__(1024) void seg_scan_kernel(int32_t* __restrict__ count, int32_t* __restrict__ offset, int32_t* __restrict__ total,
+                                                        int64_t V) {
+  __shared__ int32_t part[1024];
+  const int tid = threadIdx.x;
+  const int64_t chunk = (V + 1023) / 1024, lo = tid * chunk, hi = (lo + chunk < V) ? lo + chunk : V;
+  int32_t s = 0;
+  for (int64_t i = lo; i < hi; ++i) s += count[i];
+  part[tid] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan over the 1024 chunk sums
+    const int32_t v = tid >= off ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int32_t run = part[tid] - s;
+  for (int64_t i = lo; i < hi; ++i) {
+    const int32_t c = count[i];
+    offset[i] = run;
+    run += c;
+    count[i] = 0;
+  }
+  if (tid == 1023) total[0] = part[1023];
+}
+
+__global__ __launch_bounds__(256) void seg_fill_kernel(const int32_t* __restrict__ ids, int64_t n_tok, int64_t V,
+                                                       const int32_t* __restrict__ offset, int32_t* __restrict__ cursor,
+                                                       int32_t* __restrict__ perm, int32_t* __restrict__ sid) {
+  for (int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; t < n_tok; t += static_cast<int64_t>(gridDim.x) * 256) {
+    const int64_t id = ids[t];
+    if (id < 0 || id >= V) continue;
+    const int32_t pos = offset[id] + atomicAdd(&cursor[id], 1);
+    perm[pos] = static_cast<int32_t>(t);
+    sid[pos] = static_cast<int32_t>(id);
+  }
+}
+
+constexpr int SEG_RUN = 32;   // sorted positions one thread walks
+constexpr int SEG_RUNS = 4;   // runs per workgroup (x 64 column lanes = 256 threads)
+__global__ __launch_bounds__(256) void seg_reduce_kernel(const int32_t* __restrict__ perm, const int32_t* __restrict__ sid,
+                                                         const int32_t* __restrict__ total, int32_t* __restrict__ cursor,
+                                                         const float* __restrict__ dX, long long* __restrict__ acc, int32_t D,
+                                                         const uint32_t* __restrict__ key_ptr, uint32_t thresh, float scale,
+                                                         int32_t* __restrict__ range_flag) {
+  __shared__ int32_t s_perm[SEG_RUNS * SEG_RUN], s_id[SEG_RUNS * SEG_RUN + 2];  // s_id[0] / [last]: the neighbours of the block
+  const int n = total[0];
+  const int p0 = blockIdx.x * (SEG_RUNS * SEG_RUN);
+  if (p0 >= n) return;
+  const int tid = threadIdx.x;
+  if (tid < SEG_RUNS * SEG_RUN) {
+    const int p = p0 + tid;
+    s_perm[tid] = p < n ? perm[p] : 0;
+    s_id[tid + 1] = p < n ? sid[p] : -1;
+  }
+  if (tid == 0) s_id[0] = p0 > 0 ? sid[p0 - 1] : -1;
+  if (tid == 1) s_id[SEG_RUNS * SEG_RUN + 1] = (p0 + SEG_RUNS * SEG_RUN < n) ? sid[p0 + SEG_RUNS * SEG_RUN] : -1;
+  __syncthreads();
+  const bool do_drop = key_ptr != nullptr;
+  const uint32_t key = do_drop ? *key_ptr : 0u;
+  const int run = tid >> 6, lane = tid & 63;
+  const int q0 = run * SEG_RUN;  // first position of this thread's run inside the block
+  // the first position of every segment re-zeroes that id's fill cursor (one thread per position: lane 0 of the column loop)
+  if (lane == 0)
+    for (int j = 0; j < SEG_RUN; ++j)
+      if (p0 + q0 + j < n && s_id[q0 + j + 1] != s_id[q0 + j]) cursor[s_id[q0 + j + 1]] = 0;
+  bool bad = false;
+  for (int c = lane; c < D; c += 64) {  // consecutive lanes on consecutive columns: a row of dX is read in 256-byte pieces
+    long long sum = 0;
+    bool open_left = s_id[q0 + 1] == s_id[q0];  // the segment in progress began before this run
+    for (int j0 = 0; j0 < SEG_RUN; j0 += 8) {
+      float g[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) g[j] = dX[static_cast<int64_t>(s_perm[q0 + j0 + j]) * D + c];  // (positions >= n read token 0: ignored)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int q = q0 + j0 + j;
+        if (p0 + q >= n) break;
+        const int32_t id = s_id[q + 1];
+        float x = g[j];
+        if (do_drop) x *= ebn_drop_mult(key, static_cast<uint64_t>(s_perm[q]) * static_cast<uint64_t>(D) + static_cast<uint64_t>(c), thresh, scale);
+        if (x != 0.f) {
+          bad |= !(fabsf(x) < FIXED_TERM_MAX);
+          sum += __double2ll_rn(static_cast<double>(x) * FIXED_SCALE);
+        }
+        const bool last_of_run = (j0 + j == SEG_RUN - 1) || (p0 + q + 1 >= n);
+        const bool seg_ends = s_id[q + 2] != id;
+        if (seg_ends || last_of_run) {
+          long long* a = acc + static_cast<int64_t>(id) * D + c;
+          if (sum != 0) {
+            if (open_left || !seg_ends) atomicAdd(reinterpret_cast<unsigned long long*>(a), static_cast<unsigned long long>(sum));
+            else *a += sum;  // the whole segment lies inside this run: this thread is the only writer of acc[id][c] in the launch
+          }
+          sum = 0;
+          open_left = false;
+        }
+      }
+    }
+  }
+  if (bad && range_flag != nullptr) *range_flag = 1;
+}
+
 __global__ __launch_bounds__(GATHER_THREADS) void expand_titles_kernel(const int32_t* __restrict__ art_idx,
                                                                        const int32_t* __restrict__ token_matrix,
                                                                        int32_t* __restrict__ ids_out, int64_t n_items,
@@ -236,6 +352,40 @@ extern "C" int ebn_embedding_grad_scatter_fixed(const int32_t* ids, const float*
     hipLaunchKernelGGL(scatter_add_rows_fixed_kernel<int64_t>, dim3(static_cast<unsigned>(grid)), dim3(GATHER_THREADS), 0,
                        ebn_stream(stream), ids, dX, reinterpret_cast<long long*>(acc), n_items, D, V, dr.key_ptr,
                        dr.thresh, dr.scale, range_flag);
+  EBN_CHECK_LAUNCH();
+  return EBN_OK;
+}
+
+extern "C" int64_t ebn_embedding_grad_segmented_workspace_ints(int64_t n_tok, int64_t V) {
+  if (n_tok < 0 || V <= 0) return 0;
+  return 3 * V + 4 + 2 * n_tok;
+}
+
+extern "C" int ebn_embedding_grad_segmented_fixed(const int32_t* ids, const float* dX, int64_t* acc, int64_t n_tok, int32_t D,
+                                                  int64_t V, const ebn_step_state* st, int32_t site, float drop_p,
+                                                  int32_t* range_flag, int32_t* workspace, ebn_stream_t stream) {
+  EBN_REQUIRE(ids && dX && acc && workspace, EBN_ERR_BAD_ARG);
+  EBN_REQUIRE(n_tok >= 0 && D > 0 && V > 0, EBN_ERR_BAD_ARG);
+  EBN_REQUIRE(n_tok < 0x7FFFFFFF && V < 0x7FFFFFFF, EBN_ERR_UNSUPPORTED);
+  if (n_tok == 0) return EBN_OK;
+  const EbnDrop dr = ebn_make_drop(st, site, drop_p);
+  hipStream_t s = ebn_stream(stream);
+  int32_t* count = workspace;
+  int32_t* cursor = count + V;
+  int32_t* offset = cursor + V;
+  int32_t* total = offset + V;
+  int32_t* perm = total + 4;
+  int32_t* sid = perm + n_tok;
+  int64_t tgrid = ebn_ceil_div(n_tok, 256);
+  if (tgrid > 2048) tgrid = 2048;
+  hipLaunchKernelGGL(seg_count_kernel, dim3(static_cast<unsigned>(tgrid)), dim3(256), 0, s, ids, n_tok, V, count);
+  EBN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(seg_scan_kernel, dim3(1), dim3(1024), 0, s, count, offset, total, V);
+  EBN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(seg_fill_kernel, dim3(static_cast<unsigned>(tgrid)), dim3(256), 0, s, ids, n_tok, V, offset, cursor, perm, sid);
+  EBN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(seg_reduce_kernel, dim3(static_cast<unsigned>(ebn_ceil_div(n_tok, SEG_RUNS * SEG_RUN))), dim3(256), 0, s, perm, sid, total,
+                     cursor, dX, reinterpret_cast<long long*>(acc), D, dr.key_ptr, dr.thresh, dr.scale, range_flag);
   EBN_CHECK_LAUNCH();
   return EBN_OK;
 }

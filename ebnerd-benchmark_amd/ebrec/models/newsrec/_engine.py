@@ -200,6 +200,8 @@ class NRMSEngine:
         self.loss_dev = torch.zeros(1, device=self.device)
         self.use_graph = False  # capture the per-shape kernel sequence into hipGraphs (enable_graphs())
         self.fuse_user_head = True  # False: the per-impression head of a step as its six separate launches (validation)
+        self.segmented_table_grad = False  # True: counting sort + segmented reduction instead of one 64-bit atomic per element (same bits;
+        # measured SLOWER in its first form: profiles/r03_tuning_notes.md)
         self.overlap_collectives = True  # multi-rank: start the dense-gradient buckets under the rest of the backward (see _segments)
         self.skip_collectives = False    # bench.py only: time the step without its collectives (-> comm_exposed_us); results are wrong
         self._pending = []
@@ -945,6 +947,11 @@ class NRMSEngine:
             nb.scores = torch.empty(nb.n_seq, device=self.device)
             nb.probs = torch.empty(nb.n_seq, device=self.device)
             nb.labels = torch.empty(nb.n_seq, device=self.device)
+        if self.train_embedding and self.deterministic and self.segmented_table_grad:
+            need = int(_hip.lib().ebn_embedding_grad_segmented_workspace_ints(nb.n_seq * self.T, self.V))
+            if getattr(self, "_seg_ws", None) is None or self._seg_ws.numel() < need:  # outside any capture; count / cursor start zero
+                self._seg_ws = torch.zeros(need, dtype=torch.int32, device=self.device)
+                self._graphs.clear()
         if not hasattr(ub, "duser"):
             ub.duser = torch.empty(ub.n_seq, E, device=self.device)
             ub.loss_rows = torch.empty(ub.n_seq, device=self.device)
@@ -1046,9 +1053,7 @@ class NRMSEngine:
 
         def accumulate():  # one launch per rank's slab: the dropout mask of d(X) is indexed by the position in THAT rank's batch
             for r in range(W):
-                _hip.call("ebn_embedding_grad_scatter_fixed", _hip.ptr(ids_all[r * n_tok:]), _hip.ptr(dX_all[r * n_tok:]),
-                          _hip.ptr(self.table_acc), n_tok, self.D, self.V, _hip.ptr(self.state), site, ctypes.c_float(p),
-                          _hip.ptr(self.range_flag), _hip.stream_handle())
+                self._accumulate_fixed(ids_all[r * n_tok:], dX_all[r * n_tok:], n_tok, _hip.ptr(self.state), site, p)
 
         return [("c", gather), ("k", accumulate)]
 
@@ -1096,6 +1101,22 @@ class NRMSEngine:
                   _hip.ptr(ub.head_partials) if self.fuse_user_head else None, _hip.ptr(nb.dNE), C, self.loss_kind,
                   ctypes.c_float(1.0 / B), st, S())
 
+    def _accumulate_fixed(self, ids, dX, n_tok, st, site, p):
+        """table_acc += the (id, gradient row) pairs of n_tok tokens, in the order-independent fixed-point accumulator: counting
+        sort + segmented reduction (four launches, plain stores for every row that is not hot) or, `segmented_table_grad=False`,
+        one 64-bit integer atomic per element.  Bit-identical accumulators either way."""
+        if self.segmented_table_grad:
+            need = int(_hip.lib().ebn_embedding_grad_segmented_workspace_ints(n_tok, self.V))
+            ws = getattr(self, "_seg_ws", None)
+            if ws is None or ws.numel() < need:
+                ws = self._seg_ws = torch.zeros(need, dtype=torch.int32, device=self.device)  # (count / cursor must start zero)
+                self._graphs.clear()
+            _hip.call("ebn_embedding_grad_segmented_fixed", _hip.ptr(ids), _hip.ptr(dX), _hip.ptr(self.table_acc), n_tok, self.D, self.V, st, site,
+                      ctypes.c_float(p), _hip.ptr(self.range_flag), _hip.ptr(ws), _hip.stream_handle())
+        else:
+            _hip.call("ebn_embedding_grad_scatter_fixed", _hip.ptr(ids), _hip.ptr(dX), _hip.ptr(self.table_acc), n_tok, self.D, self.V, st, site,
+                      ctypes.c_float(p), _hip.ptr(self.range_flag), _hip.stream_handle())
+
     def _table_grad_kernels(self, nb, N, sparse_table_grads):
         S = _hip.stream_handle
         st = _hip.ptr(self.state)
@@ -1110,8 +1131,7 @@ class NRMSEngine:
                           N * self.T, self.D, d_uniq.shape[0], st, site, ctypes.c_float(p), S())
                 self.exchange.scatter_grads(nb.plan, d_uniq, self._local_scatter_add)
             elif self.deterministic:
-                _hip.call("ebn_embedding_grad_scatter_fixed", _hip.ptr(nb.ids), _hip.ptr(nb.dX), _hip.ptr(self.table_acc),
-                          N * self.T, self.D, self.V, st, site, ctypes.c_float(p), _hip.ptr(self.range_flag), S())
+                self._accumulate_fixed(nb.ids, nb.dX, N * self.T, st, site, p)
                 if not self._adam_from_acc:  # data parallel: the fp32 dense gradient is what gets all-reduced
                     _hip.call("ebn_fixed_to_f32", _hip.ptr(self.table_acc), _hip.ptr(self.table_grad), self.table.numel(),
                               _hip.ptr(self.range_flag), S())
