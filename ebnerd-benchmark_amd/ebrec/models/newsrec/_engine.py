@@ -169,6 +169,9 @@ class NRMSEngine:
         D, E, A = self.D, self.E, self.A
         # optional per-token [Dense-ReLU -> BatchNorm -> Dropout] stack between self-attention and AttLayer2 (nrms.py:142-152)
         self.units = [int(u) for u in units] if units else []
+        if self.units and self.precision == "split":
+            raise ValueError("precision='split' covers the news encoder without the optional per-token Dense stack "
+                             "(newsencoder_units_per_layer); use precision='exact' with it")
         if self.units and self.units[-1] != E:
             raise ValueError(f"newsencoder_units_per_layer must end with head_num*head_dim = {E} (the news vector is dotted with "
                              f"the {E}-wide user vector, nrms.py:201), got {self.units}")

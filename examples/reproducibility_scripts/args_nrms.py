@@ -47,6 +47,9 @@ def build_parser(docvec: bool = False) -> argparse.ArgumentParser:
     p.add_argument("--freeze_embedding", action="store_true", help="frozen lookup table (BASELINE config 2)")
     p.add_argument("--shard_table", action="store_true", help="row-shard the embedding table over the ranks")
     p.add_argument("--no_graph", action="store_true", help="do not capture the train step into hipGraphs")
+    p.add_argument("--precision", type=str, default="exact", choices=["exact", "split"],
+                   help="exact: every matmul on the exact-fp32 MFMA kernels; split: the news encoder's projection GEMMs as fp32-accurate "
+                        "bf16x6 split products on the bf16 matrix pipe (NRMS only)")
     p.add_argument("--filter_min_history", type=int, default=100,
                    help="ebnerd_nrms_doc_hist.py: keep validation users with at least this many history entries "
                         "(the reference hard-codes 100, ebnerd_nrms_doc_hist.py:253)")

@@ -87,7 +87,7 @@ def main(argv=None):
 
     def build_model():
         model = NRMSModel(hparams=hparams, word2vec_embedding=word2vec_embedding, word_emb_dim=args.word_emb_dim, vocab_size=vocab,
-                          seed=42, train_embedding=not args.freeze_embedding, shard_table=args.shard_table)
+                          seed=42, train_embedding=not args.freeze_embedding, shard_table=args.shard_table, precision=args.precision)
         model._engine.enable_graphs(not args.no_graph)
         return model
 
