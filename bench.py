@@ -586,10 +586,9 @@ def main():
         if world > 1:
             line["allreduce_bytes_per_step"] = eng.allreduce_bytes(c["B"] * (c["H"] + c["C"]) * c["T"])
             line["comm_exposed_us"] = (line["ms_per_step"] - comm["ms_per_step_without_collectives"]) * 1e3
-            line["comm"] = {**comm, "note": "comm_exposed_us = ms_per_step - the same steps with every collective skipped (measured after the timed "
-                                            "region, same graphs).  Dense gradients travel as two buckets started asynchronously under the rest of the "
-                                            "backward (everything-but-dWqkv under the attention backward + dWqkv GEMM; dWqkv under the dX GEMM and the "
-                                            "table-gradient accumulation when the table trains)"}
+            line["comm"] = {**comm, "note": "comm_exposed_us = ms_per_step - the same steps with every collective skipped (measured after the timed region, same graphs).  "
+                                            "The dense gradients travel as one flat bucket: with a trainable table it is started asynchronously after the dWqkv GEMM and "
+                                            "runs under the dX GEMM and the table-gradient accumulation; with a frozen table nothing follows dWqkv"}
         if world == 1 and not args.no_fit_loop and not sharded:
             line["fit_loop"] = fit_loop_leg(model, c)
             line["fit_loop"]["frac_of_value"] = line["fit_loop"]["value"] / line["value"]

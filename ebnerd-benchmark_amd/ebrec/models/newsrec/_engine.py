@@ -989,11 +989,10 @@ class NRMSEngine:
         step waits for, "a" = collective started asynchronously (RCCL runs it on its own stream after everything enqueued so far;
         the following kernels do not wait), "w" = wait for every started collective.
 
-        Multi-rank data parallel: the dense gradients travel as TWO buckets in the order the backward finishes them -- A = every
-        dense gradient but dWqkv (complete after the news AttLayer2 backward) starts under the attention-core backward and the
-        dWqkv GEMM; B = dWqkv starts under the dX GEMM and the table-gradient accumulation of a trainable table (with a frozen
-        table nothing is left to hide it under).  The buckets are the same two calls whether or not anything overlaps, so the
-        overlapped step is bit-identical to the serial one."""
+        Multi-rank data parallel: the dense gradients travel as ONE flat bucket.  With a trainable table it is started
+        asynchronously after the dWqkv GEMM and runs under the dX GEMM and the table-gradient accumulation; with a frozen table
+        nothing follows dWqkv and it is issued in place.  The same collective on the same buffer either way: the overlapped step
+        is bit-identical to the serial one."""
         N = B * (self.H + C)
         nb, _ub = self._train_bufs(B, C)
         multi = self.world > 1
@@ -1001,17 +1000,19 @@ class NRMSEngine:
         if self._planned:
             segs += self._lookup_segments(nb, N)
         sparse = self._sparse_dp(N * self.T)
-        if multi and self.mlp is None and self.overlap_collectives:
-            cut = self.params.offsets["n_W"]  # n_Wqkv is the first parameter of the flat buffer: bucket B = grad[:cut], A = grad[cut:]
-            segs.append(("k", lambda: self._fwd_bwd_kernels(B, C, sparse, part="a")))
-            segs.append(("a", lambda: self._allreduce_async(self.params.grad[cut:])))
-            segs.append(("k", lambda: self._fwd_bwd_kernels(B, C, sparse, part="b")))
-            segs.append(("a", lambda: self._allreduce_async(self.params.grad[:cut])))
-            if self.train_embedding:
-                segs.append(("k", lambda: self._fwd_bwd_kernels(B, C, sparse, part="c")))
-            if self._planned and self.train_embedding:
+        if multi and self.mlp is None and self.overlap_collectives and self.train_embedding:
+            # trainable table: the flat bucket of dense gradients is complete after the dWqkv GEMM and travels under the dX GEMM and the
+            # table-gradient accumulation (~430 us at c4).  ONE extra graph boundary: every asynchronous collective costs a
+            # cross-stream fork / join between graph replays -- measured with identity collectives on a 1-rank RCCL group
+            # (tools/overlap_split_probe.py): +24 us at c4 for this cut, +30-35 us more for a finer one that would also start
+            # the gradients finished before the attention backward under it -- as much as that 2.6 MB all-reduce is expected to
+            # take.  With a frozen table nothing follows dWqkv, so the step stays graph | bucket | graph.
+            segs.append(("k", lambda: (self._fwd_bwd_kernels(B, C, sparse, part="a"), self._fwd_bwd_kernels(B, C, sparse, part="b"))))
+            segs.append(("a", lambda: self._allreduce_async(self.params.grad)))  # the one flat bucket of every dense gradient
+            segs.append(("k", lambda: self._fwd_bwd_kernels(B, C, sparse, part="c")))
+            if self._planned:
                 segs += self._table_grad_segments(nb, N)
-            if self.train_embedding and self.exchange is None and not sparse:
+            if self.exchange is None and not sparse:
                 segs.append(("c", lambda: self._allreduce_table_grad()))
             if sparse:
                 segs += self._sparse_table_grad_segments(nb, N)
@@ -1143,13 +1144,9 @@ class NRMSEngine:
                           N * self.T, self.D, self.V, st, site, ctypes.c_float(p), S())
 
     def _allreduce_grads(self, dense_table=True):
-        """Data-parallel gradient all-reduce over RCCL (SUM; the 1/world is folded into Adam).  Two buckets, cut where the
-        overlapped form cuts them (same collectives on the same buffers -> bit-identical results either way)."""
+        """Data-parallel gradient all-reduce over RCCL (SUM; the 1/world is folded into Adam): one flat bucket."""
         if self.world > 1 and not self.skip_collectives:
-            cut = self.params.offsets.get("n_W", 0)
-            torch.distributed.all_reduce(self.params.grad[cut:], group=self.pg)
-            if cut:
-                torch.distributed.all_reduce(self.params.grad[:cut], group=self.pg)
+            torch.distributed.all_reduce(self.params.grad, group=self.pg)
             # (a sharded table's gradients already sit at their owner; the sparse exchange all-gathers token rows instead)
             if self.train_embedding and self.exchange is None and dense_table:
                 torch.distributed.all_reduce(self.table_grad, group=self.pg)

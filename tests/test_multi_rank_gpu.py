@@ -247,8 +247,8 @@ def test_two_rank_row_sharded_table_step_equals_the_full_batch_oracle_step(hip, 
 
 
 def _overlap_worker(rank, world, H, train_embedding, graph, exchange):
-    """The step with the dense-gradient buckets started under the rest of the backward against the step that waits for each
-    collective where it is issued: same kernels, same two buckets -> bit-identical losses and replicas."""
+    """The step with the dense-gradient bucket started under the rest of the backward (trainable table) against the step that waits for each
+    collective where it is issued: same kernels, the same flat bucket -> bit-identical losses and replicas."""
     from ebrec.models.newsrec import NRMSModel
 
     hp = make_hp(history_size=H, dropout=0.2, learning_rate=1e-3)
@@ -263,7 +263,9 @@ def _overlap_worker(rank, world, H, train_embedding, graph, exchange):
             m._engine.enable_graphs()
         ms.append(m)
     kinds = [k for k, _ in ms[0]._engine._segments(B, C)]
-    assert kinds.count("a") == 2 and "w" in kinds and [k for k, _ in ms[1]._engine._segments(B, C)].count("a") == 0
+    # a trainable table has work to hide the buckets under (dX GEMM + table-gradient accumulation); a frozen one does not
+    assert (kinds.count("a") == 1 and "w" in kinds) if train_embedding else kinds.count("a") == 0
+    assert [k for k, _ in ms[1]._engine._segments(B, C)].count("a") == 0
     for t in range(3):
         his, pred, y = batch(np.random.default_rng(1000 * t + rank), B, H, C, hp.title_size, V)
         l0, l1 = (float(m.train_step(his, pred, y).item()) for m in ms)
