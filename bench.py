@@ -405,6 +405,9 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch kernel by kernel instead of hipGraph replay")
+    ap.add_argument("--graph-collectives", action="store_true",
+                    help="N > 1 over RCCL: capture the collectives into the step's hipGraph as well (one graph per step, no eager launches "
+                         "between replays).  Verified on a one-rank RCCL group only, hence opt-in")
     ap.add_argument("--no-fit-loop", action="store_true", help="skip the model.fit(loader) leg (N = 1 only)")
     ap.add_argument("--cpu-steps", type=int, default=20, help="timed steps of the CPU baseline (after 5 warm-ups; SURVEY.md 8d)")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel roofline timing (counter-collection passes)")
@@ -474,6 +477,7 @@ def main():
         sync()
         return
 
+    eng.graph_collectives = bool(args.graph_collectives and backend == "nccl")
     eng.enable_graphs(not args.no_graph)
     times = timed_repeats(lambda k: eng.train_step(*batches[k % len(batches)]), args, sync, world, device)
     # Kernel-level rooflines: the Q|K|V projection GEMM and the embedding gather of THIS step (same buffers, same
@@ -489,15 +493,19 @@ def main():
         # what the collectives cost the step: the same steps timed again with every collective skipped (the results of those
         # steps are wrong and thrown away; all ranks skip together) -- exposed = with - without, after whatever the overlap hid
         eng.skip_collectives = True
+        if eng.graph_collectives:
+            eng._graphs.clear()  # the collectives are part of the captured step: re-capture without them
         if eng.exchange is not None:
             eng.exchange.skip = True
         t_no = timed_repeats(lambda k: eng.train_step(*batches[k % len(batches)]), argparse.Namespace(warmup=2, repeats=max(args.repeats, 3), steps=args.steps),
                              sync, world, device)
         eng.skip_collectives = False
+        if eng.graph_collectives:
+            eng._graphs.clear()
         if eng.exchange is not None:
             eng.exchange.skip = False
         ms_no = float(np.median([t / args.steps * 1e3 for t in t_no]))
-        comm = {"ms_per_step_without_collectives": ms_no, "overlap": bool(eng.overlap_collectives)}
+        comm = {"ms_per_step_without_collectives": ms_no, "overlap": bool(eng.overlap_collectives), "collectives_in_graph": bool(eng.graph_collectives)}
     eng.check_oob()  # sticky device flags of the whole run (ids out of range, exchange overflow, accumulator range): raise, don't report
 
     if rank == 0:

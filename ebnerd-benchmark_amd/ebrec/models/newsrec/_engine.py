@@ -205,6 +205,7 @@ class NRMSEngine:
         self.fuse_user_head = True  # False: the per-impression head of a step as its six separate launches (validation)
         self.segmented_table_grad = False  # True: counting sort + segmented reduction instead of one 64-bit atomic per element (same bits;
         # measured SLOWER in its first form: profiles/r03_tuning_notes.md)
+        self.graph_collectives = False  # multi-rank: capture the collectives into the step's hipGraph as well (experimental)
         self.overlap_collectives = True  # multi-rank: start the dense-gradient buckets under the rest of the backward (see _segments)
         self.skip_collectives = False    # bench.py only: time the step without its collectives (-> comm_exposed_us); results are wrong
         self._pending = []
@@ -965,6 +966,16 @@ class NRMSEngine:
         """Runs of kernel-only segments become hipGraphs; collectives stay eager launches between the replays."""
         torch.cuda.synchronize()
         segs, run, pool, i = self._segments(B, C, advanced), [], None, 0
+        if self.graph_collectives and self.world > 1:
+            # the collectives are captured too (RCCL supports stream capture): the whole multi-rank step is ONE graph, no
+            # eager launches and no cross-stream joins between replays
+            g = torch.cuda.CUDAGraph()
+            with _hip.capture(g):
+                for _kind, fn in segs:
+                    fn()
+            self._graph_objs = getattr(self, "_graph_objs", []) + [g]
+            self._graphs[(B, C, advanced)] = [g.replay]
+            return self._graphs[(B, C, advanced)]
         while i < len(segs):
             if segs[i][0] != "k":  # "c" | "a" | "w": collectives (and the wait for them) stay eager launches between the replays
                 run.append(segs[i][1])

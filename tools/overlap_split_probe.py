@@ -28,11 +28,11 @@ table = (rng.standard_normal((c["V"], c["D"]), dtype=np.float32) * 0.02) if not 
 batches = bench.synthetic_batches(c, 8, 123, dev)
 
 
-def run(world, overlap, steps=100):
+def run(world, overlap, steps=100, graph_collectives=False):
     m = NRMSModel(bench.make_hparams(c), word2vec_embedding=table, word_emb_dim=c["D"], vocab_size=c["V"], seed=42,
                   train_embedding=c["train_embedding"], device=dev, table_grad_exchange="dense")
     e = m._engine
-    e.world, e.overlap_collectives = world, overlap
+    e.world, e.overlap_collectives, e.graph_collectives = world, overlap, graph_collectives
     e.enable_graphs()
     for k in range(10):
         e.train_step(*batches[k % 8])
@@ -48,4 +48,8 @@ def run(world, overlap, steps=100):
 
 
 print(f"{cfg}: one rank {run(1, True):.4f} ms | two 'ranks', serial buckets {run(2, False):.4f} ms | overlapped buckets {run(2, True):.4f} ms")
+try:
+    print(f"{cfg}: collectives captured into the graph: serial {run(2, False, graph_collectives=True):.4f} ms | overlapped {run(2, True, graph_collectives=True):.4f} ms")
+except Exception as ex:  # noqa: BLE001
+    print("capturing the collectives failed:", repr(ex)[:300])
 dist.destroy_process_group()
