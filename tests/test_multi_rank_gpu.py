@@ -135,6 +135,37 @@ def test_every_row_sharded_form_on_one_rank_equals_the_replicated_table(hip, mod
             b._engine.check_oob()
 
 
+@pytest.mark.parametrize("train_embedding,shard,graph", [(False, False, True), (True, False, True), (False, True, True), (True, True, False)])
+def test_split_precision_steps_track_the_exact_steps_in_every_table_mode(hip, train_embedding, shard, graph):
+    """precision="split" (bf16x6 projections; the gather writes bf16 planes in a training step) in the table modes the engine
+    has: frozen / trainable, replicated / row-sharded with the device-planned lookup (the expanding gather then reads the
+    exchanged rows), eager and graph-replayed -- three steps against the exact-precision engine on identical inputs:
+    losses and weights agree to fp32 accumulation noise, and the frozen table stays bit-identical."""
+    from ebrec.models.newsrec import NRMSModel
+
+    hp = make_hp(dropout=0.2, learning_rate=1e-3)
+    rng = np.random.default_rng(57)
+    V = 300
+    emb = rng.standard_normal((V, 64)).astype(np.float32)
+    kw = dict(word2vec_embedding=emb, seed=3, train_embedding=train_embedding, shard_table=shard)
+    a, b = NRMSModel(hp, **kw), NRMSModel(hp, precision="split", **kw)
+    if graph:
+        a._engine.enable_graphs()
+        b._engine.enable_graphs()
+    for t in range(3):
+        his, pred, y = batch(rng, 5, hp.history_size, 5, hp.title_size, V)
+        la, lb = float(a.train_step(his, pred, y).item()), float(b.train_step(his, pred, y).item())
+        assert abs(la - lb) <= 2e-5 * max(1.0, abs(la)), (t, la, lb)
+    b._engine.check_oob()
+    assert getattr(b._engine._bufs[("news", True)], "planes_rows", -1) > 0  # the training gather did write planes
+    for i, (wa, wb) in enumerate(zip(a.model.get_weights(), b.model.get_weights())):
+        if i == 0 and not train_embedding:
+            assert np.array_equal(wa, wb)
+        else:  # Adam turns fp32 noise in tiny gradients into O(lr) differences of single elements: compare like the oracle tests do
+            assert np.abs(wa - wb).max() <= 2e-5 + 0.02 * 3e-3, (i, np.abs(wa - wb).max())
+    assert np.allclose(a.model.predict((his, pred)), b.model.predict((his, pred)), atol=2e-5)
+
+
 # ---------------------------------------------------------------- two ranks, one GPU, the real engine
 def _free_port():
     with socket.socket() as s:
