@@ -439,6 +439,13 @@ __global__ __launch_bounds__(64 * ATT_WAVES) void attn_mfma_bwd_kernel(MfmaAttnA
   const AttnProb p = attn_prob(prob, a.h, L);
   const float* qb = a.qkv + p.row0 * a.ld_qkv + p.head * D;
   float vr[KH];  // row form of V (lane = row), the only form V is needed in: straight from global memory
+#if defined(EBN_ATTN_BWD_PROBE) && EBN_ATTN_BWD_PROBE == 2  // tuning probe: the compute chain alone (no global loads)
+  {
+    for (int i = lane; i < 3 * region; i += 64) sq[i] = 0.001f * static_cast<float>((i * 7 + lane) & 63);
+#pragma unroll
+    for (int s = 0; s < KH; ++s) vr[s] = 0.01f * static_cast<float>(lane + s);
+  }
+#else
   {
     Staged<D> tq, tk, tg;
     stage_load<D>(tq, qb, a.ld_qkv, L, lane);
@@ -455,9 +462,29 @@ __global__ __launch_bounds__(64 * ATT_WAVES) void attn_mfma_bwd_kernel(MfmaAttnA
     if (drop) stage_store<D, true>(sg, tg, L, lane, key, static_cast<uint64_t>(p.row0) * E + p.head * D, E, a.thresh, a.scale);
     else stage_store<D, false>(sg, tg, L, lane, 0u, 0u, 0, 0u, 0.f);
   }
+#endif
   wave_lds_sync();
 
   float* ob = a.out + p.row0 * a.ld_out + p.head * D;
+#if defined(EBN_ATTN_BWD_PROBE) && EBN_ATTN_BWD_PROBE == 1  // tuning probe: the memory pattern alone (no MFMA, no softmax)
+  {
+    f32x16 t;
+    float c[16];
+    lds_col_form<D>(c, sg, L, row, hi);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = c[r] + vr[r % KH];
+    tile_rows_to_global<D, false>(ob + 2 * E, a.ld_out, t, L, row, hi, 1.0f, 0u, 0u, 0, 0u, 0.f);
+    lds_col_form<D>(c, sk, L, row, hi);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = c[r];
+    tile_rows_to_global<D, false>(ob, a.ld_out, t, L, row, hi, inv, 0u, 0u, 0, 0u, 0.f);
+    lds_col_form<D>(c, sq, L, row, hi);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = c[r];
+    tile_rows_to_global<D, false>(ob + E, a.ld_out, t, L, row, hi, inv, 0u, 0u, 0, 0u, 0.f);
+    return;
+  }
+#endif
   f32x16 P, dP;
   {
     float qr[KH], kr[KH];

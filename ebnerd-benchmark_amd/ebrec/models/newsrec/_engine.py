@@ -119,7 +119,7 @@ class EncoderBuffers:
         self.QKV, self.Y, self.U, self.w = f(R, 3 * E), f(R, E), f(R, A), f(R)
         self.out = f(n_seq, E)
         self.dY, self.dQKV, self.de = f(R, E), f(R, 3 * E), f(R)
-        self.partials = f(int(_hip.lib().ebn_attpool_partials_len(R, A)))
+        self.partials = f(max(int(_hip.lib().ebn_attpool_partials_len(R, A)), int(_hip.lib().ebn_attpool_bwd_fused_partials_len(n_seq, A))))
         wsf = _hip.lib().ebn_gemm_workspace_floats  # split-K scratch for every GEMM shape of the stage (fwd and bwd)
         ws = max(int(wsf(Din, 3 * E, R)), int(wsf(E, A, R)), int(wsf(R, 3 * E, Din)), int(wsf(R, A, E)), int(wsf(R, E, A)),
                  int(wsf(R, Din, 3 * E)), 1)
@@ -202,6 +202,7 @@ class NRMSEngine:
         self.range_flag = torch.zeros(1, dtype=torch.int32, device=self.device)  # fixed-point gradient accumulator left its range
         self.loss_dev = torch.zeros(1, device=self.device)
         self.use_graph = False  # capture the per-shape kernel sequence into hipGraphs (enable_graphs())
+        self.fuse_attpool_bwd = True  # False: the news AttLayer2 backward as its two launches (ebn_attpool_bwd_pool + _dpre)
         self.fuse_user_head = True  # False: the per-impression head of a step as its six separate launches (validation)
         self.segmented_table_grad = False  # True: counting sort + segmented reduction instead of one 64-bit atomic per element (same bits;
         # measured SLOWER in its first form: profiles/r03_tuning_notes.md)
@@ -516,9 +517,13 @@ class NRMSEngine:
         pv, g = self.params.view, self.params.g
         ws, wsn = _hip.ptr(b.ws), b.ws.numel()
         one, zero = ctypes.c_float(1.0), ctypes.c_float(0.0)
-        _hip.call("ebn_attpool_bwd_pool_f32", _hip.ptr(b.Y), _hip.ptr(b.w), _hip.ptr(dout), None, _hip.ptr(b.de), n_seq, T, E, S())
-        _hip.call("ebn_attpool_bwd_dpre_f32", _hip.ptr(b.U), _hip.ptr(pv("n_q")), _hip.ptr(b.de), _hip.ptr(g("n_q")), _hip.ptr(g("n_b")),
-                  _hip.ptr(b.partials), R, A, 0, S())
+        if self.fuse_attpool_bwd and E % 4 == 0 and E <= 1024:  # de, d(pre-tanh), dq, db in one pass per sequence
+            _hip.call("ebn_attpool_bwd_fused_f32", _hip.ptr(b.Y), _hip.ptr(b.w), _hip.ptr(dout), _hip.ptr(b.U), _hip.ptr(pv("n_q")), _hip.ptr(b.de),
+                      _hip.ptr(g("n_q")), _hip.ptr(g("n_b")), _hip.ptr(b.partials), n_seq, T, E, A, 0, S())
+        else:
+            _hip.call("ebn_attpool_bwd_pool_f32", _hip.ptr(b.Y), _hip.ptr(b.w), _hip.ptr(dout), None, _hip.ptr(b.de), n_seq, T, E, S())
+            _hip.call("ebn_attpool_bwd_dpre_f32", _hip.ptr(b.U), _hip.ptr(pv("n_q")), _hip.ptr(b.de), _hip.ptr(g("n_q")), _hip.ptr(g("n_b")),
+                      _hip.ptr(b.partials), R, A, 0, S())
         if self._fold_pooling(T):
             _hip.call("ebn_dense_bwd_pair_f32", R, E, A, _hip.ptr(b.Y), E, _hip.ptr(b.U), A, _hip.ptr(pv("n_W")), A, zero, _hip.ptr(g("n_W")), A,
                       _hip.ptr(b.dY), E, ws, wsn, S())

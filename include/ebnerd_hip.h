@@ -251,6 +251,13 @@ int64_t ebn_attpool_partials_len(int64_t R, int32_t A);
 int ebn_attpool_bwd_dpre_f32(float* U, const float* q, const float* de, float* dq, float* db,
                              float* partials, int64_t R, int32_t A, int32_t accumulate,
                              ebn_stream_t stream);
+/* ebn_attpool_bwd_pool_f32 (without the dX part) + ebn_attpool_bwd_dpre_f32 in ONE pass per sequence: de, U <- d(pre-tanh),
+ * dq, db (layers.py:65-81 backward).  E % 4 == 0, E <= 1024, 16-byte aligned X / dout; partials:
+ * ebn_attpool_bwd_fused_partials_len(n_seq, A) floats.  Same formulas, one launch less on the step's dependent chain.   */
+int64_t ebn_attpool_bwd_fused_partials_len(int64_t n_seq, int32_t A);
+int ebn_attpool_bwd_fused_f32(const float* X, const float* w, const float* dout, float* U, const float* q, float* de,
+                              float* dq, float* db, float* partials, int64_t n_seq, int32_t L, int32_t E, int32_t A,
+                              int32_t accumulate, ebn_stream_t stream);
 
 /* ---- stage level: SelfAttention + AttLayer2 over a batch of sequences -----------------
  * The news encoder after its embedding gather (nrms.py:137-156, L = title_size,

@@ -372,7 +372,18 @@ def test_attpool_forward_and_backward(hip, n_seq, L, E, A):
     part = torch.empty(int(hip.lib().ebn_attpool_partials_len(R, A)), device="cuda")
     dqd = torch.full((A,), 5.0, device="cuda")
     dbd = torch.full((A,), 5.0, device="cuda")
+    # the one-pass form (ebn_attpool_bwd_fused_f32) on a copy of U: same de and d(pre-tanh) bit for bit, dq / db summed per
+    # sequence first
+    Uf, def_, dqf, dbf = U.clone(), torch.empty(R, device="cuda"), torch.full((A,), 5.0, device="cuda"), torch.full((A,), 5.0, device="cuda")
+    partf = torch.empty(int(hip.lib().ebn_attpool_bwd_fused_partials_len(n_seq, A)), device="cuda")
+    hip.call("ebn_attpool_bwd_fused_f32", P(Xd), P(w), P(dev(dout)), P(Uf), P(dev(q)), P(def_), P(dqf), P(dbf), P(partf), n_seq, L, E, A, 0, S())
     hip.call("ebn_attpool_bwd_dpre_f32", P(U), P(dev(q)), P(de), P(dqd), P(dbd), P(part), R, A, 0, S())
+    assert np.array_equal(host(def_), host(de)) and np.array_equal(host(Uf), host(U)), "fused AttLayer2 backward: de / d(pre-tanh)"
+    assert_close(host(dqf), dq[:, 0], rtol=3e-5, atol=2e-5, what="dq (fused)")
+    assert_close(host(dbf), db, rtol=3e-5, atol=2e-5, what="db (fused)")
+    hip.call("ebn_attpool_bwd_fused_f32", P(Xd), P(w), P(dev(np.zeros((n_seq, E)))), P(Uf.copy_(U)), P(dev(q)), P(def_), P(dqf), P(dbf), P(partf),
+             n_seq, L, E, A, 1, S())
+    assert_close(host(dqf), dq[:, 0], rtol=3e-5, atol=2e-5, what="dq (fused) accumulate(0)")
     assert_close(host(dqd), dq[:, 0], rtol=3e-5, atol=2e-5, what="dq")
     assert_close(host(dbd), db, rtol=3e-5, atol=2e-5, what="db")
     dWd = torch.empty(E, A, device="cuda")
