@@ -276,7 +276,7 @@ def probe_kernels(config, batch, precision="exact"):
         for tag, flags in (("stats", ["--kernel-trace", "--stats"]), ("fetch", ["--pmc", "FETCH_SIZE", "--kernel-trace"]),
                            ("write", ["--pmc", "WRITE_SIZE", "--kernel-trace"])):
             r = subprocess.run([exe] + flags + ["--output-format", "csv", "-d", f"{tmp}/{tag}", "-o", "p", "--"] + probe,
-                               cwd=tmp, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+                               cwd=tmp, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=150)  # a pass takes ~15 s; a hung profiler (seen: 15 min after an aborted pass) falls back to the static labels
             if r.returncode != 0:
                 return None
         pick = lambda name: "gather" if "gather" in name else ("qkv_gemm" if "gemm" in name else None)

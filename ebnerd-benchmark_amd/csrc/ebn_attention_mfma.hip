@@ -20,6 +20,8 @@
 // from global memory; the others are copied once, as coalesced 16-byte loads, into wave-private LDS; result tiles leave
 // from registers.  32 < L <= 64: the attn_mfma2_* kernels further down (2 x 2 tiles, both layouts computed, results staged
 // through LDS).
+#include <stdlib.h>
+
 #include "ebn_common.h"
 
 namespace {
@@ -339,6 +341,18 @@ __device__ __forceinline__ void tile_transpose(f32x16& t, float* __restrict__ bu
   }
 }
 
+// Wave priority over a problem's phases (tuning switch EBN_ATTN_PRIO: 0 off, 1 rising with progress, 2 static per workgroup).
+#ifndef EBN_ATTN_PRIO
+#define EBN_ATTN_PRIO 0
+#endif
+#if EBN_ATTN_PRIO == 1
+#define EBN_ATTN_PRIO_AT(n) __builtin_amdgcn_s_setprio(n)
+#elif EBN_ATTN_PRIO == 2
+#define EBN_ATTN_PRIO_AT(n) do { if ((n) == 0) { switch ((blockIdx.x >> 8) & 3) { case 0: __builtin_amdgcn_s_setprio(0); break; case 1: __builtin_amdgcn_s_setprio(1); break; case 2: __builtin_amdgcn_s_setprio(2); break; default: __builtin_amdgcn_s_setprio(3); } } } while (0)
+#else
+#define EBN_ATTN_PRIO_AT(n) do { } while (0)
+#endif
+
 // LC: sequence length known at compile time (0 = use a.L).  title_size = 30 and history_size = 20 are what every
 // BASELINE config runs: with L a constant most of the row / column validity masks of a 32-wide tile fold away (only
 // registers 14, 15 of the upper lane half can be rows >= 30).
@@ -353,6 +367,24 @@ struct AttnProb {
   uint32_t seq;
   uint32_t head;
 };
+
+// Workgroup -> problem order.  The hardware deals consecutive workgroups round-robin to the 8 XCDs (private L2s), and the heads
+// of a title are neighbours in memory: head k's 80-byte row pieces share 128-byte lines with heads k - 1 / k + 1.  With the
+// dispatch order as the problem order those neighbours sit on DIFFERENT XCDs, every shared line is fetched by two L2s and --
+// what costs -- written as two partial lines from two L2s.  Remapped so that each XCD walks one contiguous run of problems
+// (bijective for any grid size; the same formula as the GEMM's tile order).  EBN_ATTN_XCD=0 switches it off (tuning).
+#ifndef EBN_ATTN_XCD
+#define EBN_ATTN_XCD 1
+#endif
+__device__ __forceinline__ uint32_t xcd_chunked_block() {
+#if EBN_ATTN_XCD
+  const uint32_t nwg = gridDim.x, orig = blockIdx.x;
+  const uint32_t q = nwg >> 3, r = nwg & 7u, xcd = orig & 7u, idx = orig >> 3;
+  return ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+#else
+  return blockIdx.x;
+#endif
+}
 
 // n_prob < 2^31 (checked by the launcher): one 32-bit scalar division per problem
 __device__ __forceinline__ AttnProb attn_prob(int64_t prob, int h, int L) {
@@ -373,7 +405,7 @@ __global__ __launch_bounds__(64 * ATT_WAVES) void attn_mfma_fwd_kernel(MfmaAttnA
   extern __shared__ __attribute__((aligned(16))) float smem[];  // ATT_WAVES x fwd_wave_floats
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform on its face: base pointers stay scalar
-  const int64_t prob = static_cast<int64_t>(blockIdx.x) * ATT_WAVES + wv;
+  const int64_t prob = static_cast<int64_t>(xcd_chunked_block()) * ATT_WAVES + wv;
   if (prob >= a.n_prob) return;  // wave-uniform; no workgroup barriers in this kernel
   const int L = LC ? LC : a.L, E = a.h * D;
   float* sv = smem + wv * fwd_wave_floats<D>(L);
@@ -423,7 +455,7 @@ __global__ __launch_bounds__(64 * ATT_WAVES) void attn_mfma_bwd_kernel(MfmaAttnA
   extern __shared__ __attribute__((aligned(16))) float smem[];  // ATT_WAVES x bwd_wave_floats
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform on its face: base pointers stay scalar
-  const int64_t prob = static_cast<int64_t>(blockIdx.x) * ATT_WAVES + wv;
+  const int64_t prob = static_cast<int64_t>(xcd_chunked_block()) * ATT_WAVES + wv;
   if (prob >= a.n_prob) return;
   const int L = LC ? LC : a.L, E = a.h * D;
   const int region = L * T::STRIDE;
@@ -436,10 +468,11 @@ __global__ __launch_bounds__(64 * ATT_WAVES) void attn_mfma_bwd_kernel(MfmaAttnA
   const bool drop = a.key_ptr != nullptr, pooled = a.pool_w != nullptr;  // wave-uniform
   const uint32_t key = drop ? *a.key_ptr : 0u;
 
+  EBN_ATTN_PRIO_AT(0);
   const AttnProb p = attn_prob(prob, a.h, L);
   const float* qb = a.qkv + p.row0 * a.ld_qkv + p.head * D;
   float vr[KH];  // row form of V (lane = row), the only form V is needed in: straight from global memory
-#if defined(EBN_ATTN_BWD_PROBE) && EBN_ATTN_BWD_PROBE == 2  // tuning probe: the compute chain alone (no global loads)
+#if defined(EBN_ATTN_BWD_PROBE) && (EBN_ATTN_BWD_PROBE == 2 || EBN_ATTN_BWD_PROBE >= 6)  // tuning probe: no global loads
   {
     for (int i = lane; i < 3 * region; i += 64) sq[i] = 0.001f * static_cast<float>((i * 7 + lane) & 63);
 #pragma unroll
@@ -451,7 +484,14 @@ __global__ __launch_bounds__(64 * ATT_WAVES) void attn_mfma_bwd_kernel(MfmaAttnA
     stage_load<D>(tq, qb, a.ld_qkv, L, lane);
     stage_load<D>(tk, qb + E, a.ld_qkv, L, lane);
     stage_load<D>(tg, a.dout + p.row0 * a.ld_dout + p.head * D, a.ld_dout, L, lane);
+#if defined(EBN_ATTN_BWD_PROBE) && EBN_ATTN_BWD_PROBE == 5  // loads alone, V as a fourth float4 tile instead of 8-byte pieces
+    Staged<D> tv;
+    stage_load<D>(tv, qb + 2 * E, a.ld_qkv, L, lane);
+#pragma unroll
+    for (int s_ = 0; s_ < KH; ++s_) vr[s_] = tv.v[s_ % Tile<D>::ROUNDS].x;
+#else
     global_row_form<D>(vr, qb + 2 * E, a.ld_qkv, L, row, hi);
+#endif
     if (pooled) {
       PoolTerm<D> pt;
       pool_load<D>(pt, a.pool_w + p.row0, a.pool_d + p.seq * a.ld_pool + p.head * D, L, lane);
@@ -466,7 +506,32 @@ __global__ __launch_bounds__(64 * ATT_WAVES) void attn_mfma_bwd_kernel(MfmaAttnA
   wave_lds_sync();
 
   float* ob = a.out + p.row0 * a.ld_out + p.head * D;
-#if defined(EBN_ATTN_BWD_PROBE) && EBN_ATTN_BWD_PROBE == 1  // tuning probe: the memory pattern alone (no MFMA, no softmax)
+#if defined(EBN_ATTN_BWD_PROBE) && (EBN_ATTN_BWD_PROBE == 3 || EBN_ATTN_BWD_PROBE == 5)  // tuning probe: the loads alone (one never-taken store)
+  {
+    float c[16], acc = vr[0] + vr[KH - 1];
+    lds_col_form<D>(c, sg, L, row, hi);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc += c[r];
+    lds_col_form<D>(c, sk, L, row, hi);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc += c[r];
+    lds_col_form<D>(c, sq, L, row, hi);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc += c[r];
+    if (acc == 123456.789f) ob[lane] = acc;
+    return;
+  }
+#endif
+#if defined(EBN_ATTN_BWD_PROBE) && EBN_ATTN_BWD_PROBE == 7  // tuning probe: the stores alone, as 80-byte row pieces out of LDS
+  {
+    wave_lds_sync();
+    stage_out<D, false>(sg, ob + 2 * E, a.ld_out, L, lane, 0u, 0u, 0, 0u, 0.f);
+    stage_out<D, false>(sk, ob, a.ld_out, L, lane, 0u, 0u, 0, 0u, 0.f);
+    stage_out<D, false>(sq, ob + E, a.ld_out, L, lane, 0u, 0u, 0, 0u, 0.f);
+    return;
+  }
+#endif
+#if defined(EBN_ATTN_BWD_PROBE) && (EBN_ATTN_BWD_PROBE == 1 || EBN_ATTN_BWD_PROBE == 6)  // the memory pattern alone (no MFMA, no softmax); 6: stores alone
   {
     f32x16 t;
     float c[16];
@@ -492,6 +557,7 @@ __global__ __launch_bounds__(64 * ATT_WAVES) void attn_mfma_bwd_kernel(MfmaAttnA
     lds_row_form<D>(kr, sk, L, row, hi);
     P = mm_rows<KH>(kr, qr);  // T[j][i]: lane i, regs j
   }
+  EBN_ATTN_PRIO_AT(1);
   softmax_in_lane(P, L, hi, inv2);  // P[i][j]: lane i, regs j
   {
     float gr[KH];
@@ -503,6 +569,7 @@ __global__ __launch_bounds__(64 * ATT_WAVES) void attn_mfma_bwd_kernel(MfmaAttnA
   for (int r = 0; r < 16; ++r) rowdot = fmaf(P[r], dP[r], rowdot);
   rowdot += __shfl_xor(rowdot, 32, 64);  // sum_j P[i][j] dP[i][j] for i = lane&31
 
+  EBN_ATTN_PRIO_AT(2);
   float col[16];
   lds_col_form<D>(col, sg, L, row, hi);
   {  // dV^T[c][i] = sum_j dO[j][c] P[i][j]
@@ -516,12 +583,170 @@ __global__ __launch_bounds__(64 * ATT_WAVES) void attn_mfma_bwd_kernel(MfmaAttnA
     const f32x16 dQ = mm_col_tile(col, P);
     tile_rows_to_global<D, false>(ob, a.ld_out, dQ, L, row, hi, inv, 0u, 0u, 0, 0u, 0.f);
   }
+  EBN_ATTN_PRIO_AT(3);
   wave_lds_sync();                    // K and dO have been read for the last time: their regions become the transpose buffer
   tile_transpose(P, sk, L, row, hi);  // dS[i][j]: lane j, regs i
   lds_col_form<D>(col, sq, L, row, hi);
   {  // dK^T[c][j] = inv * sum_i Q[i][c] dS[i][j]
     const f32x16 dK = mm_col_tile(col, P);
     tile_rows_to_global<D, false>(ob + E, a.ld_out, dK, L, row, hi, inv, 0u, 0u, 0, 0u, 0.f);
+  }
+}
+
+
+// Backward, GROUP form: a workgroup = G consecutive heads of ONE sequence, one wave per head as above, but the operands come
+// in and the results go out through the whole workgroup.  Measured on the per-wave kernel above (profiles/r03_tuning_notes.md):
+// its loads alone take 25 us, its stores alone 23 us, both together WITHOUT any arithmetic 66 us of the kernel's 75 -- the
+// memory pattern (80-byte row pieces, 16-byte result pieces scattered over 30 rows), not the MFMA chain, is what it costs,
+// with no excess HBM traffic (FETCH/WRITE_SIZE = the algorithmic bytes): it is request count and DRAM page locality.  Here the
+// G x D columns of the group are one contiguous run per row (320 bytes for G = 4), fetched as consecutive 16-byte lanes into
+// the per-head LDS tiles, and the three result tiles of every head go back through LDS the same way: half the L2 requests
+// (13.2 M against 29.6 M per 3200 titles), 75 -> 65 us per 800 titles on HBM-resident data.  G = 4 keeps one wave per SIMD and
+// 4 workgroups per CU; G = 5 (83 us) and G = 10 (97 us) lose more to the two workgroup barriers than the wider rows give.
+// LDS per wave: Q | K | dO | V tiles, K|dO later the transpose buffer; results: d(V) over V, d(Q) over Q (Q's column form is
+// pulled into registers first), d(K) over K after the transposed d(S) has been read.  Bit-identical to the per-wave kernel.
+template <int D>
+__host__ __device__ constexpr int bwd_group_v_offset(int L) {
+  return 3 * L * Tile<D>::STRIDE > L * Tile<D>::STRIDE + TP_FLOATS ? 3 * L * Tile<D>::STRIDE : L * Tile<D>::STRIDE + TP_FLOATS;
+}
+template <int D>
+__host__ __device__ constexpr int bwd_group_wave_floats(int L) {
+  return bwd_group_v_offset<D>(L) + L * Tile<D>::STRIDE;
+}
+
+template <int D, int LC, int G>
+__global__ __launch_bounds__(64 * G) void attn_mfma_bwd_group_kernel(MfmaAttnArgs a) {
+  using T = Tile<D>;
+  constexpr int KH = D / 2;
+  constexpr int NT = 64 * G;
+  constexpr int GV = G * T::VPR;                    // float4 per row of the group
+  constexpr int ROUNDS = (32 * GV + NT - 1) / NT;   // L <= 32
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // G x bwd_group_wave_floats
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int L = LC ? LC : a.L, E = a.h * D;
+  const int region = L * T::STRIDE;
+  const int wave_floats = bwd_group_wave_floats<D>(L), v_off = bwd_group_v_offset<D>(L);
+  const int row = lane & 31, hi = lane >> 5;
+  const float inv = 1.0f / sqrtf(static_cast<float>(D));
+  const float inv2 = inv * 1.44269504088896341f;
+  const bool drop = a.key_ptr != nullptr, pooled = a.pool_w != nullptr;  // uniform
+  const uint32_t key = drop ? *a.key_ptr : 0u;
+
+  const AttnProb p0 = attn_prob(static_cast<int64_t>(xcd_chunked_block()) * G, a.h, L);  // head p0.head .. + G - 1 of sequence p0.seq
+  const uint32_t gcol = p0.head * D;
+  const float* gq = a.qkv + p0.row0 * a.ld_qkv + gcol;
+  const float* gd = a.dout + p0.row0 * a.ld_dout + gcol;
+  const int nvec = L * GV;
+  {
+    float4 vq[ROUNDS], vk[ROUNDS], vv[ROUNDS], vg[ROUNDS];
+    uint32_t dst[ROUNDS];  // LDS float offset of the piece inside its head's Q tile
+#pragma unroll
+    for (int t = 0; t < ROUNDS; ++t) {
+      const int idx = tid + NT * t;
+      const int idc = idx < nvec ? idx : 0;
+      const uint32_t r = static_cast<uint32_t>(idc) / static_cast<uint32_t>(GV), c4g = static_cast<uint32_t>(idc) - r * GV;
+      const uint32_t head = c4g / T::VPR, c4 = c4g - head * T::VPR;
+      dst[t] = head * wave_floats + r * T::STRIDE + c4 * 4;
+      const uint32_t off = r * static_cast<uint32_t>(a.ld_qkv) + c4g * 4;
+      vq[t] = *reinterpret_cast<const float4*>(gq + off);
+      vk[t] = *reinterpret_cast<const float4*>(gq + E + off);
+      vv[t] = *reinterpret_cast<const float4*>(gq + 2 * E + off);
+      vg[t] = *reinterpret_cast<const float4*>(gd + (r * static_cast<uint32_t>(a.ld_dout) + c4g * 4));
+      if (pooled) {
+        const float w = a.pool_w[p0.row0 + r];
+        const float4 pd = *reinterpret_cast<const float4*>(a.pool_d + p0.seq * a.ld_pool + gcol + c4g * 4);
+        vg[t].x = fmaf(w, pd.x, vg[t].x);
+        vg[t].y = fmaf(w, pd.y, vg[t].y);
+        vg[t].z = fmaf(w, pd.z, vg[t].z);
+        vg[t].w = fmaf(w, pd.w, vg[t].w);
+      }
+      if (drop) {  // the forward mask of element (row0 + r, gcol + 4 c4g): two aligned pairs
+        const uint64_t pr = ((static_cast<uint64_t>(p0.row0) * E + gcol) >> 1) + ((r * static_cast<uint32_t>(E) + c4g * 4) >> 1);
+        const uint32_t h0 = ebn_dropout_pair_hash(key, pr), h1 = ebn_dropout_pair_hash(key, pr + 1);
+        vg[t].x *= ((h0 & 0xFFFFu) >= a.thresh) ? a.scale : 0.f;
+        vg[t].y *= ((h0 >> 16) >= a.thresh) ? a.scale : 0.f;
+        vg[t].z *= ((h1 & 0xFFFFu) >= a.thresh) ? a.scale : 0.f;
+        vg[t].w *= ((h1 >> 16) >= a.thresh) ? a.scale : 0.f;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < ROUNDS; ++t) {
+      if (tid + NT * t < nvec) {
+        *reinterpret_cast<float4*>(smem + dst[t]) = vq[t];
+        *reinterpret_cast<float4*>(smem + dst[t] + region) = vk[t];
+        *reinterpret_cast<float4*>(smem + dst[t] + 2 * region) = vg[t];
+        *reinterpret_cast<float4*>(smem + dst[t] + v_off) = vv[t];
+      }
+    }
+  }
+  __syncthreads();
+
+  float* sq = smem + wv * wave_floats;
+  float* sk = sq + region;
+  float* sg = sk + region;
+  float* sv = sq + v_off;
+  float vr[KH];
+  lds_row_form<D>(vr, sv, L, row, hi);
+  f32x16 P, dP;
+  {
+    float qr[KH], kr[KH];
+    lds_row_form<D>(qr, sq, L, row, hi);
+    lds_row_form<D>(kr, sk, L, row, hi);
+    P = mm_rows<KH>(kr, qr);  // T[j][i]: lane i, regs j
+  }
+  softmax_in_lane(P, L, hi, inv2);  // P[i][j]: lane i, regs j
+  {
+    float gr[KH];
+    lds_row_form<D>(gr, sg, L, row, hi);
+    dP = mm_rows<KH>(gr, vr);  // dP[i][j] = V[i].dO[j]: lane i, regs j
+  }
+  float rowdot = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) rowdot = fmaf(P[r], dP[r], rowdot);
+  rowdot += __shfl_xor(rowdot, 32, 64);
+
+  float col[16], colq[16];
+  lds_col_form<D>(col, sg, L, row, hi);
+  lds_col_form<D>(colq, sq, L, row, hi);
+  wave_lds_sync();  // V's row form and Q's column form are in registers: their tiles take d(V) and d(Q)
+  {  // dV^T[c][i] = sum_j dO[j][c] P[i][j]
+    const f32x16 dV = mm_col_tile(col, P);
+    tile_rows_to_lds<D>(sv, dV, L, row, hi, 1.0f);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) P[r] = P[r] * (dP[r] - rowdot);  // dS[i][j]: lane i, regs j
+  lds_col_form<D>(col, sk, L, row, hi);
+  {  // dQ^T[c][i] = inv * sum_j K[j][c] dS[i][j]
+    const f32x16 dQ = mm_col_tile(col, P);
+    tile_rows_to_lds<D>(sq, dQ, L, row, hi, inv);
+  }
+  wave_lds_sync();                    // K and dO have been read for the last time: their tiles become the transpose buffer
+  tile_transpose(P, sk, L, row, hi);  // dS[i][j]: lane j, regs i
+  wave_lds_sync();
+  {  // dK^T[c][j] = inv * sum_i Q[i][c] dS[i][j]
+    const f32x16 dK = mm_col_tile(colq, P);
+    tile_rows_to_lds<D>(sk, dK, L, row, hi, inv);
+  }
+  __syncthreads();
+
+  float* go = a.out + p0.row0 * a.ld_out + gcol;
+#pragma unroll
+  for (int t = 0; t < ROUNDS; ++t) {
+    const int idx = tid + NT * t;
+    if (idx < nvec) {
+      const uint32_t r = static_cast<uint32_t>(idx) / static_cast<uint32_t>(GV), c4g = static_cast<uint32_t>(idx) - r * GV;
+      const uint32_t head = c4g / T::VPR, c4 = c4g - head * T::VPR;
+      const float* src = smem + head * wave_floats + r * T::STRIDE + c4 * 4;
+      const float4 q4 = *reinterpret_cast<const float4*>(src);
+      const float4 k4 = *reinterpret_cast<const float4*>(src + region);
+      const float4 v4 = *reinterpret_cast<const float4*>(src + v_off);
+      float* d = go + (r * static_cast<uint32_t>(a.ld_out) + c4g * 4);
+      *reinterpret_cast<float4*>(d) = q4;
+      *reinterpret_cast<float4*>(d + E) = k4;
+      *reinterpret_cast<float4*>(d + 2 * E) = v4;
+    }
   }
 }
 
@@ -594,7 +819,7 @@ __global__ __launch_bounds__(64 * ATT2_WAVES) void attn_mfma2_fwd_kernel(MfmaAtt
   extern __shared__ __attribute__((aligned(16))) float smem[];  // ATT2_WAVES x 3 regions x L x STRIDE
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t prob = static_cast<int64_t>(blockIdx.x) * ATT2_WAVES + wv;
+  const int64_t prob = static_cast<int64_t>(xcd_chunked_block()) * ATT2_WAVES + wv;
   if (prob >= a.n_prob) return;
   const int L = LC ? LC : a.L, E = a.h * D;
   const int region = L * T::STRIDE;
@@ -670,7 +895,7 @@ __global__ __launch_bounds__(64 * ATT2_WAVES) void attn_mfma2_bwd_kernel(MfmaAtt
   extern __shared__ __attribute__((aligned(16))) float smem[];  // ATT2_WAVES x 4 regions x L x STRIDE
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t prob = static_cast<int64_t>(blockIdx.x) * ATT2_WAVES + wv;
+  const int64_t prob = static_cast<int64_t>(xcd_chunked_block()) * ATT2_WAVES + wv;
   if (prob >= a.n_prob) return;
   const int L = LC ? LC : a.L, E = a.h * D;
   const int region = L * T::STRIDE;
@@ -807,6 +1032,16 @@ __global__ __launch_bounds__(64 * ATT2_WAVES) void attn_mfma2_bwd_kernel(MfmaAtt
 
 }  // namespace
 
+#ifndef EBN_ATTN_BWD_GROUP
+#define EBN_ATTN_BWD_GROUP 4  // heads per workgroup of the group-form backward: one wave per SIMD (5 or 10 measured slower)
+#endif
+constexpr int BWD_GROUP = EBN_ATTN_BWD_GROUP;
+constexpr int64_t BWD_GROUP_MIN_PROBLEMS = 4096;  // about one resident round of waves on 256 CUs
+static bool bwd_group_off() {  // EBN_ATTN_BWD_PER_WAVE=1: the one-wave-per-head backward everywhere (validation / tuning)
+  static const bool off = [] { const char* e = getenv("EBN_ATTN_BWD_PER_WAVE"); return e && e[0] == '1'; }();
+  return off;
+}
+
 // Returns 1 when the MFMA path handles (L, d, leading dims, alignment); the caller falls back otherwise.
 static bool mfma_path_ok(int32_t L, int32_t d, int64_t lda, int64_t ldb, int64_t ldc, const void* p0,
                          const void* p1, const void* p2) {
@@ -882,6 +1117,21 @@ int ebn_attn_mfma_bwd(const float* qkv, int64_t ld_qkv, const float* dout, int64
     if (d == 16) launch_mfma2<16>(true, a, s);
     else if (d == 20) launch_mfma2<20>(true, a, s);
     else launch_mfma2<32>(true, a, s);
+    EBN_CHECK_LAUNCH();
+    return EBN_OK;
+  }
+  // G heads of a sequence per workgroup, cooperative row traffic -- where the launch is memory-bound: the 640 problems of the
+  // user-level attention (one round of waves, latency-bound) measured 8.2 us in this form against 6.6 us one wave per head
+  if (d == 20 && (h % BWD_GROUP) == 0 && a.n_prob >= BWD_GROUP_MIN_PROBLEMS && !bwd_group_off()) {
+    const size_t lds = static_cast<size_t>(BWD_GROUP) * bwd_group_wave_floats<20>(L) * sizeof(float);
+    const dim3 grid(static_cast<unsigned>(a.n_prob / BWD_GROUP)), block(64 * BWD_GROUP);
+    if (L == 30) {
+      allow_lds(attn_mfma_bwd_group_kernel<20, 30, BWD_GROUP>, lds);
+      hipLaunchKernelGGL((attn_mfma_bwd_group_kernel<20, 30, BWD_GROUP>), grid, block, lds, s, a);
+    } else {
+      allow_lds(attn_mfma_bwd_group_kernel<20, 0, BWD_GROUP>, lds);
+      hipLaunchKernelGGL((attn_mfma_bwd_group_kernel<20, 0, BWD_GROUP>), grid, block, lds, s, a);
+    }
     EBN_CHECK_LAUNCH();
     return EBN_OK;
   }

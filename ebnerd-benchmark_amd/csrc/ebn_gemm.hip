@@ -1076,6 +1076,11 @@ static int forced_tile_bm() {  // EBN_GEMM_FORCE_TILE = 64 | 128 | 256: restrict
   return bm;
 }
 
+static bool tile_128x64_on() {  // EBN_GEMM_TILE_128X64=0: the planner without the 128x64 family (tuning)
+  static const bool on = [] { const char* e = getenv("EBN_GEMM_TILE_128X64"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 static GemmPlan gemm_plan(int64_t M, int64_t N, int64_t K, int64_t ws_floats) {
   int64_t max_split = K / (4 * BK);  // keep >= 4 slabs per split
   if (max_split > 64) max_split = 64;
@@ -1086,7 +1091,8 @@ static GemmPlan gemm_plan(int64_t M, int64_t N, int64_t K, int64_t ws_floats) {
     int bm, bn;
     double ts_full, ts_lone;
     int resident;
-  } kTiles[3] = {{128, 128, 1.15, 1.5, 3}, {256, 64, 1.17, 1.5, 3}, {64, 64, 0.32, 0.48, 4}};
+    int family;  // EBN_GEMM_FORCE_TILE value
+  } kTiles[4] = {{128, 128, 1.15, 1.5, 3, 128}, {256, 64, 1.17, 1.5, 3, 256}, {64, 64, 0.32, 0.48, 4, 64}, {128, 64, 0.60, 0.8, 3, 96}};
   const double out_mb = static_cast<double>(M) * static_cast<double>(N) * 4e-6;
   GemmPlan best{128, 128, 1, ebn_ceil_div(K > 0 ? K : 1, BK) * BK, 1e300};
   {
@@ -1115,9 +1121,10 @@ static GemmPlan gemm_plan(int64_t M, int64_t N, int64_t K, int64_t ws_floats) {
       if (forced_tile_bm() == 32 || measured) return best;
     }
   }
-  for (int t = 0; t < 3; ++t) {
+  for (int t = 0; t < 4; ++t) {
     if (kTiles[t].bm == 256 && M < 256) continue;
-    if (forced_tile_bm() != 0 && forced_tile_bm() != kTiles[t].bm && !(kTiles[t].bm == 64 && M < 256 && forced_tile_bm() == 256)) continue;
+    if (forced_tile_bm() == 0 && kTiles[t].family == 96 && !tile_128x64_on()) continue;
+    if (forced_tile_bm() != 0 && forced_tile_bm() != kTiles[t].family && !(kTiles[t].bm == 64 && M < 256 && forced_tile_bm() == 256)) continue;
     const int64_t tiles = ebn_ceil_div(M, kTiles[t].bm) * ebn_ceil_div(N, kTiles[t].bn);
     int64_t prev_s = 0;
     for (int64_t c = 1; c <= max_split; ++c) {
@@ -1174,6 +1181,9 @@ static int gemm_dispatch(int32_t transA, int32_t transB, int64_t M, int64_t N, i
     return launch_gemm_small(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, vecA, vecB, s, epi);
   if (plan.bm == 256)
     rc = launch_gemm<256, 64, 4>(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, vecA, vecB, splits, kps,
+                                 workspace, s, site, epi);
+  else if (plan.bm == 128 && plan.bn == 64)
+    rc = launch_gemm<128, 64, 2>(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, vecA, vecB, splits, kps,
                                  workspace, s, site, epi);
   else if (plan.bm == 128)
     rc = launch_gemm<128, 128, 2>(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, vecA, vecB, splits, kps,

@@ -202,7 +202,10 @@ class NRMSEngine:
         self.range_flag = torch.zeros(1, dtype=torch.int32, device=self.device)  # fixed-point gradient accumulator left its range
         self.loss_dev = torch.zeros(1, device=self.device)
         self.use_graph = False  # capture the per-shape kernel sequence into hipGraphs (enable_graphs())
-        self.fuse_attpool_bwd = True  # False: the news AttLayer2 backward as its two launches (ebn_attpool_bwd_pool + _dpre)
+        # True: the news AttLayer2 backward (de, dpre, dq, db) as ONE pass per title instead of two launches.  Measured slower in the
+        # step (c2 1.2965 vs 1.2938 ms, c1 0.979 vs 0.9725): the per-title pass has 200 of 256 threads walking 30 rows each, the two
+        # streaming kernels it replaces fill the chip better -- kept for validation, off by default
+        self.fuse_attpool_bwd = False
         self.fuse_user_head = True  # False: the per-impression head of a step as its six separate launches (validation)
         self.segmented_table_grad = False  # True: counting sort + segmented reduction instead of one 64-bit atomic per element (same bits;
         # measured SLOWER in its first form: profiles/r03_tuning_notes.md)

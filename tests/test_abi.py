@@ -45,13 +45,13 @@ def _plan(M, N, K, ws=1 << 60):
 
 
 def test_gemm_planner_is_a_pure_host_query_with_sane_plans():
-    """ebn_gemm_plan / ebn_gemm_workspace_floats never touch the device: tile in the three families, split-K only
+    """ebn_gemm_plan / ebn_gemm_workspace_floats never touch the device: tile in the four families, split-K only
     with a workspace that can hold every partial, and the shapes DESIGN.md quotes pick what it says they pick."""
     wsf = _hip.lib().ebn_gemm_workspace_floats
     for (M, N, K) in [(1, 1, 1), (5, 7, 3), (640, 1200, 400), (400, 200, 24000), (24000, 1200, 1024), (1024, 1200, 24000),
                       (24000, 400, 200), (4096, 4096, 4096), (300, 1200, 24000), (97, 4099, 17)]:
         bm, bn, sp = _plan(M, N, K)
-        assert (bm, bn) in ((128, 128), (64, 64), (256, 64), (32, 32)) and 1 <= sp <= 64
+        assert (bm, bn) in ((128, 128), (64, 64), (256, 64), (128, 64), (32, 32)) and 1 <= sp <= 64
         assert sp == 1 or bm != 32, "the 32x32 small-output kernel never splits K"
         assert int(wsf(M, N, K)) == (sp * M * N if sp > 1 else 0)
         assert _plan(M, N, K, 0)[2] == 1, "no workspace, no split"
@@ -64,7 +64,7 @@ def test_gemm_planner_is_a_pure_host_query_with_sane_plans():
     # the measured picks of profiles/r02_gemm_tuning.md: the small-output kernel wherever it applies (user encoder), the
     # AttLayer2 shapes, the skinny weight gradient of a 300-wide table with a long K range (six workgroups per CU)
     assert _plan(640, 1200, 400) == (32, 32, 1) and _plan(640, 400, 1200) == (32, 32, 1) and _plan(400, 1200, 640) == (32, 32, 1)
-    assert _plan(24000, 200, 400) == (64, 64, 1) and _plan(24000, 400, 200) == (128, 128, 1) and _plan(400, 200, 24000) == (64, 64, 18)
+    assert _plan(24000, 200, 400) == (128, 64, 1) and _plan(24000, 400, 200) == (128, 128, 1) and _plan(400, 200, 24000) == (64, 64, 18)
     assert _plan(300, 1200, 24000) == (64, 64, 16) and _plan(24000, 300, 1200) == (256, 64, 1)
     assert _hip.lib().ebn_gemm_plan(-1, 1, 1, 0, None, None, None) == -1
 
@@ -81,7 +81,7 @@ def test_gemm_planner_small_tile_choice_is_bounded_to_its_measured_envelope():
     # must be a valid plan, and a long, well-filled K range must not stay on the never-splitting small kernel
     for shape in [(1024, 1024, 4096), (1024, 1024, 1537), (640, 1200, 1537), (640, 1200, 4096), (640, 1200, 4097), (1024, 1088, 1024)]:
         bm, bn, sp = _plan(*shape)
-        assert (bm, bn) in ((128, 128), (64, 64), (256, 64), (32, 32)) and 1 <= sp <= 64 and (sp == 1 or bm != 32), shape
+        assert (bm, bn) in ((128, 128), (64, 64), (256, 64), (128, 64), (32, 32)) and 1 <= sp <= 64 and (sp == 1 or bm != 32), shape
     assert _plan(640, 1200, 4097)[0] != 32 and _plan(1024, 1088, 1024)[0] != 32  # K > 4096 / tiles64 = 272: never the small kernel
     assert _plan(1024, 1024, 4096)[0] != 32  # modelled: 32 slabs x 4 workgroups per CU loses to 128x128 tiles with split-K
 

@@ -12,6 +12,8 @@ import pytest
 import torch
 
 from oracle import nrms_numpy as on
+from pathlib import Path
+
 from tests.hip_testutil import P, S, assert_close, dev, gemm, host, make_state, read_state
 
 pytestmark = pytest.mark.gpu
@@ -228,6 +230,8 @@ ATTN_CASES = [(4, 30, 20, 20), (3, 20, 20, 20), (2, 50, 16, 16), (5, 1, 2, 4), (
               (1, 64, 2, 8),
               # the other instantiations of the MFMA path (L <= 32, d in {16, 20, 32}), incl. its largest LDS footprint
               (2, 32, 4, 32), (3, 17, 2, 16), (2, 32, 2, 16), (1, 5, 3, 32), (9, 1, 1, 20),
+              # group-form backward (d = 20, head_num a multiple of 4): short and full tiles, one group per sequence
+              (1030, 7, 4, 20), (520, 32, 8, 20),
               # long sequences (64 < L <= 256): recompute-based kernels
               (2, 100, 2, 20), (1, 256, 1, 32), (3, 65, 3, 16),
               # the backward image of the one-wave kernel exceeds 64 KB here (forward fits): must route to the long kernels
@@ -334,6 +338,53 @@ def test_attention_backward_with_the_pooling_term_folded_in(hip, n_seq, L, h, d,
     assert_close(host(b), host(a), rtol=2e-5, atol=2e-5, what="pooled attn bwd")
     # shapes outside the MFMA path are refused (the caller keeps the rank-1 GEMM epilogue there)
     assert hip.lib().ebn_attn_bwd_pooled_supported(65, 20) == 0 and hip.lib().ebn_attn_bwd_pooled_supported(30, 8) == 0
+
+
+ROOT = Path(__file__).resolve().parents[1]
+_GROUP_SCRIPT = r'''
+import ctypes, hashlib, sys
+sys.path.insert(0, "{root}/ebnerd-benchmark_amd")
+import torch
+from ebrec import _hip
+P, S = _hip.ptr, _hip.stream_handle
+g = torch.Generator(device="cuda").manual_seed(5)
+st = _hip.StepState(); st.step, st.seed, st.lr = 3, 7, 1e-3
+for s_ in range(_hip.binding.EBN_N_SITES):
+    st.drop_key[s_] = (0x9E3779B9 * (s_ + 1)) & 0xFFFFFFFF
+st_dev = torch.frombuffer(bytearray(bytes(st)), dtype=torch.uint8).cuda()
+out = []
+for n_seq, L, h in ((210, 30, 20), (300, 20, 20), (1100, 11, 4)):
+    d = 20; E = h * d; R = n_seq * L
+    qkv = torch.randn(R, 3 * E, device="cuda", generator=g)
+    dY = torch.randn(R, E, device="cuda", generator=g)
+    w = torch.rand(R, device="cuda", generator=g)
+    dpool = torch.randn(n_seq, E, device="cuda", generator=g)
+    for p in (0.0, 0.2):
+        a = torch.zeros(R, 3 * E, device="cuda"); b = torch.zeros(R, 3 * E, device="cuda")
+        _hip.call("ebn_attn_bwd_f32", P(qkv), 3 * E, P(dY), E, P(a), 3 * E, n_seq, L, h, d, P(st_dev), 1, ctypes.c_float(p), S())
+        _hip.call("ebn_attn_bwd_pooled_f32", P(qkv), 3 * E, P(dY), E, P(w), P(dpool), E, P(b), 3 * E, n_seq, L, h, d, P(st_dev), 1,
+                  ctypes.c_float(p), S())
+        torch.cuda.synchronize()
+        out.append(hashlib.sha256(a.cpu().numpy().tobytes() + b.cpu().numpy().tobytes()).hexdigest())
+print("DIGESTS", " ".join(out))
+'''
+
+
+def test_group_form_attention_backward_is_the_per_wave_kernel_bit_for_bit(hip, tmp_path):
+    """The backward of the title-level attention runs four heads of a title per workgroup (operands in, results out through the
+    whole workgroup); EBN_ATTN_BWD_PER_WAVE=1 selects the one-wave-per-head kernel it replaces.  Same MFMA order, same fma for
+    the pooling term, same mask: identical bytes, with and without dropout / pooling term."""
+    import os
+    import subprocess
+    import sys
+    script = tmp_path / "attn_group.py"
+    script.write_text(_GROUP_SCRIPT.format(root=str(ROOT)))
+    got = []
+    for flag in ("0", "1"):
+        out = subprocess.run([sys.executable, str(script)], env=dict(os.environ, EBN_ATTN_BWD_PER_WAVE=flag), capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and "DIGESTS" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+        got.append(out.stdout.split("DIGESTS", 1)[1].split())
+    assert len(got[0]) == 6 and got[0] == got[1]
 
 
 def test_attention_rejects_unsupported_shapes(hip):
