@@ -441,6 +441,109 @@ __global__ __launch_bounds__(64 * ATT_WAVES) void attn_mfma_fwd_kernel(MfmaAttnA
   else tile_rows_to_global<D, false>(ob, a.ld_out, O, L, row, hi, 1.0f, 0u, 0u, 0, 0u, 0.f);
 }
 
+// Forward, GROUP form (see the backward's group form further down for the measurements behind it): G consecutive heads of one
+// sequence per workgroup, one wave per head; Q, K, V come in as contiguous G x 80-byte row runs through the whole workgroup,
+// the output tiles go back the same way (dropout applied on the way out).  LDS per wave: Q | K (later the transpose buffer) | V
+// (later the output tile).  Same MFMA order as attn_mfma_fwd_kernel: identical bytes.
+template <int D>
+__host__ __device__ constexpr int fwd_group_v_offset(int L) {
+  return 2 * L * Tile<D>::STRIDE > TP_FLOATS ? 2 * L * Tile<D>::STRIDE : TP_FLOATS;
+}
+template <int D>
+__host__ __device__ constexpr int fwd_group_wave_floats(int L) {
+  return fwd_group_v_offset<D>(L) + L * Tile<D>::STRIDE;
+}
+
+template <int D, int LC, int G>
+__global__ __launch_bounds__(64 * G) void attn_mfma_fwd_group_kernel(MfmaAttnArgs a) {
+  using T = Tile<D>;
+  constexpr int NT = 64 * G;
+  constexpr int GV = G * T::VPR;
+  constexpr int ROUNDS = (32 * GV + NT - 1) / NT;
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // G x fwd_group_wave_floats
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int L = LC ? LC : a.L, E = a.h * D;
+  const int region = L * T::STRIDE;
+  const int wave_floats = fwd_group_wave_floats<D>(L), v_off = fwd_group_v_offset<D>(L);
+  const int row = lane & 31, hi = lane >> 5;
+  const float inv2 = 1.44269504088896341f / sqrtf(static_cast<float>(D));
+  const bool drop = a.key_ptr != nullptr;
+  const uint32_t key = drop ? *a.key_ptr : 0u;
+
+  const AttnProb p0 = attn_prob(static_cast<int64_t>(xcd_chunked_block()) * G, a.h, L);
+  const uint32_t gcol = p0.head * D;
+  const float* gq = a.qkv + p0.row0 * a.ld_qkv + gcol;
+  const int nvec = L * GV;
+  {
+    float4 vq[ROUNDS], vk[ROUNDS], vv[ROUNDS];
+    uint32_t dst[ROUNDS];
+#pragma unroll
+    for (int t = 0; t < ROUNDS; ++t) {
+      const int idx = tid + NT * t;
+      const int idc = idx < nvec ? idx : 0;
+      const uint32_t r = static_cast<uint32_t>(idc) / static_cast<uint32_t>(GV), c4g = static_cast<uint32_t>(idc) - r * GV;
+      const uint32_t head = c4g / T::VPR, c4 = c4g - head * T::VPR;
+      dst[t] = head * wave_floats + r * T::STRIDE + c4 * 4;
+      const uint32_t off = r * static_cast<uint32_t>(a.ld_qkv) + c4g * 4;
+      vq[t] = *reinterpret_cast<const float4*>(gq + off);
+      vk[t] = *reinterpret_cast<const float4*>(gq + E + off);
+      vv[t] = *reinterpret_cast<const float4*>(gq + 2 * E + off);
+    }
+#pragma unroll
+    for (int t = 0; t < ROUNDS; ++t) {
+      if (tid + NT * t < nvec) {
+        *reinterpret_cast<float4*>(smem + dst[t]) = vq[t];
+        *reinterpret_cast<float4*>(smem + dst[t] + region) = vk[t];
+        *reinterpret_cast<float4*>(smem + dst[t] + v_off) = vv[t];
+      }
+    }
+  }
+  __syncthreads();
+
+  float* sq = smem + wv * wave_floats;
+  float* sk = sq + region;
+  float* sv = sq + v_off;
+  f32x16 P;
+  {
+    float qr[D / 2], kr[D / 2];
+    lds_row_form<D>(qr, sq, L, row, hi);
+    lds_row_form<D>(kr, sk, L, row, hi);
+    P = mm_rows<D / 2>(kr, qr);  // T[j][i]: lane i, regs j
+  }
+  float vc[16];
+  lds_col_form<D>(vc, sv, L, row, hi);
+  softmax_in_lane(P, L, hi, inv2);
+  wave_lds_sync();                    // Q, K, V are in registers: Q|K becomes the transpose buffer, V's tile takes the output
+  tile_transpose(P, sq, L, row, hi);  // P[i][j]: lane j, regs i
+  {
+    const f32x16 O = mm_col_tile(vc, P);  // O^T[c][j]: lane j, regs c
+    tile_rows_to_lds<D>(sv, O, L, row, hi, 1.0f);
+  }
+  __syncthreads();
+
+  float* go = a.out + p0.row0 * a.ld_out + gcol;
+#pragma unroll
+  for (int t = 0; t < ROUNDS; ++t) {
+    const int idx = tid + NT * t;
+    if (idx < nvec) {
+      const uint32_t r = static_cast<uint32_t>(idx) / static_cast<uint32_t>(GV), c4g = static_cast<uint32_t>(idx) - r * GV;
+      const uint32_t head = c4g / T::VPR, c4 = c4g - head * T::VPR;
+      float4 y = *reinterpret_cast<const float4*>(smem + head * wave_floats + v_off + r * T::STRIDE + c4 * 4);
+      if (drop) {
+        const uint64_t pr = ((static_cast<uint64_t>(p0.row0) * E + gcol) >> 1) + ((r * static_cast<uint32_t>(E) + c4g * 4) >> 1);
+        const uint32_t h0 = ebn_dropout_pair_hash(key, pr), h1 = ebn_dropout_pair_hash(key, pr + 1);
+        y.x *= ((h0 & 0xFFFFu) >= a.thresh) ? a.scale : 0.f;
+        y.y *= ((h0 >> 16) >= a.thresh) ? a.scale : 0.f;
+        y.z *= ((h1 & 0xFFFFu) >= a.thresh) ? a.scale : 0.f;
+        y.w *= ((h1 >> 16) >= a.thresh) ? a.scale : 0.f;
+      }
+      *reinterpret_cast<float4*>(go + (r * static_cast<uint32_t>(a.ld_out) + c4g * 4)) = y;
+    }
+  }
+}
+
 // Backward.  Everything but d(K) is computed in the lane-i layout (softmax row i on the lanes, j on the registers: row
 // statistics and sum_j P dP are in-lane); d(K) contracts over i and gets d(S) through one tile transpose.
 template <int D>
@@ -1036,6 +1139,7 @@ __global__ __launch_bounds__(64 * ATT2_WAVES) void attn_mfma2_bwd_kernel(MfmaAtt
 #define EBN_ATTN_BWD_GROUP 4  // heads per workgroup of the group-form backward: one wave per SIMD (5 or 10 measured slower)
 #endif
 constexpr int BWD_GROUP = EBN_ATTN_BWD_GROUP;
+constexpr int64_t FWD_GROUP_MIN_QKV_BYTES = 200'000'000;
 constexpr int64_t BWD_GROUP_MIN_PROBLEMS = 4096;  // about one resident round of waves on 256 CUs
 static bool bwd_group_off() {  // EBN_ATTN_BWD_PER_WAVE=1: the one-wave-per-head backward everywhere (validation / tuning)
   static const bool off = [] { const char* e = getenv("EBN_ATTN_BWD_PER_WAVE"); return e && e[0] == '1'; }();
@@ -1093,6 +1197,23 @@ int ebn_attn_mfma_fwd(const float* qkv, int64_t ld_qkv, float* out, int64_t ld_o
     if (d == 16) launch_mfma2<16>(false, a, s);
     else if (d == 20) launch_mfma2<20>(false, a, s);
     else launch_mfma2<32>(false, a, s);
+    EBN_CHECK_LAUNCH();
+    return EBN_OK;
+  }
+  // Group form as in the backward, but only where Q|K|V no longer sits in the 256 MB memory-side cache the projection GEMM left it
+  // in: per 800 titles 31.3 us against 39.2 us one wave per head on HBM-resident data (3200 titles), 36.5 against 32.5 us on
+  // cache-resident data (800 titles; in the c2 step 35.5 against 34.8 us); the crossover lies between 172 and 230 MB of Q|K|V
+  const bool big = a.n_prob * L * 3 * d * static_cast<int64_t>(sizeof(float)) >= FWD_GROUP_MIN_QKV_BYTES;
+  if (d == 20 && (h % BWD_GROUP) == 0 && big && !bwd_group_off()) {
+    const size_t lds = static_cast<size_t>(BWD_GROUP) * fwd_group_wave_floats<20>(L) * sizeof(float);
+    const dim3 grid(static_cast<unsigned>(a.n_prob / BWD_GROUP)), block(64 * BWD_GROUP);
+    if (L == 30) {
+      allow_lds(attn_mfma_fwd_group_kernel<20, 30, BWD_GROUP>, lds);
+      hipLaunchKernelGGL((attn_mfma_fwd_group_kernel<20, 30, BWD_GROUP>), grid, block, lds, s, a);
+    } else {
+      allow_lds(attn_mfma_fwd_group_kernel<20, 0, BWD_GROUP>, lds);
+      hipLaunchKernelGGL((attn_mfma_fwd_group_kernel<20, 0, BWD_GROUP>), grid, block, lds, s, a);
+    }
     EBN_CHECK_LAUNCH();
     return EBN_OK;
   }

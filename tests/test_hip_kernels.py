@@ -353,7 +353,7 @@ for s_ in range(_hip.binding.EBN_N_SITES):
     st.drop_key[s_] = (0x9E3779B9 * (s_ + 1)) & 0xFFFFFFFF
 st_dev = torch.frombuffer(bytearray(bytes(st)), dtype=torch.uint8).cuda()
 out = []
-for n_seq, L, h in ((210, 30, 20), (300, 20, 20), (1100, 11, 4)):
+for n_seq, L, h in ((1400, 30, 20), (300, 20, 20), (1100, 11, 4), (2100, 20, 20)):
     d = 20; E = h * d; R = n_seq * L
     qkv = torch.randn(R, 3 * E, device="cuda", generator=g)
     dY = torch.randn(R, E, device="cuda", generator=g)
@@ -364,15 +364,17 @@ for n_seq, L, h in ((210, 30, 20), (300, 20, 20), (1100, 11, 4)):
         _hip.call("ebn_attn_bwd_f32", P(qkv), 3 * E, P(dY), E, P(a), 3 * E, n_seq, L, h, d, P(st_dev), 1, ctypes.c_float(p), S())
         _hip.call("ebn_attn_bwd_pooled_f32", P(qkv), 3 * E, P(dY), E, P(w), P(dpool), E, P(b), 3 * E, n_seq, L, h, d, P(st_dev), 1,
                   ctypes.c_float(p), S())
+        y = torch.zeros(R, E, device="cuda")
+        _hip.call("ebn_attn_fwd_f32", P(qkv), 3 * E, P(y), E, n_seq, L, h, d, P(st_dev), 1, ctypes.c_float(p), S())
         torch.cuda.synchronize()
-        out.append(hashlib.sha256(a.cpu().numpy().tobytes() + b.cpu().numpy().tobytes()).hexdigest())
+        out.append(hashlib.sha256(a.cpu().numpy().tobytes() + b.cpu().numpy().tobytes() + y.cpu().numpy().tobytes()).hexdigest())
 print("DIGESTS", " ".join(out))
 '''
 
 
-def test_group_form_attention_backward_is_the_per_wave_kernel_bit_for_bit(hip, tmp_path):
-    """The backward of the title-level attention runs four heads of a title per workgroup (operands in, results out through the
-    whole workgroup); EBN_ATTN_BWD_PER_WAVE=1 selects the one-wave-per-head kernel it replaces.  Same MFMA order, same fma for
+def test_group_form_attention_kernels_are_the_per_wave_kernels_bit_for_bit(hip, tmp_path):
+    """Forward and backward of the title-level attention run four heads of a title per workgroup (operands in, results out through
+    the whole workgroup); EBN_ATTN_BWD_PER_WAVE=1 selects the one-wave-per-head kernels they replace.  Same MFMA order, same fma for
     the pooling term, same mask: identical bytes, with and without dropout / pooling term."""
     import os
     import subprocess
@@ -384,7 +386,7 @@ def test_group_form_attention_backward_is_the_per_wave_kernel_bit_for_bit(hip, t
         out = subprocess.run([sys.executable, str(script)], env=dict(os.environ, EBN_ATTN_BWD_PER_WAVE=flag), capture_output=True, text=True, timeout=600)
         assert out.returncode == 0 and "DIGESTS" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
         got.append(out.stdout.split("DIGESTS", 1)[1].split())
-    assert len(got[0]) == 6 and got[0] == got[1]
+    assert len(got[0]) == 8 and got[0] == got[1]
 
 
 def test_attention_rejects_unsupported_shapes(hip):
