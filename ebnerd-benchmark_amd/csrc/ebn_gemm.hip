@@ -31,6 +31,11 @@ __device__ ebn_f32x4 ebn_raw_buffer_load_x4(ebn_i32x4 rsrc, int voffset, int sof
 __device__ void ebn_raw_buffer_load_lds(ebn_i32x4 rsrc, __attribute__((address_space(3))) void* lds, int size, int voffset,
                                         int soffset, int offset, int aux) __asm("llvm.amdgcn.raw.buffer.load.lds");
 
+// ebn_gemm_tall.hip
+bool ebn_gemm_tall_wanted(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K, const float* C, int64_t ldc);
+int ebn_gemm_tall_launch(int32_t transB, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda, const float* B,
+                         int64_t ldb, float* C, int64_t ldc, hipStream_t s);
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -1173,6 +1178,12 @@ static int gemm_dispatch(int32_t transA, int32_t transB, int64_t M, int64_t N, i
   const int vecA = ((lda % 4) == 0 && ebn_aligned16(A) && ((transA ? M : K) % 4) == 0 && spanA) ? 1 : 0;
   const int vecB = ((ldb % 4) == 0 && ebn_aligned16(B) && ((transB ? K : N) % 4) == 0 && spanB) ? 1 : 0;
   if ((epi.bias != nullptr || epi.rs != nullptr) && !(vecA && vecB)) return EBN_ERR_UNSUPPORTED;  // epilogue kernels are VEC only
+  // tall outputs with a narrow N that 64-wide tiles pad badly: 16 x 16 MFMA blocks (ebn_gemm_tall.hip)
+  if (epi.bias == nullptr && epi.rs == nullptr && beta == 0.f && vecA && vecB && forced_tile_bm() == 0 &&
+      ebn_gemm_tall_wanted(transA, transB, M, N, K, C, ldc)) {
+    const int rc_tall = ebn_gemm_tall_launch(transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, s);
+    if (rc_tall != EBN_ERR_UNSUPPORTED) return rc_tall;
+  }
   const GemmPlan plan = gemm_plan(M, N, K, workspace ? workspace_floats : 0);
   const int splits = plan.splits;
   const int64_t kps = plan.kps;

@@ -17,6 +17,7 @@ from pathlib import Path
 from tests.hip_testutil import P, S, assert_close, dev, gemm, host, make_state, read_state
 
 pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parents[1]
 
 
 # ---------------------------------------------------------------- step state
@@ -105,7 +106,42 @@ GEMM_SHAPES = [(1, 1, 1), (5, 7, 3), (64, 64, 16), (130, 70, 33), (257, 129, 300
                # the small-output kernel with two slabs of loads in flight: 6 full slabs; 3 full + a 16-wide tail; 5 full, ragged M
                (800, 512, 768), (640, 1200, 400), (250, 768, 640),
                # the edges of the planner's small-tile envelope (K = 1536 | 1537, tiles64 = 256 at K = 4096)
-               (640, 1200, 1536), (640, 1200, 1537), (1024, 1024, 4096)]
+               (640, 1200, 1536), (640, 1200, 1537), (1024, 1024, 4096),
+               # tall outputs with an N the 64-wide tiles pad by > 10 %: the 16x16-block kernel (ebn_gemm_tall.hip) for A not
+               # transposed and beta = 0 -- AttLayer2's two shapes (short), ragged M / N / K with a partial last slab, two column panels
+               (4096, 200, 400), (4100, 400, 200), (4099, 68, 72), (4500, 416, 100), (5000, 100, 64)]
+
+
+_TALL_SCRIPT = r'''
+import ctypes, sys
+sys.path.insert(0, "{root}/ebnerd-benchmark_amd")
+import torch
+from ebrec import _hip
+P, S = _hip.ptr, _hip.stream_handle
+g = torch.Generator(device="cuda").manual_seed(3)
+worst = 0.0
+for M, N, K in ((4096, 200, 400), (4100, 400, 200), (4099, 68, 72), (4500, 416, 100)):
+    for tB in (0, 1):
+        A = torch.randn(M, K, device="cuda", generator=g)
+        B = torch.randn((N, K) if tB else (K, N), device="cuda", generator=g)
+        C = torch.full((M, N), float("nan"), device="cuda")
+        _hip.call("ebn_gemm_f32", 0, tB, M, N, K, ctypes.c_float(0.5), P(A), K, P(B), B.shape[1], ctypes.c_float(0.0), P(C), N, S())
+        ref = 0.5 * (A.double() @ (B.double().t() if tB else B.double()))
+        worst = max(worst, float((C.double() - ref).abs().max() / ref.abs().max()))
+print("TALL_WORST", worst)
+'''
+
+
+def test_tall_gemm_kernel_in_both_b_layouts(hip, tmp_path):
+    """EBN_GEMM_TALL=2 sends the [N][K] layouts to the 16x16-block kernel as well (by default only B stored [K][N] takes it)."""
+    import os
+    import subprocess
+    import sys
+    script = tmp_path / "tall.py"
+    script.write_text(_TALL_SCRIPT.format(root=str(ROOT)))
+    out = subprocess.run([sys.executable, str(script)], env=dict(os.environ, EBN_GEMM_TALL="2"), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "TALL_WORST" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+    assert float(out.stdout.split("TALL_WORST", 1)[1].split()[0]) < 2e-6
 
 
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
@@ -340,7 +376,6 @@ def test_attention_backward_with_the_pooling_term_folded_in(hip, n_seq, L, h, d,
     assert hip.lib().ebn_attn_bwd_pooled_supported(65, 20) == 0 and hip.lib().ebn_attn_bwd_pooled_supported(30, 8) == 0
 
 
-ROOT = Path(__file__).resolve().parents[1]
 _GROUP_SCRIPT = r'''
 import ctypes, hashlib, sys
 sys.path.insert(0, "{root}/ebnerd-benchmark_amd")
