@@ -1139,7 +1139,10 @@ __global__ __launch_bounds__(64 * ATT2_WAVES) void attn_mfma2_bwd_kernel(MfmaAtt
 #define EBN_ATTN_BWD_GROUP 4  // heads per workgroup of the group-form backward: one wave per SIMD (5 or 10 measured slower)
 #endif
 constexpr int BWD_GROUP = EBN_ATTN_BWD_GROUP;
-constexpr int64_t FWD_GROUP_MIN_QKV_BYTES = 200'000'000;
+#ifndef EBN_ATTN_FWD_GROUP_MIN_BYTES
+#define EBN_ATTN_FWD_GROUP_MIN_BYTES 200'000'000
+#endif
+constexpr int64_t FWD_GROUP_MIN_QKV_BYTES = EBN_ATTN_FWD_GROUP_MIN_BYTES;
 constexpr int64_t BWD_GROUP_MIN_PROBLEMS = 4096;  // about one resident round of waves on 256 CUs
 static bool bwd_group_off() {  // EBN_ATTN_BWD_PER_WAVE=1: the one-wave-per-head backward everywhere (validation / tuning)
   static const bool off = [] { const char* e = getenv("EBN_ATTN_BWD_PER_WAVE"); return e && e[0] == '1'; }();
