@@ -785,6 +785,7 @@ __global__ __launch_bounds__(64 * G) void attn_mfma_bwd_group_kernel(MfmaAttnArg
     }
   }
   __syncthreads();
+  EBN_ATTN_PRIO_AT(1);
 
   float* sq = smem + wv * wave_floats;
   float* sk = sq + region;
@@ -810,6 +811,7 @@ __global__ __launch_bounds__(64 * G) void attn_mfma_bwd_group_kernel(MfmaAttnArg
   for (int r = 0; r < 16; ++r) rowdot = fmaf(P[r], dP[r], rowdot);
   rowdot += __shfl_xor(rowdot, 32, 64);
 
+  EBN_ATTN_PRIO_AT(2);
   float col[16], colq[16];
   lds_col_form<D>(col, sg, L, row, hi);
   lds_col_form<D>(colq, sq, L, row, hi);
@@ -825,6 +827,7 @@ __global__ __launch_bounds__(64 * G) void attn_mfma_bwd_group_kernel(MfmaAttnArg
     const f32x16 dQ = mm_col_tile(col, P);
     tile_rows_to_lds<D>(sq, dQ, L, row, hi, inv);
   }
+  EBN_ATTN_PRIO_AT(3);
   wave_lds_sync();                    // K and dO have been read for the last time: their tiles become the transpose buffer
   tile_transpose(P, sk, L, row, hi);  // dS[i][j]: lane j, regs i
   wave_lds_sync();
