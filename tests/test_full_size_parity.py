@@ -44,10 +44,11 @@ def _dense_weights(eng):
     return out
 
 
-@pytest.mark.parametrize("graph", [False, True])
-def test_c2_full_size_training_step_matches_the_oracle(hip, graph):
+@pytest.mark.parametrize("graph,precision", [(False, "exact"), (True, "exact"), (True, "split")])
+def test_c2_full_size_training_step_matches_the_oracle(hip, graph, precision):
     """configs[1] as bench.py runs it: V = 250002, D = 1024, B = 32, H = 20, C = 5, T = 30, heads 20 x 20, dropout 0.2, frozen
-    table.  graph=True replays the captured hipGraph (the launch path of the timed region) -- second step, fresh keys."""
+    table.  graph=True replays the captured hipGraph (the launch path of the timed region) -- second step, fresh keys.
+    precision="split": the opt-in bf16x6 projections (`bench.py --precision split`) under the SAME tolerances."""
     from ebrec.models.newsrec import NRMSModel
 
     V, D, B, C, seed, lr = 250002, 1024, 32, 5, 7, 1e-3
@@ -55,7 +56,7 @@ def test_c2_full_size_training_step_matches_the_oracle(hip, graph):
     rng = np.random.default_rng(2024)
     table = rng.standard_normal((V, D), dtype=np.float32) * np.float32(0.05)
     P = on.random_nrms_params(1, D, hp.head_num, hp.head_dim, hp.attention_hidden_dim, seed=21)
-    m = NRMSModel(hp, word2vec_embedding=table, seed=seed, train_embedding=False)
+    m = NRMSModel(hp, word2vec_embedding=table, seed=seed, train_embedding=False, precision=precision)
     m.from_keras_weight_list([table] + weight_list(P)[1:])
     eng = m._engine
     if graph:
@@ -123,6 +124,38 @@ def test_c1_full_size_three_steps_with_the_dense_table_sweep(hip, loss):
     # rows no batch looked up never saw a gradient: with zero moments the dense sweep must leave them bit-identical
     assert (~touched).sum() > 0
     assert np.array_equal(got["emb"][~touched], P0["emb"][~touched].astype(np.float32))
+
+
+def test_c4_full_size_step_with_history_50_matches_the_oracle(hip):
+    """configs[3]'s per-rank step at bench size: history_size 50 (the 2 x 2-tile attention kernels at the user level, 52800 title
+    tokens per step: the group-form attention kernels above their size thresholds, the 16x16-block AttLayer2 GEMM), 32000 x 300
+    TRAINABLE table, B = 32, dropout 0.2; two steps through the captured graph."""
+    from ebrec.models.newsrec import NRMSModel
+
+    V, D, B, C, H, seed, lr = 32000, 300, 32, 5, 50, 13, 1e-3
+    hp = make_hp(history_size=H, dropout=0.2, learning_rate=lr)
+    rng = np.random.default_rng(41)
+    P = on.random_nrms_params(V, D, hp.head_num, hp.head_dim, hp.attention_hidden_dim, seed=6)
+    m = NRMSModel(hp, word2vec_embedding=P["emb"], seed=seed).from_keras_weight_list(weight_list(P))
+    eng = m._engine
+    eng.enable_graphs()
+    P = {k: v.astype(np.float32).astype(np.float64) for k, v in P.items()}
+    P0 = {k: v.copy() for k, v in P.items()}
+    mom = {k: (np.zeros_like(v), np.zeros_like(v)) for k, v in P.items()}
+    for t in range(1, 3):
+        his, pred, y = batch(rng, B, H, C, hp.title_size, V)
+        L, _, g = on.nrms_loss_and_grads(his, pred, y, P, hp.head_num, hp.head_dim, "cross_entropy_loss", on.Drop(0.2, seed, t))
+        got_L = float(m.train_step(his, pred, y).item())
+        assert abs(got_L - L) <= 2e-5 * max(1.0, abs(L)), (t, got_L, L)
+        if t == 1:
+            _check_dense_grads(eng, g)
+        for k in P:
+            on.adam_keras_step(P[k], g[k], mom[k][0], mom[k][1], t, lr=lr)
+    eng.check_oob()
+    got = dict(zip(on.PARAM_ORDER, m.model.get_weights()))
+    for k in on.PARAM_ORDER:
+        step = np.abs(P[k] - P0[k])
+        assert_close(got[k].reshape(P[k].shape), P[k], rtol=0, atol=2e-5 + 0.02 * float(step.max()), what=f"c4 weights {k} after 2 steps")
 
 
 def test_c3_full_size_docvec_step_matches_the_oracle(hip):
