@@ -29,7 +29,9 @@ Nothing here computes on rows: the local gather / scatter-add are callables supp
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
+from datetime import timedelta
 
 import torch
 import torch.distributed as dist
@@ -48,6 +50,42 @@ def allreduce_sum_(tensors, group=None) -> None:
         return
     for t in tensors:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+
+class LockStepGuard:
+    """Turns "a collective API entered by only some ranks" from a hang into an error.
+
+    `save_weights`, `evaluate` and `fit` are collectives when world > 1 (gradient / log / flag reductions, the table
+    all-gather of a row-sharded engine).  A caller that enters one on rank 0 only -- the natural thing to write after
+    `if rank == 0:` -- would block in RCCL until the watchdog aborts the job.  `enter(what)` runs a gloo
+    `monitored_barrier` first: when a peer does not arrive within `timeout_s` (EBN_COLLECTIVE_TIMEOUT_S, default 120 s)
+    it raises a RuntimeError naming the call and the missing ranks, on every rank that did arrive.
+
+    RCCL has no monitored barrier, so with an "nccl" group a gloo side group over the same ranks is made at construction
+    (the engine is constructed by every rank of its group, `use_local_synchronization` keeps other processes out of it)."""
+
+    def __init__(self, group=None, timeout_s: float | None = None):
+        self.rank, self.world = world_info(group)
+        self.timeout_s = float(os.environ.get("EBN_COLLECTIVE_TIMEOUT_S", "120")) if timeout_s is None else float(timeout_s)
+        self.group = None
+        if self.world > 1:
+            if dist.get_backend(group) == "gloo":
+                self.group = group if group is not None else dist.group.WORLD
+            else:
+                self.group = dist.new_group(ranks=dist.get_process_group_ranks(group if group is not None else dist.group.WORLD),
+                                            backend="gloo", timeout=timedelta(seconds=max(self.timeout_s, 30.0)),
+                                            use_local_synchronization=True)
+
+    def enter(self, what: str) -> None:
+        if self.world <= 1:
+            return
+        try:
+            dist.monitored_barrier(group=self.group, timeout=timedelta(seconds=self.timeout_s), wait_all_ranks=True)
+        except RuntimeError as e:
+            raise RuntimeError(f"{what} is a COLLECTIVE when world > 1 ({self.world} ranks): every rank of the group must call it at the "
+                               f"same point.  Rank {self.rank} entered it, but not every peer did within {self.timeout_s:.0f} s -- a call "
+                               f"guarded by `if rank == 0:`?  (rank-local inference: predict / scorer.predict / encode_news on a "
+                               f"replicated table are not collectives.)  [{str(e).splitlines()[0]}]") from e
 
 
 def rows_per_rank(V: int, world: int) -> int:
@@ -187,13 +225,13 @@ class ShardedTableExchange:
         for _kind, fn in self.grad_segments(n_tok, b, reduce_fn, scatter_fn):
             fn()
 
-    def check(self, b: PlannedBuffers, what="embedding table") -> None:
+    def check(self, b: PlannedBuffers, what="embedding table", collective: bool = True) -> None:
         """One host read of the plan's STICKY flags (the engine calls this once per epoch, not per step; the plan kernel
-        only ever raises them, this clears them).  A COLLECTIVE when world > 1: the flags are MAX-reduced over the group
-        first, so that either every rank raises or none does -- a rank raising alone would leave the others blocked in the
-        next step's all-to-all."""
+        only ever raises them, this clears them).  A COLLECTIVE when world > 1 (unless collective=False): the flags are
+        MAX-reduced over the group first, so that either every rank raises or none does -- a rank raising alone would leave
+        the others blocked in the next step's all-to-all."""
         flags = b.counts[self.world:].clone()
-        if self.world > 1:
+        if self.world > 1 and collective:
             dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.group)
         c = b.counts[: self.world].cpu().tolist() + flags.cpu().tolist()
         b.counts[self.world:].zero_()

@@ -154,6 +154,7 @@ class NRMSEngine:
         if table_grad_exchange not in ("auto", "dense", "sparse"):
             raise ValueError(f"table_grad_exchange must be auto | dense | sparse, got {table_grad_exchange}")
         self.table_grad_exchange = table_grad_exchange
+        self._sparse_pin = None  # the "auto" decision, taken once (pin_table_grad_exchange)
         self.pg = process_group
         table = np.ascontiguousarray(table, dtype=np.float32)  # copied, like weights=[...] (nrms.py:128)
         self.V, self.D = table.shape
@@ -216,6 +217,11 @@ class NRMSEngine:
         self.world = 1
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
+        self.guard = None  # world > 1: save_weights / evaluate / fit raise instead of hanging when only some ranks call them
+        if self.world > 1:
+            from ._dist import LockStepGuard
+
+            self.guard = LockStepGuard(process_group)
 
     @property
     def loss_kind(self) -> int:
@@ -309,24 +315,37 @@ class NRMSEngine:
         rank accumulates all of them in the same order-independent fixed-point accumulator and Adam reads it) instead of
         all-reducing the dense (V, D) gradient.  "auto": when the gathered rows are fewer than the table's -- a 250 002 x 1024
         table is a 1 GB all-reduce per step, 8 x 24 000 token rows are 0.8 GB of all-gather traffic and need no fp32 copy of
-        the gradient; a 32 000 x 300 table (38 MB) stays dense."""
+        the gradient; a 32 000 x 300 table (38 MB) stays dense.  The "auto" choice is PINNED the first time it is asked
+        (`pin_table_grad_exchange`: fit() asks with the loader's full-batch shape before the first step), so that a rank's
+        short last batch can never pick a different collective than its peers' full ones."""
         if not (self.world > 1 and self.train_embedding and self.exchange is None and self.deterministic and not self.keep_table_grad):
             return False
-        return self.table_grad_exchange == "sparse" or (self.table_grad_exchange == "auto" and self.world * n_tok < self.V)
+        if self.table_grad_exchange != "auto":
+            return self.table_grad_exchange == "sparse"
+        return self.pin_table_grad_exchange(n_tok)
+
+    def pin_table_grad_exchange(self, n_tok_full: int) -> bool:
+        """Decide table_grad_exchange="auto" ONCE from the FULL-batch token count (the same number on every rank: batch size and
+        title shapes are configuration).  Returns True for the sparse exchange."""
+        if self._sparse_pin is None:
+            self._sparse_pin = bool(self.world * int(n_tok_full) < self.V)
+        return self._sparse_pin
 
     @property
     def needs_equal_batches(self) -> bool:
         """True when the step's collectives are sized by the local batch SHAPE, so every rank must run the same shape in
         every step (fit() then leaves a shard's short last batch out): the row-sharded lookup's equal-split all-to-alls,
-        and the sparse table-gradient exchange of a replicated trainable table (all-gathers of n_tok ids / rows -- and
-        `_sparse_dp` itself decides by n_tok, so ranks with different shapes would not even pick the same collective).
-        The dense all-reduces are shape-independent."""
+        and the sparse table-gradient exchange of a replicated trainable table (all-gathers of n_tok ids / rows).  The dense
+        all-reduces are shape-independent: a 32 000 x 300 table under "auto" trains on every batch, like the reference."""
         if self.world <= 1:
             return False
         if self.exchange is not None:
             return True
-        return (self.train_embedding and self.deterministic and not self.keep_table_grad
-                and self.table_grad_exchange != "dense")
+        if not (self.train_embedding and self.deterministic and not self.keep_table_grad):
+            return False
+        if self.table_grad_exchange != "auto":
+            return self.table_grad_exchange == "sparse"
+        return True if self._sparse_pin is None else self._sparse_pin  # not decided yet: the conservative answer
 
     @property
     def graph_capable(self) -> bool:
@@ -374,7 +393,8 @@ class NRMSEngine:
                 ws = int(_hip.lib().ebn_shard_plan_workspace_ints(self.V, self.exchange.world))
                 b.xb = PlannedBuffers(self.exchange, N * self.T, self.device, need_grad=train and self.train_embedding, ws_ints=ws)
             self._bufs[key] = b
-            self._graphs.clear()  # captured graphs hold raw pointers into the old buffers
+            if train:
+                self._graphs.clear()  # captured training graphs hold raw pointers into the old buffers (inference is never captured)
         return b
 
     def _user_bufs(self, B, train, H=None):
@@ -387,7 +407,8 @@ class NRMSEngine:
         if b is None or b.n_seq < B:
             b = EncoderBuffers(B, H, self.E, self.E, self.A, self.device, own_input=False, need_dx=False)
             self._bufs[key] = b
-            self._graphs.clear()
+            if train and H == self.H:  # only the training step's own buffers are referenced by captured graphs: a history-length
+                self._graphs.clear()   # sweep or a truncated-history predict between epochs must not force a re-capture
         return b
 
     # ------------------------------------------------------------------ C-ABI plumbing
@@ -738,7 +759,7 @@ class NRMSEngine:
             self._upload_ids(b.ids, ids[s:s + n])
             self._news_forward(b, n, False)
             out[s:s + n].copy_(b.out[:n])
-        self._check_oob()
+        self._check_oob()  # local read with a replicated table (callers run inference on one rank), collective when row-sharded
         return out
 
     def encode_users_from_news(self, NEh: torch.Tensor) -> torch.Tensor:
@@ -806,30 +827,45 @@ class NRMSEngine:
         if pred.ndim != 3 or pred.shape[0] != his.shape[0] or pred.shape[2] != self.T:
             raise ValueError(f"pred_input_title must be (B, C, {self.T}), got {tuple(pred.shape)}")
 
-    def _check_oob(self):
-        """One host read of the device flags.  With world > 1 this is a COLLECTIVE (every rank must call it at the same point,
-        as fit()/evaluate() do once per epoch): the flags are MAX-reduced so that all ranks raise together -- a rank raising
-        alone would leave the others blocked in the next step's collectives."""
+    def _check_oob(self, collective=None):
+        """One host read of the device flags (ids out of range, fixed-point accumulator range, exchange overflow).
+
+        collective=True: the flags are MAX-reduced over the group first, so that every rank raises together -- a rank raising
+        alone would leave the others blocked in the next step's collectives.  Only the LOCK-STEP callers ask for this: the
+        once-per-epoch `check_oob()` of fit() / evaluate() and bench.py.  collective=False: a local read, no communication --
+        what the inference entry points (`encode_news`, `forward`, hence `predict` / `scorer.predict`) use with a REPLICATED
+        table, because callers run those on one rank only (the reproducibility driver predicts on rank 0 while the other ranks
+        have returned: examples/reproducibility_scripts/ebnerd_nrms.py).  Default (None): collective exactly when the table is
+        row-sharded -- there `encode_news` is itself a collective (the lookup's all-to-alls), every rank is in the call."""
+        if collective is None:
+            collective = self.exchange is not None
+        collective = bool(collective) and self.world > 1
+        err = None
         if self._planned:  # the plan's own flags first: an overflowed exchange also shows up as zero rows in the gather
-            for key in sorted(k for k, b in self._bufs.items() if hasattr(b, "xb")):
+            for key in sorted((k for k, b in self._bufs.items() if hasattr(b, "xb")), key=repr):
                 try:
-                    self.exchange.check(self._bufs[key].xb)
-                except Exception:
-                    self.oob_flag.zero_()
-                    raise
+                    self.exchange.check(self._bufs[key].xb, collective=collective)
+                except Exception as e:  # keep reading: every sticky flag is cleared by this one check, whatever is raised
+                    err = err or e
         flags = torch.cat([self.oob_flag, self.range_flag])
-        if self.world > 1:
+        if collective:
             torch.distributed.all_reduce(flags, op=torch.distributed.ReduceOp.MAX, group=self.pg)
         oob, rng_bad = (int(v) for v in flags.cpu().tolist())
+        if oob or rng_bad or err is not None:  # the values are in `flags`: clear BOTH words before raising anything, so that no
+            self.oob_flag.zero_()              # stale flag raises a second, spurious error at the next check
+            self.range_flag.zero_()
+        if err is not None:
+            raise err
         if oob != 0:
-            self.oob_flag.zero_()
             raise IndexError(f"token id out of range [0, {self.V}) for the embedding table")
         if rng_bad != 0:
-            self.range_flag.zero_()
             raise FloatingPointError("embedding gradient left the range of the deterministic fixed-point accumulator (|sum| >= 2^22 "
                                      "or NaN): the run has diverged; deterministic=False accumulates in fp32 instead")
 
-    check_oob = _check_oob  # fit()/evaluate() call this once per epoch (device-resident batches are not range-checked on the host)
+    def check_oob(self):
+        """The lock-step form: fit() / evaluate() call this once per epoch on EVERY rank (device-resident batches are not
+        range-checked on the host), bench.py after its timed region."""
+        self._check_oob(collective=True)
 
     def l2_penalty(self) -> float:
         """lambda * sum(W^2) over the regularised Dense kernels (0 without the optional per-token stack)."""

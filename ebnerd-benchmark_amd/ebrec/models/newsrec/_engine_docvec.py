@@ -54,6 +54,11 @@ class DocVecEngine:
         self.world = 1
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
+        self.guard = None  # world > 1: save_weights / evaluate / fit raise instead of hanging when only some ranks call them
+        if self.world > 1:
+            from ._dist import LockStepGuard
+
+            self.guard = LockStepGuard(process_group)
 
     @property
     def loss_kind(self) -> int:

@@ -37,6 +37,13 @@ def _allreduce_host(values, eng, op="sum"):
     return t.cpu().tolist()
 
 
+def _enter_collective(eng, what: str) -> None:
+    """world > 1: raise (instead of hanging in RCCL) when `what` is entered by only some ranks of the group."""
+    guard = getattr(eng, "guard", None)
+    if guard is not None:
+        guard.enter(what)
+
+
 def _full_batches(data) -> int:
     """number of leading batches of `data` that have the full batch size (all but possibly the last one)"""
     bs = getattr(data, "batch_size", None) or getattr(data, "bs", None)
@@ -153,8 +160,10 @@ class TrainModel:
     def save_weights(self, filepath, **_):
         """Named tensors (SURVEY.md A.6 order) in a torch file at exactly `filepath`.
         With world > 1 this is a COLLECTIVE: every rank must call it (rank 0 writes; the others take part in the table
-        all-gather of a row-sharded engine and in the closing barrier).  Calling it on rank 0 only deadlocks."""
+        all-gather of a row-sharded engine and in the closing barrier).  Calling it on rank 0 only RAISES after
+        EBN_COLLECTIVE_TIMEOUT_S (`_dist.LockStepGuard`) instead of hanging."""
         rank, world, group = _dist_of(self._engine)
+        _enter_collective(self._engine, "model.save_weights()")
         # get_weights() is a collective when the table is row-sharded: every rank calls it, rank 0 writes the file
         state = {n: torch.from_numpy(np.ascontiguousarray(w)) for n, w in zip(self._names, self._engine.get_weights())}
         extra = getattr(self._engine, "extra_state", lambda: {})()
@@ -185,11 +194,18 @@ class TrainModel:
         self.stop_training = False
         want_auc = "auc" in self.metrics_names
         eng = self._engine
+        _enter_collective(eng, "model.fit()")
         rng = np.random.default_rng(self._owner.seed)
         rank, world, _group = _dist_of(eng)
         # data parallel: every step ends in a gradient all-reduce, so every rank must run the SAME number of steps per
         # epoch -- the shortest shard decides (the surplus batches of longer shards rotate in through the shuffle)
         n_batches = len(data)
+        if world > 1 and hasattr(eng, "pin_table_grad_exchange") and n_batches:
+            # table_grad_exchange="auto" is decided ONCE, here, from the FULL-batch shape (configuration: the same on every rank) --
+            # never per step from a rank's local, possibly short, batch
+            (h0, p0), _y0 = data[0]
+            bs = int(getattr(data, "batch_size", None) or getattr(data, "bs", None) or len(h0))
+            eng.pin_table_grad_exchange(bs * (np.shape(h0)[1] + np.shape(p0)[1]) * eng.T)
         if world > 1 and getattr(eng, "needs_equal_batches", getattr(eng, "exchange", None) is not None):
             # row-sharded table / sparse table-gradient exchange: the step's collectives are sized by the batch SHAPE, which
             # must therefore be the same on every rank in every step -- a shard's short last batch is left out (it is always
@@ -254,9 +270,11 @@ class TrainModel:
     def evaluate(self, x=None, y=None, batch_size=None, verbose=0, return_dict=False, **_):
         """With world > 1 this is a COLLECTIVE: every rank evaluates ITS shard and must call this at the same point; loss,
         AUC histograms and the device error flags are reduced over the group, so the result (and any raised error) is the
-        same on every rank.  For a rank-local evaluation build the model without a process group."""
+        same on every rank.  Entered by only some ranks it raises after EBN_COLLECTIVE_TIMEOUT_S instead of hanging.  For a
+        rank-local evaluation build the model without a process group."""
         data = x if _is_loader(x) else _ArrayBatches(x, y, batch_size)
         eng = self._engine
+        _enter_collective(eng, "model.evaluate()")
         auc = StreamingAUC() if "auc" in self.metrics_names else None
         loss_sum, n_rows = torch.zeros(1, device=eng.device), 0
         # loaders of this repo: encode every article of the lookup matrix ONCE (the weights are fixed during evaluate) and

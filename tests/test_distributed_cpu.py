@@ -235,3 +235,34 @@ def _data_parallel_worker(rank, world):
 
 def test_data_parallel_allreduce_equals_full_batch_gradient():
     _run(_data_parallel_worker, 2)
+
+
+# ---------------------------------------------------------------- lock-step guard of the collective model APIs
+def _guard_worker(rank, world):
+    import time
+
+    from ebrec.models.newsrec._dist import LockStepGuard
+
+    g = LockStepGuard(timeout_s=2.0)
+    assert (g.rank, g.world) == (rank, world)
+    g.enter("model.evaluate()")  # everyone arrives: passes
+    g.enter("model.save_weights()")
+    if rank == 0:  # the `if rank == 0: model.save_weights(...)` mistake: an error naming the call, not a hang
+        t0 = time.time()
+        with pytest.raises(RuntimeError, match=r"model\.save_weights\(\) is a COLLECTIVE"):
+            g.enter("model.save_weights()")
+        assert time.time() - t0 < 30
+    else:
+        time.sleep(4.0)
+
+
+def test_collective_api_entered_by_one_rank_raises_instead_of_hanging():
+    _run(_guard_worker, 2)
+
+
+def test_lock_step_guard_is_a_no_op_without_a_process_group():
+    from ebrec.models.newsrec._dist import LockStepGuard
+
+    g = LockStepGuard()
+    assert g.world == 1 and g.group is None
+    g.enter("anything")

@@ -361,7 +361,12 @@ def _fit_worker(rank, world, shard, tmpdir, table_grad_exchange="dense"):
            ReduceLROnPlateau(monitor="val_auc", mode="max", factor=0.2, patience=1, min_lr=1e-6)]
     h = m.model.fit((his, pred), y.astype(np.float32), batch_size=16, epochs=3, verbose=0, callbacks=cbs,
                     validation_data=((vhis, vpred), vy.astype(np.float32)))
-    assert m._engine.read_state().step % (3 if equal else 4) == 0  # 4 steps per epoch (3 when only full batches may run)
+    # "auto" on a 300-row table picks the DENSE all-reduce (pinned by fit() from the full-batch shape): every batch trains, like the
+    # reference; only a step whose collectives are sized by the batch shape is restricted to full batches
+    equal_run = shard or table_grad_exchange == "sparse"
+    assert m._engine.needs_equal_batches == equal_run
+    per_epoch = 3 if equal_run else 4
+    assert m._engine.read_state().step == per_epoch * len(h.history["loss"])
     hist = {k: [float(v) for v in vs] for k, vs in h.history.items()}
     parts = [None] * world
     dist.all_gather_object(parts, (hist, [w.tobytes() for w in m.model.get_weights()], float(m.model.optimizer.learning_rate)))
@@ -378,3 +383,41 @@ def test_two_rank_fit_keeps_ranks_in_lock_step(hip, shard, table_grad_exchange, 
     are sized by the local batch shape: a short last batch on one rank next to a full one on the other would hang or corrupt
     memory (round-2 ADVICE, high) -- fit() runs only full batches then."""
     _spawn(_fit_worker, 2, shard, str(tmp_path), table_grad_exchange)
+
+
+def _one_rank_inference_worker(rank, world, tmpdir):
+    """Round-3 ADVICE (high): with a REPLICATED table the inference entry points are rank-local -- the reproducibility driver runs
+    `scorer.predict` on rank 0 while the other ranks have already returned (examples/reproducibility_scripts/ebnerd_nrms.py) -- so
+    they must not contain a collective.  The collective APIs (save_weights) entered by one rank raise instead of hanging."""
+    import time
+
+    import torch.distributed as dist
+    from ebrec.models.newsrec import NRMSModel
+
+    hp = make_hp(dropout=0.2, learning_rate=1e-3)
+    V, D = 300, 32
+    rng = np.random.default_rng(5)
+    emb = rng.standard_normal((V, D)).astype(np.float32)
+    m = NRMSModel(hp, word2vec_embedding=emb, seed=3, train_embedding=True)
+    assert m._engine.world == world and m._engine.guard is not None
+    his, pred, y = batch(rng, 6, hp.history_size, 5, hp.title_size, V)
+    m.train_step(his, pred, y)  # one lock-step training step (gradient all-reduce) on both ranks
+    if rank == 0:
+        probs = m.model.predict((his, pred))                      # forward() -> local flag read, no all-reduce
+        sc = m.scorer.predict((his, pred[:, :1]))                 # encode_news / encode_users -> the same
+        news = m.newsencoder.predict(his[0])
+        assert probs.shape == (6, 5) and sc.shape == (6, 1) and news.shape == (hp.history_size, m._engine.E)
+        bad = his.copy()
+        bad[0, 0, 0] = V  # an id out of range on ONE rank still raises there, locally
+        with pytest.raises(IndexError):
+            m._engine.forward(torch.from_numpy(bad.astype(np.int32)).cuda(), torch.from_numpy(pred.astype(np.int32)).cuda())
+        m._engine.guard.timeout_s = 2.0
+        with pytest.raises(RuntimeError, match="COLLECTIVE"):
+            m.model.save_weights(os.path.join(tmpdir, "w"))      # rank 0 only: an error after the timeout, not a hang
+    else:
+        time.sleep(6.0)
+    dist.barrier()
+
+
+def test_rank_local_inference_on_a_replicated_table_has_no_collective_and_lone_collective_calls_raise(hip, tmp_path):
+    _spawn(_one_rank_inference_worker, 2, str(tmp_path))
