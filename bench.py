@@ -84,13 +84,43 @@ def make_hparams(c):
                                              attention_hidden_dim=c["A"]))
 
 
-def synthetic_batches(c, n, seed, device):
-    """ids uniform in [0,V), one positive per row at a uniform position."""
+_ZIPF_CDF = {}
+
+
+def zipf_ids(rng, shape, V, s=1.0):
+    """SURVEY.md 8(d) "Z": token ids drawn Zipf(s) over the V rows, id = frequency rank (tokenizer vocabularies are roughly
+    frequency-ordered; id 0 -- the padding / unknown row the reference maps missing articles to, dataloader.py:43,
+    _python.py:474-484 -- is the hottest).  Inverse-CDF sampling over the FINITE support: p(k) = (k+1)^-s / H_V."""
+    cdf = _ZIPF_CDF.get((V, s))
+    if cdf is None:
+        cdf = _ZIPF_CDF[(V, s)] = np.cumsum(1.0 / np.arange(1, V + 1, dtype=np.float64) ** s)
+    return np.minimum(np.searchsorted(cdf, rng.random(shape) * cdf[-1], side="right"), V - 1).astype(np.int64)
+
+
+def synthetic_ids(rng, B, H, C, T, V, ids="uniform", pad_frac=0.15):
+    """One batch of title-token ids, SURVEY.md 8(d).  "uniform" (U): ids uniform in [0, V) (examples/quick_start/nrms_dummy.py:8-40).
+    "zipf" (Z, the realism check): Zipf(1.0) ids + `pad_frac` of the history slots all-zero titles -- the reference left-pads a
+    short history with article 0 (_behaviors.py:647-654), whose title row is all token 0: real batches hammer table row 0."""
+    if ids == "uniform":
+        return rng.integers(0, V, (B, H, T)), rng.integers(0, V, (B, C, T))
+    if ids != "zipf":
+        raise ValueError(f"ids must be uniform | zipf, got {ids}")
+    his, pred = zipf_ids(rng, (B, H, T), V), zipf_ids(rng, (B, C, T), V)
+    his[rng.random((B, H)) < pad_frac] = 0
+    return his, pred
+
+
+def synthetic_batches(c, n, seed, device, ids="uniform"):
+    """ids uniform in [0,V) (U) or Zipf + padded history (Z), one positive per row at a uniform position."""
     g = torch.Generator(device="cpu").manual_seed(seed)
+    rng = np.random.default_rng(seed)
     out = []
     for _ in range(n):
-        his = torch.randint(0, c["V"], (c["B"], c["H"], c["T"]), generator=g, dtype=torch.int32)
-        pred = torch.randint(0, c["V"], (c["B"], c["C"], c["T"]), generator=g, dtype=torch.int32)
+        if ids == "uniform":  # (torch's generator: the id streams of every earlier round's lines)
+            his = torch.randint(0, c["V"], (c["B"], c["H"], c["T"]), generator=g, dtype=torch.int32)
+            pred = torch.randint(0, c["V"], (c["B"], c["C"], c["T"]), generator=g, dtype=torch.int32)
+        else:
+            his, pred = (torch.from_numpy(a.astype(np.int32)) for a in synthetic_ids(rng, c["B"], c["H"], c["C"], c["T"], c["V"], ids))
         y = torch.zeros(c["B"], c["C"])
         y[torch.arange(c["B"]), torch.randint(0, c["C"], (c["B"],), generator=g)] = 1.0
         out.append((his.to(device), pred.to(device), y.to(device)))
@@ -253,7 +283,7 @@ def being_profiled() -> bool:
     return any(k.startswith(("ROCP_", "ROCPROF", "ROCPROFILER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
 
 
-def probe_kernels(config, batch, precision="exact"):
+def probe_kernels(config, batch, precision="exact", ids="uniform"):
     """Kernel names and HBM traffic of the two roofline kernels, observed IN THIS RUN: three rocprofv3 passes over
     `bench.py --kernel-probe` (a subprocess that builds the same engine and launches the Q|K|V projection and the gather
     eagerly on the step's buffers): (1) --kernel-trace --stats -> the names as the profiler sees them, (2) --pmc FETCH_SIZE
@@ -269,7 +299,7 @@ def probe_kernels(config, batch, precision="exact"):
         return None
     out = {}
     tmp = tempfile.mkdtemp(prefix="ebn_probe_", dir=os.environ.get("TMPDIR", "/tmp"))
-    probe = [sys.executable, str(Path(__file__).resolve()), "--kernel-probe", "--config", config, "--precision", precision] + \
+    probe = [sys.executable, str(Path(__file__).resolve()), "--kernel-probe", "--config", config, "--precision", precision, "--ids", ids] + \
         (["--batch", str(batch)] if batch else [])
     env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
     try:
@@ -403,6 +433,9 @@ def main():
     ap.add_argument("--repeats", type=int, default=5, help="the timed loop of --steps steps is run this many times; the median is reported")
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the config's)")
+    ap.add_argument("--ids", default="uniform", choices=["uniform", "zipf"],
+                    help="SURVEY.md 8(d) id distribution: uniform (U, the headline) or zipf (Z: Zipf(1.0) ids + 15 %% of the history slots "
+                         "all-zero titles -- hot row 0, as real left-padded EB-NeRD batches have)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch kernel by kernel instead of hipGraph replay")
     ap.add_argument("--graph-collectives", action="store_true",
@@ -465,7 +498,7 @@ def main():
                       train_embedding=c["train_embedding"], device=device, shard_table=sharded, precision=args.precision)
     del table
     eng = model._engine
-    batches = synthetic_batches(c, 8, 123 + rank, device)
+    batches = synthetic_batches(c, 8, 123 + rank, device, args.ids)
 
     if args.kernel_probe:
         # the two roofline kernels, eagerly, on the step's own buffers: 4 launches each (the gather over 4 different id sets)
@@ -517,7 +550,7 @@ def main():
         gemm_name = (f"gemm_f32_kernel<{bm.value}, {bn.value}, {4 if bm.value == 256 else 2}, false, false, true, 1, 0>" if bm.value != 32
                      else "gemm_small_vec_kernel<false, false, 32>") + f" (ebn_gemm_plan: tile {bm.value}x{bn.value}, split-K {sp.value})"
         gather_bytes = n_tok * (4 + 2 * c["D"] * 4)  # id + row read + row write (materialising gather)
-        probed = None if (args.no_probe or args.no_roofline or world > 1) else probe_kernels(args.config, args.batch, args.precision)
+        probed = None if (args.no_probe or args.no_roofline or world > 1) else probe_kernels(args.config, args.batch, args.precision, args.ids)
         if probed and "traffic" in probed.get("qkv_gemm", {}) and "traffic" in probed.get("gather", {}):
             traffic = {k: v["traffic"] for k, v in probed.items()}
             traffic_source = ("measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over "
@@ -529,6 +562,12 @@ def main():
             name_source = "static: the template instantiation ebn_gemm_plan selects for this shape (not observed in a trace of this run)"
             gather_name = "gather_rows_vec4_kernel"
         cfg_idx = {"c1": 0, "c2": 1, "c4": 3, "c5": 4, "c5h50": 4}[args.config]
+        ids0 = id_sets[0].cpu().numpy()
+        id_note = {"ids": args.ids, "tokens_per_step": int(ids0.size), "distinct_rows_in_a_step": int(np.unique(ids0).size),
+                   "tokens_on_row_0": int((ids0 == 0).sum()),
+                   "what": "SURVEY.md 8(d) U: uniform ids in [0, V)" if args.ids == "uniform" else
+                           "SURVEY.md 8(d) Z: Zipf(1.0) ids (id = frequency rank) + 15 % of the history slots all-zero titles (left-padded "
+                           "histories, _behaviors.py:647-654) -- the realism check; the headline is U"}
         table_kind = "trainable" if c["train_embedding"] else "frozen lookup"
         if sharded:
             table_kind += f", row-sharded over {world} rank(s) (routed all-to-all of the distinct rows)"
@@ -543,7 +582,7 @@ def main():
                                    f"history_size={c['H']} npratio={c['C'] - 1} title_len={c['T']} head={c['h']}x{c['d']} "
                                    f"att_hidden={c['A']} dropout=0.2 adam lr=1e-4 CE loss",
                        "global_batch": world * c["B"], "per_gpu_batch": c["B"], "parallelism": f"dp{world}",
-                       "final_loss": loss},
+                       "final_loss": loss, "id_distribution": id_note},
         }
         if args.precision == "split":
             line["precision_note"] = ("OPT-IN second precision, not the headline: the news encoder's projection GEMMs (forward Q|K|V and its "

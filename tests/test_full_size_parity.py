@@ -87,11 +87,14 @@ def test_c2_full_size_training_step_matches_the_oracle(hip, graph, precision):
     assert torch.equal(eng.table[uniq[:64]].cpu(), torch.from_numpy(table[uniq[:64]]))  # frozen
 
 
-@pytest.mark.parametrize("loss", ["cross_entropy_loss", "log_loss"])
-def test_c1_full_size_three_steps_with_the_dense_table_sweep(hip, loss):
+@pytest.mark.parametrize("loss,ids,segmented", [("cross_entropy_loss", "uniform", False), ("log_loss", "uniform", False),
+                                                ("cross_entropy_loss", "zipf", False), ("cross_entropy_loss", "zipf", True)])
+def test_c1_full_size_three_steps_with_the_dense_table_sweep(hip, loss, ids, segmented):
     """configs[0] at bench size: 32000 x 300 TRAINABLE table, B = 32, dropout 0.2, 3 steps.  Keras' Adam decays the
     moments of every row each step (dense sweep): rows untouched by a batch still move after step 1 -- the whole
-    32000 x 300 table is compared."""
+    32000 x 300 table is compared.  ids="zipf": SURVEY.md 8(d)'s Z inputs -- ~5000 of the 24000 gradient rows of a step land on
+    table row 0 (left-padded histories, _behaviors.py:647-654; unknown articles, dataloader.py:43), the case that decides between
+    one 64-bit atomic per element and the counting-sort + segmented reduction (segmented=True: same bits by construction)."""
     from ebrec.models.newsrec import NRMSModel
 
     V, D, B, C, seed, lr = 32000, 300, 32, 5, 11, 1e-3
@@ -100,13 +103,16 @@ def test_c1_full_size_three_steps_with_the_dense_table_sweep(hip, loss):
     P = on.random_nrms_params(V, D, hp.head_num, hp.head_dim, hp.attention_hidden_dim, seed=5)
     m = NRMSModel(hp, word2vec_embedding=P["emb"], seed=seed).from_keras_weight_list(weight_list(P))
     eng = m._engine
+    eng.segmented_table_grad = segmented
     eng.enable_graphs()
     P = {k: v.astype(np.float32).astype(np.float64) for k, v in P.items()}
     P0 = {k: v.copy() for k, v in P.items()}
     mom = {k: (np.zeros_like(v), np.zeros_like(v)) for k, v in P.items()}
     touched = np.zeros(V, bool)
     for t in range(1, 4):
-        his, pred, y = batch(rng, B, hp.history_size, C, hp.title_size, V)
+        his, pred, y = batch(rng, B, hp.history_size, C, hp.title_size, V, ids=ids)
+        if ids == "zipf":
+            assert (his == 0).sum() + (pred == 0).sum() > 3000  # the hot row is hot
         touched[his.reshape(-1)] = True
         touched[pred.reshape(-1)] = True
         L, _, g = on.nrms_loss_and_grads(his, pred, y, P, hp.head_num, hp.head_dim, loss, on.Drop(0.2, seed, t))
@@ -126,10 +132,12 @@ def test_c1_full_size_three_steps_with_the_dense_table_sweep(hip, loss):
     assert np.array_equal(got["emb"][~touched], P0["emb"][~touched].astype(np.float32))
 
 
-def test_c4_full_size_step_with_history_50_matches_the_oracle(hip):
+@pytest.mark.parametrize("ids", ["uniform", "zipf"])
+def test_c4_full_size_step_with_history_50_matches_the_oracle(hip, ids):
     """configs[3]'s per-rank step at bench size: history_size 50 (the 2 x 2-tile attention kernels at the user level, 52800 title
     tokens per step: the group-form attention kernels above their size thresholds, the 16x16-block AttLayer2 GEMM), 32000 x 300
-    TRAINABLE table, B = 32, dropout 0.2; two steps through the captured graph."""
+    TRAINABLE table, B = 32, dropout 0.2; two steps through the captured graph.  ids="zipf": SURVEY.md 8(d)'s Z inputs (hot row 0:
+    ~11 000 of the 52 800 gradient rows of a step); the accumulator's range flag must stay clean (check_oob)."""
     from ebrec.models.newsrec import NRMSModel
 
     V, D, B, C, H, seed, lr = 32000, 300, 32, 5, 50, 13, 1e-3
@@ -143,7 +151,7 @@ def test_c4_full_size_step_with_history_50_matches_the_oracle(hip):
     P0 = {k: v.copy() for k, v in P.items()}
     mom = {k: (np.zeros_like(v), np.zeros_like(v)) for k, v in P.items()}
     for t in range(1, 3):
-        his, pred, y = batch(rng, B, H, C, hp.title_size, V)
+        his, pred, y = batch(rng, B, H, C, hp.title_size, V, ids=ids)
         L, _, g = on.nrms_loss_and_grads(his, pred, y, P, hp.head_num, hp.head_dim, "cross_entropy_loss", on.Drop(0.2, seed, t))
         got_L = float(m.train_step(his, pred, y).item())
         assert abs(got_L - L) <= 2e-5 * max(1.0, abs(L)), (t, got_L, L)
@@ -156,6 +164,88 @@ def test_c4_full_size_step_with_history_50_matches_the_oracle(hip):
     for k in on.PARAM_ORDER:
         step = np.abs(P[k] - P0[k])
         assert_close(got[k].reshape(P[k].shape), P[k], rtol=0, atol=2e-5 + 0.02 * float(step.max()), what=f"c4 weights {k} after 2 steps")
+
+
+
+@pytest.mark.parametrize("H,partition,train_embedding,ids", [(20, "cyclic", False, "uniform"), (20, "block", False, "uniform"),
+                                                             (50, "cyclic", False, "uniform"), (20, "cyclic", True, "uniform"),
+                                                             (20, "cyclic", False, "zipf")])
+def test_c5_full_size_row_sharded_step_matches_the_oracle(hip, H, partition, train_embedding, ids):
+    """configs[4] at its own per-rank size: the 250002 x 1024 table behind the ROW-SHARDED code path (device-side lookup plan over
+    the whole vocabulary, request lists, the serve gather, the expanding gather with dropout on the exchanged rows -- and with a
+    trainable table the per-slot gradient reduction and the owner-side accumulation), B = 64 per rank, history 20 and 50 (48 000 /
+    105 600 title tokens per step), block and cyclic ownership, hipGraph segments on; two steps (the second one replays).  One
+    rank holds every shard here (world = 1: the exchanges are the identity); the two-rank run at this width is
+    tests/test_multi_rank_gpu.py::test_two_rank_c5_full_width_*.  Compacted-vocabulary float64 oracle as in the c2 test.  ids="zipf":
+    the duplicate-heavy plan (row 0 requested by ~20 % of the tokens collapses to one slot)."""
+    from ebrec.models.newsrec import NRMSModel
+
+    V, D, B, C, seed, lr = 250002, 1024, 64, 5, 17, 1e-3
+    hp = make_hp(history_size=H, dropout=0.2, learning_rate=lr)
+    rng = np.random.default_rng(555)
+    table = rng.standard_normal((V, D), dtype=np.float32) * np.float32(0.05)
+    P = on.random_nrms_params(1, D, hp.head_num, hp.head_dim, hp.attention_hidden_dim, seed=23)
+    m = NRMSModel(hp, word2vec_embedding=table, seed=seed, train_embedding=train_embedding, shard_table=True, shard_partition=partition,
+                  deterministic=False)
+    m.from_keras_weight_list([table] + weight_list(P)[1:])
+    eng = m._engine
+    assert eng._planned and eng.exchange.partition == partition
+    eng.enable_graphs()
+    P = {k: v.astype(np.float32).astype(np.float64) for k, v in P.items()}
+    P0 = {k: v.copy() for k, v in P.items()}
+    mom = {k: (np.zeros_like(v), np.zeros_like(v)) for k, v in P.items()}
+    emb_m, emb_v = {}, {}  # Adam moments of the table rows the oracle has seen so far (zero for every other row)
+    emb_now = {}
+    touched = np.zeros(V, bool)
+    for t in range(1, 3):
+        his, pred, y = batch(rng, B, H, C, hp.title_size, V, ids=ids)
+        uniq, inv = np.unique(np.concatenate([his.reshape(-1), pred.reshape(-1)]), return_inverse=True)
+        touched[uniq] = True
+        cur = np.stack([emb_now.get(int(u), table[u].astype(np.float64)) for u in uniq]) if train_embedding and t > 1 else table[uniq].astype(np.float64)
+        P["emb"] = cur
+        his_c, pred_c = inv[: his.size].reshape(his.shape), inv[his.size:].reshape(pred.shape)
+        L, _, g = on.nrms_loss_and_grads(his_c, pred_c, y, P, hp.head_num, hp.head_dim, "cross_entropy_loss", on.Drop(0.2, seed, t),
+                                         need_emb_grad=train_embedding)
+        got_L = float(m.train_step(his, pred, y).item())
+        assert abs(got_L - L) <= 2e-5 * max(1.0, abs(L)), (t, got_L, L)
+        _check_dense_grads(eng, g)
+        for k in on.PARAM_ORDER[1:]:
+            on.adam_keras_step(P[k], g[k], mom[k][0], mom[k][1], t, lr=lr)
+        if train_embedding:
+            if t == 1:  # the shard's gradient (one rank owns every row: owner-local order = global order) against the oracle's compacted one
+                assert eng.table_grad.shape[0] == V
+                got_g = eng.table_grad[torch.from_numpy(uniq).to(eng.device)].cpu().numpy()
+                assert_close(got_g, g["emb"], rtol=1e-4, atol=1e-6 + 1e-4 * np.abs(g["emb"]).max(), what="c5 d(table rows)")
+                nz = (eng.table_grad != 0).any(dim=1).cpu().numpy()
+                assert not nz[~touched].any()
+            # Keras' dense Adam over the table: rows with zero gradient AND zero moments do not move; rows seen in an earlier step decay
+            seen = sorted(set(emb_m) | {int(u) for u in uniq})
+            pos = {int(u): i for i, u in enumerate(uniq)}
+            rows = np.stack([emb_now.get(r, table[r].astype(np.float64)) for r in seen])
+            gr = np.stack([g["emb"][pos[r]] if r in pos else np.zeros(D) for r in seen])
+            mm = np.stack([emb_m.get(r, np.zeros(D)) for r in seen])
+            vv = np.stack([emb_v.get(r, np.zeros(D)) for r in seen])
+            on.adam_keras_step(rows, gr, mm, vv, t, lr=lr)
+            for i, r in enumerate(seen):
+                emb_now[r], emb_m[r], emb_v[r] = rows[i], mm[i], vv[i]
+    got = _dense_weights(eng)
+    for k in on.PARAM_ORDER[1:]:
+        step = np.abs(P[k] - P0[k])
+        assert_close(got[k].reshape(P[k].shape), P[k], rtol=0, atol=2e-5 + 0.02 * float(step.max()), what=f"c5 weights {k} after Adam")
+    eng.check_oob()  # plan overflow / out-of-range / gradient flags of both steps
+    full = eng._full_table()
+    if eng.exchange.world == 1 and partition == "cyclic":
+        assert full.shape[0] == V
+    idx = torch.from_numpy(np.flatnonzero(~touched)[:4096]).to(full.device)
+    assert torch.equal(full[idx].cpu(), torch.from_numpy(table[idx.cpu().numpy()]))  # rows no batch looked up: bit-identical
+    if train_embedding:
+        seen = np.array(sorted(emb_now))
+        want = np.stack([emb_now[int(r)] for r in seen])
+        gotr = full[torch.from_numpy(seen).to(full.device)].cpu().numpy()
+        assert_close(gotr, want, rtol=0, atol=2e-5 + 0.02 * 2 * lr, what="c5 table rows after 2 Adam steps")
+    else:
+        tidx = torch.from_numpy(uniq[:4096]).to(full.device)
+        assert torch.equal(full[tidx].cpu(), torch.from_numpy(table[uniq[:4096]]))  # frozen
 
 
 def test_c3_full_size_docvec_step_matches_the_oracle(hip):

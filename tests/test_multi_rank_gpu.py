@@ -421,3 +421,64 @@ def _one_rank_inference_worker(rank, world, tmpdir):
 
 def test_rank_local_inference_on_a_replicated_table_has_no_collective_and_lone_collective_calls_raise(hip, tmp_path):
     _spawn(_one_rank_inference_worker, 2, str(tmp_path))
+
+
+def _c5_full_width_worker(rank, world, train_embedding):
+    """configs[4] at its own table size on TWO ranks: 250002 x 1024 rows split cyclically, B = 32 per rank (global 64: the per-rank
+    batch of c5), device-planned lookups with the default capacity, the equal-split all-to-all buffers at 4 KB rows
+    (2 x 15 040 slots x 4 KB each way), hipGraph segments on; against the float64 oracle stepping on the GLOBAL batch with the
+    compacted vocabulary."""
+    from ebrec.models.newsrec import NRMSModel
+    from tests.test_full_size_parity import _check_dense_grads, _dense_weights
+
+    V, D, B, C, H, seed, lr = 250002, 1024, 32, 5, 20, 19, 1e-3
+    hp = make_hp(history_size=H, dropout=0.0, learning_rate=lr)
+    rng = np.random.default_rng(4242)  # identical streams on both ranks
+    table = rng.standard_normal((V, D), dtype=np.float32) * np.float32(0.05)
+    P = on.random_nrms_params(1, D, hp.head_num, hp.head_dim, hp.attention_hidden_dim, seed=29)
+    m = NRMSModel(hp, word2vec_embedding=table, seed=seed, train_embedding=train_embedding, shard_table=True, deterministic=False)
+    m.from_keras_weight_list([table] + weight_list(P)[1:])
+    eng = m._engine
+    assert eng.world == world and eng.exchange.partition == "cyclic" and eng.table.shape[0] == len(range(rank, V, world))
+    cap = eng.exchange.capacity(B * (H + C) * hp.title_size)
+    assert cap < B * (H + C) * hp.title_size  # the DEFAULT capacity factor (1.25 x n_tok / W), not the can-never-overflow one
+    eng.enable_graphs()
+    P = {k: v.astype(np.float32).astype(np.float64) for k, v in P.items()}
+    P0 = {k: v.copy() for k, v in P.items()}
+    mom = {k: (np.zeros_like(v), np.zeros_like(v)) for k, v in P.items()}
+    for t in range(1, 3):
+        his, pred, y = batch(rng, B * world, H, C, hp.title_size, V)  # the GLOBAL batch
+        uniq, inv = np.unique(np.concatenate([his.reshape(-1), pred.reshape(-1)]), return_inverse=True)
+        P["emb"] = table[uniq].astype(np.float64)
+        his_c, pred_c = inv[: his.size].reshape(his.shape), inv[his.size:].reshape(pred.shape)
+        need = train_embedding and t == 1
+        L, _, g = on.nrms_loss_and_grads(his_c, pred_c, y, P, hp.head_num, hp.head_dim, "cross_entropy_loss", None, need_emb_grad=need)
+        sl = slice(rank * B, (rank + 1) * B)
+        probs_loc = on.nrms_forward(his_c[sl], pred_c[sl], P, hp.head_num, hp.head_dim)[0]
+        got = float(eng.train_step(his[sl], pred[sl], y[sl]).item())  # each rank steps on ITS rows
+        want_loc = float(-np.log(probs_loc[y[sl].astype(bool)]).mean())
+        assert abs(got - want_loc) <= 2e-5 * max(1.0, abs(want_loc)), (rank, t, got, want_loc)
+        if t == 1:  # the all-reduced (SUM) dense gradients = world x the full-batch mean gradient
+            _check_dense_grads(eng, {k: v * world for k, v in g.items() if k != "emb"})
+            if train_embedding:  # my shard's gradient rows: the sum over BOTH ranks' requests, routed to me (never all-reduced)
+                mine = uniq[uniq % world == rank]
+                got_g = eng.table_grad[torch.from_numpy(mine // world).to(eng.device)].cpu().numpy()
+                want_g = g["emb"][uniq % world == rank] * world
+                assert_close(got_g, want_g, rtol=1e-4, atol=1e-6 + 1e-4 * np.abs(want_g).max(), what=f"rank {rank}: d(shard rows)")
+        if train_embedding:
+            break  # (a second float64 step would need the moved rows of a 1 GB table: the dense weights + shard gradient pin the path)
+        for k in on.PARAM_ORDER[1:]:
+            on.adam_keras_step(P[k], g[k], mom[k][0], mom[k][1], t, lr=lr)
+    eng.check_oob()  # the default capacity held (uniform ids: ~11 000 distinct rows per owner against 15 040 slots)
+    if not train_embedding:
+        got = _dense_weights(eng)
+        for k in on.PARAM_ORDER[1:]:
+            step = np.abs(P[k] - P0[k])
+            assert_close(got[k].reshape(P[k].shape), P[k], rtol=0, atol=2e-5 + 0.02 * float(step.max()), what=f"rank {rank}: c5 weights {k}")
+    st = eng.exchange.stats()["bytes_sent_per_lookup_remote"]
+    assert st["rows"] == (world - 1) * cap * D * 4
+
+
+@pytest.mark.parametrize("train_embedding", [False, True])
+def test_two_rank_c5_full_width_row_sharded_step_equals_the_full_batch_oracle_step(hip, train_embedding):
+    _spawn(_c5_full_width_worker, 2, train_embedding)

@@ -38,11 +38,17 @@ def weight_list(P):
     return [P[k] for k in on.PARAM_ORDER]
 
 
-def batch(rng, B, H, C, T, V, pad_frac=0.15):
-    his = rng.integers(0, V, (B, H, T))
+def batch(rng, B, H, C, T, V, pad_frac=0.15, ids="uniform"):
+    """ids="zipf": SURVEY.md 8(d)'s Z distribution (Zipf(1.0) over the V rows, id = frequency rank) -- with the padded history
+    slots both distributions have, table row 0 then carries ~20 % of a batch's tokens."""
+    if ids == "zipf":
+        from bench import zipf_ids
+
+        his, pred = zipf_ids(rng, (B, H, T), V), zipf_ids(rng, (B, C, T), V)
+    else:
+        his, pred = rng.integers(0, V, (B, H, T)), rng.integers(0, V, (B, C, T))
     pad = rng.random((B, H)) < pad_frac  # padded history slots = all-zero titles (SURVEY quirk 3)
     his[pad] = 0
-    pred = rng.integers(0, V, (B, C, T))
     y = np.zeros((B, C), np.int8)
     y[np.arange(B), rng.integers(0, C, B)] = 1
     return his, pred, y
