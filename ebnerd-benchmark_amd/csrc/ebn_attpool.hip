@@ -379,7 +379,7 @@ __global__ __launch_bounds__(POOL_THREADS) void attpool_bwd_fused_kernel(const f
 
 }  // namespace
 
-extern "C" int64_t ebn_attpool_partials_len(int64_t R, int32_t A) { return ebn_colred_blocks(R) * 2 * A; }
+extern "C" int64_t ebn_attpool_partials_len(int64_t R, int32_t A) { return ebn_dim_ok(R, A) ? ebn_colred_blocks(R) * 2 * A : 0; }
 
 extern "C" int ebn_attpool_fwd_f32(float* U, const float* b, const float* q, const float* X, float* out,
                                    float* w, int64_t n_seq, int32_t L, int32_t E, int32_t A,
@@ -434,7 +434,9 @@ extern "C" int ebn_attpool_bwd_dpre_f32(float* U, const float* q, const float* d
   return EBN_OK;
 }
 
-extern "C" int64_t ebn_attpool_bwd_fused_partials_len(int64_t n_seq, int32_t A) { return n_seq * 2 * static_cast<int64_t>(A); }
+extern "C" int64_t ebn_attpool_bwd_fused_partials_len(int64_t n_seq, int32_t A) {
+  return ebn_dim_ok(n_seq, A) ? n_seq * 2 * static_cast<int64_t>(A) : 0;
+}
 
 extern "C" int ebn_attpool_bwd_fused_f32(const float* X, const float* w, const float* dout, float* U, const float* q, float* de,
                                          float* dq, float* db, float* partials, int64_t n_seq, int32_t L, int32_t E, int32_t A,

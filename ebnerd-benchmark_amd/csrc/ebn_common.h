@@ -18,6 +18,27 @@
     if (!(cond)) return (code); \
   } while (0)
 
+// Largest extent any single dimension of a problem may have: row counts, widths and contraction lengths are multiplied into 64-bit
+// element counts and narrowed into 32-bit launch geometry; beyond this bound the host-side planners would overflow (found by the
+// ASAN / fuzz pass of tests/test_abi_asan.py).  2^31 - 1 rows of 4-byte columns is already past the 288 GB of the device.
+#define EBN_DIM_MAX ((int64_t)INT32_MAX)
+
+// size queries answer 0 ("nothing to allocate") for extents outside [0, EBN_DIM_MAX]; the entry points themselves reject them
+static inline bool ebn_dim_ok(int64_t a, int64_t b = 0, int64_t c = 0, int64_t d = 0) {
+  return a >= 0 && b >= 0 && c >= 0 && d >= 0 && a <= EBN_DIM_MAX && b <= EBN_DIM_MAX && c <= EBN_DIM_MAX && d <= EBN_DIM_MAX;
+}
+
+// saturating int64 arithmetic for the size queries: an impossible problem answers INT64_MAX (an allocation that fails), never a
+// wrapped, small or negative size
+static inline int64_t ebn_sat_mul(int64_t a, int64_t b) {
+  int64_t r;
+  return (a < 0 || b < 0) ? 0 : (__builtin_mul_overflow(a, b, &r) ? INT64_MAX : r);
+}
+static inline int64_t ebn_sat_add(int64_t a, int64_t b) {
+  int64_t r;
+  return __builtin_add_overflow(a, b, &r) ? INT64_MAX : r;
+}
+
 static inline hipStream_t ebn_stream(ebn_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 static inline bool ebn_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

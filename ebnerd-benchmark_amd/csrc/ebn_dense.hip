@@ -550,6 +550,7 @@ constexpr int L2_BLOCKS = 256;
 extern "C" int64_t ebn_colsum_partials_len(int64_t R, int32_t Ccols) {
   // 2 reduction kinds x row blocks x C, plus 2*C floats of per-site scratch (dgamma/dbeta of one call site);
   // never less than the L2_BLOCKS floats ebn_l2_reg_f32 needs
+  if (!ebn_dim_ok(R, Ccols)) return 0;
   const int64_t n = ebn_colred_blocks(R) * 2 * Ccols + 2 * static_cast<int64_t>(Ccols);
   return n > L2_BLOCKS ? n : L2_BLOCKS;
 }

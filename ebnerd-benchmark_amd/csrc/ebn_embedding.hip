@@ -357,7 +357,7 @@ extern "C" int ebn_embedding_grad_scatter_fixed(const int32_t* ids, const float*
 }
 
 extern "C" int64_t ebn_embedding_grad_segmented_workspace_ints(int64_t n_tok, int64_t V) {
-  if (n_tok < 0 || V <= 0) return 0;
+  if (!ebn_dim_ok(n_tok, V) || V == 0) return 0;
   return 3 * V + 4 + 2 * n_tok;
 }
 

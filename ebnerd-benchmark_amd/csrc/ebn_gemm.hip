@@ -1153,8 +1153,9 @@ static GemmPlan gemm_plan(int64_t M, int64_t N, int64_t K, int64_t ws_floats) {
 }
 
 extern "C" int64_t ebn_gemm_workspace_floats(int64_t M, int64_t N, int64_t K) {
+  if (!ebn_dim_ok(M, N, K)) return 0;
   const GemmPlan p = gemm_plan(M, N, K, INT64_MAX / 4);
-  return (p.splits > 1) ? static_cast<int64_t>(p.splits) * M * N : 0;
+  return (p.splits > 1) ? ebn_sat_mul(static_cast<int64_t>(p.splits) * M, N) : 0;
 }
 
 extern "C" int ebn_gemm_plan(int64_t M, int64_t N, int64_t K, int64_t workspace_floats, int32_t* bm, int32_t* bn,

@@ -497,14 +497,15 @@ SplitPlan split_plan(int64_t M, int64_t N, int64_t K) {
     if (splits < 1) splits = 1;
     if (splits > 64) splits = 64;
   }
-  p.slabs_per_split = static_cast<int>(ebn_ceil_div(slabs, splits));
-  p.splits = static_cast<int>(ebn_ceil_div(slabs, p.slabs_per_split));
+  const int64_t per = ebn_ceil_div(slabs, splits);  // (64-bit until the end: a K beyond 2^35 used to truncate to 0 slabs per split)
+  p.slabs_per_split = static_cast<int>(per > INT32_MAX ? INT32_MAX : per);
+  p.splits = static_cast<int>(ebn_ceil_div(slabs, per));
   return p;
 }
 
 }  // namespace
 
-extern "C" int64_t ebn_planes_bytes(int64_t rows, int64_t K) { return 3 * pad_rows(rows) * pad_k(K) * 2; }
+extern "C" int64_t ebn_planes_bytes(int64_t rows, int64_t K) { return ebn_dim_ok(rows, K) ? ebn_sat_mul(6 * pad_rows(rows), pad_k(K)) : 0; }
 
 extern "C" int ebn_split_planes_f32(const float* src, int64_t ld, int64_t rows, int64_t K, int32_t trans, void* planes,
                                     ebn_stream_t stream) {
@@ -555,8 +556,8 @@ extern "C" int ebn_gather_split_planes_f32(const int32_t* ids, const float* tabl
 }
 
 extern "C" int64_t ebn_gemm_planes_workspace_floats(int64_t M, int64_t N, int64_t K) {
-  if (M <= 0 || N <= 0 || K < 0) return 0;
-  return static_cast<int64_t>(split_plan(M, N, K).splits) * M * N;  // (one slice when K is not split: the beta != 0 combine reads it)
+  if (M <= 0 || N <= 0 || !ebn_dim_ok(M, N, K)) return 0;
+  return ebn_sat_mul(static_cast<int64_t>(split_plan(M, N, K).splits) * M, N);  // (one slice when K is not split: the beta != 0 combine reads it)
 }
 
 extern "C" int ebn_gemm_planes_f32(const void* a_planes, int64_t M, const void* b_planes, int64_t N, int64_t K, float alpha, float beta,
@@ -600,8 +601,9 @@ extern "C" int ebn_gemm_planes_f32(const void* a_planes, int64_t M, const void* 
 
 // bytes of workspace ebn_gemm_f32_split needs for (M, N, K): both operands' bf16 planes and the split-K partials
 extern "C" int64_t ebn_gemm_split_workspace_bytes(int64_t M, int64_t N, int64_t K) {
-  if (M <= 0 || N <= 0 || K < 0) return 0;
-  return ebn_planes_bytes(M, K) + ebn_planes_bytes(N, K) + ebn_gemm_planes_workspace_floats(M, N, K) * 4 + 256;
+  if (M <= 0 || N <= 0 || !ebn_dim_ok(M, N, K)) return 0;
+  return ebn_sat_add(ebn_sat_add(ebn_planes_bytes(M, K), ebn_planes_bytes(N, K)),
+                     ebn_sat_add(ebn_sat_mul(ebn_gemm_planes_workspace_floats(M, N, K), 4), 256));
 }
 
 extern "C" int ebn_gemm_f32_split(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K, float alpha, const float* A,
@@ -635,7 +637,7 @@ extern "C" int ebn_gemm_f32_split(int32_t transA, int32_t transB, int64_t M, int
 // bf16 planes and the partials: ebn_gemm_prec_workspace_bytes).
 extern "C" int64_t ebn_gemm_prec_workspace_bytes(int64_t M, int64_t N, int64_t K, int32_t precision) {
   if (precision == 1) return ebn_gemm_split_workspace_bytes(M, N, K);
-  return ebn_gemm_workspace_floats(M, N, K) * 4;
+  return ebn_sat_mul(ebn_gemm_workspace_floats(M, N, K), 4);
 }
 
 extern "C" int ebn_gemm_f32_prec(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K, float alpha, const float* A,

@@ -176,7 +176,7 @@ ShardGeom make_geom(int64_t V, int32_t world, int32_t cyclic, int64_t cap) {
 }  // namespace
 
 extern "C" int64_t ebn_shard_plan_workspace_ints(int64_t V, int32_t world) {
-  if (V <= 0 || world <= 0) return 0;
+  if (V <= 0 || world <= 0 || !ebn_dim_ok(V, world)) return 0;
   const ShardGeom g = make_geom(V, world, 0, 1);
   return static_cast<int64_t>(world) * g.per + static_cast<int64_t>(world) * g.chunks_per_owner;
 }

@@ -315,7 +315,7 @@ extern "C" int ebn_user_head_supported(int32_t L, int32_t C, int32_t E, int32_t 
   return head_lds_bytes(L, C, E, A) <= 150 * 1024 ? 1 : 0;  // one workgroup's LDS (160 KB per CU)
 }
 
-extern "C" int64_t ebn_user_head_partials_len(int64_t B, int32_t A) { return B * 2 * static_cast<int64_t>(A); }
+extern "C" int64_t ebn_user_head_partials_len(int64_t B, int32_t A) { return ebn_dim_ok(B, A) ? B * 2 * static_cast<int64_t>(A) : 0; }
 
 extern "C" int ebn_user_head_train_f32(float* U, const float* b, const float* q, const float* X, const float* cand,
                                        const float* labels, float* w, float* user, float* scores, float* probs,

@@ -92,8 +92,9 @@ class CpuNRMSTrainer:
     """fp32 CPU train step used as the cpu_baseline 'port'."""
 
     def __init__(self, P_np: dict, h, d, loss="cross_entropy_loss", lr=1e-4, dropout=0.2,
-                 train_embedding=True, seed=0):
+                 train_embedding=True, seed=0, mask_threads=1):
         self.h, self.d, self.loss, self.lr, self.p = h, d, loss, lr, dropout
+        self.mask_threads, self.seed = int(mask_threads), seed
         self.P = {k: torch.tensor(v, dtype=torch.float32) for k, v in P_np.items()}
         self.train_names = [k for k in self.P if train_embedding or k != "emb"]
         for k in self.train_names:
@@ -102,6 +103,27 @@ class CpuNRMSTrainer:
         self.v = {k: torch.zeros_like(self.P[k]) for k in self.train_names}
         self.t = 0
         self.gen = torch.Generator().manual_seed(seed)
+
+    def _rand(self, N, T, W):
+        """(N, T, W) uniform draws.  torch's CPU generator is serial (43 M draws per c2 step on one thread); with mask_threads > 1
+        the rows are drawn in slabs by a thread pool, one generator per slab (torch releases the GIL inside the fill)."""
+        if self.mask_threads <= 1:
+            return torch.rand(N, T, W, generator=self.gen)
+        from concurrent.futures import ThreadPoolExecutor
+
+        out = torch.empty(N, T, W)
+        k = self.mask_threads
+        if getattr(self, "_pool", None) is None:
+            self._pool = ThreadPoolExecutor(k)
+            self._gens = [torch.Generator().manual_seed(int(self.seed) * 1000 + i) for i in range(k)]
+        bounds = [N * i // k for i in range(k + 1)]
+
+        def fill(i):
+            if bounds[i + 1] > bounds[i]:
+                out[bounds[i]: bounds[i + 1]].uniform_(generator=self._gens[i])
+
+        list(self._pool.map(fill, range(k)))
+        return out
 
     def step(self, his, pred, y):
         his, pred, y = (torch.as_tensor(a) for a in (his, pred, y))
@@ -113,8 +135,8 @@ class CpuNRMSTrainer:
             D = self.P["emb"].shape[1]
             E = self.h * self.d
             sc = 1.0 / (1.0 - self.p)
-            m0 = (torch.rand(N, T, D, generator=self.gen) >= self.p).float() * sc
-            m1 = (torch.rand(N, T, E, generator=self.gen) >= self.p).float() * sc
+            m0 = (self._rand(N, T, D) >= self.p).float() * sc
+            m1 = (self._rand(N, T, E) >= self.p).float() * sc
             masks = (m0, m1)
         s = nrms_scores(his.long(), pred.long(), self.P, self.h, self.d, masks)
         L = loss_from_scores(s, y, self.loss)
