@@ -492,9 +492,9 @@ def main():
                     help="exact: every matmul on the exact-fp32 MFMA kernels (the headline). split: the news encoder's projection GEMMs as "
                          "bf16x6 split products on the bf16 matrix pipe -- fp32-accurate (three bf16 planes per operand, six cross products, "
                          "fp32 accumulate), an opt-in second precision with its own line")
-    ap.add_argument("--segmented-table-grad", action="store_true",
-                    help="trainable table: counting sort + segmented reduction of the gradient rows instead of one 64-bit atomic per element "
-                         "(same bits; the A/B behind DESIGN's choice, see --ids zipf)")
+    ap.add_argument("--atomic-table-grad", action="store_true",
+                    help="trainable table: one 64-bit atomic per gradient element instead of combining the duplicate ids of every 64 consecutive "
+                         "tokens first (same bits; the A/B behind DESIGN's choice, see --ids zipf)")
     ap.add_argument("--kernel-probe", action="store_true", help="internal: launch the two roofline kernels a few times on the step's "
                                                                 "buffers and exit (what probe_kernels() wraps rocprofv3 around)")
     args = ap.parse_args()
@@ -556,7 +556,7 @@ def main():
         sync()
         return
 
-    eng.segmented_table_grad = bool(args.segmented_table_grad)
+    eng.atomic_table_grad = bool(args.atomic_table_grad)
     eng.graph_collectives = bool(args.graph_collectives and backend == "nccl")
     eng.enable_graphs(not args.no_graph)
     times = timed_repeats(lambda k: eng.train_step(*batches[k % len(batches)]), args, sync, world, device)
@@ -631,7 +631,7 @@ def main():
                                    f"att_hidden={c['A']} dropout=0.2 adam lr=1e-4 CE loss",
                        "global_batch": world * c["B"], "per_gpu_batch": c["B"], "parallelism": f"dp{world}",
                        "final_loss": loss, "id_distribution": id_note,
-                       **({"table_gradient": "counting sort + segmented reduction" if args.segmented_table_grad else "64-bit fixed-point atomics"}
+                       **({"table_gradient": "64-bit fixed-point atomics, one per element" if args.atomic_table_grad else "64-bit fixed-point atomics after combining the duplicate ids of every 64 tokens"}
                           if c["train_embedding"] else {})},
         }
         if args.precision == "split":

@@ -196,115 +196,68 @@ __global__ __launch_bounds__(256) void adam_keras_fixed_kernel(float* __restrict
   if (bad && range_flag != nullptr) *range_flag = 1;
 }
 
-// ---- the same deterministic accumulation WITHOUT a 64-bit atomic per gradient element: counting sort of the tokens by id
-// (histogram -> exclusive scan -> bucket fill), then a segmented reduction over the sorted positions in which every table
-// row that lies wholly inside a thread's run of positions is added with plain loads / stores by its one owner; only the rows
-// that straddle a run boundary (a hot row such as token 0 of padded titles spans many runs) use the integer atomics.  The sums
-// are 2^40-scaled integers either way, so the result is bit-identical to scatter_add_rows_fixed_kernel.
-// workspace (int32): count[V] | cursor[V] | offset[V] | total[1] | perm[n_tok] | sid[n_tok]; count and cursor are zero on
-// entry and are left zero (first use: the caller zeroes them once).
-__global__ __launch_bounds__(256) void seg_count_kernel(const int32_t* __restrict__ ids, int64_t n_tok, int64_t V, int32_t* __restrict__ count) {
-  for (int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; t < n_tok; t += static_cast<int64_t>(gridDim.x) * 256) {
-    const int64_t id = ids[t];
-    if (id >= 0 && id < V) atomicAdd(&count[id], 1);
+// ---- the same deterministic accumulation with the duplicates of a workgroup's tokens combined BEFORE they reach the atomics.
+// Real EB-NeRD batches hammer a few table rows: a left-padded history slot is a title of 30 x token 0 (_behaviors.py:647-654),
+// unknown articles map to the all-zero title too (dataloader.py:43), and token frequencies are Zipfian -- under SURVEY 8(d)'s Z
+// inputs ~20 % of a step's gradient rows land on row 0 and the one-atomic-per-element kernel above runs 2.8-3.1 x slower than on
+// uniform ids (c1 49 -> 139 us, c4 102 -> 318 us: thousands of 64-bit atomics serialising on each of row 0's D addresses).
+// Here a workgroup owns RUN_CHUNK consecutive tokens: wave 0 sorts their (id, position) pairs (bitonic network over the 64
+// lanes, shuffles only), then thread = column walks the tokens in id order, sums every run of equal ids in a register and
+// issues ONE atomic per (distinct id, column).  The sums are 2^40-scaled integers (wrapping int64 addition is associative), so
+// the accumulator is bit-identical to the plain kernel's whatever the grouping -- uniform ids pay one shuffle sort per 64 tokens
+// and issue the same atomics as before; Zipf ids issue fewer atomics than uniform ones.
+// (Round 3 built a global counting sort + segmented reduction instead: four launches, 204 us at c1 -- measured slower than
+// the atomics on uniform AND on Zipf ids (round 4: 1.127 / 1.244 ms per c1 step against 0.968 / 1.060), and removed.)
+constexpr int RUN_CHUNK = 64;
+__global__ __launch_bounds__(1024) void scatter_add_rows_fixed_runs_kernel(
+    const int32_t* __restrict__ ids, const float* __restrict__ dX, long long* __restrict__ acc, int64_t n_tok, int32_t D, int64_t V,
+    const uint32_t* __restrict__ key_ptr, uint32_t thresh, float scale, int32_t* __restrict__ range_flag) {
+  __shared__ int32_t s_id[RUN_CHUNK + 1], s_pos[RUN_CHUNK];
+  const int64_t t0 = static_cast<int64_t>(blockIdx.x) * RUN_CHUNK;
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    const int64_t t = t0 + lane;
+    const int64_t id = t < n_tok ? static_cast<int64_t>(ids[t]) : -1;
+    // key = (id, position): unique, so the sort is a total order; ids outside [0, V) (and the tail of a short chunk) sort last
+    long long k = (id >= 0 && id < V) ? ((id << 6) | lane) : 0x7FFFFFFFFFFFFFFFll;
+#pragma unroll
+    for (int size = 2; size <= 64; size <<= 1) {
+#pragma unroll
+      for (int j = size >> 1; j > 0; j >>= 1) {
+        const long long o = __shfl_xor(k, j, 64);
+        const bool asc = (lane & size) == 0, lower = (lane & j) == 0;
+        k = (lower == asc) ? (k < o ? k : o) : (k > o ? k : o);
+      }
+    }
+    const bool ok = k != 0x7FFFFFFFFFFFFFFFll;
+    s_id[lane] = ok ? static_cast<int32_t>(k >> 6) : -1;
+    s_pos[lane] = ok ? static_cast<int32_t>(k & 63) : 0;
+    if (lane == 0) s_id[RUN_CHUNK] = -1;
   }
-}
-
-// one workgroup: offset = exclusive scan of count (count is re-zeroed), total[0] = number of in-range tokens
-__global__ __launch_bounds__(1024) void seg_scan_kernel(int32_t* __restrict__ count, int32_t* __restrict__ offset, int32_t* __restrict__ total,
-                                                        int64_t V) {
-  __shared__ int32_t part[1024];
-  const int tid = threadIdx.x;
-  const int64_t chunk = (V + 1023) / 1024, lo = tid * chunk, hi = (lo + chunk < V) ? lo + chunk : V;
-  int32_t s = 0;
-  for (int64_t i = lo; i < hi; ++i) s += count[i];
-  part[tid] = s;
-  __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan over the 1024 chunk sums
-    const int32_t v = tid >= off ? part[tid - off] : 0;
-    __syncthreads();
-    part[tid] += v;
-    __syncthreads();
-  }
-  int32_t run = part[tid] - s;
-  for (int64_t i = lo; i < hi; ++i) {
-    const int32_t c = count[i];
-    offset[i] = run;
-    run += c;
-    count[i] = 0;
-  }
-  if (tid == 1023) total[0] = part[1023];
-}
-
-__global__ __launch_bounds__(256) void seg_fill_kernel(const int32_t* __restrict__ ids, int64_t n_tok, int64_t V,
-                                                       const int32_t* __restrict__ offset, int32_t* __restrict__ cursor,
-                                                       int32_t* __restrict__ perm, int32_t* __restrict__ sid) {
-  for (int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; t < n_tok; t += static_cast<int64_t>(gridDim.x) * 256) {
-    const int64_t id = ids[t];
-    if (id < 0 || id >= V) continue;
-    const int32_t pos = offset[id] + atomicAdd(&cursor[id], 1);
-    perm[pos] = static_cast<int32_t>(t);
-    sid[pos] = static_cast<int32_t>(id);
-  }
-}
-
-constexpr int SEG_RUN = 32;   // sorted positions one thread walks
-constexpr int SEG_RUNS = 4;   // runs per workgroup (x 64 column lanes = 256 threads)
-__global__ __launch_bounds__(256) void seg_reduce_kernel(const int32_t* __restrict__ perm, const int32_t* __restrict__ sid,
-                                                         const int32_t* __restrict__ total, int32_t* __restrict__ cursor,
-                                                         const float* __restrict__ dX, long long* __restrict__ acc, int32_t D,
-                                                         const uint32_t* __restrict__ key_ptr, uint32_t thresh, float scale,
-                                                         int32_t* __restrict__ range_flag) {
-  __shared__ int32_t s_perm[SEG_RUNS * SEG_RUN], s_id[SEG_RUNS * SEG_RUN + 2];  // s_id[0] / [last]: the neighbours of the block
-  const int n = total[0];
-  const int p0 = blockIdx.x * (SEG_RUNS * SEG_RUN);
-  if (p0 >= n) return;
-  const int tid = threadIdx.x;
-  if (tid < SEG_RUNS * SEG_RUN) {
-    const int p = p0 + tid;
-    s_perm[tid] = p < n ? perm[p] : 0;
-    s_id[tid + 1] = p < n ? sid[p] : -1;
-  }
-  if (tid == 0) s_id[0] = p0 > 0 ? sid[p0 - 1] : -1;
-  if (tid == 1) s_id[SEG_RUNS * SEG_RUN + 1] = (p0 + SEG_RUNS * SEG_RUN < n) ? sid[p0 + SEG_RUNS * SEG_RUN] : -1;
   __syncthreads();
   const bool do_drop = key_ptr != nullptr;
   const uint32_t key = do_drop ? *key_ptr : 0u;
-  const int run = tid >> 6, lane = tid & 63;
-  const int q0 = run * SEG_RUN;  // first position of this thread's run inside the block
-  // the first position of every segment re-zeroes that id's fill cursor (one thread per position: lane 0 of the column loop)
-  if (lane == 0)
-    for (int j = 0; j < SEG_RUN; ++j)
-      if (p0 + q0 + j < n && s_id[q0 + j + 1] != s_id[q0 + j]) cursor[s_id[q0 + j + 1]] = 0;
   bool bad = false;
-  for (int c = lane; c < D; c += 64) {  // consecutive lanes on consecutive columns: a row of dX is read in 256-byte pieces
-    long long sum = 0;
-    bool open_left = s_id[q0 + 1] == s_id[q0];  // the segment in progress began before this run
-    for (int j0 = 0; j0 < SEG_RUN; j0 += 8) {
+  for (int c = threadIdx.x; c < D; c += blockDim.x) {  // consecutive lanes on consecutive columns: dX rows are read in 256-byte pieces
+    unsigned long long run = 0;
+    for (int j0 = 0; j0 < RUN_CHUNK; j0 += 8) {
+      if (s_id[j0] < 0) break;  // (block-uniform) nothing but skipped tokens from here on
       float g[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) g[j] = dX[static_cast<int64_t>(s_perm[q0 + j0 + j]) * D + c];  // (positions >= n read token 0: ignored)
+      for (int j = 0; j < 8; ++j) g[j] = dX[(t0 + s_pos[j0 + j]) * D + c];  // all 8 loads first; skipped slots re-read position 0 of the chunk
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const int q = q0 + j0 + j;
-        if (p0 + q >= n) break;
-        const int32_t id = s_id[q + 1];
+        const int32_t id = s_id[j0 + j];
+        if (id < 0) break;
         float x = g[j];
-        if (do_drop) x *= ebn_drop_mult(key, static_cast<uint64_t>(s_perm[q]) * static_cast<uint64_t>(D) + static_cast<uint64_t>(c), thresh, scale);
+        if (do_drop) x *= ebn_drop_mult(key, static_cast<uint64_t>(t0 + s_pos[j0 + j]) * static_cast<uint64_t>(D) + static_cast<uint64_t>(c), thresh, scale);
         if (x != 0.f) {
           bad |= !(fabsf(x) < FIXED_TERM_MAX);
-          sum += __double2ll_rn(static_cast<double>(x) * FIXED_SCALE);
+          run += static_cast<unsigned long long>(__double2ll_rn(static_cast<double>(x) * FIXED_SCALE));
         }
-        const bool last_of_run = (j0 + j == SEG_RUN - 1) || (p0 + q + 1 >= n);
-        const bool seg_ends = s_id[q + 2] != id;
-        if (seg_ends || last_of_run) {
-          long long* a = acc + static_cast<int64_t>(id) * D + c;
-          if (sum != 0) {
-            if (open_left || !seg_ends) atomicAdd(reinterpret_cast<unsigned long long*>(a), static_cast<unsigned long long>(sum));
-            else *a += sum;  // the whole segment lies inside this run: this thread is the only writer of acc[id][c] in the launch
-          }
-          sum = 0;
-          open_left = false;
+        if (s_id[j0 + j + 1] != id) {  // (block-uniform) last token of this id in the chunk
+          if (run != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&acc[static_cast<int64_t>(id) * D + c]), run);
+          run = 0;
         }
       }
     }
@@ -334,6 +287,23 @@ __global__ __launch_bounds__(GATHER_THREADS) void expand_titles_kernel(const int
 
 }  // namespace
 
+namespace {
+int scatter_fixed_atomic_launch(const int32_t* ids, const float* dX, int64_t* acc, int64_t n_tok, int32_t D, int64_t V, const EbnDrop& dr,
+                                int32_t* range_flag, hipStream_t s) {
+  const int64_t n_items = n_tok * D;
+  int64_t grid = ebn_ceil_div(n_items, GATHER_THREADS);
+  if (grid > 256 * 32) grid = 256 * 32;
+  if (n_items + grid * GATHER_THREADS < (static_cast<int64_t>(1) << 32))
+    hipLaunchKernelGGL(scatter_add_rows_fixed_kernel<uint32_t>, dim3(static_cast<unsigned>(grid)), dim3(GATHER_THREADS), 0, s, ids, dX,
+                       reinterpret_cast<long long*>(acc), n_items, D, V, dr.key_ptr, dr.thresh, dr.scale, range_flag);
+  else
+    hipLaunchKernelGGL(scatter_add_rows_fixed_kernel<int64_t>, dim3(static_cast<unsigned>(grid)), dim3(GATHER_THREADS), 0, s, ids, dX,
+                       reinterpret_cast<long long*>(acc), n_items, D, V, dr.key_ptr, dr.thresh, dr.scale, range_flag);
+  EBN_CHECK_LAUNCH();
+  return EBN_OK;
+}
+}  // namespace
+
 extern "C" int ebn_embedding_grad_scatter_fixed(const int32_t* ids, const float* dX, int64_t* acc, int64_t n_tok,
                                                 int32_t D, int64_t V, const ebn_step_state* st, int32_t site,
                                                 float drop_p, int32_t* range_flag, ebn_stream_t stream) {
@@ -341,53 +311,24 @@ extern "C" int ebn_embedding_grad_scatter_fixed(const int32_t* ids, const float*
   EBN_REQUIRE(n_tok >= 0 && D > 0 && V > 0, EBN_ERR_BAD_ARG);
   if (n_tok == 0) return EBN_OK;
   const EbnDrop dr = ebn_make_drop(st, site, drop_p);
-  const int64_t n_items = n_tok * D;
-  int64_t grid = ebn_ceil_div(n_items, GATHER_THREADS);
-  if (grid > 256 * 32) grid = 256 * 32;
-  if (n_items + grid * GATHER_THREADS < (static_cast<int64_t>(1) << 32))
-    hipLaunchKernelGGL(scatter_add_rows_fixed_kernel<uint32_t>, dim3(static_cast<unsigned>(grid)), dim3(GATHER_THREADS), 0,
-                       ebn_stream(stream), ids, dX, reinterpret_cast<long long*>(acc), n_items, D, V, dr.key_ptr,
-                       dr.thresh, dr.scale, range_flag);
-  else
-    hipLaunchKernelGGL(scatter_add_rows_fixed_kernel<int64_t>, dim3(static_cast<unsigned>(grid)), dim3(GATHER_THREADS), 0,
-                       ebn_stream(stream), ids, dX, reinterpret_cast<long long*>(acc), n_items, D, V, dr.key_ptr,
-                       dr.thresh, dr.scale, range_flag);
+  // (id << 6) | position must fit the sort key, and a chunk index the grid: both hold for every table this path can address
+  if (V >= (int64_t{1} << 56) || ebn_ceil_div(n_tok, RUN_CHUNK) >= (int64_t{1} << 31))
+    return scatter_fixed_atomic_launch(ids, dX, acc, n_tok, D, V, dr, range_flag, ebn_stream(stream));
+  int threads = static_cast<int>(ebn_ceil_div(D, 64) * 64);
+  if (threads > 1024) threads = 1024;
+  hipLaunchKernelGGL(scatter_add_rows_fixed_runs_kernel, dim3(static_cast<unsigned>(ebn_ceil_div(n_tok, RUN_CHUNK))), dim3(threads), 0,
+                     ebn_stream(stream), ids, dX, reinterpret_cast<long long*>(acc), n_tok, D, V, dr.key_ptr, dr.thresh, dr.scale, range_flag);
   EBN_CHECK_LAUNCH();
   return EBN_OK;
 }
 
-extern "C" int64_t ebn_embedding_grad_segmented_workspace_ints(int64_t n_tok, int64_t V) {
-  if (!ebn_dim_ok(n_tok, V) || V == 0) return 0;
-  return 3 * V + 4 + 2 * n_tok;
-}
-
-extern "C" int ebn_embedding_grad_segmented_fixed(const int32_t* ids, const float* dX, int64_t* acc, int64_t n_tok, int32_t D,
-                                                  int64_t V, const ebn_step_state* st, int32_t site, float drop_p,
-                                                  int32_t* range_flag, int32_t* workspace, ebn_stream_t stream) {
-  EBN_REQUIRE(ids && dX && acc && workspace, EBN_ERR_BAD_ARG);
+extern "C" int ebn_embedding_grad_scatter_fixed_atomic(const int32_t* ids, const float* dX, int64_t* acc, int64_t n_tok,
+                                                       int32_t D, int64_t V, const ebn_step_state* st, int32_t site,
+                                                       float drop_p, int32_t* range_flag, ebn_stream_t stream) {
+  EBN_REQUIRE(ids && dX && acc, EBN_ERR_BAD_ARG);
   EBN_REQUIRE(n_tok >= 0 && D > 0 && V > 0, EBN_ERR_BAD_ARG);
-  EBN_REQUIRE(n_tok < 0x7FFFFFFF && V < 0x7FFFFFFF, EBN_ERR_UNSUPPORTED);
   if (n_tok == 0) return EBN_OK;
-  const EbnDrop dr = ebn_make_drop(st, site, drop_p);
-  hipStream_t s = ebn_stream(stream);
-  int32_t* count = workspace;
-  int32_t* cursor = count + V;
-  int32_t* offset = cursor + V;
-  int32_t* total = offset + V;
-  int32_t* perm = total + 4;
-  int32_t* sid = perm + n_tok;
-  int64_t tgrid = ebn_ceil_div(n_tok, 256);
-  if (tgrid > 2048) tgrid = 2048;
-  hipLaunchKernelGGL(seg_count_kernel, dim3(static_cast<unsigned>(tgrid)), dim3(256), 0, s, ids, n_tok, V, count);
-  EBN_CHECK_LAUNCH();
-  hipLaunchKernelGGL(seg_scan_kernel, dim3(1), dim3(1024), 0, s, count, offset, total, V);
-  EBN_CHECK_LAUNCH();
-  hipLaunchKernelGGL(seg_fill_kernel, dim3(static_cast<unsigned>(tgrid)), dim3(256), 0, s, ids, n_tok, V, offset, cursor, perm, sid);
-  EBN_CHECK_LAUNCH();
-  hipLaunchKernelGGL(seg_reduce_kernel, dim3(static_cast<unsigned>(ebn_ceil_div(n_tok, SEG_RUNS * SEG_RUN))), dim3(256), 0, s, perm, sid, total,
-                     cursor, dX, reinterpret_cast<long long*>(acc), D, dr.key_ptr, dr.thresh, dr.scale, range_flag);
-  EBN_CHECK_LAUNCH();
-  return EBN_OK;
+  return scatter_fixed_atomic_launch(ids, dX, acc, n_tok, D, V, ebn_make_drop(st, site, drop_p), range_flag, ebn_stream(stream));
 }
 
 extern "C" int ebn_fixed_to_f32(int64_t* acc, float* out, int64_t n, int32_t* range_flag, ebn_stream_t stream) {

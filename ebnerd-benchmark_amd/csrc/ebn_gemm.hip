@@ -36,6 +36,11 @@ bool ebn_gemm_tall_wanted(int32_t transA, int32_t transB, int64_t M, int64_t N, 
 int ebn_gemm_tall_launch(int32_t transB, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda, const float* B,
                          int64_t ldb, float* C, int64_t ldc, hipStream_t s);
 
+// ebn_gemm_direct.hip
+bool ebn_gemm_direct_wanted(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K);
+int ebn_gemm_direct_launch(int32_t transB, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda, const float* B,
+                           int64_t ldb, float* C, int64_t ldc, hipStream_t s);
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -1179,6 +1184,13 @@ static int gemm_dispatch(int32_t transA, int32_t transB, int64_t M, int64_t N, i
   const int vecA = ((lda % 4) == 0 && ebn_aligned16(A) && ((transA ? M : K) % 4) == 0 && spanA) ? 1 : 0;
   const int vecB = ((ldb % 4) == 0 && ebn_aligned16(B) && ((transB ? K : N) % 4) == 0 && spanB) ? 1 : 0;
   if ((epi.bias != nullptr || epi.rs != nullptr) && !(vecA && vecB)) return EBN_ERR_UNSUPPORTED;  // epilogue kernels are VEC only
+  // tall output x small second operand: the LDS-free 16 x 16-block kernel, operand fragments straight from global memory
+  // (ebn_gemm_direct.hip): A [M][K] by float4 (vecA), B [N][K] by float4 (vecB) or B [K][N] by dwords (no alignment needed)
+  if (epi.bias == nullptr && epi.rs == nullptr && beta == 0.f && vecA && (vecB || !transB) && forced_tile_bm() == 0 &&
+      ebn_gemm_direct_wanted(transA, transB, M, N, K)) {
+    const int rc_dir = ebn_gemm_direct_launch(transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, s);
+    if (rc_dir != EBN_ERR_UNSUPPORTED) return rc_dir;
+  }
   // tall outputs with a narrow N that 64-wide tiles pad badly: 16 x 16 MFMA blocks (ebn_gemm_tall.hip)
   if (epi.bias == nullptr && epi.rs == nullptr && beta == 0.f && vecA && vecB && forced_tile_bm() == 0 &&
       ebn_gemm_tall_wanted(transA, transB, M, N, K, C, ldc)) {

@@ -208,8 +208,8 @@ class NRMSEngine:
         # streaming kernels it replaces fill the chip better -- kept for validation, off by default
         self.fuse_attpool_bwd = False
         self.fuse_user_head = True  # False: the per-impression head of a step as its six separate launches (validation)
-        self.segmented_table_grad = False  # True: counting sort + segmented reduction instead of one 64-bit atomic per element (same bits;
-        # measured SLOWER in its first form: profiles/r03_tuning_notes.md)
+        self.atomic_table_grad = False  # True: one 64-bit atomic per gradient element instead of combining the duplicates of every 64
+        # consecutive tokens first (same bits; the validation / A-B form: 2.8-3.1x slower on Zipf ids, profiles/r04_*zipf*)
         self.graph_collectives = False  # multi-rank: capture the collectives into the step's hipGraph as well (experimental)
         self.overlap_collectives = True  # multi-rank: start the dense-gradient buckets under the rest of the backward (see _segments)
         self.skip_collectives = False    # bench.py only: time the step without its collectives (-> comm_exposed_us); results are wrong
@@ -995,11 +995,6 @@ class NRMSEngine:
             nb.scores = torch.empty(nb.n_seq, device=self.device)
             nb.probs = torch.empty(nb.n_seq, device=self.device)
             nb.labels = torch.empty(nb.n_seq, device=self.device)
-        if self.train_embedding and self.deterministic and self.segmented_table_grad:
-            need = int(_hip.lib().ebn_embedding_grad_segmented_workspace_ints(nb.n_seq * self.T, self.V))
-            if getattr(self, "_seg_ws", None) is None or self._seg_ws.numel() < need:  # outside any capture; count / cursor start zero
-                self._seg_ws = torch.zeros(need, dtype=torch.int32, device=self.device)
-                self._graphs.clear()
         if not hasattr(ub, "duser"):
             ub.duser = torch.empty(ub.n_seq, E, device=self.device)
             ub.loss_rows = torch.empty(ub.n_seq, device=self.device)
@@ -1161,20 +1156,13 @@ class NRMSEngine:
                   ctypes.c_float(1.0 / B), st, S())
 
     def _accumulate_fixed(self, ids, dX, n_tok, st, site, p):
-        """table_acc += the (id, gradient row) pairs of n_tok tokens, in the order-independent fixed-point accumulator: counting
-        sort + segmented reduction (four launches, plain stores for every row that is not hot) or, `segmented_table_grad=False`,
-        one 64-bit integer atomic per element.  Bit-identical accumulators either way."""
-        if self.segmented_table_grad:
-            need = int(_hip.lib().ebn_embedding_grad_segmented_workspace_ints(n_tok, self.V))
-            ws = getattr(self, "_seg_ws", None)
-            if ws is None or ws.numel() < need:
-                ws = self._seg_ws = torch.zeros(need, dtype=torch.int32, device=self.device)  # (count / cursor must start zero)
-                self._graphs.clear()
-            _hip.call("ebn_embedding_grad_segmented_fixed", _hip.ptr(ids), _hip.ptr(dX), _hip.ptr(self.table_acc), n_tok, self.D, self.V, st, site,
-                      ctypes.c_float(p), _hip.ptr(self.range_flag), _hip.ptr(ws), _hip.stream_handle())
-        else:
-            _hip.call("ebn_embedding_grad_scatter_fixed", _hip.ptr(ids), _hip.ptr(dX), _hip.ptr(self.table_acc), n_tok, self.D, self.V, st, site,
-                      ctypes.c_float(p), _hip.ptr(self.range_flag), _hip.stream_handle())
+        """table_acc += the (id, gradient row) pairs of n_tok tokens, in the order-independent fixed-point accumulator.  Duplicate
+        ids among every 64 consecutive tokens are combined in registers first (one atomic per distinct id and column: left-padded
+        history slots and Zipfian tokens put ~20 % of a real batch on table row 0); `atomic_table_grad=True`: one 64-bit integer
+        atomic per element.  Bit-identical accumulators either way."""
+        _hip.call("ebn_embedding_grad_scatter_fixed_atomic" if self.atomic_table_grad else "ebn_embedding_grad_scatter_fixed", _hip.ptr(ids),
+                  _hip.ptr(dX), _hip.ptr(self.table_acc), n_tok, self.D, self.V, st, site, ctypes.c_float(p), _hip.ptr(self.range_flag),
+                  _hip.stream_handle())
 
     def _table_grad_kernels(self, nb, N, sparse_table_grads):
         S = _hip.stream_handle

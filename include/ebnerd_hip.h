@@ -90,15 +90,13 @@ int ebn_embedding_grad_scatter_f32(const int32_t* ids, const float* dX, float* d
 int ebn_embedding_grad_scatter_fixed(const int32_t* ids, const float* dX, int64_t* acc, int64_t n_tok,
                                      int32_t D, int64_t V, const ebn_step_state* st, int32_t site,
                                      float drop_p, int32_t* range_flag, ebn_stream_t stream);
-/* The same accumulation (bit-identical sums: 2^40-scaled integers either way) without a 64-bit atomic per gradient element:
- * the tokens are counting-sorted by id on the device (histogram, scan, bucket fill) and a segmented reduction adds every table
- * row that lies inside one thread's run of sorted positions with plain loads / stores; only rows that straddle a run boundary
- * (hot rows) use the integer atomics.  Four launches.  `workspace`: ebn_embedding_grad_segmented_workspace_ints(n_tok, V) int32;
- * its first 2 * V entries must be zero before the FIRST call and are left zero by every call.                           */
-int64_t ebn_embedding_grad_segmented_workspace_ints(int64_t n_tok, int64_t V);
-int ebn_embedding_grad_segmented_fixed(const int32_t* ids, const float* dX, int64_t* acc, int64_t n_tok, int32_t D,
-                                       int64_t V, const ebn_step_state* st, int32_t site, float drop_p,
-                                       int32_t* range_flag, int32_t* workspace, ebn_stream_t stream);
+/* ebn_embedding_grad_scatter_fixed combines the duplicates among each run of 64 consecutive tokens before they reach the
+ * atomics (one atomic per distinct id, column and run: padded titles and Zipfian tokens hammer table row 0 -- reference
+ * _behaviors.py:647-654, dataloader.py:43).  This is the plain form, one atomic per non-zero gradient element: same sums
+ * bit for bit (wrapping integer addition is associative), kept as the validation / A-B form.                              */
+int ebn_embedding_grad_scatter_fixed_atomic(const int32_t* ids, const float* dX, int64_t* acc, int64_t n_tok,
+                                            int32_t D, int64_t V, const ebn_step_state* st, int32_t site,
+                                            float drop_p, int32_t* range_flag, ebn_stream_t stream);
 int ebn_fixed_to_f32(int64_t* acc, float* out, int64_t n, int32_t* range_flag, ebn_stream_t stream);
 /* ebn_fixed_to_f32 + ebn_adam_keras_step_f32 in one pass over the table: the gradient is read from the accumulator
  * (which is re-zeroed), never materialised -- the single-GPU step of a trainable table (nrms.py:129 trainable=True with

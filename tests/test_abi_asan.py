@@ -58,7 +58,6 @@ def test_size_queries_bound_their_extents():
     big = 1 << 40
     assert L.ebn_gemm_planes_workspace_floats(big, big, big) == 0  # (used to divide by zero: K / 16 slabs truncated to int 0)
     assert L.ebn_planes_bytes(big, 16) == 0 and L.ebn_gemm_workspace_floats(big, 8, 8) == 0
-    assert L.ebn_embedding_grad_segmented_workspace_ints((1 << 62) + 3, (1 << 62) + 3) == 0
     assert L.ebn_shard_plan_workspace_ints(big, 8) == 0
     m = (1 << 31) - 1
     assert L.ebn_gemm_split_workspace_bytes(m, m, m) == (1 << 63) - 1  # saturated, not negative

@@ -87,14 +87,14 @@ def test_c2_full_size_training_step_matches_the_oracle(hip, graph, precision):
     assert torch.equal(eng.table[uniq[:64]].cpu(), torch.from_numpy(table[uniq[:64]]))  # frozen
 
 
-@pytest.mark.parametrize("loss,ids,segmented", [("cross_entropy_loss", "uniform", False), ("log_loss", "uniform", False),
-                                                ("cross_entropy_loss", "zipf", False), ("cross_entropy_loss", "zipf", True)])
-def test_c1_full_size_three_steps_with_the_dense_table_sweep(hip, loss, ids, segmented):
+@pytest.mark.parametrize("loss,ids,atomic", [("cross_entropy_loss", "uniform", False), ("log_loss", "uniform", False),
+                                             ("cross_entropy_loss", "zipf", False), ("cross_entropy_loss", "zipf", True)])
+def test_c1_full_size_three_steps_with_the_dense_table_sweep(hip, loss, ids, atomic):
     """configs[0] at bench size: 32000 x 300 TRAINABLE table, B = 32, dropout 0.2, 3 steps.  Keras' Adam decays the
     moments of every row each step (dense sweep): rows untouched by a batch still move after step 1 -- the whole
     32000 x 300 table is compared.  ids="zipf": SURVEY.md 8(d)'s Z inputs -- ~5000 of the 24000 gradient rows of a step land on
-    table row 0 (left-padded histories, _behaviors.py:647-654; unknown articles, dataloader.py:43), the case that decides between
-    one 64-bit atomic per element and the counting-sort + segmented reduction (segmented=True: same bits by construction)."""
+    table row 0 (left-padded histories, _behaviors.py:647-654; unknown articles, dataloader.py:43), the case the duplicate-combining
+    accumulation was built for (atomic=True: the plain one-atomic-per-element form, same bits by construction)."""
     from ebrec.models.newsrec import NRMSModel
 
     V, D, B, C, seed, lr = 32000, 300, 32, 5, 11, 1e-3
@@ -103,7 +103,7 @@ def test_c1_full_size_three_steps_with_the_dense_table_sweep(hip, loss, ids, seg
     P = on.random_nrms_params(V, D, hp.head_num, hp.head_dim, hp.attention_hidden_dim, seed=5)
     m = NRMSModel(hp, word2vec_embedding=P["emb"], seed=seed).from_keras_weight_list(weight_list(P))
     eng = m._engine
-    eng.segmented_table_grad = segmented
+    eng.atomic_table_grad = atomic
     eng.enable_graphs()
     P = {k: v.astype(np.float32).astype(np.float64) for k, v in P.items()}
     P0 = {k: v.copy() for k, v in P.items()}

@@ -1073,16 +1073,28 @@ def test_gather_split_planes_is_the_gather_then_the_split(hip, R, D, V, p):
     assert int(flag.item()) == 1
 
 
-@pytest.mark.parametrize("n_tok,D,V,p", [(24000, 300, 32000, 0.2), (52800, 300, 32000, 0.0), (700, 64, 50, 0.5), (5, 7, 1000, 0.0), (4099, 33, 3, 0.2)])
-def test_segmented_gradient_accumulation_is_the_atomic_one_bit_for_bit(hip, n_tok, D, V, p):
-    """ebn_embedding_grad_segmented_fixed (counting sort + segmented reduction) against ebn_embedding_grad_scatter_fixed (one
-    64-bit atomic per element): the sums are 2^40-scaled integers either way -> identical accumulators, with hot rows (padded
-    titles: thousands of tokens of id 0, a segment spanning many runs), ids outside the table (skipped by both), two calls in a row
-    accumulating into the same buffer (the sparse data-parallel exchange does that), and the workspace left zero."""
+@pytest.mark.parametrize("ids_kind", ["hot", "zipf", "one_id", "uniform"])
+@pytest.mark.parametrize("n_tok,D,V,p", [(24000, 300, 32000, 0.2), (52800, 300, 32000, 0.0), (700, 64, 50, 0.5), (5, 7, 1000, 0.0), (4099, 33, 3, 0.2),
+                                         (130, 1100, 70, 0.2), (64, 4, 9, 0.0), (65, 1024, 250002, 0.2)])
+def test_duplicate_combining_gradient_accumulation_is_the_atomic_one_bit_for_bit(hip, n_tok, D, V, p, ids_kind):
+    """ebn_embedding_grad_scatter_fixed (the duplicates of every 64 consecutive tokens combined in registers, one atomic per
+    distinct id and column) against ebn_embedding_grad_scatter_fixed_atomic (one 64-bit atomic per element): the sums are
+    2^40-scaled integers either way -> identical accumulators.  Hot rows (padded titles: runs of id 0, SURVEY 8(d) Z: Zipf ids),
+    every token on one row, ids outside the table (skipped by both), chunks that end in a partial run (n_tok % 64 != 0), D beyond
+    one pass of a 1024-thread workgroup, two calls in a row accumulating into the same buffer (the sparse data-parallel
+    exchange does that)."""
+    from bench import zipf_ids
+
     rng = np.random.default_rng(n_tok + D)
-    ids = rng.integers(0, V, n_tok).astype(np.int32)
-    if n_tok > 100:
-        ids[rng.random(n_tok) < 0.15] = 0      # a hot row
+    if ids_kind == "zipf":
+        ids = zipf_ids(rng, n_tok, V).astype(np.int32)
+    elif ids_kind == "one_id":
+        ids = np.full(n_tok, V // 2, np.int32)
+    else:
+        ids = rng.integers(0, V, n_tok).astype(np.int32)
+    if n_tok > 100 and ids_kind in ("hot", "zipf"):
+        pad = (rng.random(n_tok // 30 + 1) < 0.15).repeat(30)[:n_tok]   # padded titles: 30 consecutive tokens of id 0
+        ids[pad] = 0
         ids[10:14] = [V, -1, V + 5, -7]        # out of range: skipped
         ids[20:60] = V - 1
     dX = rng.standard_normal((n_tok, D)).astype(np.float32)
@@ -1090,21 +1102,19 @@ def test_segmented_gradient_accumulation_is_the_atomic_one_bit_for_bit(hip, n_to
     d_ids, d_dx = torch.from_numpy(ids).cuda(), dev(dX)
     acc_a = torch.zeros(V, D, dtype=torch.int64, device="cuda")
     acc_s = torch.zeros(V, D, dtype=torch.int64, device="cuda")
-    ws = torch.zeros(int(hip.lib().ebn_embedding_grad_segmented_workspace_ints(n_tok, V)), dtype=torch.int32, device="cuda")
     fa, fs = torch.zeros(1, dtype=torch.int32, device="cuda"), torch.zeros(1, dtype=torch.int32, device="cuda")
     for rep in range(2):
-        hip.call("ebn_embedding_grad_scatter_fixed", P(d_ids), P(d_dx), P(acc_a), n_tok, D, V, P(st), 0, ctypes.c_float(p), P(fa), S())
-        hip.call("ebn_embedding_grad_segmented_fixed", P(d_ids), P(d_dx), P(acc_s), n_tok, D, V, P(st), 0, ctypes.c_float(p), P(fs), P(ws), S())
+        hip.call("ebn_embedding_grad_scatter_fixed_atomic", P(d_ids), P(d_dx), P(acc_a), n_tok, D, V, P(st), 0, ctypes.c_float(p), P(fa), S())
+        hip.call("ebn_embedding_grad_scatter_fixed", P(d_ids), P(d_dx), P(acc_s), n_tok, D, V, P(st), 0, ctypes.c_float(p), P(fs), S())
         assert torch.equal(acc_a, acc_s), rep
-        assert int(ws[: 2 * V].abs().sum().item()) == 0  # count / cursor are left zero for the next call
     assert int(fa.item()) == 0 and int(fs.item()) == 0
     # against the oracle's dense gradient (float64), through the fixed-point scale
     mask = on.dropout_keep_mask(on.dropout_key(4, 3, 0), n_tok * D, p).reshape(n_tok, D) / (1.0 - p) if p > 0 else 1.0
     ok = (ids >= 0) & (ids < V)
     want = on.embedding_bwd(ids[ok], (dX * mask)[ok].astype(np.float64), V) * 2
     got = acc_s.cpu().numpy().astype(np.float64) / 2.0 ** 40
-    assert_close(got, want, rtol=1e-6, atol=1e-6 + 1e-6 * np.abs(want).max(), what="segmented accumulator vs dense gradient")
+    assert_close(got, want, rtol=1e-6, atol=1e-6 + 1e-6 * np.abs(want).max(), what="duplicate-combining accumulator vs dense gradient")
     big = dX.copy()
     big[3, 1] = 3e6  # a term beyond 2^21: the range flag, like the atomic form
-    hip.call("ebn_embedding_grad_segmented_fixed", P(d_ids), P(dev(big)), P(acc_s), n_tok, D, V, None, -1, ctypes.c_float(0.0), P(fs), P(ws), S())
+    hip.call("ebn_embedding_grad_scatter_fixed", P(d_ids), P(dev(big)), P(acc_s), n_tok, D, V, None, -1, ctypes.c_float(0.0), P(fs), S())
     assert int(fs.item()) == (1 if (0 <= ids[3] < V) else 0)
