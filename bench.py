@@ -127,7 +127,7 @@ def synthetic_batches(c, n, seed, device, ids="uniform"):
     return out
 
 
-def cpu_baseline(c, steps=20, warmup=5, max_seconds=150.0, ids="uniform", sweep=(16, 32, 64, 128)):
+def cpu_baseline(c, steps=20, warmup=5, max_seconds=150.0, ids="uniform", sweep=(4, 8, 16, 32, 64, 128)):
     """fp32 torch-eager port of the reference train step on the host cores: SURVEY.md 8(d)'s protocol -- `warmup` untimed
     steps, then `steps` timed ones (median) -- cut short only if the timed part would pass `max_seconds` (said so in `sample`).
     The intra-op thread count is SWEPT first (1 warm-up + 2 timed steps at each of `sweep` that the box has, plus torch's
@@ -156,8 +156,9 @@ def cpu_baseline(c, steps=20, warmup=5, max_seconds=150.0, ids="uniform", sweep=
         y[np.arange(c["B"]), rng.integers(0, c["C"], c["B"])] = 1
         return his, pred, y
 
-    # thread sweep.  (Round 3 kept torch's default = the physical cores after measuring set_num_threads(os.cpu_count()) -- all SMT
-    # siblings, 256 on the GPU box -- 11x SLOWER on this eager workload; the sweep stays at or below the default's neighbourhood.)
+    # thread sweep.  (Round 3 kept torch's default = the physical cores, 128 on the GPU box; round 4's first sweep measured 16 threads
+    # 5.7x FASTER than that on this eager workload -- 438 vs 2505 ms per c2 step: the step is dominated by memory-bound elementwise
+    # ops and small batched matmuls that do not scale over two sockets -- so the sweep starts low.)
     tr.step(*batch())  # allocator, first touch of the table
     t_sweep0 = time.perf_counter()
     sweep_ms = {}
@@ -170,8 +171,8 @@ def cpu_baseline(c, steps=20, warmup=5, max_seconds=150.0, ids="uniform", sweep=
             tr.step(*batch())
             ts.append(time.perf_counter() - t1)
         sweep_ms[nt] = min(ts) * 1e3
-        if time.perf_counter() - t_sweep0 > 0.4 * max_seconds:
-            break
+        if time.perf_counter() - t_sweep0 > 0.4 * max_seconds or (len(sweep_ms) >= 3 and sweep_ms[nt] > 3.0 * min(sweep_ms.values())):
+            break  # (far past the optimum: the remaining, larger counts only get slower)
     best = min(sweep_ms, key=sweep_ms.get)
     torch.set_num_threads(best)
     n_untimed = 1 + 3 * len(sweep_ms)
@@ -278,17 +279,35 @@ def time_kernel(fns, sync, reps=10, replays=5):
 
 def hbm_calibration(sync, device, mib=1024):
     """What this box's HBM delivers to a plain streaming kernel, measured in this run ("confirm on the box with a
-    DtoD / stream calibration and report both"): a device-to-device copy of `mib` MiB (4x the 256 MB memory-side cache, so
-    neither side is cache-resident), counted as bytes read + bytes written, timed like the kernels (graph of 10 launches,
-    warm replays, HIP events on the launch stream).  The spec figure (8 TB/s) stays the `peak` of the roofline objects;
-    this is the `achievable_gbs` next to it."""
+    DtoD / stream calibration and report both"), on `mib` MiB (4x the 256 MB memory-side cache, so neither side is
+    cache-resident), counted as bytes read + bytes written, timed like the kernels (graph of 10 launches, warm replays, HIP
+    events on the launch stream).  Two copies: torch's device-to-device `copy_` and a float4 row copy -- this library's gather
+    kernel over the identity permutation of 4 KB rows, no dropout: the same 16-byte-per-lane streaming access as
+    MI355X_MICROARCH.md's "float4 copy" (6.29 TB/s there).  `achievable_gbs` = the better of the two; the spec figure (8 TB/s)
+    stays the `peak` of the roofline objects."""
+    from ebrec import _hip
+
     n = mib * (1 << 20) // 4
     src, dst = torch.empty(n, device=device).normal_(), torch.empty(n, device=device)
-    t = time_kernel(lambda: dst.copy_(src), sync)
+    t_copy = time_kernel(lambda: dst.copy_(src), sync)
+    rows = n // 1024
+    ids = torch.arange(rows, dtype=torch.int32, device=device)
+    flag = torch.zeros(1, dtype=torch.int32, device=device)
+
+    def row_copy():
+        _hip.call("ebn_gather_rows_f32", _hip.ptr(ids), _hip.ptr(src), _hip.ptr(dst), rows, 1024, rows, None, -1, ctypes.c_float(0.0), _hip.ptr(flag),
+                  _hip.stream_handle())
+
+    t_rows = time_kernel(row_copy, sync)
+    assert torch.equal(dst[:4096], src[:4096])
     del src, dst
     torch.cuda.empty_cache()
-    return {"achievable_gbs": 2.0 * n * 4 / t / 1e9, "method": f"device-to-device copy of {mib} MiB (read + write bytes / time), graph of 10 launches, "
-            "HIP events around 5 warm replays", "spec_gbs": HBM_PEAK_GBS, "avg_copy_us": t * 1e6}
+    copy_gbs, rows_gbs = 2.0 * n * 4 / t_copy / 1e9, (2.0 * n * 4 + rows * 4) / t_rows / 1e9
+    return {"achievable_gbs": max(copy_gbs, rows_gbs), "torch_copy_gbs": copy_gbs, "float4_row_copy_gbs": rows_gbs, "spec_gbs": HBM_PEAK_GBS,
+            "guide_float4_copy_gbs": 6290.0,
+            "method": f"device-to-device copies of {mib} MiB, (read + write bytes) / time, graph of 10 launches, HIP events around 5 warm replays: "
+                      "torch copy_ and a float4 row copy (gather_rows_vec4_kernel over the identity permutation of 4 KB rows, no dropout); "
+                      "achievable_gbs = the better one"}
 
 
 def fit_loop_leg(model, c, n_steps=100):
@@ -317,6 +336,45 @@ def fit_loop_leg(model, c, n_steps=100):
     return {"value": n_imp / dt, "unit": "impressions/s", "ms_per_step": dt / len(loader) * 1e3, "steps": len(loader),
             "what": "model.fit(NRMSDataLoader) end to end (host loop + loader + pinned staging + device step), one timed epoch after a warm-up epoch; "
                     "the headline `value` replays batches already resident in HBM"}
+
+
+def split_precision_leg(c, make_model, batches, args, sync, device, exact_ms):
+    """The opt-in second precision of the projection GEMMs (every fp32 operand split exactly into three bf16 values, six
+    bf16 MFMA cross products, fp32 accumulate), timed in the SAME run as the exact-fp32 headline so that the driver's line carries
+    it: K steps x R repeats of the same batches on a second engine, and the accuracy evidence next to it -- the max abs error of
+    the Q|K|V projection of one real step (this run's gathered, dropped-out X and this model's Wqkv) against float64, for the
+    split GEMM and for the exact-fp32 GEMM on the same operands."""
+    from ebrec import _hip
+
+    model = make_model("split")
+    eng = model._engine
+    eng.enable_graphs(not args.no_graph)
+    times = timed_repeats(lambda k: eng.train_step(*batches[k % len(batches)]), argparse.Namespace(warmup=args.warmup, repeats=args.repeats, steps=args.steps),
+                          sync, 1, device)
+    ms = float(np.median([t / args.steps * 1e3 for t in times]))
+    # accuracy of the projection on a sample of real operands: 2048 token rows of an eager exact-precision gather
+    ex = make_model("exact")._engine
+    ex.train_step(*batches[0])
+    sync()
+    nb = ex._bufs[("news", True)]
+    R, D, E3 = 2048, c["D"], 3 * c["h"] * c["d"]
+    X, W = nb.X[:R].contiguous(), ex.params.view("n_Wqkv").contiguous()
+    ref = X.double() @ W.double()
+    errs = {}
+    for name, prec in (("exact_fp32", 0), ("split_bf16x6", 1)):
+        nbytes = int(_hip.lib().ebn_gemm_prec_workspace_bytes(R, E3, D, prec))
+        ws, C = torch.empty(nbytes // 4 + 64, device=device), torch.empty(R, E3, device=device)
+        _hip.call("ebn_gemm_f32_prec", 0, 0, R, E3, D, ctypes.c_float(1.0), _hip.ptr(X), D, _hip.ptr(W), E3, ctypes.c_float(0.0), _hip.ptr(C), E3,
+                  _hip.ptr(ws), nbytes, prec, _hip.stream_handle())
+        errs[name] = float((C.double() - ref).abs().max())
+    del model, ex
+    torch.cuda.empty_cache()
+    return {"value": c["B"] / (ms * 1e-3), "unit": "impressions/s", "ms_per_step": ms, "ms_per_step_repeats": [t / args.steps * 1e3 for t in times],
+            "speedup_vs_exact": exact_ms / ms, "dtype": "f32 (bf16x6 split, fp32 accumulate)",
+            "projection_max_abs_err_vs_fp64": errs, "projection_ref_max_abs": float(ref.abs().max()),
+            "what": "OPT-IN second precision, never the headline `value`: the news encoder's projection GEMMs as six bf16 MFMA products of "
+                    "exactly-split fp32 operands with fp32 accumulation; same steps, same batches, same run.  `projection_max_abs_err_vs_fp64`: "
+                    f"{R} token rows of this run's X . Wqkv against float64, for both GEMM kernels"}
 
 
 def being_profiled() -> bool:
@@ -485,6 +543,8 @@ def main():
                     help="N > 1 over RCCL: capture the collectives into the step's hipGraph as well (one graph per step, no eager launches "
                          "between replays).  Verified on a one-rank RCCL group only, hence opt-in")
     ap.add_argument("--no-fit-loop", action="store_true", help="skip the model.fit(loader) leg (N = 1 only)")
+    ap.add_argument("--no-split-leg", action="store_true", help="skip the split-precision leg (the opt-in bf16x6 projections timed next to the "
+                                                               "exact-fp32 headline, N = 1 only)")
     ap.add_argument("--cpu-steps", type=int, default=20, help="timed steps of the CPU baseline (after 5 warm-ups; SURVEY.md 8d)")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel roofline timing (counter-collection passes)")
     ap.add_argument("--no-probe", action="store_true", help="skip the rocprofv3 passes behind roofline.kernel / roofline.traffic (labelled static then)")
@@ -540,9 +600,11 @@ def main():
     sharded = bool(c.get("shard_table"))
     rng = np.random.default_rng(42)  # identical weights on every rank (data-parallel replicas)
     table = (rng.standard_normal((c["V"], c["D"]), dtype=np.float32) * 0.02) if not c["train_embedding"] else None
-    model = NRMSModel(make_hparams(c), word2vec_embedding=table, word_emb_dim=c["D"], vocab_size=c["V"], seed=42,
-                      train_embedding=c["train_embedding"], device=device, shard_table=sharded, precision=args.precision)
-    del table
+    def make_model(precision):
+        return NRMSModel(make_hparams(c), word2vec_embedding=table, word_emb_dim=c["D"], vocab_size=c["V"], seed=42,
+                         train_embedding=c["train_embedding"], device=device, shard_table=sharded, precision=precision)
+
+    model = make_model(args.precision)
     eng = model._engine
     batches = synthetic_batches(c, 8, 123 + rank, device, args.ids)
 
@@ -698,6 +760,8 @@ def main():
             line["comm"] = {**comm, "note": "comm_exposed_us = ms_per_step - the same steps with every collective skipped (measured after the timed region, same graphs).  "
                                             "The dense gradients travel as one flat bucket: with a trainable table it is started asynchronously after the dWqkv GEMM and "
                                             "runs under the dX GEMM and the table-gradient accumulation; with a frozen table nothing follows dWqkv"}
+        if world == 1 and not args.no_split_leg and args.precision == "exact" and not sharded and not args.no_graph:
+            line["split_precision"] = split_precision_leg(c, make_model, batches, args, sync, device, line["ms_per_step"])
         if world == 1 and not args.no_fit_loop and not sharded:
             line["fit_loop"] = fit_loop_leg(model, c)
             line["fit_loop"]["frac_of_value"] = line["fit_loop"]["value"] / line["value"]

@@ -111,7 +111,7 @@ __device__ __forceinline__ void dir_mma(f32x4 (&acc)[R][NC], const DirFrags<R, N
 }
 
 // One wave task: row blocks [rb0, rb0 + R) x column blocks [cb0, cb0 + NC) of C = alpha * A . op(B).
-template <int R, int NC, bool B_KC>
+template <int R, int NC, bool B_KC, int DEPTH>
 __device__ __forceinline__ void dir_task(int64_t M, int64_t N, int64_t K, float alpha, const float* __restrict__ A, int64_t lda,
                                          const float* __restrict__ B, int64_t ldb, float* __restrict__ C, int64_t ldc, int64_t rb0,
                                          int cb0, int lane) {
@@ -143,40 +143,77 @@ __device__ __forceinline__ void dir_task(int64_t M, int64_t N, int64_t K, float 
 
   const int nkf = static_cast<int>(K / 16);         // full k groups
   const int krem = static_cast<int>(K - 16 * static_cast<int64_t>(nkf));  // 0, 4, 8 or 12 (K % 4 == 0)
-  DirFrags<R, NC> f0, f1;
+  DirFrags<R, NC> f0, f1, f2;
   uint32_t sa = 0, sb = 0;
-  if (nkf > 0) {
-    dir_fetch(f0, p, sa, sb);
-    sa += step_a;
-    sb += step_b;
-    int g = 0;
-    // Two groups per iteration, the register sets alternating with literal names; the loop holds ONLY unconditional fetches (a
-    // conditional one merging into it makes the compiler wait vmcnt(0), i.e. for the group it has just requested)
-    for (; g + 2 < nkf; g += 2) {
-      dir_fetch(f1, p, sa, sb);
-      sa += step_a;
-      sb += step_b;
-      __builtin_amdgcn_sched_barrier(0);  // keep the requests in front of the multiplies: the scheduler sinks loads to their uses
-      dir_mma(acc, f0);
-      __builtin_amdgcn_sched_barrier(0);
-      dir_fetch(f0, p, sa, sb);
-      sa += step_a;
-      sb += step_b;
-      __builtin_amdgcn_sched_barrier(0);
-      dir_mma(acc, f1);
-      __builtin_amdgcn_sched_barrier(0);
+#define EBN_DIR_FETCH(F)               \
+  do {                                 \
+    dir_fetch(F, p, sa, sb);           \
+    sa += step_a;                      \
+    sb += step_b;                      \
+    __builtin_amdgcn_sched_barrier(0); \
+  } while (0)
+#define EBN_DIR_MMA(F)                 \
+  do {                                 \
+    dir_mma(acc, F);                   \
+    __builtin_amdgcn_sched_barrier(0); \
+  } while (0)
+  // The sched_barriers keep the requests in front of the multiplies (the scheduler sinks loads to their uses).  The loops hold
+  // ONLY unconditional fetches: a conditional one merging into them makes the compiler wait vmcnt(0), i.e. for the group it has
+  // just requested.  Register sets alternate with literal names.
+  if (DEPTH == 2) {  // one group ahead
+    if (nkf > 0) {
+      EBN_DIR_FETCH(f0);
+      int g = 0;
+      for (; g + 2 < nkf; g += 2) {
+        EBN_DIR_FETCH(f1);
+        EBN_DIR_MMA(f0);
+        EBN_DIR_FETCH(f0);
+        EBN_DIR_MMA(f1);
+      }
+      if (g + 1 < nkf) {  // two groups left: g is in f0
+        EBN_DIR_FETCH(f1);
+        EBN_DIR_MMA(f0);
+        EBN_DIR_MMA(f1);
+      } else {
+        EBN_DIR_MMA(f0);
+      }
     }
-    if (g + 1 < nkf) {  // two groups left: g is in f0
-      dir_fetch(f1, p, sa, sb);
-      sa += step_a;
-      sb += step_b;
-      __builtin_amdgcn_sched_barrier(0);
-      dir_mma(acc, f0);
-      dir_mma(acc, f1);
-    } else {
-      dir_mma(acc, f0);
+  } else {  // two groups ahead: a group's operands have two groups' worth of MFMAs (2 x R*NC*128 cycles) to arrive
+    if (nkf > 0) {
+      EBN_DIR_FETCH(f0);
+      if (nkf > 1) EBN_DIR_FETCH(f1);
+      int g = 0;
+      for (; g + 4 < nkf; g += 3) {  // top: f0 = group g, f1 = group g + 1 requested, f2 free
+        EBN_DIR_FETCH(f2);
+        EBN_DIR_MMA(f0);
+        EBN_DIR_FETCH(f0);
+        EBN_DIR_MMA(f1);
+        EBN_DIR_FETCH(f1);
+        EBN_DIR_MMA(f2);
+      }
+      const int left = nkf - g;  // 1..4 groups left, f0 (and f1 when left > 1) requested
+      if (left == 1) {
+        EBN_DIR_MMA(f0);
+      } else if (left == 2) {
+        EBN_DIR_MMA(f0);
+        EBN_DIR_MMA(f1);
+      } else if (left == 3) {
+        EBN_DIR_FETCH(f2);
+        EBN_DIR_MMA(f0);
+        EBN_DIR_MMA(f1);
+        EBN_DIR_MMA(f2);
+      } else {
+        EBN_DIR_FETCH(f2);
+        EBN_DIR_MMA(f0);
+        EBN_DIR_FETCH(f0);
+        EBN_DIR_MMA(f1);
+        EBN_DIR_MMA(f2);
+        EBN_DIR_MMA(f0);
+      }
     }
   }
+#undef EBN_DIR_FETCH
+#undef EBN_DIR_MMA
   if (krem > 0) {
     dir_fetch_tail(f0, p, sa, sb, 4 * kq < krem);
     dir_mma(acc, f0);
@@ -201,8 +238,8 @@ __device__ __forceinline__ void dir_task(int64_t M, int64_t N, int64_t K, float 
 // one row group sit in one workgroup, so the A panel they share is fetched into one CU's L1.  Column group j covers the column
 // blocks of its share: the first n_wide groups hold CW of them, the others CW - 1 (the two block counts an instantiation carries;
 // the host plan only offers splits of that form).
-template <int R, int CW, bool B_KC>
-__global__ __launch_bounds__(256, 2) void gemm_direct16_kernel(int64_t M, int64_t N, int64_t K, float alpha, const float* __restrict__ A,
+template <int R, int CW, bool B_KC, int DEPTH>
+__global__ __launch_bounds__(256, (DEPTH == 3 && R * CW >= 14) ? 1 : 2) void gemm_direct16_kernel(int64_t M, int64_t N, int64_t K, float alpha, const float* __restrict__ A,
                                                                int64_t lda, const float* __restrict__ B, int64_t ldb,
                                                                float* __restrict__ C, int64_t ldc, int32_t G, int32_t n_wide, int64_t n_tasks) {
   const int lane = threadIdx.x & 63;
@@ -213,8 +250,8 @@ __global__ __launch_bounds__(256, 2) void gemm_direct16_kernel(int64_t M, int64_
   const int cg = static_cast<int>(t - rg * G);
   // the first n_wide groups hold CW blocks, the others CW - 1
   const int cb0 = cg < n_wide ? cg * CW : n_wide * CW + (cg - n_wide) * (CW - 1);
-  if (cg < n_wide) dir_task<R, CW, B_KC>(M, N, K, alpha, A, lda, B, ldb, C, ldc, rg * R, cb0, lane);
-  else dir_task<R, CW - 1, B_KC>(M, N, K, alpha, A, lda, B, ldb, C, ldc, rg * R, cb0, lane);
+  if (cg < n_wide) dir_task<R, CW, B_KC, DEPTH>(M, N, K, alpha, A, lda, B, ldb, C, ldc, rg * R, cb0, lane);
+  else dir_task<R, CW - 1, B_KC, DEPTH>(M, N, K, alpha, A, lda, B, ldb, C, ldc, rg * R, cb0, lane);
 }
 
 int direct_mode() {  // EBN_GEMM_DIRECT = 0: never (validation / tuning: the LDS-staged kernels take these shapes again); default 1
@@ -234,12 +271,15 @@ struct DirectPlan {
 DirectPlan direct_plan(int64_t M, int64_t N) {
   const int64_t MB = ebn_ceil_div(M, 16), NB = ebn_ceil_div(N, 16);
   DirectPlan best{0, 0, 0, 0, 0, 1e300};
+  static const int force_r = [] { const char* e = getenv("EBN_GEMM_DIRECT_R"); return e ? atoi(e) : 0; }();   // tuning: restrict the
+  static const int force_c = [] { const char* e = getenv("EBN_GEMM_DIRECT_C"); return e ? atoi(e) : 0; }();   // plan to one R / CW
   static const int kR[4] = {4, 3, 2, 1}, kC[3] = {7, 5, 4};
   for (int ci = 0; ci < 3; ++ci) {
     const int64_t cw = kC[ci], G = ebn_ceil_div(NB, cw), n_wide = NB - G * (cw - 1);
-    if (n_wide < 0 || n_wide > G) continue;
+    if (n_wide < 0 || n_wide > G || (force_c != 0 && force_c != cw)) continue;
     const int64_t width = n_wide > 0 ? cw : cw - 1;  // blocks of the widest task
     for (int ri = 0; ri < 4; ++ri) {
+      if (force_r != 0 && force_r != kR[ri]) continue;
       const int64_t tasks = ebn_ceil_div(MB, kR[ri]) * G;
       const double rounds = static_cast<double>(ebn_ceil_div(tasks, 1024));
       // a task's issue time ~ R * width blocks; fewer, fatter tasks fetch less per MFMA (R + width fragments for R * width blocks):
@@ -251,14 +291,25 @@ DirectPlan direct_plan(int64_t M, int64_t N) {
   return best;
 }
 
+int direct_depth() {  // EBN_GEMM_DIRECT_DEPTH = 2 | 3: register sets of operand fragments (groups requested ahead + 1); tuning
+  static const int d = [] { const char* e = getenv("EBN_GEMM_DIRECT_DEPTH"); const int v = e ? atoi(e) : 3; return v == 2 ? 2 : 3; }();
+  return d;
+}
+
 template <int R, int CW>
 int direct_launch_rc(bool b_kc, const DirectPlan& pl, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda, const float* B,
                      int64_t ldb, float* C, int64_t ldc, hipStream_t s) {
   const dim3 grid(static_cast<unsigned>(ebn_ceil_div(pl.tasks, 4))), block(256);
-  if (b_kc)
-    hipLaunchKernelGGL((gemm_direct16_kernel<R, CW, true>), grid, block, 0, s, M, N, K, alpha, A, lda, B, ldb, C, ldc, pl.G, pl.n_wide, pl.tasks);
-  else
-    hipLaunchKernelGGL((gemm_direct16_kernel<R, CW, false>), grid, block, 0, s, M, N, K, alpha, A, lda, B, ldb, C, ldc, pl.G, pl.n_wide, pl.tasks);
+#define EBN_DIR_GO(KC, DP) \
+  hipLaunchKernelGGL((gemm_direct16_kernel<R, CW, KC, DP>), grid, block, 0, s, M, N, K, alpha, A, lda, B, ldb, C, ldc, pl.G, pl.n_wide, pl.tasks)
+  if (direct_depth() == 2) {
+    if (b_kc) EBN_DIR_GO(true, 2);
+    else EBN_DIR_GO(false, 2);
+  } else {
+    if (b_kc) EBN_DIR_GO(true, 3);
+    else EBN_DIR_GO(false, 3);
+  }
+#undef EBN_DIR_GO
   EBN_CHECK_LAUNCH();
   return EBN_OK;
 }

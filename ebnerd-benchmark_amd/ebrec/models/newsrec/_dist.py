@@ -61,20 +61,18 @@ class LockStepGuard:
     `monitored_barrier` first: when a peer does not arrive within `timeout_s` (EBN_COLLECTIVE_TIMEOUT_S, default 120 s)
     it raises a RuntimeError naming the call and the missing ranks, on every rank that did arrive.
 
-    RCCL has no monitored barrier, so with an "nccl" group a gloo side group over the same ranks is made at construction
-    (the engine is constructed by every rank of its group, `use_local_synchronization` keeps other processes out of it)."""
+    The barrier runs on a gloo SIDE group over the same ranks, made at construction (the engine is constructed by every rank of
+    its group; `use_local_synchronization` keeps other processes out of it): RCCL has no monitored barrier, and a gloo group
+    whose barrier timed out closes its connection pairs -- on a side group the caller's own group stays usable after the error."""
 
     def __init__(self, group=None, timeout_s: float | None = None):
         self.rank, self.world = world_info(group)
         self.timeout_s = float(os.environ.get("EBN_COLLECTIVE_TIMEOUT_S", "120")) if timeout_s is None else float(timeout_s)
         self.group = None
         if self.world > 1:
-            if dist.get_backend(group) == "gloo":
-                self.group = group if group is not None else dist.group.WORLD
-            else:
-                self.group = dist.new_group(ranks=dist.get_process_group_ranks(group if group is not None else dist.group.WORLD),
-                                            backend="gloo", timeout=timedelta(seconds=max(self.timeout_s, 30.0)),
-                                            use_local_synchronization=True)
+            self.group = dist.new_group(ranks=dist.get_process_group_ranks(group if group is not None else dist.group.WORLD),
+                                        backend="gloo", timeout=timedelta(seconds=max(self.timeout_s, 30.0)),
+                                        use_local_synchronization=True)
 
     def enter(self, what: str) -> None:
         if self.world <= 1:

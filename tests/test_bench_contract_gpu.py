@@ -44,6 +44,15 @@ def test_bench_line_carries_the_contract_fields(cfg):
                     assert abs(rr["traffic"] - alg) < 0.02 * alg, (rr["traffic"], alg)
         fl = d["fit_loop"]  # the host loop + loader keep up with the device step (the timed region itself replays staged batches)
         assert fl["steps"] == 100 and fl["value"] > 0.8 * d["value"] and abs(fl["frac_of_value"] - fl["value"] / d["value"]) < 1e-9
+        sp = d["split_precision"]  # the opt-in bf16x6 projections, timed in the same run, with their accuracy evidence beside them
+        assert sp["value"] > 0 and sp["dtype"].startswith("f32 (bf16x6") and abs(sp["speedup_vs_exact"] - d["ms_per_step"] / sp["ms_per_step"]) < 1e-9
+        e = sp["projection_max_abs_err_vs_fp64"]
+        assert e["split_bf16x6"] < 4 * e["exact_fp32"] + 1e-6 and e["split_bf16x6"] < 1e-5 * max(1.0, sp["projection_ref_max_abs"])
+        rg = d["roofline_gather"]
+        assert rg["achievable_gbs"] >= max(rg["calibration"]["torch_copy_gbs"], rg["calibration"]["float4_row_copy_gbs"]) - 1e-6
+        assert abs(rg["frac_of_achievable"] - rg["achieved"] / rg["achievable_gbs"]) < 1e-9 and "table_residency" in rg
+        assert len(d["ms_per_step_repeats"]) == d["repeats"] and d["config"]["id_distribution"]["ids"] == "uniform"
+        assert set(d["cpu_baseline"]["thread_sweep_ms_per_step"]) and d["cpu_baseline"]["cores"] >= 1
         st = d["roofline_step"]
         assert st["bound"] == "mfma" and abs(st["frac"] - st["achieved"] / st["peak"]) < 1e-9 and 0 < st["frac"] < d["roofline"]["frac"]
         assert abs(st["achieved"] * 1e12 - st["algorithmic_flops_per_step"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * st["achieved"] * 1e12

@@ -254,6 +254,10 @@ def _guard_worker(rank, world):
         assert time.time() - t0 < 30
     else:
         time.sleep(4.0)
+    # the barrier that timed out ran on the guard's own side group: the caller's group is still usable after the error
+    t = torch.ones(1) * (rank + 1)
+    dist.all_reduce(t)
+    assert float(t) == 3.0
 
 
 def test_collective_api_entered_by_one_rank_raises_instead_of_hanging():
