@@ -539,9 +539,11 @@ def main():
                          "all-zero titles -- hot row 0, as real left-padded EB-NeRD batches have)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch kernel by kernel instead of hipGraph replay")
-    ap.add_argument("--graph-collectives", action="store_true",
+    ap.add_argument("--graph-collectives", nargs="?", const="on", default="off", choices=["off", "on", "auto"],
                     help="N > 1 over RCCL: capture the collectives into the step's hipGraph as well (one graph per step, no eager launches "
-                         "between replays).  Verified on a one-rank RCCL group only, hence opt-in")
+                         "between replays).  on: unconditionally.  auto: after a start-up self-check (one step both ways from the same state, "
+                         "compared bit for bit, verdict MIN-reduced over the ranks: engine.verify_graph_collectives).  The form has only ever "
+                         "met a one-rank RCCL group, hence off by default")
     ap.add_argument("--no-fit-loop", action="store_true", help="skip the model.fit(loader) leg (N = 1 only)")
     ap.add_argument("--no-split-leg", action="store_true", help="skip the split-precision leg (the opt-in bf16x6 projections timed next to the "
                                                                "exact-fp32 headline, N = 1 only)")
@@ -619,8 +621,10 @@ def main():
         return
 
     eng.atomic_table_grad = bool(args.atomic_table_grad)
-    eng.graph_collectives = bool(args.graph_collectives and backend == "nccl")
     eng.enable_graphs(not args.no_graph)
+    eng.graph_collectives = bool(args.graph_collectives == "on" and backend == "nccl")
+    if args.graph_collectives == "auto" and world > 1 and not args.no_graph:
+        eng.verify_graph_collectives(*batches[0])
     times = timed_repeats(lambda k: eng.train_step(*batches[k % len(batches)]), args, sync, world, device)
     # Kernel-level rooflines: the Q|K|V projection GEMM and the embedding gather of THIS step (same buffers, same
     # arguments), each captured into a hipGraph of 10 launches and timed with HIP events on the launch stream.
@@ -648,7 +652,7 @@ def main():
         if eng.exchange is not None:
             eng.exchange.skip = False
         ms_no = float(np.median([t / args.steps * 1e3 for t in t_no]))
-        comm = {"ms_per_step_without_collectives": ms_no, "overlap": bool(eng.overlap_collectives), "collectives_in_graph": bool(eng.graph_collectives)}
+        comm = {"ms_per_step_without_collectives": ms_no, "overlap": bool(eng.overlap_collectives), "collectives_in_graph": bool(eng.graph_collectives), "graph_collectives_mode": args.graph_collectives}
     eng.check_oob()  # sticky device flags of the whole run (ids out of range, exchange overflow, accumulator range): raise, don't report
 
     if rank == 0:

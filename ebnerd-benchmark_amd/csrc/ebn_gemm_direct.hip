@@ -26,8 +26,13 @@ typedef int ebn_dir_i32x4 __attribute__((ext_vector_type(4)));
 __device__ ebn_dir_f32x4 ebn_dir_buffer_load_x4(ebn_dir_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
 __device__ float ebn_dir_buffer_load_x1(ebn_dir_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
 
+#ifndef EBN_DIRECT_INTERLEAVE
+#define EBN_DIRECT_INTERLEAVE 1  // 0: all requests of a k group in front of the previous group's MFMAs (tuning / A-B)
+#endif
+
 namespace {
 
+constexpr bool INTERLEAVE = EBN_DIRECT_INTERLEAVE != 0;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ ebn_dir_i32x4 dir_rsrc(const float* base) {
@@ -145,6 +150,27 @@ __device__ __forceinline__ void dir_task(int64_t M, int64_t N, int64_t K, float 
   const int krem = static_cast<int>(K - 16 * static_cast<int64_t>(nkf));  // 0, 4, 8 or 12 (K % 4 == 0)
   DirFrags<R, NC> f0, f1, f2;
   uint32_t sa = 0, sb = 0;
+  // A wave issues in order and a VMEM instruction holds its issue slot for tens of cycles (address + data path hand-off): a clump
+  // of 31 loads in front of 84 MFMAs leaves the matrix pipe idle for the length of the clump -- with one wave per SIMD nobody
+  // else fills it (measured: 52 % pipe busy, 72 % of the wave cycles in SQ_WAIT_INST_ANY, although tools/microbench/mfma16_issue
+  // sustains 32.6 cycles per MFMA from one wave).  So the requests of group g + 1 are INTERLEAVED with the MFMAs of group g: one
+  // VMEM read after every PER_LOAD MFMAs (sched_group_barrier pattern), each hidden behind the 32 pipe cycles of the MFMA before it.
+  constexpr int N_LOADS = R + (B_KC ? NC : 4 * NC), N_MFMA = 4 * R * NC, PER_LOAD = (N_MFMA / N_LOADS) > 0 ? (N_MFMA / N_LOADS) : 1;
+#define EBN_DIR_STEP(FL, FM)                                                   \
+  do {                                                                         \
+    dir_fetch(FL, p, sa, sb);                                                  \
+    sa += step_a;                                                              \
+    sb += step_b;                                                              \
+    dir_mma(acc, FM);                                                          \
+    if (INTERLEAVE) {                                                          \
+      _Pragma("unroll") for (int i__ = 0; i__ < N_LOADS; ++i__) {              \
+        __builtin_amdgcn_sched_group_barrier(0x008, PER_LOAD, 0); /* MFMA */   \
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);        /* VMEM read */ \
+      }                                                                        \
+      __builtin_amdgcn_sched_group_barrier(0x008, N_MFMA - PER_LOAD * N_LOADS, 0); \
+    }                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                         \
+  } while (0)
 #define EBN_DIR_FETCH(F)               \
   do {                                 \
     dir_fetch(F, p, sa, sb);           \
@@ -165,14 +191,11 @@ __device__ __forceinline__ void dir_task(int64_t M, int64_t N, int64_t K, float 
       EBN_DIR_FETCH(f0);
       int g = 0;
       for (; g + 2 < nkf; g += 2) {
-        EBN_DIR_FETCH(f1);
-        EBN_DIR_MMA(f0);
-        EBN_DIR_FETCH(f0);
-        EBN_DIR_MMA(f1);
+        EBN_DIR_STEP(f1, f0);
+        EBN_DIR_STEP(f0, f1);
       }
       if (g + 1 < nkf) {  // two groups left: g is in f0
-        EBN_DIR_FETCH(f1);
-        EBN_DIR_MMA(f0);
+        EBN_DIR_STEP(f1, f0);
         EBN_DIR_MMA(f1);
       } else {
         EBN_DIR_MMA(f0);
@@ -184,12 +207,9 @@ __device__ __forceinline__ void dir_task(int64_t M, int64_t N, int64_t K, float 
       if (nkf > 1) EBN_DIR_FETCH(f1);
       int g = 0;
       for (; g + 4 < nkf; g += 3) {  // top: f0 = group g, f1 = group g + 1 requested, f2 free
-        EBN_DIR_FETCH(f2);
-        EBN_DIR_MMA(f0);
-        EBN_DIR_FETCH(f0);
-        EBN_DIR_MMA(f1);
-        EBN_DIR_FETCH(f1);
-        EBN_DIR_MMA(f2);
+        EBN_DIR_STEP(f2, f0);
+        EBN_DIR_STEP(f0, f1);
+        EBN_DIR_STEP(f1, f2);
       }
       const int left = nkf - g;  // 1..4 groups left, f0 (and f1 when left > 1) requested
       if (left == 1) {
@@ -214,6 +234,7 @@ __device__ __forceinline__ void dir_task(int64_t M, int64_t N, int64_t K, float 
   }
 #undef EBN_DIR_FETCH
 #undef EBN_DIR_MMA
+#undef EBN_DIR_STEP
   if (krem > 0) {
     dir_fetch_tail(f0, p, sa, sb, 4 * kq < krem);
     dir_mma(acc, f0);
@@ -292,7 +313,7 @@ DirectPlan direct_plan(int64_t M, int64_t N) {
 }
 
 int direct_depth() {  // EBN_GEMM_DIRECT_DEPTH = 2 | 3: register sets of operand fragments (groups requested ahead + 1); tuning
-  static const int d = [] { const char* e = getenv("EBN_GEMM_DIRECT_DEPTH"); const int v = e ? atoi(e) : 3; return v == 2 ? 2 : 3; }();
+  static const int d = [] { const char* e = getenv("EBN_GEMM_DIRECT_DEPTH"); const int v = e ? atoi(e) : 2; return v == 3 ? 3 : 2; }();
   return d;
 }
 

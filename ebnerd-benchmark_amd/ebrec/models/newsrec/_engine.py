@@ -986,6 +986,56 @@ class NRMSEngine:
             return self.loss_dev, nb.probs[: B * C].view(B, C), nb.labels[: B * C].view(B, C)
         return self.loss_dev
 
+    # ------------------------------------------------------------------ one-graph multi-rank step: self-check
+    def _state_tensors(self):
+        ts = [self.params.data, self.params.grad, self.params.m, self.params.v, self.state, self.loss_dev]
+        if self.train_embedding:
+            ts += [self.table, self.table_grad, self.table_m, self.table_v] + ([self.table_acc] if self.deterministic else [])
+        return ts
+
+    def verify_graph_collectives(self, his, pred, y) -> bool:
+        """Multi-rank: decide whether the WHOLE step -- kernels and collectives -- may run as one hipGraph (`graph_collectives`).
+        Runs ONE training step from the current state twice, as the default form (hipGraph segments with eager collectives between
+        the replays) and as the one-graph form (collectives captured: no eager launches, no cross-stream fork / join between
+        replays), and compares every parameter, Adam moment, gradient and the loss BIT FOR BIT; the state (weights, moments, step
+        counter, dropout keys) is restored in between and afterwards, so the check leaves no trace.  The verdict is MIN-reduced
+        over the group: every rank adopts the one-graph form or none does.  Any exception while capturing or replaying the
+        one-graph form counts as a failed check.  A collective (all ranks call it with their own batch of the same shape)."""
+        if not (self.use_graph and self.graph_capable and self.world > 1):
+            self.graph_collectives = False
+            return False
+        torch.cuda.synchronize()
+        snap = [t.clone() for t in self._state_tensors()]
+
+        def restore():
+            for t, s in zip(self._state_tensors(), snap):
+                t.copy_(s)
+
+        def one_step(flag):
+            self.graph_collectives = flag
+            self._graphs.clear()
+            self.train_step(his, pred, y)   # captures
+            restore()
+            self.train_step(his, pred, y)   # replays from the same state
+            torch.cuda.synchronize()
+            out = [t.clone() for t in self._state_tensors()]
+            restore()
+            return out
+
+        ok = True
+        try:
+            ref = one_step(False)
+            got = one_step(True)
+            ok = all(torch.equal(a, b) for a, b in zip(ref, got))
+        except Exception:  # capture of a collective refused, a replay failed: keep the segment form
+            ok = False
+            restore()
+        verdict = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device)
+        torch.distributed.all_reduce(verdict, op=torch.distributed.ReduceOp.MIN, group=self.pg)
+        self.graph_collectives = bool(int(verdict.item()))
+        self._graphs.clear()
+        return self.graph_collectives
+
     def _train_bufs(self, B, C):
         N, E = B * (self.H + C), self.E
         nb = self._news_bufs(N, True)

@@ -87,21 +87,24 @@ def test_c2_full_size_training_step_matches_the_oracle(hip, graph, precision):
     assert torch.equal(eng.table[uniq[:64]].cpu(), torch.from_numpy(table[uniq[:64]]))  # frozen
 
 
-@pytest.mark.parametrize("loss,ids,atomic", [("cross_entropy_loss", "uniform", False), ("log_loss", "uniform", False),
-                                             ("cross_entropy_loss", "zipf", False), ("cross_entropy_loss", "zipf", True)])
-def test_c1_full_size_three_steps_with_the_dense_table_sweep(hip, loss, ids, atomic):
+@pytest.mark.parametrize("loss,ids,atomic,precision", [("cross_entropy_loss", "uniform", False, "exact"), ("log_loss", "uniform", False, "exact"),
+                                                       ("cross_entropy_loss", "zipf", False, "exact"), ("cross_entropy_loss", "zipf", True, "exact"),
+                                                       ("cross_entropy_loss", "uniform", False, "split")])
+def test_c1_full_size_three_steps_with_the_dense_table_sweep(hip, loss, ids, atomic, precision):
     """configs[0] at bench size: 32000 x 300 TRAINABLE table, B = 32, dropout 0.2, 3 steps.  Keras' Adam decays the
     moments of every row each step (dense sweep): rows untouched by a batch still move after step 1 -- the whole
     32000 x 300 table is compared.  ids="zipf": SURVEY.md 8(d)'s Z inputs -- ~5000 of the 24000 gradient rows of a step land on
     table row 0 (left-padded histories, _behaviors.py:647-654; unknown articles, dataloader.py:43), the case the duplicate-combining
-    accumulation was built for (atomic=True: the plain one-atomic-per-element form, same bits by construction)."""
+    accumulation was built for (atomic=True: the plain one-atomic-per-element form, same bits by construction).
+    precision="split": the opt-in bf16x6 projections with a TRAINABLE table -- forward, dWqkv and dX = dQKV.Wqkv^T all through the
+    split path -- under the exact path's tolerances."""
     from ebrec.models.newsrec import NRMSModel
 
     V, D, B, C, seed, lr = 32000, 300, 32, 5, 11, 1e-3
     hp = make_hp(dropout=0.2, learning_rate=lr, loss=loss)
     rng = np.random.default_rng(31)
     P = on.random_nrms_params(V, D, hp.head_num, hp.head_dim, hp.attention_hidden_dim, seed=5)
-    m = NRMSModel(hp, word2vec_embedding=P["emb"], seed=seed).from_keras_weight_list(weight_list(P))
+    m = NRMSModel(hp, word2vec_embedding=P["emb"], seed=seed, precision=precision).from_keras_weight_list(weight_list(P))
     eng = m._engine
     eng.atomic_table_grad = atomic
     eng.enable_graphs()
@@ -132,8 +135,8 @@ def test_c1_full_size_three_steps_with_the_dense_table_sweep(hip, loss, ids, ato
     assert np.array_equal(got["emb"][~touched], P0["emb"][~touched].astype(np.float32))
 
 
-@pytest.mark.parametrize("ids", ["uniform", "zipf"])
-def test_c4_full_size_step_with_history_50_matches_the_oracle(hip, ids):
+@pytest.mark.parametrize("ids,precision", [("uniform", "exact"), ("zipf", "exact"), ("uniform", "split")])
+def test_c4_full_size_step_with_history_50_matches_the_oracle(hip, ids, precision):
     """configs[3]'s per-rank step at bench size: history_size 50 (the 2 x 2-tile attention kernels at the user level, 52800 title
     tokens per step: the group-form attention kernels above their size thresholds, the 16x16-block AttLayer2 GEMM), 32000 x 300
     TRAINABLE table, B = 32, dropout 0.2; two steps through the captured graph.  ids="zipf": SURVEY.md 8(d)'s Z inputs (hot row 0:
@@ -144,7 +147,7 @@ def test_c4_full_size_step_with_history_50_matches_the_oracle(hip, ids):
     hp = make_hp(history_size=H, dropout=0.2, learning_rate=lr)
     rng = np.random.default_rng(41)
     P = on.random_nrms_params(V, D, hp.head_num, hp.head_dim, hp.attention_hidden_dim, seed=6)
-    m = NRMSModel(hp, word2vec_embedding=P["emb"], seed=seed).from_keras_weight_list(weight_list(P))
+    m = NRMSModel(hp, word2vec_embedding=P["emb"], seed=seed, precision=precision).from_keras_weight_list(weight_list(P))
     eng = m._engine
     eng.enable_graphs()
     P = {k: v.astype(np.float32).astype(np.float64) for k, v in P.items()}

@@ -482,3 +482,35 @@ def _c5_full_width_worker(rank, world, train_embedding):
 @pytest.mark.parametrize("train_embedding", [False, True])
 def test_two_rank_c5_full_width_row_sharded_step_equals_the_full_batch_oracle_step(hip, train_embedding):
     _spawn(_c5_full_width_worker, 2, train_embedding)
+
+
+def _graph_collectives_check_worker(rank, world):
+    """verify_graph_collectives under gloo: host-side collectives cannot be captured into a hipGraph, so the self-check must come
+    back False on every rank, leave weights / moments / step counter / dropout keys exactly as they were, and training must go on
+    in the segment form -- bit-identical to a twin engine that never ran the check."""
+    from ebrec.models.newsrec import NRMSModel
+
+    hp = make_hp(dropout=0.2, learning_rate=1e-3)
+    V, D, B, C = 300, 32, 3, 5
+    emb = np.random.default_rng(5).standard_normal((V, D)).astype(np.float32)
+    a = NRMSModel(hp, word2vec_embedding=emb, seed=3, train_embedding=True, table_grad_exchange="dense")
+    b = NRMSModel(hp, word2vec_embedding=emb, seed=3, train_embedding=True, table_grad_exchange="dense")
+    a._engine.enable_graphs()
+    b._engine.enable_graphs()
+    rng = np.random.default_rng(100 + rank)
+    his, pred, y = batch(rng, B, hp.history_size, C, hp.title_size, V)
+    a.train_step(his, pred, y)
+    b.train_step(his, pred, y)
+    before = [t.clone() for t in a._engine._state_tensors()]
+    assert a._engine.verify_graph_collectives(his, pred, y) is False and not a._engine.graph_collectives
+    assert all(torch.equal(x, z) for x, z in zip(before, a._engine._state_tensors()))
+    for t in range(2):
+        his, pred, y = batch(rng, B, hp.history_size, C, hp.title_size, V)
+        la, lb = float(a.train_step(his, pred, y).item()), float(b.train_step(his, pred, y).item())
+        assert la == lb, (rank, t, la, lb)
+    for wa, wb in zip(a.model.get_weights(), b.model.get_weights()):
+        assert np.array_equal(wa, wb)
+
+
+def test_graph_collectives_self_check_falls_back_cleanly_where_collectives_cannot_be_captured(hip):
+    _spawn(_graph_collectives_check_worker, 2)

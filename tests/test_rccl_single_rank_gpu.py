@@ -79,6 +79,17 @@ for frozen in (False, True):
     e2.train_step(his, pred, y)
     e2.skip_collectives = False
     e2.check_oob()
+    # the start-up self-check of the one-graph form (collectives captured into the step's hipGraph): one step both ways from the
+    # same state, compared bit for bit, state restored -- on RCCL the capture is accepted and the check adopts the form; the
+    # steps that follow equal the reference engine's, which never ran the check
+    before = [t.clone() for t in e2._state_tensors()]
+    assert e2.verify_graph_collectives(his, pred, y) is True and e2.graph_collectives
+    assert all(torch.equal(a_, b_) for a_, b_ in zip(before, e2._state_tensors()))  # the check left no trace
+    for _ in range(2):
+        l2 = float(e2.train_step(his, pred, y).item()); lr = float(ref._engine.train_step(his, pred, y).item())
+        assert l2 == lr, ("one-graph form", frozen, l2, lr)
+    for a_, b_ in zip(m2.model.get_weights(), ref.model.get_weights()):
+        assert np.array_equal(a_, b_)
 torch.cuda.synchronize()
 dist.destroy_process_group()
 print("RCCL_SINGLE_RANK_OK", float(eng.loss_dev.item()))
