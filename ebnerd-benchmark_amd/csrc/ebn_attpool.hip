@@ -421,7 +421,7 @@ extern "C" int ebn_attpool_bwd_pool_f32(const float* X, const float* w, const fl
 extern "C" int ebn_attpool_bwd_dpre_f32(float* U, const float* q, const float* de, float* dq, float* db,
                                         float* partials, int64_t R, int32_t A, int32_t accumulate,
                                         ebn_stream_t stream) {
-  EBN_REQUIRE(U && q && de && dq && db && partials, EBN_ERR_BAD_ARG);
+  EBN_REQUIRE(U && q && de && partials && ((dq != nullptr) == (db != nullptr)), EBN_ERR_BAD_ARG);
   EBN_REQUIRE(R >= 0 && A > 0, EBN_ERR_BAD_ARG);
   if (R == 0) return EBN_OK;
   const int64_t nb = ebn_colred_blocks(R);
@@ -429,6 +429,7 @@ extern "C" int ebn_attpool_bwd_dpre_f32(float* U, const float* q, const float* d
   hipLaunchKernelGGL(attpool_bwd_dpre_kernel, dim3(static_cast<unsigned>(nb)), dim3(POOL_THREADS), 0,
                      ebn_stream(stream), U, q, de, partials, R, A, rpb);
   EBN_CHECK_LAUNCH();
+  if (dq == nullptr) return EBN_OK;  // the sum over the row blocks is left to ebn_grad_finish_f32 (EBN_FINISH_COLRED job over `partials`)
   ebn_reduce_partials(partials, nb, 2, A, 1.0f, dq, db, accumulate, nullptr, nullptr, ebn_stream(stream));
   EBN_CHECK_LAUNCH();
   return EBN_OK;

@@ -22,6 +22,7 @@
 #include <stdlib.h>
 
 #include "ebn_common.h"
+#include "ebn_finish.h"
 
 // Buffer-load intrinsics bound by name (the __amdgpu_buffer_rsrc_t builtins make the HOST pass drop the launch stub of
 // a kernel that uses them).  Declared outside the anonymous namespace: they are external symbols of the compiler.
@@ -596,27 +597,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
                                                             float* __restrict__ C, int64_t ldc, GemmEpi epi) {
   // M * N < 2^31 (checked by the launcher): 32-bit index arithmetic -- a 64-bit division per element costs more than
   // the sum itself
-  const uint32_t total = static_cast<uint32_t>(M * N);
-  const uint32_t n32 = static_cast<uint32_t>(N);
-  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
-    float s = 0.f;
-    int z = 0;
-    for (; z + 4 <= splits; z += 4) {  // 4 independent loads in flight
-      const float v0 = part[static_cast<int64_t>(z) * total + i], v1 = part[static_cast<int64_t>(z + 1) * total + i];
-      const float v2 = part[static_cast<int64_t>(z + 2) * total + i], v3 = part[static_cast<int64_t>(z + 3) * total + i];
-      s += v0;
-      s += v1;
-      s += v2;
-      s += v3;
-    }
-    for (; z < splits; ++z) s += part[static_cast<int64_t>(z) * total + i];
-    const uint32_t row = i / n32;
-    const uint32_t col = i - row * n32;
-    float* c = C + static_cast<int64_t>(row) * ldc + col;
-    if (epi.rs != nullptr) s = fmaf(epi.rs[row], epi.cv[static_cast<int64_t>(row / static_cast<uint32_t>(epi.L)) * epi.ldcv + col], s);
-    if (epi.bias != nullptr) s = fmaxf(s + epi.bias[col], 0.f);
-    *c = (beta != 0.f) ? (s + beta * *c) : s;
-  }
+  ebn_splitk_sum_body(blockIdx.x * 256u + threadIdx.x, gridDim.x * 256u, part, splits, static_cast<uint32_t>(M * N), static_cast<uint32_t>(N),
+                      beta, C, ldc, epi.rs, epi.cv, epi.ldcv, epi.L, epi.bias);
 }
 
 template <int BM, int BN, int WAVES_M>
@@ -1175,7 +1157,15 @@ extern "C" int ebn_gemm_plan(int64_t M, int64_t N, int64_t K, int64_t workspace_
 
 static int gemm_dispatch(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K, float alpha, const float* A,
                          int64_t lda, const float* B, int64_t ldb, float beta, float* C, int64_t ldc, float* workspace,
-                         int64_t workspace_floats, int32_t site, GemmEpi epi, hipStream_t s) {
+                         int64_t workspace_floats, int32_t site, GemmEpi epi, hipStream_t s, int32_t* defer_parts = nullptr) {
+  // defer_parts != NULL (ebn_gemm_f32_partials): the product is left as *defer_parts dense [M][N] slices in `workspace` -- the
+  // split-K partials without their combining launch, or the product itself as one slice -- for ebn_grad_finish_f32 to sum
+  if (defer_parts != nullptr) {
+    C = workspace;
+    ldc = N;
+    beta = 0.f;
+    *defer_parts = 1;
+  }
   // contiguous-axis extent must be a multiple of 4 too (K for k-contiguous operands, M/N otherwise)
   // ... and the fast tile fetch addresses an operand tile with 32-bit BYTE offsets from the tile's origin: 256 tile rows
   // (or the K range, for operands stored [K][mn]) times the leading dimension must stay below 4 GB
@@ -1216,6 +1206,10 @@ static int gemm_dispatch(int32_t transA, int32_t transB, int64_t M, int64_t N, i
     rc = launch_gemm<64, 64, 2>(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, vecA, vecB, splits, kps,
                                 workspace, s, site, epi);
   if (rc != EBN_OK) return rc;
+  if (splits > 1 && defer_parts != nullptr) {
+    *defer_parts = splits;
+    return EBN_OK;
+  }
   if (splits > 1) {
     int64_t grid = ebn_ceil_div(M * N, 256);
     if (grid > 4096) grid = 4096;
@@ -1224,6 +1218,22 @@ static int gemm_dispatch(int32_t transA, int32_t transB, int64_t M, int64_t N, i
     EBN_CHECK_LAUNCH();
   }
   return EBN_OK;
+}
+
+extern "C" int64_t ebn_gemm_partials_workspace_floats(int64_t M, int64_t N, int64_t K) {
+  if (!ebn_dim_ok(M, N, K)) return 0;
+  const GemmPlan p = gemm_plan(M, N, K, INT64_MAX / 4);
+  return ebn_sat_mul(static_cast<int64_t>(p.splits > 1 ? p.splits : 1) * M, N);
+}
+
+extern "C" int ebn_gemm_f32_partials(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K, float alpha, const float* A,
+                                     int64_t lda, const float* B, int64_t ldb, float* workspace, int64_t workspace_floats,
+                                     int32_t* n_parts, ebn_stream_t stream) {
+  EBN_REQUIRE(M > 0 && N > 0 && K >= 0 && n_parts, EBN_ERR_BAD_ARG);
+  EBN_REQUIRE(A && B && workspace && workspace_floats >= M * N, EBN_ERR_BAD_ARG);
+  EBN_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? K : N), EBN_ERR_BAD_ARG);
+  return gemm_dispatch(transA, transB, M, N, K, alpha, A, lda, B, ldb, 0.0f, workspace, N, workspace, workspace_floats, 0,
+                       GemmEpi{nullptr, nullptr, 0, 1, nullptr}, ebn_stream(stream), n_parts);
 }
 
 extern "C" int ebn_gemm_f32_site(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K, float alpha,

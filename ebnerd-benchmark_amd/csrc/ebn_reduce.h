@@ -49,15 +49,13 @@ static inline void ebn_colred_stage1(F f, float* partials, int64_t R, int C, hip
 // One 1024-thread block per 32 flattened (s,k) outputs: thread (col = t%32, part = t/32) sums every 32nd block
 // (coalesced 128-byte rows of partials; 4 independent loads in flight), then the 32 parts are combined in a fixed
 // order through LDS.  (With 8 parts the ~94 dependent iterations of a 24,000-row call site cost 15 us.)
-static __global__ __launch_bounds__(1024) void ebn_reduce_partials_kernel(const float* __restrict__ partials,
-                                                                         int nblk, int S, int A, float scale,
-                                                                         float* __restrict__ out0,
-                                                                         float* __restrict__ out1, int accumulate,
-                                                                         float* __restrict__ site0,
-                                                                         float* __restrict__ site1) {
-  __shared__ float sm[32][33];
+// (the body, shared with the merged finishing pass of a training step: ebn_grad_finish_f32 in ebn_finish.hip; `blk` = index of the
+// 1024-thread block among the blocks of THIS reduction, `sm` = 32 x 33 floats of LDS)
+static __device__ __forceinline__ void ebn_reduce_partials_body(float (*sm)[33], int blk, const float* __restrict__ partials, int nblk, int S, int A,
+                                                              float scale, float* __restrict__ out0, float* __restrict__ out1, int accumulate,
+                                                              float* __restrict__ site0, float* __restrict__ site1) {
   const int col = threadIdx.x & 31, part = threadIdx.x >> 5;
-  const int idx = blockIdx.x * 32 + col;  // flattened (s, k)
+  const int idx = blk * 32 + col;  // flattened (s, k)
   const bool ok = idx < S * A;
   float acc = 0.f;
   if (ok) {
@@ -83,6 +81,16 @@ static __global__ __launch_bounds__(1024) void ebn_reduce_partials_kernel(const 
     float* st = (s == 0) ? site0 : site1;
     if (st != nullptr) st[k] = t;
   }
+}
+
+static __global__ __launch_bounds__(1024) void ebn_reduce_partials_kernel(const float* __restrict__ partials,
+                                                                         int nblk, int S, int A, float scale,
+                                                                         float* __restrict__ out0,
+                                                                         float* __restrict__ out1, int accumulate,
+                                                                         float* __restrict__ site0,
+                                                                         float* __restrict__ site1) {
+  __shared__ float sm[32][33];
+  ebn_reduce_partials_body(sm, blockIdx.x, partials, nblk, S, A, scale, out0, out1, accumulate, site0, site1);
 }
 
 static inline void ebn_reduce_partials(const float* partials, int64_t nb, int S, int A, float scale, float* out0,

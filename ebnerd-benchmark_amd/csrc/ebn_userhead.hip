@@ -12,6 +12,7 @@
 // Same formulas as ebn_attpool.hip / ebn_score_optim.hip (un-stabilised exp with +1e-7, softmax scorer, the three loss
 // kinds); summation orders are this kernel's own and fixed.
 #include "ebn_common.h"
+#include "ebn_finish.h"
 
 namespace {
 
@@ -273,34 +274,12 @@ __global__ __launch_bounds__(HEAD_THREADS) void user_head_train_kernel(HeadArgs 
   }
 }
 
-// d(q), d(b) = sum over impressions of the partials (fixed order b = 0, 1, ...); block gridDim.x - 1: the batch loss
 __global__ __launch_bounds__(256) void user_head_finish_kernel(const float* __restrict__ partials, int64_t B, int A,
                                                                float* __restrict__ dq, float* __restrict__ db,
                                                                const float* __restrict__ loss_rows,
                                                                float* __restrict__ loss_out) {
-  if (blockIdx.x == gridDim.x - 1) {
-    __shared__ float sw[4];
-    float s = 0.f;
-    for (int64_t i = threadIdx.x; i < B; i += 256) s += loss_rows[i];
-    s = ebn_wave_sum(s);
-    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) loss_out[0] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
-    return;
-  }
-  const int idx = blockIdx.x * 256 + threadIdx.x;  // flattened (s, k)
-  if (idx >= 2 * A) return;
-  const int s = idx / A, k = idx - s * A;
-  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;  // four loads in flight; combined in a fixed order
-  int64_t b = 0;
-  for (; b + 4 <= B; b += 4) {
-    acc0 += partials[((b + 0) * 2 + s) * A + k];
-    acc1 += partials[((b + 1) * 2 + s) * A + k];
-    acc2 += partials[((b + 2) * 2 + s) * A + k];
-    acc3 += partials[((b + 3) * 2 + s) * A + k];
-  }
-  for (; b < B; ++b) acc0 += partials[(b * 2 + s) * A + k];
-  (s == 0 ? dq : db)[k] = (acc0 + acc1) + (acc2 + acc3);
+  __shared__ float sw[4];
+  ebn_user_head_finish_body(sw, blockIdx.x, gridDim.x, partials, B, A, dq, db, loss_rows, loss_out);
 }
 
 size_t head_lds_bytes(int L, int C, int E, int A) {
@@ -323,7 +302,7 @@ extern "C" int ebn_user_head_train_f32(float* U, const float* b, const float* q,
                                        float* db, float* partials, int64_t B, int32_t L, int32_t C, int32_t E, int32_t A,
                                        int32_t loss_kind, float inv_batch, ebn_stream_t stream) {
   EBN_REQUIRE(U && b && q && X && cand && labels && w && user && scores && probs && loss_rows && loss_out && dcand && duser &&
-                  de && dq && db && partials,
+                  de && partials && ((dq != nullptr) == (db != nullptr)),
               EBN_ERR_BAD_ARG);
   EBN_REQUIRE(B >= 0 && L > 0 && C > 0 && E > 0 && A > 0, EBN_ERR_BAD_ARG);
   EBN_REQUIRE(loss_kind >= 0 && loss_kind <= 2 && ebn_user_head_supported(L, C, E, A), EBN_ERR_UNSUPPORTED);
@@ -340,6 +319,7 @@ extern "C" int ebn_user_head_train_f32(float* U, const float* b, const float* q,
   HeadArgs a{U, b, q, X, cand, labels, w, user, scores, probs, loss_rows, dcand, duser, de, partials, L, C, E, A, loss_kind, inv_batch};
   hipLaunchKernelGGL(user_head_train_kernel, dim3(static_cast<unsigned>(B)), dim3(HEAD_THREADS), lds, s, a);
   EBN_CHECK_LAUNCH();
+  if (dq == nullptr) return EBN_OK;  // d(q), d(b) and the batch loss are left to ebn_grad_finish_f32 (EBN_FINISH_HEAD job)
   hipLaunchKernelGGL(user_head_finish_kernel, dim3(static_cast<unsigned>(ebn_ceil_div(2 * A, 256) + 1)), dim3(256), 0, s, partials, B, A,
                      dq, db, loss_rows, loss_out);
   EBN_CHECK_LAUNCH();

@@ -55,6 +55,16 @@ class EncoderScratch(ctypes.Structure):
                 ("gemm_ws_floats", ctypes.c_int64)]
 
 
+class FinishJob(ctypes.Structure):
+    """ebn_finish_job: one finishing pass of ebn_grad_finish_f32 (kind 0 split-K sum, 1 column-partials sum, 2 head finish)."""
+    _fields_ = [("kind", ctypes.c_int32), ("n_parts", ctypes.c_int32), ("rows", ctypes.c_int64), ("cols", ctypes.c_int64),
+                ("partials", ctypes.c_void_p), ("out0", ctypes.c_void_p), ("out1", ctypes.c_void_p), ("ld", ctypes.c_int64),
+                ("beta", ctypes.c_float), ("scale", ctypes.c_float), ("loss_rows", ctypes.c_void_p), ("loss_out", ctypes.c_void_p)]
+
+
+FINISH_SPLITK, FINISH_COLRED, FINISH_HEAD, FINISH_MAX_JOBS = 0, 1, 2, 6
+
+
 # ---- header parser -------------------------------------------------------
 _PROTO = re.compile(r"^(int64_t|int|const char\*)\s+(ebn_\w+)\s*\(([^;{}]*?)\)\s*;", re.M | re.S)
 

@@ -208,6 +208,10 @@ class NRMSEngine:
         # streaming kernels it replaces fill the chip better -- kept for validation, off by default
         self.fuse_attpool_bwd = False
         self.fuse_user_head = True  # False: the per-impression head of a step as its six separate launches (validation)
+        # True: the four small finishing passes of the backward (split-K sums of dW and dWqkv, AttLayer2 d(q) / d(b) column sums, the
+        # per-impression head's d(q) / d(b) / loss sums) run as ONE launch at the end of the backward (ebn_grad_finish_f32) instead
+        # of four launches of the dependent chain; same summation orders, same bits (False: the stand-alone passes -- validation)
+        self.defer_finish = True
         self.atomic_table_grad = False  # True: one 64-bit atomic per gradient element instead of combining the duplicates of every 64
         # consecutive tokens first (same bits; the validation / A-B form: 2.8-3.1x slower on Zipf ids, profiles/r04_*zipf*)
         self.graph_collectives = False  # multi-rank: capture the collectives into the step's hipGraph as well (experimental)
@@ -1004,6 +1008,11 @@ class NRMSEngine:
         if not (self.use_graph and self.graph_capable and self.world > 1):
             self.graph_collectives = False
             return False
+        if torch.distributed.get_backend(self.pg) != "nccl":
+            # only RCCL's collectives are stream operations that a hipGraph can hold; gloo's run on the host (attempting to capture
+            # one invalidates the capture and leaves the stream unusable) -- nothing to try, the segment form stays
+            self.graph_collectives = False
+            return False
         torch.cuda.synchronize()
         snap = [t.clone() for t in self._state_tensors()]
 
@@ -1045,6 +1054,8 @@ class NRMSEngine:
             nb.scores = torch.empty(nb.n_seq, device=self.device)
             nb.probs = torch.empty(nb.n_seq, device=self.device)
             nb.labels = torch.empty(nb.n_seq, device=self.device)
+        if self._deferred(C):
+            self._defer_bufs(nb)  # (outside any capture)
         if not hasattr(ub, "duser"):
             ub.duser = torch.empty(ub.n_seq, E, device=self.device)
             ub.loss_rows = torch.empty(ub.n_seq, device=self.device)
@@ -1171,17 +1182,104 @@ class NRMSEngine:
         nb, ub = self._train_bufs(B, C)
         st = _hip.ptr(self.state)
         site1, p1 = (1, self.p) if self.p > 0 else (-1, 0.0)
+        deferred = self._deferred(C)
         if part == "b":
+            if deferred:
+                return self._news_bwd_deferred(nb, ub, B, N, "p2")
             return self._news_bwd_p2(nb, N, nb.X, nb.dNE, site1, p1)
         if part in ("all", "a"):
-            self._fwd_user_stage_kernels(B, C, nb, ub)
+            if deferred:
+                self._news_forward(nb, N, True, B * H, looked_up=True)
+                self._user_stage_deferred(B, C, nb, ub)
+            else:
+                self._fwd_user_stage_kernels(B, C, nb, ub)
         if part == "a":
+            if deferred:
+                return self._news_bwd_deferred(nb, ub, B, N, "p1")
             return self._news_bwd_p1(nb, N, nb.dNE)
-        if part == "all":
+        if part == "all" and deferred:
+            self._news_bwd_deferred(nb, ub, B, N, "p1")
+            self._news_bwd_deferred(nb, ub, B, N, "p2")
+            if nb.dX is not None:
+                self._news_bwd_p3(nb, N, nb.dX)
+        elif part == "all":
             self._encoder_bwd("n", nb, N, nb.X, nb.dNE, nb.dX, B * H)
         elif nb.dX is not None:  # part "c"
             self._news_bwd_p3(nb, N, nb.dX)
         self._table_grad_kernels(nb, N, sparse_table_grads)
+
+    def _deferred(self, C) -> bool:
+        """whether this step leaves its finishing passes to ONE ebn_grad_finish_f32 launch (the standard configuration: no
+        per-token Dense stack, exact precision, the one-launch head and the pooling term folded into the attention backward)"""
+        L = _hip.lib()
+        return bool(self.defer_finish and self.mlp is None and self.precision == "exact" and self.fuse_user_head and not self.fuse_attpool_bwd
+                    and self._fold_pooling(self.T) and self._fold_pooling(self.H)
+                    and int(L.ebn_user_head_supported(self.H, C, self.E, self.A)) != 0)
+
+    def _defer_bufs(self, nb):
+        if getattr(nb, "ws_dw", None) is None:
+            L = _hip.lib()
+            nb.ws_dw = torch.empty(max(int(L.ebn_gemm_partials_workspace_floats(self.E, self.A, nb.R)), 1), device=self.device)
+            nb.ws_dwqkv = torch.empty(max(int(L.ebn_gemm_partials_workspace_floats(self.D, 3 * self.E, nb.R)), 1), device=self.device)
+            nb.finish_jobs = {}
+        return nb
+
+    def _user_stage_deferred(self, B, C, nb, ub):
+        """ebn_user_stage_train_f32's fused branch (csrc/ebn_encoder.hip), kernel by kernel, with the head's reduction launch left
+        out: user encoder forward up to the AttLayer2 matmul, the one-launch head, the two gradient-GEMM pairs around the
+        attention backward.  Writes d(cand), d(history news vectors) = dNE[:B*H], the user encoder's weight gradients except
+        d(q) / d(b), and the per-impression partials / loss rows the finishing pass sums."""
+        S, H, E, A = _hip.stream_handle, self.H, self.E, self.A
+        R = B * H
+        pv, g = self.params.view, self.params.g
+        ws, wsn = _hip.ptr(ub.ws), ub.ws.numel()
+        one, zero = ctypes.c_float(1.0), ctypes.c_float(0.0)
+        X, cand, dcand = nb.out, nb.out[B * H:], nb.dNE[B * H:]
+        _hip.call("ebn_gemm_f32_site", 0, 0, R, 3 * E, E, one, _hip.ptr(X), E, _hip.ptr(pv("u_Wqkv")), 3 * E, zero, _hip.ptr(ub.QKV), 3 * E, ws, wsn, 1, S())
+        _hip.call("ebn_attn_fwd_f32", _hip.ptr(ub.QKV), 3 * E, _hip.ptr(ub.Y), E, B, H, self.h, self.d, None, -1, zero, S())
+        _hip.call("ebn_gemm_f32_ws", 0, 0, R, A, E, one, _hip.ptr(ub.Y), E, _hip.ptr(pv("u_W")), A, zero, _hip.ptr(ub.U), A, ws, wsn, S())
+        _hip.call("ebn_user_head_train_f32", _hip.ptr(ub.U), _hip.ptr(pv("u_b")), _hip.ptr(pv("u_q")), _hip.ptr(ub.Y), _hip.ptr(cand), _hip.ptr(nb.labels),
+                  _hip.ptr(ub.w), _hip.ptr(ub.out), _hip.ptr(nb.scores), _hip.ptr(nb.probs), _hip.ptr(ub.loss_rows), _hip.ptr(self.loss_dev), _hip.ptr(dcand),
+                  _hip.ptr(ub.duser), _hip.ptr(ub.de), None, None, _hip.ptr(ub.head_partials), B, H, C, E, A, self.loss_kind, ctypes.c_float(1.0 / B), S())
+        _hip.call("ebn_dense_bwd_pair_f32", R, E, A, _hip.ptr(ub.Y), E, _hip.ptr(ub.U), A, _hip.ptr(pv("u_W")), A, zero, _hip.ptr(g("u_W")), A,
+                  _hip.ptr(ub.dY), E, ws, wsn, S())
+        _hip.call("ebn_attn_bwd_pooled_f32", _hip.ptr(ub.QKV), 3 * E, _hip.ptr(ub.dY), E, _hip.ptr(ub.w), _hip.ptr(ub.duser), E, _hip.ptr(ub.dQKV), 3 * E,
+                  B, H, self.h, self.d, None, -1, zero, S())
+        _hip.call("ebn_dense_bwd_pair_f32", R, E, 3 * E, _hip.ptr(X), E, _hip.ptr(ub.dQKV), 3 * E, _hip.ptr(pv("u_Wqkv")), 3 * E, zero, _hip.ptr(g("u_Wqkv")),
+                  3 * E, _hip.ptr(nb.dNE), E, ws, wsn, S())
+
+    def _news_bwd_deferred(self, nb, ub, B, N, part):
+        """The news encoder's backward (the kernels of ebn_encoder_bwd_f32 in its order) with the combining passes of its three
+        reductions left out, then -- after the last weight gradient -- ONE finishing launch for them and for the user head's.
+        part: "p1" AttLayer2 backward | "p2" attention core + dWqkv + the finishing launch."""
+        S, E, A, T, D = _hip.stream_handle, self.E, self.A, self.T, self.D
+        R = N * T
+        pv, g = self.params.view, self.params.g
+        one, zero = ctypes.c_float(1.0), ctypes.c_float(0.0)
+        L = _hip.lib()
+        self._defer_bufs(nb)
+        if part == "p1":
+            _hip.call("ebn_attpool_bwd_pool_f32", _hip.ptr(nb.Y), _hip.ptr(nb.w), _hip.ptr(nb.dNE), None, _hip.ptr(nb.de), N, T, E, S())
+            _hip.call("ebn_attpool_bwd_dpre_f32", _hip.ptr(nb.U), _hip.ptr(pv("n_q")), _hip.ptr(nb.de), None, None, _hip.ptr(nb.partials), R, A, 0, S())
+            n = ctypes.c_int32(0)
+            _hip.call("ebn_gemm_f32_partials", 1, 0, E, A, R, one, _hip.ptr(nb.Y), E, _hip.ptr(nb.U), A, _hip.ptr(nb.ws_dw), nb.ws_dw.numel(), ctypes.byref(n), S())
+            nb.finish_jobs["dW"] = int(n.value)
+            _hip.call("ebn_gemm_f32_ws", 0, 1, R, E, A, one, _hip.ptr(nb.U), A, _hip.ptr(pv("n_W")), A, zero, _hip.ptr(nb.dY), E, _hip.ptr(nb.ws), nb.ws.numel(), S())
+            return
+        site, p = (1, self.p) if self.p > 0 else (-1, 0.0)
+        _hip.call("ebn_attn_bwd_pooled_f32", _hip.ptr(nb.QKV), 3 * E, _hip.ptr(nb.dY), E, _hip.ptr(nb.w), _hip.ptr(nb.dNE), E, _hip.ptr(nb.dQKV), 3 * E,
+                  N, T, self.h, self.d, _hip.ptr(self.state), site, ctypes.c_float(p), S())
+        n = ctypes.c_int32(0)
+        _hip.call("ebn_gemm_f32_partials", 1, 0, D, 3 * E, R, one, _hip.ptr(nb.X), D, _hip.ptr(nb.dQKV), 3 * E, _hip.ptr(nb.ws_dwqkv), nb.ws_dwqkv.numel(),
+                  ctypes.byref(n), S())
+        jobs = (_hip.FinishJob * 4)()
+        jobs[0] = _hip.FinishJob(_hip.FINISH_SPLITK, int(n.value), D, 3 * E, nb.ws_dwqkv.data_ptr(), g("n_Wqkv").data_ptr(), None, 3 * E, 0.0, 1.0, None, None)
+        jobs[1] = _hip.FinishJob(_hip.FINISH_SPLITK, nb.finish_jobs["dW"], E, A, nb.ws_dw.data_ptr(), g("n_W").data_ptr(), None, A, 0.0, 1.0, None, None)
+        jobs[2] = _hip.FinishJob(_hip.FINISH_COLRED, int(L.ebn_attpool_partials_len(R, A)) // (2 * A), 1, A, nb.partials.data_ptr(), g("n_q").data_ptr(),
+                                 g("n_b").data_ptr(), A, 0.0, 1.0, None, None)
+        jobs[3] = _hip.FinishJob(_hip.FINISH_HEAD, 1, B, A, ub.head_partials.data_ptr(), g("u_q").data_ptr(), g("u_b").data_ptr(), A, 0.0, 1.0,
+                                 ub.loss_rows.data_ptr(), self.loss_dev.data_ptr())
+        _hip.call("ebn_grad_finish_f32", jobs, 4, S())
 
     def _fwd_user_stage_kernels(self, B, C, nb, ub):
         H, E = self.H, self.E

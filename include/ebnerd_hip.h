@@ -176,6 +176,41 @@ int ebn_gemm_f32_ws(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_
                     const float* A, int64_t lda, const float* B, int64_t ldb, float beta, float* C,
                     int64_t ldc, float* workspace, int64_t workspace_floats, ebn_stream_t stream);
 
+/* The product WITHOUT its combining pass: alpha * op(A).op(B) is left in `workspace` as *n_parts dense [M][N] slices whose sum it
+ * is -- the deterministic split-K partials of a weight-gradient GEMM (K.dot backward, layers.py:65,214-226), or the product
+ * itself as one slice when the plan does not split K.  ebn_grad_finish_f32 (EBN_FINISH_SPLITK job) sums them, together with the
+ * other small finishing passes of the step, in one launch.  workspace: ebn_gemm_partials_workspace_floats(M, N, K) floats
+ * (with fewer, down to M * N, the plan settles for fewer slices); *n_parts is a HOST out-parameter, known when the call returns. */
+int64_t ebn_gemm_partials_workspace_floats(int64_t M, int64_t N, int64_t K);
+int ebn_gemm_f32_partials(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K, float alpha, const float* A,
+                          int64_t lda, const float* B, int64_t ldb, float* workspace, int64_t workspace_floats,
+                          int32_t* n_parts, ebn_stream_t stream);
+
+/* ---- the finishing passes of a training step's backward as ONE launch ----------------------------------------------------
+ * Second stages of deterministic reductions their producers left out (see ebn_gemm_f32_partials, ebn_attpool_bwd_dpre_f32,
+ * ebn_user_head_train_f32); same summation order as the stand-alone passes, hence the same bits.  `jobs` is a HOST array (copied
+ * into the launch).  kind EBN_FINISH_SPLITK: out0[r * ld + c] = sum_z partials[z][r][c] (+ beta * out0), z < n_parts, r < rows,
+ * c < cols.  EBN_FINISH_COLRED: partials [n_parts][2][cols] -> out0[c] = scale * sum_p partials[p][0][c], out1 likewise with
+ * [p][1][c] (accumulated into when beta != 0).  EBN_FINISH_HEAD: partials [rows][2][cols] -> out0 = d(q), out1 = d(b) summed
+ * over the rows in a fixed order, loss_out[0] = sum(loss_rows[0 .. rows)).                                                  */
+#define EBN_FINISH_SPLITK 0
+#define EBN_FINISH_COLRED 1
+#define EBN_FINISH_HEAD 2
+#define EBN_FINISH_MAX_JOBS 6
+typedef struct {
+  int32_t kind;
+  int32_t n_parts;
+  int64_t rows, cols;
+  const float* partials;
+  float* out0;
+  float* out1;
+  int64_t ld;
+  float beta, scale;
+  const float* loss_rows;
+  float* loss_out;
+} ebn_finish_job;
+int ebn_grad_finish_f32(const ebn_finish_job* jobs, int32_t n_jobs, ebn_stream_t stream);
+
 /* Same again; `site` only labels the kernel instantiation (0 generic, 1 = Q|K|V projection of an encoder) so that
  * per-kernel profiler summaries keep the roofline kernel of bench.py apart from other call sites.               */
 int ebn_gemm_f32_site(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K, float alpha,
@@ -244,7 +279,9 @@ int ebn_attpool_bwd_pool_f32(const float* X, const float* w, const float* dout, 
                              ebn_stream_t stream);
 /* bwd step 2: dq[k] = sum_r de[r] U[r,k]; U <- dpre = de*q*(1-U^2) in place;
  * db[k] = sum_r dpre[r,k].  `partials` is scratch of ebn_attpool_partials_len(R, A)
- * floats; dq/db are ACCUMULATED into when accumulate != 0 (else overwritten).       */
+ * floats; dq/db are ACCUMULATED into when accumulate != 0 (else overwritten).
+ * dq == db == NULL: only the row-block partials are written -- their sum is left to ebn_grad_finish_f32
+ * (EBN_FINISH_COLRED job: partials, n_parts = ebn_attpool_partials_len(R, A) / (2 A) row blocks, cols = A).  */
 int64_t ebn_attpool_partials_len(int64_t R, int32_t A);
 int ebn_attpool_bwd_dpre_f32(float* U, const float* q, const float* de, float* dq, float* db,
                              float* partials, int64_t R, int32_t A, int32_t accumulate,
@@ -361,7 +398,9 @@ int ebn_score_loss_train_f32(const float* cand, const float* user, const float* 
  * its L x A, L x E and C x E rows in LDS: ebn_user_head_supported(L, C, E, A) says whether they fit (E, A multiples of 4;
  * history_size 50 at E = 400, A = 200 does).  U [B*L, A], X [B*L, E], cand / dcand [B*C, E], labels / scores / probs [B*C],
  * w / de [B*L], user / duser [B, E], loss_rows [B], loss_out [1] = sum(loss_rows), dq / db [A] (overwritten),
- * partials: ebn_user_head_partials_len(B, A) floats of scratch.  16-byte aligned pointers.                              */
+ * partials: ebn_user_head_partials_len(B, A) floats of scratch.  16-byte aligned pointers.
+ * dq == db == NULL: the fixed-order reduction is left to ebn_grad_finish_f32 (EBN_FINISH_HEAD job: partials, rows = B, cols = A,
+ * loss_rows -> loss_out); loss_out is not written by this call then.                                                       */
 int ebn_user_head_supported(int32_t L, int32_t C, int32_t E, int32_t A);
 int64_t ebn_user_head_partials_len(int64_t B, int32_t A);
 int ebn_user_head_train_f32(float* U, const float* b, const float* q, const float* X, const float* cand, const float* labels,

@@ -16,7 +16,7 @@ sys.path.insert(0, str(ROOT / "ebnerd-benchmark_amd"))
 from ebrec._hip import binding as B  # noqa: E402  (header parser + struct mirrors; does not load the product library)
 
 HOST_STRUCTS = {"ebn_encoder_dims": B.EncoderDims, "ebn_encoder_params": B.EncoderParams, "ebn_encoder_acts": B.EncoderActs,
-                "ebn_encoder_grads": B.EncoderGrads, "ebn_encoder_scratch": B.EncoderScratch}
+                "ebn_encoder_grads": B.EncoderGrads, "ebn_encoder_scratch": B.EncoderScratch, "ebn_finish_job": B.FinishJob * B.FINISH_MAX_JOBS}
 FAKE_DEV = 0x7E0000000000  # a 16-byte-aligned address no host mapping uses: device pointers are never dereferenced on the host
 SIZES = [0, 1, 2, 3, 5, 7, 16, 20, 30, 31, 32, 33, 50, 63, 64, 65, 100, 127, 128, 200, 255, 256, 257, 300, 400, 512, 768, 1000, 1024, 1200,
          4096, 24000, 32000, 52800, 250002, 1 << 20, (1 << 24) + 1, (1 << 31) - 1, 1 << 31, (1 << 31) + 7, 1 << 33, 1 << 40, (1 << 62) + 3]
@@ -37,6 +37,18 @@ def value(decl, rng, mode, keep):
         stype = next((t for n, t in HOST_STRUCTS.items() if n in decl), None)
         if stype is not None:  # host structs the entry point reads: real memory, random contents
             s = stype()
+            if isinstance(s, ctypes.Array):  # a host ARRAY of structs (ebn_finish_job jobs[]): random contents in every element
+                for el in s:
+                    for fname, ftype in el._fields_:
+                        if ftype is ctypes.c_void_p:
+                            setattr(el, fname, None if rng.random() < 0.1 else FAKE_DEV + 4096 * rng.randrange(1 << 16))
+                        elif ftype is ctypes.c_float:
+                            setattr(el, fname, rng.choice([0.0, 1.0, -1.0]))
+                        else:
+                            bits = 63 if ftype is ctypes.c_int64 else 31
+                            setattr(el, fname, rng.choice([v for v in SIZES[:30] + [-1, 0, 1, 2, 3] if v < (1 << bits)]))
+                keep.append(s)
+                return ctypes.cast(s, ctypes.c_void_p)
             for fname, ftype in s._fields_:
                 if ftype is ctypes.c_void_p:
                     setattr(s, fname, None if rng.random() < 0.05 else FAKE_DEV + 4096 * rng.randrange(1 << 16))
@@ -47,7 +59,7 @@ def value(decl, rng, mode, keep):
                     setattr(s, fname, rng.choice([v for v in SIZES + [-1] if v < (1 << bits)]))
             keep.append(s)
             return ctypes.cast(ctypes.pointer(s), ctypes.c_void_p)
-        if decl.startswith("int32_t*") and decl.split()[-1] in ("bm", "bn", "splits"):  # host out-parameters of ebn_gemm_plan
+        if decl.startswith("int32_t*") and decl.split()[-1] in ("bm", "bn", "splits", "n_parts"):  # host out-parameters of ebn_gemm_plan
             v = ctypes.c_int32()
             keep.append(v)
             return ctypes.cast(ctypes.pointer(v), ctypes.c_void_p)

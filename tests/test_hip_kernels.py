@@ -1118,3 +1118,100 @@ def test_duplicate_combining_gradient_accumulation_is_the_atomic_one_bit_for_bit
     big[3, 1] = 3e6  # a term beyond 2^21: the range flag, like the atomic form
     hip.call("ebn_embedding_grad_scatter_fixed", P(d_ids), P(dev(big)), P(acc_s), n_tok, D, V, None, -1, ctypes.c_float(0.0), P(fs), S())
     assert int(fs.item()) == (1 if (0 <= ids[3] < V) else 0)
+
+
+# ---------------------------------------------------------------- the finishing passes of a step's backward as one launch
+def _finish_job(hip, kind, n_parts, rows, cols, partials, out0, out1=None, ld=0, beta=0.0, scale=1.0, loss_rows=None, loss_out=None):
+    dp = lambda t: None if t is None else t.data_ptr()
+    return hip.FinishJob(kind, n_parts, rows, cols, dp(partials), dp(out0), dp(out1), ld, beta, scale, dp(loss_rows), dp(loss_out))
+
+
+@pytest.mark.parametrize("tA,tB,M,N,K", [(1, 0, 400, 200, 24000), (1, 0, 1024, 1200, 6000), (0, 0, 64, 64, 16), (1, 0, 300, 1200, 5000), (0, 1, 640, 400, 200),
+                                         (0, 0, 4096, 200, 400)])
+def test_gemm_partials_plus_finishing_pass_is_the_gemm_bit_for_bit(hip, tA, tB, M, N, K):
+    """ebn_gemm_f32_partials leaves alpha * op(A).op(B) as n_parts dense slices (the split-K partials without their combining launch, or
+    the product itself); ebn_grad_finish_f32 (EBN_FINISH_SPLITK) sums them in the order of the stand-alone combine: the same bits as
+    ebn_gemm_f32_ws on the same workspace size -- split (weight gradients), unsplit, small-output and LDS-free kernels."""
+    rng = np.random.default_rng(M + N + K)
+    A = dev(rng.standard_normal((K, M) if tA else (M, K)).astype(np.float32))
+    B = dev(rng.standard_normal((N, K) if tB else (K, N)).astype(np.float32))
+    n_ws = int(hip.lib().ebn_gemm_partials_workspace_floats(M, N, K))
+    assert n_ws >= M * N and n_ws % (M * N) == 0
+    ws, ws2 = torch.empty(n_ws, device="cuda"), torch.empty(n_ws, device="cuda")
+    C1, C2 = torch.full((M, N), 3.0, device="cuda"), torch.full((M, N + 8), 5.0, device="cuda")
+    gemm(tA, tB, M, N, K, 0.5, A, A.shape[1], B, B.shape[1], 0.0, C1, N, ws)
+    n = ctypes.c_int32(-1)
+    hip.call("ebn_gemm_f32_partials", tA, tB, M, N, K, ctypes.c_float(0.5), P(A), A.shape[1], P(B), B.shape[1], P(ws2), n_ws, ctypes.byref(n), S())
+    assert 1 <= n.value <= n_ws // (M * N)
+    jobs = (hip.FinishJob * 1)(_finish_job(hip, hip.FINISH_SPLITK, n.value, M, N, ws2, C2, ld=N + 8))
+    hip.call("ebn_grad_finish_f32", jobs, 1, S())
+    assert torch.equal(C2[:, :N], C1) and bool((C2[:, N:] == 5.0).all())  # same bits; the padding of a strided C untouched
+    ref = 0.5 * ((A.double().t() if tA else A.double()) @ (B.double().t() if tB else B.double()))
+    assert_close(host(C2[:, :N]), ref.cpu().numpy(), rtol=2e-6, atol=1e-5 + 3e-7 * K, what="partials + finish vs float64")
+    # beta != 0: C = sum + beta * C
+    C3 = C1.clone()
+    jobs = (hip.FinishJob * 1)(_finish_job(hip, hip.FINISH_SPLITK, n.value, M, N, ws2, C3, ld=N, beta=2.0))
+    hip.call("ebn_grad_finish_f32", jobs, 1, S())
+    assert_close(host(C3), 3.0 * host(C1), rtol=1e-6, atol=1e-6, what="finish with beta")
+
+
+def test_one_finishing_launch_equals_the_four_stand_alone_passes(hip):
+    """ebn_grad_finish_f32 with the jobs of a c2-shaped step -- two split-K sums, the AttLayer2 d(q) / d(b) column sums of 24000 rows, the
+    per-impression head's d(q) / d(b) / loss sums of 32 impressions -- against the producers run WITH their own finishing launches:
+    every output bit for bit (the device bodies and summation orders are shared)."""
+    rng = np.random.default_rng(77)
+    R, A, E, B, L, C = 24000, 200, 400, 32, 20, 5
+    f = lambda *shape: torch.full(shape, 7.0, device="cuda")
+    # AttLayer2 backward step 2 (news level): stand-alone vs deferred
+    U0 = np.tanh(rng.standard_normal((R, A))).astype(np.float32)
+    q, de = (rng.standard_normal(A) * 0.3).astype(np.float32), rng.standard_normal(R).astype(np.float32)
+    n_part = int(hip.lib().ebn_attpool_partials_len(R, A))
+    Ua, Ub, pa, pb = dev(U0), dev(U0), f(n_part), f(n_part)
+    dq_a, db_a, dq_b, db_b = f(A), f(A), f(A), f(A)
+    hip.call("ebn_attpool_bwd_dpre_f32", P(Ua), P(dev(q)), P(dev(de)), P(dq_a), P(db_a), P(pa), R, A, 0, S())
+    hip.call("ebn_attpool_bwd_dpre_f32", P(Ub), P(dev(q)), P(dev(de)), None, None, P(pb), R, A, 0, S())
+    assert torch.equal(Ua, Ub) and torch.equal(pa, pb) and bool((dq_b == 7.0).all())  # the deferred call wrote the partials, not d(q)
+    # the per-impression head: stand-alone vs deferred
+    Upre = (rng.standard_normal((B * L, A)) * 0.7).astype(np.float32)
+    bb, X = (rng.standard_normal(A) * 0.2).astype(np.float32), (rng.standard_normal((B * L, E)) * 0.5).astype(np.float32)
+    cand = (rng.standard_normal((B * C, E)) * 0.4).astype(np.float32)
+    y = np.eye(C, dtype=np.float32)[rng.integers(0, C, B)]
+
+    def head(defer):
+        o = dict(U=dev(Upre), w=f(B * L), user=f(B, E), scores=f(B * C), probs=f(B * C), rows=f(B), loss=f(1), dcand=f(B * C, E), duser=f(B, E), de=f(B * L),
+                 dq=f(A), db=f(A), part=f(int(hip.lib().ebn_user_head_partials_len(B, A))))
+        hip.call("ebn_user_head_train_f32", P(o["U"]), P(dev(bb)), P(dev(q)), P(dev(X)), P(dev(cand)), P(dev(y)), P(o["w"]), P(o["user"]), P(o["scores"]),
+                 P(o["probs"]), P(o["rows"]), P(o["loss"]), P(o["dcand"]), P(o["duser"]), P(o["de"]), None if defer else P(o["dq"]), None if defer else P(o["db"]),
+                 P(o["part"]), B, L, C, E, A, 0, ctypes.c_float(1.0 / B), S())
+        return o
+
+    ha, hb = head(False), head(True)
+    assert torch.equal(ha["part"], hb["part"]) and torch.equal(ha["rows"], hb["rows"]) and float(hb["loss"].item()) == 7.0
+    # two weight-gradient GEMMs: stand-alone vs partials
+    Y, dpre = dev(rng.standard_normal((R, E)).astype(np.float32)), dev(rng.standard_normal((R, A)).astype(np.float32))
+    Xs, dQ = dev(rng.standard_normal((6000, 256)).astype(np.float32)), dev(rng.standard_normal((6000, 1200)).astype(np.float32))
+    dW_a, dW_b, dWq_a, dWq_b = f(E, A), f(E, A), f(256, 1200), f(256, 1200)
+    n1, n2 = int(hip.lib().ebn_gemm_partials_workspace_floats(E, A, R)), int(hip.lib().ebn_gemm_partials_workspace_floats(256, 1200, 6000))
+    w1, w2, wa = torch.empty(n1, device="cuda"), torch.empty(n2, device="cuda"), torch.empty(max(n1, n2), device="cuda")
+    gemm(1, 0, E, A, R, 1.0, Y, E, dpre, A, 0.0, dW_a, A, wa[:n1])
+    gemm(1, 0, 256, 1200, 6000, 1.0, Xs, 256, dQ, 1200, 0.0, dWq_a, 1200, wa[:n2])
+    p1, p2 = ctypes.c_int32(), ctypes.c_int32()
+    hip.call("ebn_gemm_f32_partials", 1, 0, E, A, R, ctypes.c_float(1.0), P(Y), E, P(dpre), A, P(w1), n1, ctypes.byref(p1), S())
+    hip.call("ebn_gemm_f32_partials", 1, 0, 256, 1200, 6000, ctypes.c_float(1.0), P(Xs), 256, P(dQ), 1200, P(w2), n2, ctypes.byref(p2), S())
+    assert p1.value > 1 and p2.value > 1
+    jobs = (hip.FinishJob * 4)(
+        _finish_job(hip, hip.FINISH_SPLITK, p2.value, 256, 1200, w2, dWq_b, ld=1200),
+        _finish_job(hip, hip.FINISH_SPLITK, p1.value, E, A, w1, dW_b, ld=A),
+        _finish_job(hip, hip.FINISH_COLRED, n_part // (2 * A), 1, A, pb, dq_b, db_b, ld=A),
+        _finish_job(hip, hip.FINISH_HEAD, 1, B, A, hb["part"], hb["dq"], hb["db"], ld=A, loss_rows=hb["rows"], loss_out=hb["loss"]))
+    hip.call("ebn_grad_finish_f32", jobs, 4, S())
+    for got, ref, what in ((dWq_b, dWq_a, "dWqkv"), (dW_b, dW_a, "dW"), (dq_b, dq_a, "news d(q)"), (db_b, db_a, "news d(b)"), (hb["dq"], ha["dq"], "user d(q)"),
+                           (hb["db"], ha["db"], "user d(b)"), (hb["loss"], ha["loss"], "batch loss")):
+        assert torch.equal(got, ref), what
+    # an empty list and empty jobs are no-ops; a malformed job is refused
+    hip.call("ebn_grad_finish_f32", None, 0, S())
+    jobs = (hip.FinishJob * 1)(_finish_job(hip, hip.FINISH_SPLITK, 3, 0, 200, w1, dW_b, ld=A))
+    hip.call("ebn_grad_finish_f32", jobs, 1, S())
+    bad = (hip.FinishJob * 1)(_finish_job(hip, 7, 1, 4, 4, w1, dW_b, ld=4))
+    with pytest.raises(hip.HipError):
+        hip.call("ebn_grad_finish_f32", bad, 1, S())

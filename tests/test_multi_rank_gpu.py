@@ -485,9 +485,10 @@ def test_two_rank_c5_full_width_row_sharded_step_equals_the_full_batch_oracle_st
 
 
 def _graph_collectives_check_worker(rank, world):
-    """verify_graph_collectives under gloo: host-side collectives cannot be captured into a hipGraph, so the self-check must come
-    back False on every rank, leave weights / moments / step counter / dropout keys exactly as they were, and training must go on
-    in the segment form -- bit-identical to a twin engine that never ran the check."""
+    """verify_graph_collectives under gloo: host-side collectives cannot be captured into a hipGraph (the check does not even try:
+    a failed capture leaves the stream unusable), so it must come back False on every rank, leave weights / moments / step counter
+    / dropout keys exactly as they were, and training must go on in the segment form -- bit-identical to a twin engine that never
+    ran the check.  (The accepting side of the check runs on RCCL: tests/test_rccl_single_rank_gpu.py.)"""
     from ebrec.models.newsrec import NRMSModel
 
     hp = make_hp(dropout=0.2, learning_rate=1e-3)

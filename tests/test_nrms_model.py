@@ -603,3 +603,32 @@ def test_news_encoder_units_per_layer_branch_matches_oracle(nrms, p, l2):
         assert_close(eng.mlp.bn_var[l].cpu().numpy(), Pn[f"n_bn{l}_var"], rtol=1e-5, atol=1e-6, what=f"moving var {l}")
     with pytest.raises(ValueError, match="must end with"):
         nrms(make_hp(head_num=4, head_dim=8, newsencoder_units_per_layer=[48, 30]), word_emb_dim=8, vocab_size=10)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("train_embedding,graph", [(False, True), (True, False)])
+def test_one_finishing_launch_of_the_backward_changes_no_bit_of_a_training_run(hip, train_embedding, graph):
+    """engine.defer_finish (default): the split-K sums of dW / dWqkv, the AttLayer2 d(q) / d(b) column sums and the head's d(q) / d(b) /
+    loss sums run as ONE launch at the end of the backward instead of four launches of the dependent chain.  Same summation orders:
+    three steps with it are bit-identical -- losses, every gradient, every weight -- to three steps with the stand-alone passes."""
+    from ebrec.models.newsrec import NRMSModel
+
+    hp = make_hp(dropout=0.2, learning_rate=1e-3)
+    rng = np.random.default_rng(3)
+    V, D = 700, 128
+    emb = rng.standard_normal((V, D)).astype(np.float32)
+    a = NRMSModel(hp, word2vec_embedding=emb, seed=5, train_embedding=train_embedding)
+    b = NRMSModel(hp, word2vec_embedding=emb, seed=5, train_embedding=train_embedding)
+    assert a._engine.defer_finish and a._engine._deferred(5)
+    b._engine.defer_finish = False
+    assert not b._engine._deferred(5)
+    if graph:
+        a._engine.enable_graphs()
+        b._engine.enable_graphs()
+    for t in range(3):
+        his, pred, y = batch(rng, 40, hp.history_size, 5, hp.title_size, V)  # 30 000 title tokens: the weight-gradient GEMMs split K
+        la, lb = float(a.train_step(his, pred, y).item()), float(b.train_step(his, pred, y).item())
+        assert la == lb, (t, la, lb)
+        assert torch.equal(a._engine.params.grad, b._engine.params.grad), t
+    for wa, wb in zip(a.model.get_weights(), b.model.get_weights()):
+        assert np.array_equal(wa, wb)
