@@ -5,15 +5,23 @@
 # --pmc passes are separate runs with --kernel-trace only (no sys/hip/hsa trace domains), as the pool requires.
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
-tag=${1:-r03}
+tag=${1:-r04}
 out=gpurun_out/$tag
 mkdir -p $out
 timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -5 > $out/pytest_gpu.log
 # the driver's command first (c2, CPU baseline included), then every other config
 python bench.py --steps 20 --warmup 5 > $out/bench_c2.json 2> $out/bench_c2.err
 for c in c1 c3 c4 c5 c5h50; do
-  python bench.py --config $c --steps 20 --warmup 5 --no-cpu-baseline > $out/bench_$c.json 2> $out/bench_$c.err
+  python bench.py --config $c --steps 20 --warmup 5 --no-cpu-baseline --no-split-leg > $out/bench_$c.json 2> $out/bench_$c.err
 done
+# SURVEY.md 8(d) "Z" inputs (Zipf ids + 15 % padded history slots): every trainable / sharded config, and the A/B of the table-gradient
+# accumulation on them (duplicate-combining default vs one atomic per element)
+for c in c1 c2 c4 c5; do
+  python bench.py --config $c --ids zipf --steps 20 --warmup 5 --no-cpu-baseline --no-fit-loop --no-split-leg > $out/bench_${c}_zipf.json 2> $out/bench_${c}_zipf.err
+done
+for c in c1 c4; do for ids in uniform zipf; do
+  python bench.py --config $c --ids $ids --steps 20 --warmup 5 --no-cpu-baseline --no-probe --no-fit-loop --no-split-leg --atomic-table-grad > $out/bench_${c}_${ids}_atomic.json 2> $out/bench_${c}_${ids}_atomic.err
+done; done
 # the opt-in second precision (bf16x6 split projections): its own line, next to an exact line from the same box
 python bench.py --config c2 --steps 20 --warmup 5 --no-cpu-baseline --precision split > $out/bench_c2_split.json 2> $out/bench_c2_split.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_c2_split -o c2_split -- \
@@ -26,19 +34,19 @@ done
 # per-kernel statistics of the same bench command, per config
 for c in c2 c1 c3 c4 c5; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$c -o $c -- \
-    python bench.py --config $c --steps 20 --warmup 5 --no-cpu-baseline --no-probe --no-fit-loop > $out/bench_${c}_under_rocprof.json 2> $out/rocprof_$c.err
+    python bench.py --config $c --steps 20 --warmup 5 --no-cpu-baseline --no-probe --no-fit-loop --no-split-leg > $out/bench_${c}_under_rocprof.json 2> $out/rocprof_$c.err
   rm -f $out/stats_$c/*kernel_trace.csv $out/stats_$c/*agent_info.csv
 done
 # HBM traffic counters (c2): separate --pmc passes, kernel by kernel (no graphs: counters are per dispatch)
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_$c -o b -- \
-    python bench.py --no-graph --no-roofline --no-probe --no-fit-loop --no-cpu-baseline --steps 10 --warmup 2 --repeats 1 > /dev/null 2> $out/pmc_$c.err
+    python bench.py --no-graph --no-roofline --no-probe --no-fit-loop --no-split-leg --no-cpu-baseline --steps 10 --warmup 2 --repeats 1 > /dev/null 2> $out/pmc_$c.err
   rm -f $out/pmc_$c/*kernel_trace.csv $out/pmc_$c/*agent_info.csv
 done
 rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/pmc_mfma_a -o b -- \
-  python bench.py --no-graph --no-roofline --no-probe --no-fit-loop --no-cpu-baseline --steps 10 --warmup 2 --repeats 1 > /dev/null 2> $out/pmc_mfma_a.err
+  python bench.py --no-graph --no-roofline --no-probe --no-fit-loop --no-split-leg --no-cpu-baseline --steps 10 --warmup 2 --repeats 1 > /dev/null 2> $out/pmc_mfma_a.err
 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $out/pmc_mfma_b -o b -- \
-  python bench.py --no-graph --no-roofline --no-probe --no-fit-loop --no-cpu-baseline --steps 10 --warmup 2 --repeats 1 > /dev/null 2> $out/pmc_mfma_b.err
+  python bench.py --no-graph --no-roofline --no-probe --no-fit-loop --no-split-leg --no-cpu-baseline --steps 10 --warmup 2 --repeats 1 > /dev/null 2> $out/pmc_mfma_b.err
 rm -f $out/pmc_mfma_*/*kernel_trace.csv $out/pmc_mfma_*/*agent_info.csv
 bash tools/trace_kernel.sh c2 "256, 64, 4, false, false, true, 1" > $out/gemm_launch_trace.txt 2>&1
 cat $out/pytest_gpu.log

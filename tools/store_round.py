@@ -9,7 +9,7 @@ import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 G, P = ROOT / "gpurun_out" / tag, ROOT / "profiles"
 
 
@@ -66,6 +66,10 @@ for kind in ("", "_under_rocprof"):  # the opt-in split precision
 st = find(G / "stats_c2_split", "kernel_stats.csv") if (G / "stats_c2_split").exists() else None
 if st:
     shutil.copy(st, P / f"{tag}_kernel_stats_bench_c2_split_precision.csv")
+for src in sorted(G.glob("bench_*_zipf*.json")) + sorted(G.glob("bench_*_uniform_atomic.json")):  # SURVEY 8(d) Z lines and the accumulation A/B
+    line = last_json(src)
+    if line:
+        (P / f"{tag}_{src.stem}_1gpu.json").write_text(json.dumps(line) + "\n")
 for c in ("c2", "c4", "c5"):
     src = G / f"bench_{c}_2ranks_gloo.json"
     line = last_json(src) if src.exists() else None
