@@ -38,6 +38,9 @@ int ebn_gemm_tall_launch(int32_t transB, int64_t M, int64_t N, int64_t K, float 
                          int64_t ldb, float* C, int64_t ldc, hipStream_t s);
 
 // ebn_gemm_direct.hip
+int ebn_gemm_direct_tn_slices(int64_t M, int64_t N, int64_t K);
+int ebn_gemm_direct_tn_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda, const float* B, int64_t ldb,
+                              float* part, hipStream_t s);
 bool ebn_gemm_direct_wanted(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K);
 int ebn_gemm_direct_launch(int32_t transB, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda, const float* B,
                            int64_t ldb, float* C, int64_t ldc, hipStream_t s);
@@ -1142,7 +1145,10 @@ static GemmPlan gemm_plan(int64_t M, int64_t N, int64_t K, int64_t ws_floats) {
 extern "C" int64_t ebn_gemm_workspace_floats(int64_t M, int64_t N, int64_t K) {
   if (!ebn_dim_ok(M, N, K)) return 0;
   const GemmPlan p = gemm_plan(M, N, K, INT64_MAX / 4);
-  return (p.splits > 1) ? ebn_sat_mul(static_cast<int64_t>(p.splits) * M, N) : 0;
+  int64_t slices = p.splits > 1 ? p.splits : 0;
+  const int64_t tn = ebn_gemm_direct_tn_slices(M, N, K);  // (either operand layout may ask: the size covers the TN form's chunks)
+  if (tn > slices) slices = tn;
+  return ebn_sat_mul(slices * M, N);
 }
 
 extern "C" int ebn_gemm_plan(int64_t M, int64_t N, int64_t K, int64_t workspace_floats, int32_t* bm, int32_t* bn,
@@ -1187,6 +1193,27 @@ static int gemm_dispatch(int32_t transA, int32_t transB, int64_t M, int64_t N, i
     const int rc_tall = ebn_gemm_tall_launch(transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, s);
     if (rc_tall != EBN_ERR_UNSUPPORTED) return rc_tall;
   }
+  // weight gradient of a tall product with a small, awkward output (AttLayer2 dW = Y^T.dpre): 16 x 16 blocks, K chunks across
+  // workgroups, dense slices like any split-K product (ebn_gemm_direct.hip) -- combined below or left to ebn_grad_finish_f32
+  if (transA && !transB && epi.bias == nullptr && epi.rs == nullptr && forced_tile_bm() == 0 && workspace != nullptr &&
+      M * N < (int64_t{1} << 31)) {
+    const int z = ebn_gemm_direct_tn_slices(M, N, K);
+    if (z >= 2 && workspace_floats >= static_cast<int64_t>(z) * M * N) {
+      const int rc_tn = ebn_gemm_direct_tn_launch(M, N, K, alpha, A, lda, B, ldb, workspace, s);
+      if (rc_tn == EBN_OK) {
+        if (defer_parts != nullptr) {
+          *defer_parts = z;
+          return EBN_OK;
+        }
+        int64_t grid = ebn_ceil_div(M * N, 256);
+        if (grid > 4096) grid = 4096;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(static_cast<unsigned>(grid)), dim3(256), 0, s, workspace, z, M, N, beta, C, ldc, epi);
+        EBN_CHECK_LAUNCH();
+        return EBN_OK;
+      }
+      if (rc_tn != EBN_ERR_UNSUPPORTED) return rc_tn;
+    }
+  }
   const GemmPlan plan = gemm_plan(M, N, K, workspace ? workspace_floats : 0);
   const int splits = plan.splits;
   const int64_t kps = plan.kps;
@@ -1223,7 +1250,10 @@ static int gemm_dispatch(int32_t transA, int32_t transB, int64_t M, int64_t N, i
 extern "C" int64_t ebn_gemm_partials_workspace_floats(int64_t M, int64_t N, int64_t K) {
   if (!ebn_dim_ok(M, N, K)) return 0;
   const GemmPlan p = gemm_plan(M, N, K, INT64_MAX / 4);
-  return ebn_sat_mul(static_cast<int64_t>(p.splits > 1 ? p.splits : 1) * M, N);
+  int64_t slices = p.splits > 1 ? p.splits : 1;
+  const int64_t tn = ebn_gemm_direct_tn_slices(M, N, K);
+  if (tn > slices) slices = tn;
+  return ebn_sat_mul(slices * M, N);
 }
 
 extern "C" int ebn_gemm_f32_partials(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K, float alpha, const float* A,

@@ -275,6 +275,226 @@ __global__ __launch_bounds__(256, (DEPTH == 3 && R * CW >= 14) ? 1 : 2) void gem
   else dir_task<R, CW - 1, B_KC, DEPTH>(M, N, K, alpha, A, lda, B, ldb, C, ldc, rg * R, cb0, lane);
 }
 
+// ---- TN: the weight gradient of a tall product, dW[M][N] = A^T . B with A [K][M], B [K][N], K in the tens of thousands and an
+// output of a few hundred columns (AttLayer2: dW = Y^T . dpre, 400 x 200 x 24000).  64 x 64 tiles pad that output to 448 x 256
+// (43 % of the MFMA work), so it is tiled in 16 x 16 blocks as well: a workgroup owns R x NC blocks of the output and ONE chunk
+// of the K range; its four waves walk the chunk's 16-deep groups interleaved (wave w: groups w, w + 4, ...), fetching both
+// fragments by dword rows (k rows are contiguous along m / n: 64 bytes per 16 lanes), and are summed through LDS in the fixed
+// order ((w0 + w1) + w2) + w3.  The chunks' results are the dense slices of a deterministic split-K product: the caller's
+// combining pass (or ebn_grad_finish_f32) sums them like any other split-K GEMM's.
+template <int R, int NC>
+struct TnPlan {
+  ebn_dir_i32x4 arsrc, brsrc;
+  uint32_t oa[R], ob[NC];
+  uint32_t lda4, ldb4;
+};
+
+template <int R, int NC>
+__device__ __forceinline__ void tn_fetch(DirFrags<R, NC>& f, const TnPlan<R, NC>& p, uint32_t sa, uint32_t sb) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      f.a[r][s] = ebn_dir_buffer_load_x1(p.arsrc, static_cast<int>(p.oa[r]), static_cast<int>(sa + static_cast<uint32_t>(s) * p.lda4), 0);
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+      f.b[c][s] = ebn_dir_buffer_load_x1(p.brsrc, static_cast<int>(p.ob[c]), static_cast<int>(sb + static_cast<uint32_t>(s) * p.ldb4), 0);
+  }
+}
+
+// the partial last group of the K range: row 4 kq + s of the group exists iff it is < krem
+template <int R, int NC>
+__device__ __forceinline__ void tn_fetch_tail(DirFrags<R, NC>& f, const TnPlan<R, NC>& p, uint32_t sa, uint32_t sb, int kq, int krem) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const bool ok = 4 * kq + s < krem;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const float t = ebn_dir_buffer_load_x1(p.arsrc, static_cast<int>(ok ? p.oa[r] + sa + static_cast<uint32_t>(s) * p.lda4 : 0u), 0, 0);
+      f.a[r][s] = ok ? t : 0.f;
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const float t = ebn_dir_buffer_load_x1(p.brsrc, static_cast<int>(ok ? p.ob[c] + sb + static_cast<uint32_t>(s) * p.ldb4 : 0u), 0, 0);
+      f.b[c][s] = ok ? t : 0.f;
+    }
+  }
+}
+
+template <int R, int NC>
+__device__ __forceinline__ void tn_task(float* red, int64_t M, int64_t N, float alpha, const float* __restrict__ A, int64_t lda,
+                                        const float* __restrict__ B, int64_t ldb, float* __restrict__ out, int64_t k0, int64_t klen,
+                                        int64_t rb0, int cb0, int lane, int wave) {
+  const int ln = lane & 15, kq = lane >> 4;
+  TnPlan<R, NC> p;
+  p.arsrc = dir_rsrc(A + k0 * lda);
+  p.brsrc = dir_rsrc(B + k0 * ldb);
+  p.lda4 = static_cast<uint32_t>(lda * 4);
+  p.ldb4 = static_cast<uint32_t>(ldb * 4);
+#pragma unroll
+  for (int r = 0; r < R; ++r) {  // columns past M / N are CLAMPED: they only feed outputs that are never stored
+    int64_t m = (rb0 + r) * 16 + ln;
+    m = m < M ? m : M - 1;
+    p.oa[r] = static_cast<uint32_t>((4 * kq * lda + m) * 4);
+  }
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    int64_t n = static_cast<int64_t>(cb0 + c) * 16 + ln;
+    n = n < N ? n : N - 1;
+    p.ob[c] = static_cast<uint32_t>((4 * kq * ldb + n) * 4);
+  }
+  f32x4 acc[R][NC];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // this wave's groups: wave, wave + 4, ... of the chunk's ceil(klen / 16); only the chunk's very last group can be partial
+  const int ng = static_cast<int>((klen + 15) / 16), krem = static_cast<int>(klen - 16 * (klen / 16));
+  const int mine = ng > wave ? (ng - wave + 3) / 4 : 0;
+  const bool tail_mine = krem > 0 && mine > 0 && ((ng - 1) & 3) == wave;
+  const int nkf = mine - (tail_mine ? 1 : 0);  // full groups of this wave
+  const uint32_t step_a = 64u * p.lda4, step_b = 64u * p.ldb4;  // 4 groups of 16 rows
+  uint32_t sa = static_cast<uint32_t>(wave) * 16u * p.lda4, sb = static_cast<uint32_t>(wave) * 16u * p.ldb4;
+  DirFrags<R, NC> f0, f1;
+  constexpr int N_LOADS = 4 * (R + NC), N_MFMA = 4 * R * NC, PER_LOAD = (N_MFMA / N_LOADS) > 0 ? (N_MFMA / N_LOADS) : 1;
+#define EBN_TN_FETCH(F)                \
+  do {                                 \
+    tn_fetch(F, p, sa, sb);            \
+    sa += step_a;                      \
+    sb += step_b;                      \
+    __builtin_amdgcn_sched_barrier(0); \
+  } while (0)
+#define EBN_TN_STEP(FL, FM)                                                    \
+  do {                                                                         \
+    tn_fetch(FL, p, sa, sb);                                                   \
+    sa += step_a;                                                              \
+    sb += step_b;                                                              \
+    dir_mma(acc, FM);                                                          \
+    if (INTERLEAVE) {                                                          \
+      _Pragma("unroll") for (int i__ = 0; i__ < N_LOADS; ++i__) {              \
+        __builtin_amdgcn_sched_group_barrier(0x008, PER_LOAD, 0);              \
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                     \
+      }                                                                        \
+      __builtin_amdgcn_sched_group_barrier(0x008, N_MFMA - PER_LOAD * N_LOADS, 0); \
+    }                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                         \
+  } while (0)
+  if (nkf > 0) {
+    EBN_TN_FETCH(f0);
+    int g = 0;
+    for (; g + 2 < nkf; g += 2) {
+      EBN_TN_STEP(f1, f0);
+      EBN_TN_STEP(f0, f1);
+    }
+    if (g + 1 < nkf) {
+      EBN_TN_STEP(f1, f0);
+      dir_mma(acc, f1);
+    } else {
+      dir_mma(acc, f0);
+    }
+  }
+#undef EBN_TN_FETCH
+#undef EBN_TN_STEP
+  if (tail_mine) {
+    tn_fetch_tail(f0, p, sa, sb, kq, krem);
+    dir_mma(acc, f0);
+  }
+
+  // ((w0 + w1) + w2) + w3 through one LDS image of a wave's accumulators
+#pragma unroll 1
+  for (int w = 1; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) *reinterpret_cast<f32x4*>(red + ((r * NC + c) * 64 + lane) * 4) = acc[r][c];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[r][c] += *reinterpret_cast<const f32x4*>(red + ((r * NC + c) * 64 + lane) * 4);
+    }
+    __syncthreads();
+  }
+  if (wave != 0) return;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int64_t col = static_cast<int64_t>(cb0 + c) * 16 + ln;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t row = (rb0 + r) * 16 + 4 * kq + i;
+        if (row < M && col < N) out[row * N + col] = alpha * acc[r][c][i];
+      }
+    }
+  }
+}
+
+// grid = tiles x chunks workgroups in XCD-contiguous order (the tiles of one chunk read the same k rows: one L2); slice z of
+// `part` ([Z][M][N] dense) receives alpha * A[k in chunk z]^T . B[k in chunk z]
+template <int R, int CW>
+__global__ __launch_bounds__(256, (R * CW >= 20) ? 1 : 2) void gemm_direct16_tn_kernel(int64_t M, int64_t N, int64_t K, float alpha, const float* __restrict__ A,
+                                                                  int64_t lda, const float* __restrict__ B, int64_t ldb,
+                                                                  float* __restrict__ part, int32_t G, int32_t n_wide, int32_t tiles,
+                                                                  int64_t kps) {
+  __shared__ __attribute__((aligned(16))) float red[R * CW * 256];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int64_t lin = blockIdx.x;
+  {
+    const int64_t nwg = gridDim.x, q = nwg / 8, r = nwg % 8, xcd = lin % 8, idx = lin / 8;
+    lin = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int64_t z = lin / tiles;
+  const int tile = static_cast<int>(lin - z * tiles);
+  const int rg = tile / G, cg = tile - rg * G;
+  const int cb0 = cg < n_wide ? cg * CW : n_wide * CW + (cg - n_wide) * (CW - 1);
+  const int64_t k0 = z * kps;
+  const int64_t klen = (k0 + kps < K) ? kps : K - k0;
+  float* out = part + z * M * N;
+  if (cg < n_wide) tn_task<R, CW>(red, M, N, alpha, A, lda, B, ldb, out, k0, klen, static_cast<int64_t>(rg) * R, cb0, lane, wave);
+  else tn_task<R, CW - 1>(red, M, N, alpha, A, lda, B, ldb, out, k0, klen, static_cast<int64_t>(rg) * R, cb0, lane, wave);
+}
+
+struct TnDirectPlan {
+  int R, CW, G, n_wide, tiles, Z;
+  int64_t kps;
+};
+
+// Output tiling: R x CW blocks per workgroup with the fewest wasted blocks; K chunks so that tiles x chunks fill the 256 CUs once
+// (kps a multiple of 64 rows: every wave of a workgroup gets whole groups).
+TnDirectPlan tn_direct_plan(int64_t M, int64_t N, int64_t K) {
+  const int64_t MB = ebn_ceil_div(M, 16), NB = ebn_ceil_div(N, 16);
+  TnDirectPlan best{0, 0, 0, 0, 0, 0, 0};
+  double best_cost = 1e300;
+  static const int kR[3] = {5, 4, 3}, kC[2] = {5, 4};
+  for (int ci = 0; ci < 2; ++ci) {
+    const int64_t cw = kC[ci], G = ebn_ceil_div(NB, cw), n_wide = NB - G * (cw - 1);
+    if (n_wide < 0 || n_wide > G) continue;
+    for (int ri = 0; ri < 3; ++ri) {
+      const int64_t tiles = ebn_ceil_div(MB, kR[ri]) * G;
+      if (tiles > 256) continue;
+      int64_t Z = 256 / tiles;
+      if (Z < 2) continue;
+      if (Z > 64) Z = 64;
+      const int64_t kps = ebn_ceil_div(ebn_ceil_div(K, Z), 64) * 64;
+      Z = ebn_ceil_div(K, kps);
+      if (Z < 2 || kps < 256) continue;
+      // cost ~ blocks per workgroup (incl. padding blocks) x groups per wave
+      const double cost = static_cast<double>(kR[ri] * (n_wide > 0 ? cw : cw - 1)) * static_cast<double>(kps / 64) * (tiles * Z > 256 ? 2.0 : 1.0);
+      if (cost < best_cost) {
+        best_cost = cost;
+        best = TnDirectPlan{kR[ri], static_cast<int>(cw), static_cast<int>(G), static_cast<int>(n_wide), static_cast<int>(tiles), static_cast<int>(Z), kps};
+      }
+    }
+  }
+  return best;
+}
+
 int direct_mode() {  // EBN_GEMM_DIRECT = 0: never (validation / tuning: the LDS-staged kernels take these shapes again); default 1
   static const int mode = [] { const char* e = getenv("EBN_GEMM_DIRECT"); return e ? atoi(e) : 1; }();
   return mode;
@@ -361,5 +581,31 @@ int ebn_gemm_direct_launch(int32_t transB, int64_t M, int64_t N, int64_t K, floa
   EBN_DIR_CASE(4, 5); EBN_DIR_CASE(3, 5); EBN_DIR_CASE(2, 5); EBN_DIR_CASE(1, 5);
   EBN_DIR_CASE(4, 4); EBN_DIR_CASE(3, 4); EBN_DIR_CASE(2, 4); EBN_DIR_CASE(1, 4);
 #undef EBN_DIR_CASE
+  return EBN_ERR_UNSUPPORTED;
+}
+
+// The TN form (weight gradient of a tall product).  Returns the number of K chunks (= dense [Z][M][N] slices the launch writes into
+// `part`), 0 when the shape is not this kernel's: a small output (<= 512 x 512) under a long contraction.
+int ebn_gemm_direct_tn_slices(int64_t M, int64_t N, int64_t K) {
+  if (direct_mode() == 0 || M < 48 || N < 48 || M > 512 || N > 512 || K < 4096) return 0;
+  if (ebn_ceil_div(M, 64) * ebn_ceil_div(N, 64) * 64 * 64 * 10 < M * N * 12) return 0;  // 64 x 64 tiles pad it by < 20 %: they keep it
+  return tn_direct_plan(M, N, K).Z;
+}
+
+int ebn_gemm_direct_tn_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda, const float* B, int64_t ldb,
+                              float* part, hipStream_t s) {
+  const TnDirectPlan pl = tn_direct_plan(M, N, K);
+  if (pl.Z < 2) return EBN_ERR_UNSUPPORTED;
+  if ((pl.kps + 16) * (lda > ldb ? lda : ldb) * 4 >= (int64_t{1} << 31)) return EBN_ERR_UNSUPPORTED;  // 32-bit offsets inside a chunk
+  const dim3 grid(static_cast<unsigned>(pl.tiles * pl.Z)), block(256);
+#define EBN_TN_CASE(RR, CC)                                                                                                        \
+  if (pl.R == RR && pl.CW == CC) {                                                                                                 \
+    hipLaunchKernelGGL((gemm_direct16_tn_kernel<RR, CC>), grid, block, 0, s, M, N, K, alpha, A, lda, B, ldb, part, pl.G, pl.n_wide, pl.tiles, \
+                       pl.kps);                                                                                                    \
+    EBN_CHECK_LAUNCH();                                                                                                            \
+    return EBN_OK;                                                                                                                 \
+  }
+  EBN_TN_CASE(5, 5) EBN_TN_CASE(4, 5) EBN_TN_CASE(3, 5) EBN_TN_CASE(5, 4) EBN_TN_CASE(4, 4) EBN_TN_CASE(3, 4)
+#undef EBN_TN_CASE
   return EBN_ERR_UNSUPPORTED;
 }

@@ -109,7 +109,11 @@ GEMM_SHAPES = [(1, 1, 1), (5, 7, 3), (64, 64, 16), (130, 70, 33), (257, 129, 300
                (640, 1200, 1536), (640, 1200, 1537), (1024, 1024, 4096),
                # tall outputs with an N the 64-wide tiles pad by > 10 %: the 16x16-block kernel (ebn_gemm_tall.hip) for A not
                # transposed and beta = 0 -- AttLayer2's two shapes (short), ragged M / N / K with a partial last slab, two column panels
-               (4096, 200, 400), (4100, 400, 200), (4099, 68, 72), (4500, 416, 100), (5000, 100, 64)]
+               (4096, 200, 400), (4100, 400, 200), (4099, 68, 72), (4500, 416, 100), (5000, 100, 64),
+               # small, awkward outputs under a long contraction (AttLayer2's weight gradient and ragged relatives): the transposed-A layout
+               # takes the 16x16-block K-chunked kernel of ebn_gemm_direct.hip -- partial last group (K % 16 != 0), partial last chunk,
+               # M / N not multiples of 16, every (R, CW) instantiation the plan can pick
+               (400, 200, 24000), (416, 208, 9000), (100, 500, 5003), (500, 60, 4100), (72, 72, 30001), (330, 330, 7777)]
 
 
 _TALL_SCRIPT = r'''
