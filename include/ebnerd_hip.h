@@ -192,7 +192,8 @@ int ebn_gemm_f32_partials(int32_t transA, int32_t transB, int64_t M, int64_t N, 
  * into the launch).  kind EBN_FINISH_SPLITK: out0[r * ld + c] = sum_z partials[z][r][c] (+ beta * out0), z < n_parts, r < rows,
  * c < cols.  EBN_FINISH_COLRED: partials [n_parts][2][cols] -> out0[c] = scale * sum_p partials[p][0][c], out1 likewise with
  * [p][1][c] (accumulated into when beta != 0).  EBN_FINISH_HEAD: partials [rows][2][cols] -> out0 = d(q), out1 = d(b) summed
- * over the rows in a fixed order, loss_out[0] = sum(loss_rows[0 .. rows)).                                                  */
+ * over the rows in a fixed order, loss_out[0] = sum(loss_rows[0 .. rows)).  Jobs get consecutive block ranges in list order and
+ * blocks are dispatched in order: list the latency-bound jobs (COLRED, HEAD: a few blocks, long chains) before the bulk sums.   */
 #define EBN_FINISH_SPLITK 0
 #define EBN_FINISH_COLRED 1
 #define EBN_FINISH_HEAD 2
