@@ -472,20 +472,24 @@ TnDirectPlan tn_direct_plan(int64_t M, int64_t N, int64_t K) {
   TnDirectPlan best{0, 0, 0, 0, 0, 0, 0};
   double best_cost = 1e300;
   static const int kR[3] = {5, 4, 3}, kC[2] = {5, 4};
+  static const int wgs = [] { const char* e = getenv("EBN_GEMM_DIRECT_TN_WGS"); const int v = e ? atoi(e) : 256; return v > 0 ? v : 256; }();  // tuning
+  static const int force_r = [] { const char* e = getenv("EBN_GEMM_DIRECT_TN_R"); return e ? atoi(e) : 0; }();
+  static const int force_c = [] { const char* e = getenv("EBN_GEMM_DIRECT_TN_C"); return e ? atoi(e) : 0; }();
   for (int ci = 0; ci < 2; ++ci) {
     const int64_t cw = kC[ci], G = ebn_ceil_div(NB, cw), n_wide = NB - G * (cw - 1);
-    if (n_wide < 0 || n_wide > G) continue;
+    if (n_wide < 0 || n_wide > G || (force_c != 0 && force_c != cw)) continue;
     for (int ri = 0; ri < 3; ++ri) {
+      if (force_r != 0 && force_r != kR[ri]) continue;
       const int64_t tiles = ebn_ceil_div(MB, kR[ri]) * G;
-      if (tiles > 256) continue;
-      int64_t Z = 256 / tiles;
+      if (tiles > wgs) continue;
+      int64_t Z = wgs / tiles;
       if (Z < 2) continue;
       if (Z > 64) Z = 64;
       const int64_t kps = ebn_ceil_div(ebn_ceil_div(K, Z), 64) * 64;
       Z = ebn_ceil_div(K, kps);
       if (Z < 2 || kps < 256) continue;
       // cost ~ blocks per workgroup (incl. padding blocks) x groups per wave
-      const double cost = static_cast<double>(kR[ri] * (n_wide > 0 ? cw : cw - 1)) * static_cast<double>(kps / 64) * (tiles * Z > 256 ? 2.0 : 1.0);
+      const double cost = static_cast<double>(kR[ri] * (n_wide > 0 ? cw : cw - 1)) * static_cast<double>(kps / 64) * (tiles * Z > wgs ? 2.0 : 1.0);
       if (cost < best_cost) {
         best_cost = cost;
         best = TnDirectPlan{kR[ri], static_cast<int>(cw), static_cast<int>(G), static_cast<int>(n_wide), static_cast<int>(tiles), static_cast<int>(Z), kps};
