@@ -513,7 +513,7 @@ struct DirectPlan {
 // (R, CW) that fill the 1024 SIMDs in the fewest, fullest rounds: cost = rounds x blocks per wave (x the K / 4 MFMAs of a block,
 // common to all candidates).  Column groups: the NB column blocks over G = ceil(NB / CW) groups, n_wide of them CW blocks wide and
 // the rest CW - 1 (the two block counts a (R, CW) instantiation carries): valid when 0 <= n_wide = NB - G (CW - 1) <= G.
-DirectPlan direct_plan(int64_t M, int64_t N) {
+DirectPlan direct_plan(int64_t M, int64_t N, bool b_kc) {
   const int64_t MB = ebn_ceil_div(M, 16), NB = ebn_ceil_div(N, 16);
   DirectPlan best{0, 0, 0, 0, 0, 1e300};
   static const int force_r = [] { const char* e = getenv("EBN_GEMM_DIRECT_R"); return e ? atoi(e) : 0; }();   // tuning: restrict the
@@ -525,6 +525,10 @@ DirectPlan direct_plan(int64_t M, int64_t N) {
     const int64_t width = n_wide > 0 ? cw : cw - 1;  // blocks of the widest task
     for (int ri = 0; ri < 4; ++ri) {
       if (force_r != 0 && force_r != kR[ri]) continue;
+      // one row block per wave with a [N][K] B: 6 float4 fragments (6 KB) per 20 MFMAs -- the fetch path, not the matrix pipe, sets
+      // the pace (52800 x 400 x 200: 114 us against 90 us for two or three row blocks); with a [K][N] B the dword rows come out of
+      // L1 and one row block per wave is the best-filling split (52800 x 200 x 400: 82 us)
+      if (b_kc && kR[ri] == 1 && force_r == 0) continue;
       const int64_t tasks = ebn_ceil_div(MB, kR[ri]) * G;
       const double rounds = static_cast<double>(ebn_ceil_div(tasks, 1024));
       // a task's issue time ~ R * width blocks; fewer, fatter tasks fetch less per MFMA (R + width fragments for R * width blocks):
@@ -569,14 +573,14 @@ bool ebn_gemm_direct_wanted(int32_t transA, int32_t transB, int64_t M, int64_t N
   if (transA || direct_mode() == 0) return false;
   if (M < 4096 || N < 48 || N > 512 || K < 32 || K > 2048 || (K % 4)) return false;
   if (N * K * 4 > (int64_t{1} << 20)) return false;  // B beyond 1 MB would stream from L2 / MALL for every wave
-  return direct_plan(M, N).R != 0;
+  return direct_plan(M, N, transB != 0).R != 0;
 }
 
 int ebn_gemm_direct_launch(int32_t transB, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda, const float* B,
                            int64_t ldb, float* C, int64_t ldc, hipStream_t s) {
   // 32-bit byte offsets: a row group's A panel (64 rows) and the whole of B
   if ((64 * lda + K) * 4 >= (int64_t{1} << 31) || ((transB ? N : K) * ldb + (transB ? K : N) + 16 * ldb) * 4 >= (int64_t{1} << 31)) return EBN_ERR_UNSUPPORTED;
-  const DirectPlan pl = direct_plan(M, N);
+  const DirectPlan pl = direct_plan(M, N, transB != 0);
   if (pl.R == 0 || ebn_ceil_div(pl.tasks, 4) >= (int64_t{1} << 31)) return EBN_ERR_UNSUPPORTED;
   const bool kc = transB != 0;
 #define EBN_DIR_CASE(RR, CC) \
