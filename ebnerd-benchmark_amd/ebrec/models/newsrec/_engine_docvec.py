@@ -58,7 +58,12 @@ class DocVecEngine:
         if self.world > 1:
             from ._dist import LockStepGuard
 
-            self.guard = LockStepGuard(process_group)
+            try:
+                self.guard = LockStepGuard(process_group)
+            except Exception as e:  # a diagnostics aid must never keep a job from starting (e.g. no usable gloo interface on the box)
+                import warnings
+
+                warnings.warn(f"lock-step guard of the collective model APIs disabled: {type(e).__name__}: {e}")
 
     @property
     def loss_kind(self) -> int:
