@@ -182,11 +182,15 @@ struct GemmEpi {
 // Cpart + z*M*N (dense ld = N) and a reduce kernel finishes; else writes C directly.
 // SITE only labels the instantiation (0 = generic, 1 = the encoders' Q|K|V projection) so that per-kernel profiler
 // summaries separate the roofline kernel of bench.py from the other GEMM call sites of the same shape class.
-template <int BM, int BN, int WAVES_M, bool TA, bool TB, bool VEC, int SITE, int EPI = 0>
+// PERSIST: the launch holds only as many workgroups as the chip keeps resident (vgx x vgy x vgz is the VIRTUAL grid of tiles x K
+// splits); a workgroup walks the tiles blockIdx.x, blockIdx.x + gridDim.x, ... of the same XCD-contiguous order, and requests the
+// first slab of its NEXT tile before it stores the current one -- the fetch latency of a tile's prologue then lies under the C
+// stores of the tile before it instead of in front of its first MFMA (it matters for short contractions: K = 300 is 19 slabs).
+template <int BM, int BN, int WAVES_M, bool TA, bool TB, bool VEC, int SITE, int EPI = 0, bool PERSIST = false>
 __global__ __launch_bounds__(GEMM_THREADS, EBN_GEMM_WPE) void gemm_f32_kernel(
     int64_t M, int64_t N, int64_t K, float alpha, const float* __restrict__ A, int64_t lda,
     const float* __restrict__ B, int64_t ldb, float beta, float* __restrict__ C, int64_t ldc,
-    int64_t k_per_split, float* __restrict__ Cpart, GemmEpi epi) {
+    int64_t k_per_split, float* __restrict__ Cpart, GemmEpi epi, int32_t vgx, int32_t vgy, int32_t vgz) {
   constexpr int WAVES_N = 4 / WAVES_M;    // the 4 waves form a WAVES_M x WAVES_N grid over the block tile
   constexpr int WTM = BM / WAVES_M;       // rows / columns owned by one wave
   constexpr int WTN = BN / WAVES_N;
@@ -227,35 +231,17 @@ __global__ __launch_bounds__(GEMM_THREADS, EBN_GEMM_WPE) void gemm_f32_kernel(
   // XCD-aware tile order: hardware deals consecutive workgroups round-robin to the 8 XCDs (private
   // L2s); remap so that each XCD walks a CONTIGUOUS run of tiles (neighbouring tiles share their A
   // row-panel / B column-panel in one L2).  Bijective for any grid size; speed only, never correctness.
-  int64_t tile_id = static_cast<int64_t>(blockIdx.y) * gridDim.x + blockIdx.x;
-  int64_t zsplit = blockIdx.z;
-#if EBN_GEMM_XCD
-  {
-    const int64_t per_z = static_cast<int64_t>(gridDim.x) * gridDim.y;
-    const int64_t nwg = per_z * gridDim.z;
-    const int64_t orig = tile_id + per_z * blockIdx.z;  // hardware dispatch order
-    const int64_t q = nwg / 8, r = nwg % 8, xcd = orig % 8, idx = orig / 8;
-    const int64_t lin = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    zsplit = lin / per_z;  // tiles of one K-split share their A/B K-range: keep them on one XCD too
-    tile_id = lin - zsplit * per_z;
-  }
-#endif
-  const int64_t m0 = (tile_id / gridDim.x) * BM;
-  const int64_t n0 = (tile_id % gridDim.x) * BN;
-  const int64_t kbeg = zsplit * k_per_split;
-  const int64_t kend = (kbeg + k_per_split < K) ? (kbeg + k_per_split) : K;
+  const int64_t GX = PERSIST ? vgx : gridDim.x, GY = PERSIST ? vgy : gridDim.y, GZ = PERSIST ? vgz : gridDim.z;
+  const int64_t per_z = GX * GY, nwg = per_z * GZ;
+  // position in the hardware dispatch order (PERSIST: of the virtual grid)
+  int64_t vb = PERSIST ? static_cast<int64_t>(blockIdx.x)
+                       : static_cast<int64_t>(blockIdx.y) * gridDim.x + blockIdx.x + per_z * blockIdx.z;
+  int64_t m0 = 0, n0 = 0, kbeg = 0, kend = 0, zsplit = 0;
+  int nk = 0, nk_full = 0, nk_main = 0;
 
   f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   float4 ra[LA::PER_THREAD], rb[LB::PER_THREAD];
-  const int nk = static_cast<int>((kend - kbeg + BK - 1) / BK);
-  const int nk_full = static_cast<int>((kend - kbeg) / BK);  // slabs that lie completely inside [kbeg, kend)
 
   // Fast tile fetch (VEC): one source pointer per float4 a thread owns, advanced by a constant per slab -- the slab
   // loop issues bare 16-byte loads, no index arithmetic, compares or selects (they cost ~11 % of the MFMA issue time
@@ -270,40 +256,10 @@ __global__ __launch_bounds__(GEMM_THREADS, EBN_GEMM_WPE) void gemm_f32_kernel(
   // 32-bit lane offset and a scalar slab offset: the slab loop issues bare buffer_loads and one s_add per operand.
   // (Offsets are BYTES in 32 bits: the launcher checks that 256 tile rows and the K range of an operand span < 4 GB.)
   uint32_t oa[LA::PER_THREAD], ob[LB::PER_THREAD];
-  const i32x4n arsrc = make_rsrc(TA ? A + kbeg * lda + m0 : A + m0 * lda + kbeg);
-  const i32x4n brsrc = make_rsrc(TB ? B + n0 * ldb + kbeg : B + kbeg * ldb + n0);
+  i32x4n arsrc, brsrc;
   const uint32_t step_a = static_cast<uint32_t>((TA ? BK * lda : BK) * 4);  // bytes per slab
   const uint32_t step_b = static_cast<uint32_t>((TB ? BK : BK * ldb) * 4);
   uint32_t sa = 0, sb = 0;                                                   // scalar slab offsets
-  if (VEC) {
-#pragma unroll
-    for (int i = 0; i < LA::PER_THREAD; ++i) {
-      const int v = tid + i * GEMM_THREADS;
-      if (!TA) {  // A is [M][K]
-        int64_t row = m0 + v / (BK / 4);
-        row = row < M ? row : M - 1;
-        oa[i] = static_cast<uint32_t>(((row - m0) * lda + (v % (BK / 4)) * 4) * 4);
-      } else {  // A is [K][M]
-        int64_t col = m0 + (v % (BM / 4)) * 4;
-        col = col < M ? col : M - 4;
-        oa[i] = static_cast<uint32_t>(((v / (BM / 4)) * lda + (col - m0)) * 4);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < LB::PER_THREAD; ++i) {
-      const int v = tid + i * GEMM_THREADS;
-      if (TB) {  // B is [N][K]
-        int64_t row = n0 + v / (BK / 4);
-        row = row < N ? row : N - 1;
-        ob[i] = static_cast<uint32_t>(((row - n0) * ldb + (v % (BK / 4)) * 4) * 4);
-      } else {  // B is [K][N]
-        int64_t col = n0 + (v % (BN / 4)) * 4;
-        col = col < N ? col : N - 4;
-        ob[i] = static_cast<uint32_t>(((v / (BN / 4)) * ldb + (col - n0)) * 4);
-      }
-    }
-  }
-
   // ---- direct-to-LDS fetch (GLDS kernels): wave w issues IPW instructions per operand and slab.  [K][mn] operands:
   // instruction q covers RPI consecutive k rows (64 lanes x 16 B = RPI rows of BMN floats).  [mn][K] operands: instruction
   // q covers the 16 rows (64 chunks of 16 B) number (q * 4 + w).
@@ -311,38 +267,91 @@ __global__ __launch_bounds__(GEMM_THREADS, EBN_GEMM_WPE) void gemm_f32_kernel(
   constexpr int B_LPR = BN / 4, B_RPI = 64 / (B_LPR < 64 ? B_LPR : 64), B_IPW = B_KC ? BN / 64 : (BK / B_RPI) / 4;
   static_assert(BM <= 256 && BN <= 256 && A_IPW >= 1 && B_IPW >= 1, "glds tiling");
   uint32_t gao[GLDS_A ? A_IPW : 1], gbo[GLDS_B ? B_IPW : 1];  // lane byte offsets into arsrc / brsrc
-  if (GLDS_A) {
-#pragma unroll
-    for (int q = 0; q < A_IPW; ++q) {
-      if (A_KC) {
-        const int r = ((q * 4 + wave) * 64 + lane) >> 2, kq = (lane & 3) ^ ((r >> 2) & 3);
-        int64_t row = m0 + r;
-        row = row < M ? row : M - 1;
-        gao[q] = static_cast<uint32_t>(((row - m0) * lda + kq * 4) * 4);
-      } else {
-        const int krow = (wave * A_IPW + q) * A_RPI + lane / A_LPR;
-        int64_t col = m0 + (lane % A_LPR) * 4;
-        col = col < M ? col : M - 4;
-        gao[q] = static_cast<uint32_t>((krow * lda + (col - m0)) * 4);
+  // Everything that depends on WHICH tile (and K split) this is: origin, K range, buffer resources, lane offsets.
+  auto tile_setup = [&](int64_t v) {
+    int64_t lin = v;
+#if EBN_GEMM_XCD
+    {
+      const int64_t q = nwg / 8, r = nwg % 8, xcd = v % 8, idx = v / 8;
+      lin = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+#endif
+    zsplit = lin / per_z;  // tiles of one K-split share their A/B K-range: keep them on one XCD too
+    const int64_t tile_id = lin - zsplit * per_z;
+    m0 = (tile_id / GX) * BM;
+    n0 = (tile_id % GX) * BN;
+    kbeg = zsplit * k_per_split;
+    kend = (kbeg + k_per_split < K) ? (kbeg + k_per_split) : K;
+    nk = static_cast<int>((kend - kbeg + BK - 1) / BK);
+    nk_full = static_cast<int>((kend - kbeg) / BK);  // slabs that lie completely inside [kbeg, kend)
+    nk_main = VEC ? nk_full : 0;
+      arsrc = make_rsrc(TA ? A + kbeg * lda + m0 : A + m0 * lda + kbeg);
+      brsrc = make_rsrc(TB ? B + n0 * ldb + kbeg : B + kbeg * ldb + n0);
+      sa = 0;
+      sb = 0;
+    if (VEC) {
+  #pragma unroll
+      for (int i = 0; i < LA::PER_THREAD; ++i) {
+        const int v = tid + i * GEMM_THREADS;
+        if (!TA) {  // A is [M][K]
+          int64_t row = m0 + v / (BK / 4);
+          row = row < M ? row : M - 1;
+          oa[i] = static_cast<uint32_t>(((row - m0) * lda + (v % (BK / 4)) * 4) * 4);
+        } else {  // A is [K][M]
+          int64_t col = m0 + (v % (BM / 4)) * 4;
+          col = col < M ? col : M - 4;
+          oa[i] = static_cast<uint32_t>(((v / (BM / 4)) * lda + (col - m0)) * 4);
+        }
+      }
+  #pragma unroll
+      for (int i = 0; i < LB::PER_THREAD; ++i) {
+        const int v = tid + i * GEMM_THREADS;
+        if (TB) {  // B is [N][K]
+          int64_t row = n0 + v / (BK / 4);
+          row = row < N ? row : N - 1;
+          ob[i] = static_cast<uint32_t>(((row - n0) * ldb + (v % (BK / 4)) * 4) * 4);
+        } else {  // B is [K][N]
+          int64_t col = n0 + (v % (BN / 4)) * 4;
+          col = col < N ? col : N - 4;
+          ob[i] = static_cast<uint32_t>(((v / (BN / 4)) * ldb + (col - n0)) * 4);
+        }
       }
     }
-  }
-  if (GLDS_B) {
-#pragma unroll
-    for (int q = 0; q < B_IPW; ++q) {
-      if (B_KC) {
-        const int r = ((q * 4 + wave) * 64 + lane) >> 2, kq = (lane & 3) ^ ((r >> 2) & 3);
-        int64_t row = n0 + r;
-        row = row < N ? row : N - 1;
-        gbo[q] = static_cast<uint32_t>(((row - n0) * ldb + kq * 4) * 4);
-      } else {
-        const int krow = (wave * B_IPW + q) * B_RPI + lane / B_LPR;
-        int64_t col = n0 + (lane % B_LPR) * 4;
-        col = col < N ? col : N - 4;
-        gbo[q] = static_cast<uint32_t>((krow * ldb + (col - n0)) * 4);
+
+    if (GLDS_A) {
+  #pragma unroll
+      for (int q = 0; q < A_IPW; ++q) {
+        if (A_KC) {
+          const int r = ((q * 4 + wave) * 64 + lane) >> 2, kq = (lane & 3) ^ ((r >> 2) & 3);
+          int64_t row = m0 + r;
+          row = row < M ? row : M - 1;
+          gao[q] = static_cast<uint32_t>(((row - m0) * lda + kq * 4) * 4);
+        } else {
+          const int krow = (wave * A_IPW + q) * A_RPI + lane / A_LPR;
+          int64_t col = m0 + (lane % A_LPR) * 4;
+          col = col < M ? col : M - 4;
+          gao[q] = static_cast<uint32_t>((krow * lda + (col - m0)) * 4);
+        }
       }
     }
-  }
+    if (GLDS_B) {
+  #pragma unroll
+      for (int q = 0; q < B_IPW; ++q) {
+        if (B_KC) {
+          const int r = ((q * 4 + wave) * 64 + lane) >> 2, kq = (lane & 3) ^ ((r >> 2) & 3);
+          int64_t row = n0 + r;
+          row = row < N ? row : N - 1;
+          gbo[q] = static_cast<uint32_t>(((row - n0) * ldb + kq * 4) * 4);
+        } else {
+          const int krow = (wave * B_IPW + q) * B_RPI + lane / B_LPR;
+          int64_t col = n0 + (lane % B_LPR) * 4;
+          col = col < N ? col : N - 4;
+          gbo[q] = static_cast<uint32_t>((krow * ldb + (col - n0)) * 4);
+        }
+      }
+    }
+  };
+  tile_setup(vb);
   // LDS float offset of the 1 KB that instruction q of this wave fills
 #define EBN_GLDS_A_DST(Q) (A_KC ? ((Q) * 4 + wave) * 256 : (wave * A_IPW + (Q)) * A_RPI * BM)
 #define EBN_GLDS_B_DST(Q) (B_KC ? ((Q) * 4 + wave) * 256 : (wave * B_IPW + (Q)) * B_RPI * BN)
@@ -421,15 +430,23 @@ __global__ __launch_bounds__(GEMM_THREADS, EBN_GEMM_WPE) void gemm_f32_kernel(
   // nothing but full-slab fetches inside (a partial-slab path merging into this loop makes the compiler wait vmcnt(0)
   // before the first LDS read of every slab -- i.e. for the glds fetch it has just issued).  REST: a partial last slab,
   // or every slab of a non-VEC kernel, through registers with a run-time buffer index.
-  const int nk_main = VEC ? nk_full : 0;
-  if (nk_main > 0) {
-    EBN_FETCH_FULL(0);
-    EBN_STORE_FULL(0);
-    __syncthreads();
-  }
-
   const int kl = lane >> 5;
   const int il = lane & 31;
+  bool fetched = false;  // PERSIST: slab 0 of this tile was requested under the previous tile's stores
+  while (true) {
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  if (nk_main > 0) {
+    if (!fetched) {
+      EBN_FETCH_FULL(0);
+      EBN_STORE_FULL(0);
+    }
+    __syncthreads();
+  }
   // The MFMAs of one slab out of LDS buffer CUR.  MFMA contraction index = (instruction, lane half); the slab's 16 k are
   // assigned as   step 4j + w of half kl  <->  k = 8j + 4kl + w      (A and B agree, so any assignment is valid)
   // which makes the four values a lane feeds to steps 4j..4j+3 one float4 of a k-contiguous operand.
@@ -505,17 +522,18 @@ _Pragma("unroll")  \
       cur ^= 1;
     }
   }
-#undef EBN_MMA
-#undef EBN_FETCH_FULL
-#undef EBN_FETCH_PART
-#undef EBN_STORE_FULL
-#undef EBN_STORE_PART
-#undef EBN_TAIL_PIECE
-#undef EBN_GLDS_A_DST
-#undef EBN_GLDS_B_DST
-#undef EBN_AS
-#undef EBN_BS
-#undef EBN_STORE_SLAB
+  // the tile just multiplied: what its epilogue needs, saved before the NEXT tile's setup overwrites the working set
+  const int64_t em0 = m0, en0 = n0, ezs = zsplit;
+  bool has_next = false;
+  if (PERSIST) {
+    vb += gridDim.x;
+    has_next = vb < nwg;
+    if (has_next) {
+      tile_setup(vb);
+      fetched = GLDS_A && GLDS_B && nk_main > 0;
+      if (fetched) EBN_FETCH_FULL(0);  // both LDS buffers are free (the last slab's barrier has passed): slab 0 of the next tile
+    }                                  // travels while this tile's results are stored
+  }
 
   // epilogue. C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
   if constexpr (EPI != 0) {
@@ -523,18 +541,18 @@ _Pragma("unroll")  \
     // unconditionally and with clamped indices; validity only guards the stores.  Reads placed next to the per-element
     // guards are serialised -- one global round trip per element, 128 per lane for the rank-1 form.  (The plain
     // epilogue below is kept as it was: restructuring it costs the big projections 2 % through register allocation.)
-    const bool split = gridDim.z > 1;
-    float* out = split ? (Cpart + zsplit * M * N) : C;
+    const bool split = GZ > 1;
+    float* out = split ? (Cpart + ezs * M * N) : C;
     const int64_t ldo = split ? N : ldc;
     const bool read_c = !split && beta != 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const int64_t col = n0 + wn * WTN + j * 32 + (lane & 31);
+        const int64_t col = en0 + wn * WTN + j * 32 + (lane & 31);
         const bool col_ok = col < N;
         const int64_t colc = col_ok ? col : N - 1;
-        const int64_t row_base = m0 + wm * WTM + i * 32 + 4 * (lane >> 5);
+        const int64_t row_base = em0 + wm * WTM + i * 32 + 4 * (lane >> 5);
         float add[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) add[r] = 0.f;
@@ -569,18 +587,18 @@ _Pragma("unroll")  \
     }
 
   } else {
-    const bool split = gridDim.z > 1;
-    float* out = split ? (Cpart + zsplit * M * N) : C;
+    const bool split = GZ > 1;
+    float* out = split ? (Cpart + ezs * M * N) : C;
     const int64_t ldo = split ? N : ldc;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const int64_t col = n0 + wn * WTN + j * 32 + (lane & 31);
+        const int64_t col = en0 + wn * WTN + j * 32 + (lane & 31);
         if (col >= N) continue;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int64_t row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          const int64_t row = em0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
           if (row >= M) continue;
           float v = alpha * acc[i][j][r];
           if (!split && beta != 0.f) v += beta * out[row * ldo + col];
@@ -593,6 +611,19 @@ _Pragma("unroll")  \
     }
 
   }
+  if (!has_next) break;
+  }  // while (true): next tile of a persistent workgroup
+#undef EBN_MMA
+#undef EBN_FETCH_FULL
+#undef EBN_FETCH_PART
+#undef EBN_STORE_FULL
+#undef EBN_STORE_PART
+#undef EBN_TAIL_PIECE
+#undef EBN_GLDS_A_DST
+#undef EBN_GLDS_B_DST
+#undef EBN_AS
+#undef EBN_BS
+#undef EBN_STORE_SLAB
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int splits,
@@ -604,6 +635,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
                       beta, C, ldc, epi.rs, epi.cv, epi.ldcv, epi.L, epi.bias);
 }
 
+static int persist_mode() {  // EBN_GEMM_PERSIST = 0: one workgroup per tile (hardware dispatch); 1: persistent workgroups with the next tile's
+  static const int m = [] { const char* e = getenv("EBN_GEMM_PERSIST"); return e ? atoi(e) : 0; }();  // first slab requested under the stores
+  return m;
+}
+
 template <int BM, int BN, int WAVES_M>
 int launch_gemm(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha, const float* A,
                 int64_t lda, const float* B, int64_t ldb, float beta, float* C, int64_t ldc, int vecA,
@@ -611,24 +647,36 @@ int launch_gemm(int transA, int transB, int64_t M, int64_t N, int64_t K, float a
   dim3 grid(static_cast<unsigned>(ebn_ceil_div(N, BN)), static_cast<unsigned>(ebn_ceil_div(M, BM)),
             static_cast<unsigned>(splits));
   dim3 block(GEMM_THREADS);
+  const int64_t total = static_cast<int64_t>(grid.x) * grid.y * grid.z;
+  // persistent form: as many workgroups as stay resident (three per CU by registers and LDS; four of the 64 x 64 tile)
+  const int64_t slots = 256 * (BM == 64 ? 4 : 3);
+  const bool persist = persist_mode() != 0 && vecA && vecB && epi.bias == nullptr && epi.rs == nullptr && total > slots;
+  const dim3 pgrid(static_cast<unsigned>(total < slots ? total : slots));
+  const int32_t gx = static_cast<int32_t>(grid.x), gy = static_cast<int32_t>(grid.y), gz = static_cast<int32_t>(grid.z);
 #define EBN_GEMM_LAUNCH(TA, TB)                                                                            \
   do {                                                                                                    \
-    if (vecA && vecB)                                                                                     \
+    if (persist)                                                                                          \
+      hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WAVES_M, TA, TB, true, 0, 0, true>), pgrid, block, 0, s, M, N, K, alpha, A, lda, \
+                         B, ldb, beta, C, ldc, k_per_split, part, epi, gx, gy, gz);                       \
+    else if (vecA && vecB)                                                                                \
       hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WAVES_M, TA, TB, true, 0>), grid, block, 0, s, M, N, K, alpha, A, lda, \
-                         B, ldb, beta, C, ldc, k_per_split, part, epi);                                   \
+                         B, ldb, beta, C, ldc, k_per_split, part, epi, gx, gy, gz);                       \
     else                                                                                                  \
       hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WAVES_M, TA, TB, false, 0>), grid, block, 0, s, M, N, K, alpha, A,  \
-                         lda, B, ldb, beta, C, ldc, k_per_split, part, epi);                              \
+                         lda, B, ldb, beta, C, ldc, k_per_split, part, epi, gx, gy, gz);                  \
   } while (0)
   if (epi.bias != nullptr)  // caller guarantees !transA && !transB && vecA && vecB
     hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WAVES_M, false, false, true, 0, 2>), grid, block, 0, s, M, N, K, alpha, A, lda,
-                       B, ldb, beta, C, ldc, k_per_split, part, epi);
+                       B, ldb, beta, C, ldc, k_per_split, part, epi, gx, gy, gz);
   else if (epi.rs != nullptr)  // caller guarantees !transA && transB && vecA && vecB
     hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WAVES_M, false, true, true, 0, 1>), grid, block, 0, s, M, N, K, alpha, A, lda,
-                       B, ldb, beta, C, ldc, k_per_split, part, epi);
+                       B, ldb, beta, C, ldc, k_per_split, part, epi, gx, gy, gz);
+  else if (!transA && !transB && site == 1 && vecA && vecB && persist)
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WAVES_M, false, false, true, 1, 0, true>), pgrid, block, 0, s, M, N, K, alpha, A, lda, B,
+                       ldb, beta, C, ldc, k_per_split, part, epi, gx, gy, gz);
   else if (!transA && !transB && site == 1 && vecA && vecB)
     hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WAVES_M, false, false, true, 1>), grid, block, 0, s, M, N, K, alpha, A, lda, B,
-                       ldb, beta, C, ldc, k_per_split, part, epi);
+                       ldb, beta, C, ldc, k_per_split, part, epi, gx, gy, gz);
   else if (!transA && !transB) EBN_GEMM_LAUNCH(false, false);
   else if (!transA && transB) EBN_GEMM_LAUNCH(false, true);
   else if (transA && !transB) EBN_GEMM_LAUNCH(true, false);
