@@ -593,10 +593,15 @@ int ebn_gemm_direct_launch(int32_t transB, int64_t M, int64_t N, int64_t K, floa
 }
 
 // The TN form (weight gradient of a tall product).  Returns the number of K chunks (= dense [Z][M][N] slices the launch writes into
-// `part`), 0 when the shape is not this kernel's: a small output (<= 512 x 512) under a long contraction.
+// `part`), 0 when the shape is not this kernel's: an output of at most 512 rows (32 row blocks) and 1280 columns under a long
+// contraction.  Measured envelope (MI355X, GEMM + combining pass, against the 64 x 64 split-K tiles): 400 x 200 x 24000 47.6 vs 55.0 us,
+// x 52800 82 vs 105 us (43 % tile padding removed); 300 x 1200 x 24000 152.6 vs 170.7 us, x 52800 308.5 vs 345.0 us (only 8 %
+// padding there: the gain is the barrier-free, wave-private pipeline).  EBN_GEMM_DIRECT_TN_MAXN / _PADONLY: tuning.
 int ebn_gemm_direct_tn_slices(int64_t M, int64_t N, int64_t K) {
-  if (direct_mode() == 0 || M < 48 || N < 48 || M > 512 || N > 512 || K < 4096) return 0;
-  if (ebn_ceil_div(M, 64) * ebn_ceil_div(N, 64) * 64 * 64 * 10 < M * N * 12) return 0;  // 64 x 64 tiles pad it by < 20 %: they keep it
+  static const int64_t max_n = [] { const char* e = getenv("EBN_GEMM_DIRECT_TN_MAXN"); return e ? static_cast<int64_t>(atoi(e)) : int64_t{1280}; }();
+  static const bool pad_only = getenv("EBN_GEMM_DIRECT_TN_PADONLY") != nullptr;  // only outputs the 64 x 64 tiles pad by >= 20 %
+  if (direct_mode() == 0 || M < 48 || N < 48 || M > 512 || N > max_n || K < 4096) return 0;
+  if (pad_only && ebn_ceil_div(M, 64) * ebn_ceil_div(N, 64) * 64 * 64 * 10 < M * N * 12) return 0;
   return tn_direct_plan(M, N, K).Z;
 }
 

@@ -113,7 +113,7 @@ GEMM_SHAPES = [(1, 1, 1), (5, 7, 3), (64, 64, 16), (130, 70, 33), (257, 129, 300
                # small, awkward outputs under a long contraction (AttLayer2's weight gradient and ragged relatives): the transposed-A layout
                # takes the 16x16-block K-chunked kernel of ebn_gemm_direct.hip -- partial last group (K % 16 != 0), partial last chunk,
                # M / N not multiples of 16, every (R, CW) instantiation the plan can pick
-               (400, 200, 24000), (416, 208, 9000), (100, 500, 5003), (500, 60, 4100), (72, 72, 30001), (330, 330, 7777)]
+               (400, 200, 24000), (416, 208, 9000), (100, 500, 5003), (500, 60, 4100), (72, 72, 30001), (330, 330, 7777), (300, 1200, 9000), (512, 1280, 4100)]
 
 
 _TALL_SCRIPT = r'''
