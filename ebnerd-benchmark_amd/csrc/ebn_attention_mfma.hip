@@ -22,8 +22,6 @@
 // through LDS).
 #include <stdlib.h>
 
-#include <type_traits>
-
 #include "ebn_common.h"
 
 namespace {
@@ -55,15 +53,6 @@ struct MfmaAttnArgs {
   // group-form kernels: start-up stagger of the first round of workgroups (see stagger_first_round); 0 = off
   uint32_t stagger_units, stagger_shift, stagger_mod;
 };
-
-// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>)
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (N > 0) {
-    static_for<N - 1>(f);
-    f(std::integral_constant<int, N - 1>{});
-  }
-}
 
 __device__ __forceinline__ int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
@@ -399,11 +388,15 @@ __device__ __forceinline__ uint32_t xcd_chunked_block() {
 #endif
 }
 
-// The workgroups of a launch's FIRST dispatch round start together, and a workgroup of the group-form kernels is three phases
+// The workgroups of a launch's FIRST dispatch round start together, and a workgroup of the group-form backward is three phases
 // of fixed length -- fetch (memory), MFMA / softmax chain (ALU), store (memory) -- so the `mod` workgroups that share a CU stay
-// in phase: all of them wait for memory together, then all compete for the ALU together (measured: backward = 69 us where its
-// memory phase alone is 45 and its MFMA work 28).  De-phased at start-up: workgroup b of the first round sleeps
-// ((b >> shift) % mod) x units x 512 cycles before it begins; later rounds inherit the offsets of the slots they fill.
+// in phase: all of them wait for memory together, then all compete for the ALU together (measured: 69 us where the memory
+// phases alone take 45 and the MFMAs 28; a padded-LDS control with 3 instead of 4 workgroups per CU: 76 us; 5: 67 us).
+// De-phased at start-up: workgroup b of the first round sleeps ((b >> shift) % mod) x units x 512 cycles before it begins;
+// later rounds inherit the offsets of the slots they fill.  800 titles: 69 -> 62 us, 1760: 150 -> 139 us (units 6-8, shift 8 =
+// the dispatcher deals 256 consecutive workgroups one per CU; shift 3: no gain); c4 step -16 us, c2 -3 us.
+// (Measured instead of this and NOT kept, profiles/r04_tuning_notes.md: a persistent, software-pipelined form of the kernel that
+// requests the next group's Q | K | dO pieces into 36 registers before it computes -- 128 VGPRs, bit-identical, 66.6 us.)
 __device__ __forceinline__ void stagger_first_round(const MfmaAttnArgs& a) {
   if (a.stagger_units != 0u && blockIdx.x < (a.stagger_mod << 8)) {
     const uint32_t n = ((blockIdx.x >> a.stagger_shift) % a.stagger_mod) * a.stagger_units;
@@ -432,7 +425,6 @@ __global__ __launch_bounds__(64 * ATT_WAVES) void attn_mfma_fwd_kernel(MfmaAttnA
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform on its face: base pointers stay scalar
   const int64_t prob = static_cast<int64_t>(xcd_chunked_block()) * ATT_WAVES + wv;
   if (prob >= a.n_prob) return;  // wave-uniform; no workgroup barriers in this kernel
-  stagger_first_round(a);
   const int L = LC ? LC : a.L, E = a.h * D;
   float* sv = smem + wv * fwd_wave_floats<D>(L);
   const int row = lane & 31, hi = lane >> 5;
@@ -498,7 +490,6 @@ __global__ __launch_bounds__(64 * G) void attn_mfma_fwd_group_kernel(MfmaAttnArg
   const bool drop = a.key_ptr != nullptr;
   const uint32_t key = drop ? *a.key_ptr : 0u;
 
-  stagger_first_round(a);
   const AttnProb p0 = attn_prob(static_cast<int64_t>(xcd_chunked_block()) * G, a.h, L);
   const uint32_t gcol = p0.head * D;
   const float* gq = a.qkv + p0.row0 * a.ld_qkv + gcol;
@@ -731,30 +722,20 @@ __global__ __launch_bounds__(64 * ATT_WAVES) void attn_mfma_bwd_kernel(MfmaAttnA
 // with no excess HBM traffic (FETCH/WRITE_SIZE = the algorithmic bytes): it is request count and DRAM page locality.  Here the
 // G x D columns of the group are one contiguous run per row (320 bytes for G = 4), fetched as consecutive 16-byte lanes into
 // the per-head LDS tiles, and the three result tiles of every head go back through LDS the same way: half the L2 requests
-// (13.2 M against 29.6 M per 3200 titles), 75 -> 65 us per 800 titles on HBM-resident data.  G = 4 keeps one wave per SIMD and
-// 4 workgroups per CU; G = 5 (83 us) and G = 10 (97 us) lose more to the two workgroup barriers than the wider rows give.
-// LDS per wave: Q | K | dO | V tiles, K|dO later the transpose buffer; results: d(V) over V, d(Q) over Q (Q's column form is
-// pulled into registers first), d(K) over K after the transposed d(S) has been read.  Bit-identical to the per-wave kernel.
-// EBN_ATTN_BWD_VDIRECT (tuning switch): V -- wanted in row form only -- straight from global memory into registers, as the
-// per-wave kernel takes it, and THREE tiles per wave instead of four (Q | K | dO; Q|K later the transpose buffer, d(V) over dO,
-// d(Q) held in registers across the transpose): 28.8 instead of 38.4 KB per workgroup = five workgroups per CU instead of four.
-#ifndef EBN_ATTN_BWD_VDIRECT
-#define EBN_ATTN_BWD_VDIRECT 0
-#endif
-#ifndef EBN_ATTN_BWD_LDS_PAD
-#define EBN_ATTN_BWD_LDS_PAD 0  // tuning: extra floats per wave (occupancy experiments)
-#endif
+// (13.2 M against 29.6 M per 3200 titles), 75 -> 65 us per 800 titles on HBM-resident data.  G = 4 keeps one wave per SIMD;
+// G = 2 (72 us), G = 5 (83 us) and G = 10 (97 us) lose more to request count or to the two workgroup barriers.
+// LDS per wave: THREE tiles, Q | K | dO (28.8 KB per workgroup of four heads: five workgroups per CU; round 3's fourth tile
+// for V, 38.4 KB and four workgroups, measured 2 % slower).  V is needed in row form only and comes straight from global memory
+// into registers, as in the per-wave kernel.  Results: d(V) over dO once dO's row and column forms are in registers; Q|K become
+// the transpose buffer once their forms are in registers, d(Q) waits in registers across the transpose and then takes Q's tile,
+// d(K) K's.  Bit-identical to the per-wave kernel.
 template <int D>
-__host__ __device__ constexpr int bwd_group_v_offset(int L) {
-#if EBN_ATTN_BWD_VDIRECT
-  return 2 * L * Tile<D>::STRIDE > TP_FLOATS ? 2 * L * Tile<D>::STRIDE : TP_FLOATS;  // offset of the dO tile
-#else
-  return 3 * L * Tile<D>::STRIDE > L * Tile<D>::STRIDE + TP_FLOATS ? 3 * L * Tile<D>::STRIDE : L * Tile<D>::STRIDE + TP_FLOATS;
-#endif
+__host__ __device__ constexpr int bwd_group_g_offset(int L) {  // offset of the dO tile: behind Q | K and behind the transpose buffer
+  return 2 * L * Tile<D>::STRIDE > TP_FLOATS ? 2 * L * Tile<D>::STRIDE : TP_FLOATS;
 }
 template <int D>
 __host__ __device__ constexpr int bwd_group_wave_floats(int L) {
-  return bwd_group_v_offset<D>(L) + L * Tile<D>::STRIDE + EBN_ATTN_BWD_LDS_PAD;
+  return bwd_group_g_offset<D>(L) + L * Tile<D>::STRIDE;
 }
 
 template <int D, int LC, int G>
@@ -770,7 +751,7 @@ __global__ __launch_bounds__(64 * G) void attn_mfma_bwd_group_kernel(MfmaAttnArg
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int L = LC ? LC : a.L, E = a.h * D;
   const int region = L * T::STRIDE;
-  const int wave_floats = bwd_group_wave_floats<D>(L), v_off = bwd_group_v_offset<D>(L);
+  const int wave_floats = bwd_group_wave_floats<D>(L), g_off = bwd_group_g_offset<D>(L);
   const int row = lane & 31, hi = lane >> 5;
   const float inv = 1.0f / sqrtf(static_cast<float>(D));
   const float inv2 = inv * 1.44269504088896341f;
@@ -783,15 +764,10 @@ __global__ __launch_bounds__(64 * G) void attn_mfma_bwd_group_kernel(MfmaAttnArg
   const float* gq = a.qkv + p0.row0 * a.ld_qkv + gcol;
   const float* gd = a.dout + p0.row0 * a.ld_dout + gcol;
   const int nvec = L * GV;
-#if EBN_ATTN_BWD_VDIRECT
   float vr[KH];
   global_row_form<D>(vr, gq + 2 * E + wv * D, a.ld_qkv, L, row, hi);
-#endif
   {
     float4 vq[ROUNDS], vk[ROUNDS], vg[ROUNDS];
-#if !EBN_ATTN_BWD_VDIRECT
-    float4 vv[ROUNDS];
-#endif
     uint32_t dst[ROUNDS];  // LDS float offset of the piece inside its head's Q tile
 #pragma unroll
     for (int t = 0; t < ROUNDS; ++t) {
@@ -803,9 +779,6 @@ __global__ __launch_bounds__(64 * G) void attn_mfma_bwd_group_kernel(MfmaAttnArg
       const uint32_t off = r * static_cast<uint32_t>(a.ld_qkv) + c4g * 4;
       vq[t] = *reinterpret_cast<const float4*>(gq + off);
       vk[t] = *reinterpret_cast<const float4*>(gq + E + off);
-#if !EBN_ATTN_BWD_VDIRECT
-      vv[t] = *reinterpret_cast<const float4*>(gq + 2 * E + off);
-#endif
       vg[t] = *reinterpret_cast<const float4*>(gd + (r * static_cast<uint32_t>(a.ld_dout) + c4g * 4));
       if (pooled) {
         const float w = a.pool_w[p0.row0 + r];
@@ -829,12 +802,7 @@ __global__ __launch_bounds__(64 * G) void attn_mfma_bwd_group_kernel(MfmaAttnArg
       if (tid + NT * t < nvec) {
         *reinterpret_cast<float4*>(smem + dst[t]) = vq[t];
         *reinterpret_cast<float4*>(smem + dst[t] + region) = vk[t];
-#if EBN_ATTN_BWD_VDIRECT
-        *reinterpret_cast<float4*>(smem + dst[t] + v_off) = vg[t];
-#else
-        *reinterpret_cast<float4*>(smem + dst[t] + 2 * region) = vg[t];
-        *reinterpret_cast<float4*>(smem + dst[t] + v_off) = vv[t];
-#endif
+        *reinterpret_cast<float4*>(smem + dst[t] + g_off) = vg[t];
       }
     }
   }
@@ -843,15 +811,7 @@ __global__ __launch_bounds__(64 * G) void attn_mfma_bwd_group_kernel(MfmaAttnArg
 
   float* sq = smem + wv * wave_floats;
   float* sk = sq + region;
-#if EBN_ATTN_BWD_VDIRECT
-  float* sg = sq + v_off;
-  float* sv = sg;  // d(V) goes over dO once dO's row and column forms are in registers
-#else
-  float* sg = sk + region;
-  float* sv = sq + v_off;
-  float vr[KH];
-  lds_row_form<D>(vr, sv, L, row, hi);
-#endif
+  float* sg = sq + g_off;
   f32x16 P, dP;
   {
     float qr[KH], kr[KH];
@@ -874,15 +834,14 @@ __global__ __launch_bounds__(64 * G) void attn_mfma_bwd_group_kernel(MfmaAttnArg
   float col[16], colq[16];
   lds_col_form<D>(col, sg, L, row, hi);
   lds_col_form<D>(colq, sq, L, row, hi);
-  wave_lds_sync();  // V's row form and Q's column form are in registers: their tiles take d(V) and d(Q)
+  wave_lds_sync();  // dO's row and column forms are in registers: its tile takes d(V)
   {  // dV^T[c][i] = sum_j dO[j][c] P[i][j]
     const f32x16 dV = mm_col_tile(col, P);
-    tile_rows_to_lds<D>(sv, dV, L, row, hi, 1.0f);
+    tile_rows_to_lds<D>(sg, dV, L, row, hi, 1.0f);
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) P[r] = P[r] * (dP[r] - rowdot);  // dS[i][j]: lane i, regs j
   lds_col_form<D>(col, sk, L, row, hi);
-#if EBN_ATTN_BWD_VDIRECT
   const f32x16 dQ = mm_col_tile(col, P);  // dQ^T[c][i] = inv * sum_j K[j][c] dS[i][j]; stays in registers over the transpose
   EBN_ATTN_PRIO_AT(3);
   wave_lds_sync();                    // Q and K have been read for the last time: their tiles become the transpose buffer
@@ -893,20 +852,6 @@ __global__ __launch_bounds__(64 * G) void attn_mfma_bwd_group_kernel(MfmaAttnArg
     const f32x16 dK = mm_col_tile(colq, P);
     tile_rows_to_lds<D>(sk, dK, L, row, hi, inv);
   }
-#else
-  {  // dQ^T[c][i] = inv * sum_j K[j][c] dS[i][j]
-    const f32x16 dQ = mm_col_tile(col, P);
-    tile_rows_to_lds<D>(sq, dQ, L, row, hi, inv);
-  }
-  EBN_ATTN_PRIO_AT(3);
-  wave_lds_sync();                    // K and dO have been read for the last time: their tiles become the transpose buffer
-  tile_transpose(P, sk, L, row, hi);  // dS[i][j]: lane j, regs i
-  wave_lds_sync();
-  {  // dK^T[c][j] = inv * sum_i Q[i][c] dS[i][j]
-    const f32x16 dK = mm_col_tile(colq, P);
-    tile_rows_to_lds<D>(sk, dK, L, row, hi, inv);
-  }
-#endif
   __syncthreads();
 
   float* go = a.out + p0.row0 * a.ld_out + gcol;
@@ -919,253 +864,12 @@ __global__ __launch_bounds__(64 * G) void attn_mfma_bwd_group_kernel(MfmaAttnArg
       const float* src = smem + head * wave_floats + r * T::STRIDE + c4 * 4;
       const float4 q4 = *reinterpret_cast<const float4*>(src);
       const float4 k4 = *reinterpret_cast<const float4*>(src + region);
-      const float4 v4 = *reinterpret_cast<const float4*>(src + v_off);
+      const float4 v4 = *reinterpret_cast<const float4*>(src + g_off);
       float* d = go + (r * static_cast<uint32_t>(a.ld_out) + c4g * 4);
       *reinterpret_cast<float4*>(d) = q4;
       *reinterpret_cast<float4*>(d + E) = k4;
       *reinterpret_cast<float4*>(d + 2 * E) = v4;
     }
-  }
-}
-
-
-// Backward, PIPELINED group form: the group kernel above with its three phases overlapped INSIDE a workgroup instead of hoping
-// that co-resident workgroups drift out of phase.  A resident workgroup walks groups v, v + gridDim, ...; while it runs the
-// MFMA / softmax chain of group v the Q | K | dO pieces of group v + gridDim are already on their way into registers (36
-// VGPRs), and the row form of V plus the pooling operands follow while the results of v are stored.  Order of one turn:
-//   barrier A (tiles of v in LDS) -> request Q|K|dO of the next group -> compute v -> barrier B (results in LDS) -> request
-//   V rows / pooling operands of the next group -> store v -> barrier C (tiles free) -> adjust + write the next tiles.
-// The first group's tiles are written ahead of the loop, so the wait in front of "adjust + write" only ever sees one request
-// pattern (Q|K|dO, then V / pooling, then the stores of v) and does not have to wait for the stores' acknowledgements.
-// Three tiles per wave as with EBN_ATTN_BWD_VDIRECT.  Same arithmetic in the same order as the other two backward kernels.
-template <int D>
-__host__ __device__ constexpr int bwd_pipe_g_offset(int L) {
-  return 2 * L * Tile<D>::STRIDE > TP_FLOATS ? 2 * L * Tile<D>::STRIDE : TP_FLOATS;
-}
-template <int D>
-__host__ __device__ constexpr int bwd_pipe_wave_floats(int L) {
-  return bwd_pipe_g_offset<D>(L) + L * Tile<D>::STRIDE;
-}
-
-// the XCD-contiguous order of xcd_chunked_block() for a virtual block index (v & 7 = the XCD of the workgroup that runs it:
-// the grid is a multiple of 8)
-__device__ __forceinline__ uint32_t xcd_chunked_index(uint32_t v, uint32_t n) {
-#if EBN_ATTN_XCD
-  const uint32_t q = n >> 3, r = n & 7u, xcd = v & 7u, idx = v >> 3;
-  return ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-#else
-  return v;
-#endif
-}
-
-#ifndef EBN_ATTN_PIPE_WAVES_PER_EU
-#define EBN_ATTN_PIPE_WAVES_PER_EU 4
-#endif
-
-// piece t of a thread: row r, float4 column c4g of the group's G x D columns -- the same for every group.  Recomputed from a
-// laundered thread index at every use: hoisted out of the group loop this geometry costs ~20 VGPRs that the loop does not have.
-template <int NT, int GV>
-struct PipePiece {
-  uint32_t r, c4g;
-  bool ok;
-  __device__ __forceinline__ PipePiece(int tid, int t, int nvec) {
-    int tl = tid;
-    asm volatile("" : "+v"(tl));
-    const int idx = tl + NT * t;
-    ok = idx < nvec;
-    const uint32_t idc = ok ? static_cast<uint32_t>(idx) : 0u;
-    r = idc / static_cast<uint32_t>(GV);
-    c4g = idc - r * GV;
-  }
-};
-
-// the pieces of one group in flight.  Native vectors, not float4: a float4 that is only copied (global -> register -> LDS) is a
-// memcpy into a private array that nothing ever types, and what does not become SSA values there is left to the backend's
-// alloca promotion, whose budget (a quarter of the VGPRs of the requested occupancy) put Q and K pieces into scratch memory.
-typedef float f32x4v __attribute__((ext_vector_type(4)));
-template <int ROUNDS>
-struct PipeRegs {
-  f32x4v q[ROUNDS], k[ROUNDS], g[ROUNDS];
-};
-template <int ROUNDS>
-struct PipeLate {
-  float w[ROUNDS];
-  f32x4v d[ROUNDS];
-};
-
-template <int D, int LC, int G>
-__global__ __launch_bounds__(64 * G) __attribute__((amdgpu_waves_per_eu(EBN_ATTN_PIPE_WAVES_PER_EU, EBN_ATTN_PIPE_WAVES_PER_EU)))
-void attn_mfma_bwd_pipe_kernel(MfmaAttnArgs a) {
-  using T = Tile<D>;
-  constexpr int KH = D / 2;
-  constexpr int NT = 64 * G;
-  constexpr int GV = G * T::VPR;
-  constexpr int ROUNDS = (32 * GV + NT - 1) / NT;
-  using Piece = PipePiece<NT, GV>;
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // G x bwd_pipe_wave_floats
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int L = LC ? LC : a.L, E = a.h * D;
-  const int region = L * T::STRIDE;
-  const int wave_floats = bwd_pipe_wave_floats<D>(L), g_off = bwd_pipe_g_offset<D>(L);
-  const int row = lane & 31, hi = lane >> 5;
-  const float inv = 1.0f / sqrtf(static_cast<float>(D));
-  const float inv2 = inv * 1.44269504088896341f;
-  const bool drop = a.key_ptr != nullptr, pooled = a.pool_w != nullptr;  // uniform
-  const uint32_t key = drop ? *a.key_ptr : 0u;
-  const uint32_t n_groups = static_cast<uint32_t>(a.n_prob) / G;
-  const int nvec = L * GV;
-  float* sq = smem + wv * wave_floats;
-  float* sk = sq + region;
-  float* sg = sq + g_off;
-
-  stagger_first_round(a);
-  PipeRegs<ROUNDS> pr;
-  PipeLate<ROUNDS> pl;
-  float vr[KH], vl[KH];  // V's rows: as requested (vl), and as the dP product reads them (vr, copied once they have arrived)
-
-  auto request_main = [&](const AttnProb& p) __attribute__((always_inline)) {  // Q | K | dO pieces of group p
-    const float* gq = a.qkv + p.row0 * a.ld_qkv + p.head * D;
-    const float* gd = a.dout + p.row0 * a.ld_dout + p.head * D;
-    static_for<ROUNDS>([&](auto tc) __attribute__((always_inline)) {
-      constexpr int t = decltype(tc)::value;
-      const Piece pc(tid, t, nvec);
-      const uint32_t off = pc.r * static_cast<uint32_t>(a.ld_qkv) + pc.c4g * 4;
-      pr.q[t] = *reinterpret_cast<const f32x4v*>(gq + off);
-      pr.k[t] = *reinterpret_cast<const f32x4v*>(gq + E + off);
-      pr.g[t] = *reinterpret_cast<const f32x4v*>(gd + (pc.r * static_cast<uint32_t>(a.ld_dout) + pc.c4g * 4));
-    });
-  };
-  auto request_late = [&](const AttnProb& p) __attribute__((always_inline)) {  // V in row form (this wave's head) and the pooling operands of the dO pieces
-    global_row_form<D>(vl, a.qkv + p.row0 * a.ld_qkv + p.head * D + 2 * E + wv * D, a.ld_qkv, L, row, hi);
-    if (pooled) {
-      static_for<ROUNDS>([&](auto tc) __attribute__((always_inline)) {
-        constexpr int t = decltype(tc)::value;
-        const Piece pc(tid, t, nvec);
-        pl.w[t] = a.pool_w[p.row0 + pc.r];
-        pl.d[t] = *reinterpret_cast<const f32x4v*>(a.pool_d + p.seq * a.ld_pool + p.head * D + pc.c4g * 4);
-      });
-    }
-  };
-  auto write_tiles = [&](const AttnProb& p) __attribute__((always_inline)) {  // pooling term and forward dropout mask onto dO, then the three tiles into LDS
-    static_for<ROUNDS>([&](auto tc) __attribute__((always_inline)) {
-      constexpr int t = decltype(tc)::value;
-      const Piece pc(tid, t, nvec);
-      f32x4v g4 = pr.g[t];
-      if (pooled) {
-        g4.x = fmaf(pl.w[t], pl.d[t].x, g4.x);
-        g4.y = fmaf(pl.w[t], pl.d[t].y, g4.y);
-        g4.z = fmaf(pl.w[t], pl.d[t].z, g4.z);
-        g4.w = fmaf(pl.w[t], pl.d[t].w, g4.w);
-      }
-      if (drop) {  // the forward mask of element (row0 + r, gcol + 4 c4g): two aligned pairs
-        const uint32_t gcol = p.head * D;
-        const uint64_t e2 = ((static_cast<uint64_t>(p.row0) * E + gcol) >> 1) + ((pc.r * static_cast<uint32_t>(E) + pc.c4g * 4) >> 1);
-        const uint32_t h0 = ebn_dropout_pair_hash(key, e2), h1 = ebn_dropout_pair_hash(key, e2 + 1);
-        g4.x *= ((h0 & 0xFFFFu) >= a.thresh) ? a.scale : 0.f;
-        g4.y *= ((h0 >> 16) >= a.thresh) ? a.scale : 0.f;
-        g4.z *= ((h1 & 0xFFFFu) >= a.thresh) ? a.scale : 0.f;
-        g4.w *= ((h1 >> 16) >= a.thresh) ? a.scale : 0.f;
-      }
-      if (pc.ok) {
-        const uint32_t head = pc.c4g / T::VPR, c4 = pc.c4g - head * T::VPR;
-        float* d = smem + head * wave_floats + pc.r * T::STRIDE + c4 * 4;
-        *reinterpret_cast<f32x4v*>(d) = pr.q[t];
-        *reinterpret_cast<f32x4v*>(d + region) = pr.k[t];
-        *reinterpret_cast<f32x4v*>(d + g_off) = g4;
-      }
-    });
-  };
-
-  uint32_t v = blockIdx.x;  // < n_groups: the grid never exceeds the number of groups
-  AttnProb p0 = attn_prob(static_cast<int64_t>(xcd_chunked_index(v, n_groups)) * G, a.h, L);
-  request_main(p0);
-  request_late(p0);
-  write_tiles(p0);
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), see the end of the loop
-#pragma unroll
-  for (int i = 0; i < KH; ++i) asm volatile("v_mov_b32 %0, %1" : "=v"(vr[i]) : "v"(vl[i]));
-  for (;;) {
-    __syncthreads();  // A
-    const uint32_t vn = v + gridDim.x;
-    const bool has_next = vn < n_groups;  // uniform
-    AttnProb pn = p0;
-    if (has_next) {
-      pn = attn_prob(static_cast<int64_t>(xcd_chunked_index(vn, n_groups)) * G, a.h, L);
-      request_main(pn);
-    }
-    f32x16 P, dP;
-    {
-      float qr[KH], kr[KH];
-      lds_row_form<D>(qr, sq, L, row, hi);
-      lds_row_form<D>(kr, sk, L, row, hi);
-      P = mm_rows<KH>(kr, qr);  // T[j][i]: lane i, regs j
-    }
-    softmax_in_lane(P, L, hi, inv2);  // P[i][j]: lane i, regs j
-    {
-      float gr[KH];
-      lds_row_form<D>(gr, sg, L, row, hi);
-      dP = mm_rows<KH>(gr, vr);  // dP[i][j] = V[i].dO[j]: lane i, regs j
-    }
-    float rowdot = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) rowdot = fmaf(P[r], dP[r], rowdot);
-    rowdot += __shfl_xor(rowdot, 32, 64);
-    float col[16], colq[16];
-    __builtin_amdgcn_sched_barrier(0);  // not above the dP product: the next group's 36 piece registers are live through all of this
-    lds_col_form<D>(col, sg, L, row, hi);
-    wave_lds_sync();  // dO's row and column forms are in registers: its tile takes d(V)
-    {  // dV^T[c][i] = sum_j dO[j][c] P[i][j]
-      const f32x16 dV = mm_col_tile(col, P);
-      tile_rows_to_lds<D>(sg, dV, L, row, hi, 1.0f);
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) P[r] = P[r] * (dP[r] - rowdot);  // dS[i][j]: lane i, regs j
-    __builtin_amdgcn_sched_barrier(0);  // Q's column form only now: 16 registers fewer while d(V) is formed (the next group's pieces are live)
-    lds_col_form<D>(col, sk, L, row, hi);
-    lds_col_form<D>(colq, sq, L, row, hi);
-    const f32x16 dQ = mm_col_tile(col, P);  // dQ^T[c][i] = inv * sum_j K[j][c] dS[i][j]; in registers over the transpose
-    wave_lds_sync();                    // Q and K have been read for the last time: their tiles become the transpose buffer
-    tile_transpose(P, sq, L, row, hi);  // dS[i][j]: lane j, regs i
-    wave_lds_sync();
-    tile_rows_to_lds<D>(sq, dQ, L, row, hi, inv);
-    {  // dK^T[c][j] = inv * sum_i Q[i][c] dS[i][j]
-      const f32x16 dK = mm_col_tile(colq, P);
-      tile_rows_to_lds<D>(sk, dK, L, row, hi, inv);
-    }
-    __syncthreads();  // B
-    if (has_next) request_late(pn);
-    {
-      float* go = a.out + p0.row0 * a.ld_out + p0.head * D;
-      static_for<ROUNDS>([&](auto tc) __attribute__((always_inline)) {
-        constexpr int t = decltype(tc)::value;
-        const Piece pc(tid, t, nvec);
-        if (pc.ok) {
-          const uint32_t head = pc.c4g / T::VPR, c4 = pc.c4g - head * T::VPR;
-          const float* src = smem + head * wave_floats + pc.r * T::STRIDE + c4 * 4;
-          const f32x4v q4 = *reinterpret_cast<const f32x4v*>(src);
-          const f32x4v k4 = *reinterpret_cast<const f32x4v*>(src + region);
-          const f32x4v v4 = *reinterpret_cast<const f32x4v*>(src + g_off);
-          float* d = go + (pc.r * static_cast<uint32_t>(a.ld_out) + pc.c4g * 4);
-          *reinterpret_cast<f32x4v*>(d) = q4;
-          *reinterpret_cast<f32x4v*>(d + E) = k4;
-          *reinterpret_cast<f32x4v*>(d + 2 * E) = v4;
-        }
-      });
-    }
-    if (!has_next) break;
-    __syncthreads();  // C
-    write_tiles(pn);
-    // Every request so far has been consumed; say so outside the per-piece `ok` branches.  (gfx9 has ONE counter for loads and
-    // stores and the compiler treats a mix of both as unordered: any wait with v's stores pending is vmcnt(0) anyway, and without
-    // this line the V rows count as possibly pending on the path that skips a piece -- which put a vmcnt(0) BEHIND the next
-    // group's requests, in front of the dP product.)
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-#pragma unroll
-    for (int i = 0; i < KH; ++i) asm volatile("v_mov_b32 %0, %1" : "=v"(vr[i]) : "v"(vl[i]));  // ... and V's rows are plain register values from here on
-    p0 = pn;
-    v = vn;
   }
 }
 
@@ -1517,12 +1221,6 @@ int ebn_attn_mfma_fwd(const float* qkv, int64_t ld_qkv, float* out, int64_t ld_o
   *handled = mfma_path_ok(L, d, ld_qkv, ld_out, ld_out, qkv, out, out) && n_seq * h < (int64_t{1} << 31);
   if (!*handled) return EBN_OK;
   MfmaAttnArgs a{qkv, ld_qkv, nullptr, 0, out, ld_out, n_seq * h, L, h, dr.key_ptr, dr.thresh, dr.scale, nullptr, nullptr, 0, 0u, 0u, 1u};
-  if (L <= 32) {
-    a.stagger_units = env_u32("EBN_ATTN_FWD_STAGGER", 0u);
-    a.stagger_shift = env_u32("EBN_ATTN_FWD_STAGGER_SHIFT", 8u);
-    a.stagger_mod = env_u32("EBN_ATTN_FWD_STAGGER_MOD", 4u);
-    if (a.stagger_mod == 0u) a.stagger_mod = 1u;
-  }
   if (L > 32) {
     if (d == 16) launch_mfma2<16>(false, a, s);
     else if (d == 20) launch_mfma2<20>(false, a, s);
@@ -1576,24 +1274,10 @@ int ebn_attn_mfma_bwd(const float* qkv, int64_t ld_qkv, const float* dout, int64
   if (d == 20 && (h % BWD_GROUP) == 0 && a.n_prob >= BWD_GROUP_MIN_PROBLEMS && !bwd_group_off()) {
     const size_t lds = static_cast<size_t>(BWD_GROUP) * bwd_group_wave_floats<20>(L) * sizeof(float);
     const dim3 grid(static_cast<unsigned>(a.n_prob / BWD_GROUP)), block(64 * BWD_GROUP);
-    a.stagger_units = env_u32("EBN_ATTN_STAGGER", 0u);
+    a.stagger_units = env_u32("EBN_ATTN_STAGGER", 7u);  // x 512 cycles per step; 0 = off (tuning switches)
     a.stagger_shift = env_u32("EBN_ATTN_STAGGER_SHIFT", 8u);
-    a.stagger_mod = env_u32("EBN_ATTN_STAGGER_MOD", 4u);
+    a.stagger_mod = env_u32("EBN_ATTN_STAGGER_MOD", 5u);  // workgroups per CU: 28.8 KB of LDS each
     if (a.stagger_mod == 0u) a.stagger_mod = 1u;
-    if (L == 30 && env_u32("EBN_ATTN_BWD_PIPE", 0u) != 0u) {  // title_size 30 only: with L a run-time value the pipelined form spills
-      // resident workgroups walking the groups in equal shares: `turns` groups each, the grid a multiple of 8 (XCD order)
-      const int64_t n_groups = a.n_prob / BWD_GROUP;
-      const int64_t slots = static_cast<int64_t>(env_u32("EBN_ATTN_BWD_PIPE_SLOTS", 1024u));
-      const int64_t turns = (n_groups + slots - 1) / slots;
-      int64_t nwg = ((n_groups + turns - 1) / turns + 7) / 8 * 8;
-      if (nwg > n_groups) nwg = n_groups;
-      const size_t lds_p = static_cast<size_t>(BWD_GROUP) * bwd_pipe_wave_floats<20>(L) * sizeof(float);
-      const dim3 grid_p(static_cast<unsigned>(nwg));
-      allow_lds(attn_mfma_bwd_pipe_kernel<20, 30, BWD_GROUP>, lds_p);
-      hipLaunchKernelGGL((attn_mfma_bwd_pipe_kernel<20, 30, BWD_GROUP>), grid_p, block, lds_p, s, a);
-      EBN_CHECK_LAUNCH();
-      return EBN_OK;
-    }
     if (L == 30) {
       allow_lds(attn_mfma_bwd_group_kernel<20, 30, BWD_GROUP>, lds);
       hipLaunchKernelGGL((attn_mfma_bwd_group_kernel<20, 30, BWD_GROUP>), grid, block, lds, s, a);
