@@ -842,10 +842,16 @@ __device__ __forceinline__ void small_store_t(float* __restrict__ S, const float
 #pragma unroll
   for (int i = 0; i < SBK / T; ++i) {
     const int v = tid + i * THREADS;
+    // Column swizzle k ^ 8 * bit 4 of the row (a whole float4 moves, the reader of a 16-row block just swaps its lane quarters):
+    // the transposed scalar stores of a wave go to rows 4 (v % 8) + j and columns v / 8 + const, i.e. banks 16 (v % 8) + 4 j +
+    // v / 8 -- rows 16 apart collided pairwise (1.1 M / 1.9 M bank-conflict cycles per launch in profiles/r03_pmc); with the swizzle
+    // they land 8 banks apart.
     if (KC) {
-      *reinterpret_cast<float4*>(&S[(v / (SBK / 4)) * SLD + (v % (SBK / 4)) * 4]) = r[i];
+      const int row = v / (SBK / 4);
+      *reinterpret_cast<float4*>(&S[row * SLD + (((v % (SBK / 4)) * 4) ^ (((row >> 4) & 1) << 3))]) = r[i];
     } else {  // k = v / (T/4), rows 4*(v % (T/4))..+3: transposed scalar stores
-      const int k = v / (T / 4), m4 = (v % (T / 4)) * 4;
+      const int m4 = (v % (T / 4)) * 4;
+      const int k = (v / (T / 4)) ^ (((m4 >> 4) & 1) << 3);
       S[(m4 + 0) * SLD + k] = r[i].x;
       S[(m4 + 1) * SLD + k] = r[i].y;
       S[(m4 + 2) * SLD + k] = r[i].z;
@@ -947,8 +953,8 @@ __device__ __forceinline__ void small_vec_body(int64_t M, int64_t N, int64_t K, 
   // contraction index of MFMA step s in lane quarter kq: k = 32 g + 8 kq + s (the same for A and B)
 #define EBN_SM_MMA(BUF, KT)                                                                                         \
   do {                                                                                                              \
-    const float* ap__ = smem_small + (BUF) * 2 * TILE + (wm * 16 + r16) * SLD + kq * 8;                             \
-    const float* bp__ = smem_small + (BUF) * 2 * TILE + TILE + (wn * 16 + r16) * SLD + kq * 8;                      \
+    const float* ap__ = smem_small + (BUF) * 2 * TILE + (wm * 16 + r16) * SLD + (kq ^ (wm & 1)) * 8;                \
+    const float* bp__ = smem_small + (BUF) * 2 * TILE + TILE + (wn * 16 + r16) * SLD + (kq ^ (wn & 1)) * 8;         \
     float4 fa__[2][2], fb__[2][2];                                                                                  \
     if ((KT) < nk_full) {                                                                                           \
       EBN_SM_READ(0, 0);                                                                                            \
