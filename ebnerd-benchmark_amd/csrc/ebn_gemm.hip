@@ -700,6 +700,7 @@ constexpr int SBM = 32, SBN = 32;
 constexpr int SBK = 128;       // slab depth: these GEMMs are load-latency bound (one or two workgroups per CU), so a slab
                                // carries 4 x 16 bytes per thread and operand -- 4x the bytes in flight of a 32-deep slab
 constexpr int SLD = SBK + 4;   // LDS row stride (floats): 16-byte rows; the 16 rows of a b128 read group cover all 64 banks
+constexpr int SLV = SBK + 8;   // row stride of the vector-path kernels' swizzled image (small_store_t)
 constexpr int SPT = SBM * SBK / 4 / GEMM_THREADS;  // float4 per thread, operand and slab (4)
 
 // One operand tile = SPT float4 per thread.  KC: memory is [mn][k] (k contiguous): item v -> row v/32, k 4*(v%32); else memory
@@ -791,7 +792,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_small_kernel(int64_t M, int
 #pragma unroll
     for (int g = 0; g < SBK / 32; ++g) {
       if (g >= groups) break;  // wave-uniform: the zero-filled tail of the last slab is not multiplied
-      // contraction index of MFMA step s in lane quarter kq: k = 32 g + 8 kq + s (the same for A and B)
+      // contraction index of MFMA step (h, c) in lane quarter kq: k = 32 g + 16 h + 4 kq + c (the same for A and B)
       const float4 a0 = *reinterpret_cast<const float4*>(ap + 32 * g), a1 = *reinterpret_cast<const float4*>(ap + 32 * g + 4);
       const float4 b0 = *reinterpret_cast<const float4*>(bp + 32 * g), b1 = *reinterpret_cast<const float4*>(bp + 32 * g + 4);
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc, 0, 0, 0);
@@ -842,20 +843,21 @@ __device__ __forceinline__ void small_store_t(float* __restrict__ S, const float
 #pragma unroll
   for (int i = 0; i < SBK / T; ++i) {
     const int v = tid + i * THREADS;
-    // Column swizzle k ^ 8 * bit 4 of the row (a whole float4 moves, the reader of a 16-row block just swaps its lane quarters):
-    // the transposed scalar stores of a wave go to rows 4 (v % 8) + j and columns v / 8 + const, i.e. banks 16 (v % 8) + 4 j +
-    // v / 8 -- rows 16 apart collided pairwise (1.1 M / 1.9 M bank-conflict cycles per launch in profiles/r03_pmc); with the swizzle
-    // they land 8 banks apart.
+    // Column swizzle: column c of row r lives at c ^ 4 ((r >> 2) & 7) (whole float4s move), row stride 136 floats.  With the
+    // reader's k mapping below this is free of bank conflicts for all three access forms (tools/lds/bank_sim.py, the lane groups
+    // and bank moduli of MI355X_MICROARCH.md): the transposed scalar stores of a wave go to rows 4 (v % 8) + j, columns v / 8 +
+    // const -- unswizzled with stride 132 that was banks 16 (v % 8) + 4 j + v / 8 mod 32, four lanes per bank (1.1 M / 1.9 M
+    // conflict cycles per launch in profiles/r03_pmc) -- and the b128 operand reads were 2-way in every lane group.
     if (KC) {
       const int row = v / (SBK / 4);
-      *reinterpret_cast<float4*>(&S[row * SLD + (((v % (SBK / 4)) * 4) ^ (((row >> 4) & 1) << 3))]) = r[i];
+      *reinterpret_cast<float4*>(&S[row * SLV + (((v % (SBK / 4)) * 4) ^ (((row >> 2) & 7) << 2))]) = r[i];
     } else {  // k = v / (T/4), rows 4*(v % (T/4))..+3: transposed scalar stores
       const int m4 = (v % (T / 4)) * 4;
-      const int k = (v / (T / 4)) ^ (((m4 >> 4) & 1) << 3);
-      S[(m4 + 0) * SLD + k] = r[i].x;
-      S[(m4 + 1) * SLD + k] = r[i].y;
-      S[(m4 + 2) * SLD + k] = r[i].z;
-      S[(m4 + 3) * SLD + k] = r[i].w;
+      const int k = (v / (T / 4)) ^ (((m4 >> 2) & 7) << 2);
+      S[(m4 + 0) * SLV + k] = r[i].x;
+      S[(m4 + 1) * SLV + k] = r[i].y;
+      S[(m4 + 2) * SLV + k] = r[i].z;
+      S[(m4 + 3) * SLV + k] = r[i].w;
     }
   }
 }
@@ -870,7 +872,7 @@ __device__ __forceinline__ void small_vec_body(int64_t M, int64_t N, int64_t K, 
   const int wm = wave / WPR, wn = wave % WPR;
   const int64_t m0 = tile_y * T, n0 = tile_x * T;
   const int nk = static_cast<int>((K + SBK - 1) / SBK), nk_full = static_cast<int>(K / SBK);
-  constexpr int TILE = T * SLD;
+  constexpr int TILE = T * SLV;
   constexpr bool A_KC = !TA, B_KC = TB;
   const i32x4n arsrc = make_rsrc(A_KC ? A + m0 * lda : A + m0), brsrc = make_rsrc(B_KC ? B + n0 * ldb : B + n0);
   const uint32_t step_a = static_cast<uint32_t>((A_KC ? SBK : SBK * lda) * 4), step_b = static_cast<uint32_t>((B_KC ? SBK : SBK * ldb) * 4);
@@ -928,16 +930,19 @@ __device__ __forceinline__ void small_vec_body(int64_t M, int64_t N, int64_t K, 
     small_store_t<B_KC, T>(smem_small + (BUF) * 2 * TILE + TILE, rb[SET], tid); \
   } while (0)
   const int r16 = lane & 15, kq = lane >> 4;
+  // swizzled columns of a lane's two float4 per 32-deep group (ca: row wm * 16 + r16 of A's image, cb: row wn * 16 + r16 of B's)
+  const int ca0 = (4 * kq) ^ ((((wm * 16 + r16) >> 2) & 7) << 2), ca1 = ca0 ^ 16;
+  const int cb0 = (4 * kq) ^ ((((wn * 16 + r16) >> 2) & 7) << 2), cb1 = cb0 ^ 16;
   // A full slab multiplies its four 32-deep groups with the operand reads of group g + 1 issued BEFORE the MFMAs of group g
   // (explicit double buffer: left to itself the compiler reuses one register set and waits for every group's LDS reads
   // in front of its MFMAs -- with one wave per SIMD nothing else covers that latency).  The partial last slab stops at its
   // last non-empty group.
 #define EBN_SM_READ(SET, g)                                                     \
   do {                                                                          \
-    fa__[SET][0] = *reinterpret_cast<const float4*>(ap__ + 32 * (g));           \
-    fa__[SET][1] = *reinterpret_cast<const float4*>(ap__ + 32 * (g) + 4);       \
-    fb__[SET][0] = *reinterpret_cast<const float4*>(bp__ + 32 * (g));           \
-    fb__[SET][1] = *reinterpret_cast<const float4*>(bp__ + 32 * (g) + 4);       \
+    fa__[SET][0] = *reinterpret_cast<const float4*>(ap__ + 32 * (g) + ca0);     \
+    fa__[SET][1] = *reinterpret_cast<const float4*>(ap__ + 32 * (g) + ca1);     \
+    fb__[SET][0] = *reinterpret_cast<const float4*>(bp__ + 32 * (g) + cb0);     \
+    fb__[SET][1] = *reinterpret_cast<const float4*>(bp__ + 32 * (g) + cb1);     \
   } while (0)
 #define EBN_SM_MUL(SET)                                                                             \
   do {                                                                                              \
@@ -953,8 +958,8 @@ __device__ __forceinline__ void small_vec_body(int64_t M, int64_t N, int64_t K, 
   // contraction index of MFMA step s in lane quarter kq: k = 32 g + 8 kq + s (the same for A and B)
 #define EBN_SM_MMA(BUF, KT)                                                                                         \
   do {                                                                                                              \
-    const float* ap__ = smem_small + (BUF) * 2 * TILE + (wm * 16 + r16) * SLD + (kq ^ (wm & 1)) * 8;                \
-    const float* bp__ = smem_small + (BUF) * 2 * TILE + TILE + (wn * 16 + r16) * SLD + (kq ^ (wn & 1)) * 8;         \
+    const float* ap__ = smem_small + (BUF) * 2 * TILE + (wm * 16 + r16) * SLV;                                      \
+    const float* bp__ = smem_small + (BUF) * 2 * TILE + TILE + (wn * 16 + r16) * SLV;                               \
     float4 fa__[2][2], fb__[2][2];                                                                                  \
     if ((KT) < nk_full) {                                                                                           \
       EBN_SM_READ(0, 0);                                                                                            \
@@ -1067,7 +1072,7 @@ int launch_gemm_small(int transA, int transB, int64_t M, int64_t N, int64_t K, f
   } while (0)
 #define EBN_SMALL_VEC_T(TA, TB, T)                                                                                         \
   do {                                                                                                                     \
-    constexpr size_t lds_t = static_cast<size_t>(2) * 2 * (T) * SLD * sizeof(float);                                       \
+    constexpr size_t lds_t = static_cast<size_t>(2) * 2 * (T) * SLV * sizeof(float);                                       \
     static const hipError_t attr__ = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_small_vec_kernel<TA, TB, T>), \
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_t)); \
     if (attr__ != hipSuccess) return static_cast<int>(attr__);                                                            \
@@ -1417,7 +1422,7 @@ extern "C" int ebn_dense_bwd_pair_f32(int64_t R, int64_t K_in, int64_t N_out, co
     p0.tiles = p0.tiles_x * static_cast<int32_t>(ebn_ceil_div(K_in, SBM));
     SmallProblem p1{R, K_in, N_out, 1.0f, dY, lddy, W, ldw, 0.0f, dX, lddx, static_cast<int32_t>(ebn_ceil_div(K_in, SBN)), 0};
     p1.tiles = p1.tiles_x * static_cast<int32_t>(ebn_ceil_div(R, SBM));
-    constexpr size_t lds = static_cast<size_t>(2) * 2 * SBM * SLD * sizeof(float);
+    constexpr size_t lds = static_cast<size_t>(2) * 2 * SBM * SLV * sizeof(float);
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_small_pair_kernel),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     if (attr != hipSuccess) return static_cast<int>(attr);
