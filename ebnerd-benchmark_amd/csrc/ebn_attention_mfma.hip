@@ -467,9 +467,10 @@ template <int D>
 __host__ __device__ constexpr int fwd_group_v_offset(int L) {
   return 2 * L * Tile<D>::STRIDE > TP_FLOATS ? 2 * L * Tile<D>::STRIDE : TP_FLOATS;
 }
+__host__ __device__ constexpr int group_tile_pad(int L);
 template <int D>
 __host__ __device__ constexpr int fwd_group_wave_floats(int L) {
-  return fwd_group_v_offset<D>(L) + L * Tile<D>::STRIDE;
+  return fwd_group_v_offset<D>(L) + L * Tile<D>::STRIDE + group_tile_pad(L);
 }
 
 template <int D, int LC, int G>
@@ -733,9 +734,14 @@ template <int D>
 __host__ __device__ constexpr int bwd_group_g_offset(int L) {  // offset of the dO tile: behind Q | K and behind the transpose buffer
   return 2 * L * Tile<D>::STRIDE > TP_FLOATS ? 2 * L * Tile<D>::STRIDE : TP_FLOATS;
 }
+// Distance between the tiles of neighbouring heads.  The cooperative float4 stores / reads walk 5 lanes of one head's row, then
+// jump to the next head's tile: with the tiles 1800 floats apart (L = 30) the 8-lane store groups and 16-lane read groups hit
+// the same banks from two heads -- 564 extra LDS cycles per workgroup of 684 in all (tools/lds/bank_sim.py; counters: 3.2 M conflict
+// cycles per launch).  12 floats of padding: 156.  (Found by search for L = 30; other lengths keep the tight layout.)
+__host__ __device__ constexpr int group_tile_pad(int L) { return L == 30 ? 12 : 0; }
 template <int D>
 __host__ __device__ constexpr int bwd_group_wave_floats(int L) {
-  return bwd_group_g_offset<D>(L) + L * Tile<D>::STRIDE;
+  return bwd_group_g_offset<D>(L) + L * Tile<D>::STRIDE + group_tile_pad(L);
 }
 
 template <int D, int LC, int G>
