@@ -132,7 +132,7 @@ class DocVecEngine:
                  "scores": f(N), "probs": f(N), "labels": f(N)}
             b["partials"] = f(int(_hip.lib().ebn_colsum_partials_len(N, self.E)))
             wsf = _hip.lib().ebn_gemm_workspace_floats
-            b["ws"] = f(max(int(wsf(self.mlp.out_dim, self.E, N)), int(wsf(N, self.E, self.mlp.out_dim)), 1))
+            b["ws"] = f(max(int(wsf(self.mlp.out_dim, self.E, N)), int(wsf(N, self.E, self.mlp.out_dim)), int(wsf(N, self.mlp.out_dim, self.E)), 1))
             self.mlp.bufs(N)
             self._bufs["mlp"] = b
             self._graphs.clear()  # captured graphs hold raw pointers into the old buffers (an eval pass may grow them)
@@ -176,10 +176,14 @@ class DocVecEngine:
         dpre = mb["dNE"]  # relu backward in place
         _hip.call("ebn_bias_relu_bwd_f32", _hip.ptr(mb["NE"]), _hip.ptr(mb["dNE"]), _hip.ptr(dpre), _hip.ptr(g("out_b")),
                   _hip.ptr(mb["partials"]), N, self.E, 0, _hip.stream_handle())
-        self._gemm(1, 0, prev, self.E, N, x_last, prev, dpre, self.E, 0.0, g("out_W"), self.E, mb["ws"])
-        if self.units:
-            self._gemm(0, 1, N, prev, self.E, dpre, self.E, pv("out_W"), self.E, 0.0, mb["dXl"], prev)
+        if self.units:  # dW = X^T.dpre and dX = dpre.W^T of the output Dense: independent of each other, one launch for the pair
+            ws = mb["ws"]
+            _hip.call("ebn_dense_bwd_pair_f32", N, prev, self.E, _hip.ptr(x_last), prev, _hip.ptr(dpre), self.E, _hip.ptr(pv("out_W")), self.E,
+                      ctypes.c_float(0.0), _hip.ptr(g("out_W")), self.E, _hip.ptr(mb["dXl"]), prev,
+                      _hip.ptr(ws) if ws is not None else None, ws.numel() if ws is not None else 0, _hip.stream_handle())
             self.mlp.backward(mb["dXl"], mb["X0"], n_hist, n_cand, self.state, self.p, need_dx0=False, loss_dev=self.loss_dev)
+        else:
+            self._gemm(1, 0, prev, self.E, N, x_last, prev, dpre, self.E, 0.0, g("out_W"), self.E, mb["ws"])
 
     @staticmethod
     def _fwd_scratch(b):
