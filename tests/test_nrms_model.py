@@ -196,7 +196,7 @@ def test_fused_user_head_step_equals_the_step_with_separate_kernels(nrms, H):
 
 @pytest.mark.parametrize("precision", ["exact", "split"])
 def test_one_pass_news_attlayer2_backward_equals_the_two_launch_form(nrms, precision):
-    """`fuse_attpool_bwd` (default on): de, d(pre-tanh), dq, db of the news encoder's AttLayer2 in one pass per title
+    """`fuse_attpool_bwd` (off by default: measured slower in the step): de, d(pre-tanh), dq, db of the news encoder's AttLayer2 in one pass per title
     (ebn_attpool_bwd_fused_f32) against the two launches it replaces -- the same loss, gradients to summation-order noise."""
     hp = make_hp(dropout=0.2)
     V, D, seed = 300, 64, 4
