@@ -572,8 +572,16 @@ int direct_launch_rc(bool b_kc, const DirectPlan& pl, int64_t M, int64_t N, int6
 bool ebn_gemm_direct_wanted(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K) {
   if (transA || direct_mode() == 0) return false;
   if (M < 4096 || N < 48 || N > 512 || K < 32 || K > 2048 || (K % 4)) return false;
-  if (N * K * 4 > (int64_t{1} << 20)) return false;  // B beyond 1 MB would stream from L2 / MALL for every wave
-  return direct_plan(M, N, transB != 0).R != 0;
+  static const int64_t max_b = [] { const char* e = getenv("EBN_GEMM_DIRECT_MAXB"); return e ? static_cast<int64_t>(atoll(e)) : (int64_t{2} << 20); }();  // tuning
+  if (N * K * 4 > max_b) return false;  // a larger B streams from L2 / MALL for every wave
+  const DirectPlan pl = direct_plan(M, N, transB != 0);
+  if (pl.R == 0) return false;
+  // B of 1-2 MB (the input-gradient product dQKV . Wqkv^T of a trainable table, N = 300, K = 1200): measured 139.6 against 150.3 us
+  // for the LDS-staged tiles at 24000 rows, where A (115 MB, just written by the attention backward) still sits in the 256 MB
+  // memory-side cache, but 343 against 325 us at 52800 rows (A = 253 MB from HBM; every (R, CW) plan): the 16-row fragment fetches
+  // of the wave tasks stream worse from DRAM than the tile loads do -- taken only while A is at most half of that cache
+  if (N * K * 4 > (int64_t{1} << 20) && M * K * 4 > (int64_t{128} << 20)) return false;
+  return true;
 }
 
 int ebn_gemm_direct_launch(int32_t transB, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda, const float* B,
