@@ -498,7 +498,7 @@ def bench_docvec(args, c, world, rank, device, sync, dfields):
                 "config": {"workload": f"NRMSDocVec train step, BASELINE.json configs[2] (c3): {c['n_articles']} x {c['doc']} document vectors in HBM, "
                                        f"MLP {c['units']} -> {c['h'] * c['d']}, history_size={c['H']} npratio={c['C'] - 1}, dropout 0.2, adam lr=1e-4",
                            "global_batch": world * c["B"], "per_gpu_batch": c["B"], "parallelism": f"dp{world}",
-                           "final_loss": float(eng.loss_dev.item())}, **dfields}
+                           "final_loss": float(eng.loss_dev.item())}, **dfields, "oracle_pin": oracle_pin_status(), "env": nondefault_env()}
         gather_bytes = n_rows * (4 + 2 * c["doc"] * 4)
         if "dense0" in kt:
             fl = 2.0 * n_rows * c["doc"] * c["units"][0]
@@ -512,7 +512,134 @@ def bench_docvec(args, c, world, rank, device, sync, dfields):
                                    "achieved": gather_bytes / kt["gather"] / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": gather_bytes / kt["gather"] / 1e9 / HBM_PEAK_GBS, "traffic": None,
                                    "avg_launch_us": kt["gather"] * 1e6, "algorithmic_bytes_per_launch": gather_bytes}
-        print(json.dumps(line), flush=True)
+        print("\n" + json.dumps(line), flush=True)  # (own line even when a library -- gloo -- has left an unterminated one on stdout)
+
+
+class HangWatchdog:
+    """N > 1: a phase of the benchmark that makes no progress for `timeout_s` (EBN_COLLECTIVE_TIMEOUT_S, default 180 s per phase)
+    ends the process with exit code 124 and a message naming the phase and -- from the engine's SegmentTrace -- the segment of the
+    step the host was launching and the first one the device has not completed, instead of sitting in RCCL until the driver's
+    own limit kills the run without a word.  torch.distributed.run then tears the other ranks down: rc != 0."""
+
+    def __init__(self, rank, describe=lambda: ""):
+        import threading
+
+        self.timeout_s = float(os.environ.get("EBN_COLLECTIVE_TIMEOUT_S", "180"))
+        self.rank, self.describe, self._deadline, self._what = rank, describe, None, ""
+        threading.Thread(target=self._loop, daemon=True, name="ebn-bench-watchdog").start()
+
+    def arm(self, what):
+        self._what, self._deadline = what, time.monotonic() + self.timeout_s
+
+    def disarm(self):
+        self._deadline = None
+
+    def _loop(self):
+        while True:
+            time.sleep(0.25)
+            d = self._deadline
+            if d is not None and time.monotonic() > d:
+                try:
+                    where = self.describe()
+                except Exception as e:
+                    where = f"(no segment trace: {type(e).__name__}: {e})"
+                sys.stderr.write(f"bench.py: rank {self.rank} HUNG: no progress for {self.timeout_s:.0f} s in phase [{self._what}]; {where}.  "
+                                 "Exit 124 (a collective that not every rank joined, or a lost peer).\n")
+                sys.stderr.flush()
+                os._exit(124)
+
+
+def rccl_view(world, rank, device, backend):
+    """What the communication library itself saw (a COLLECTIVE): the group's world size, the library version, every rank's id
+    as delivered by an all-gather on the device, and who sits on which GPU -- so that "did RCCL run with N ranks on N distinct
+    GPUs" is answerable from the JSON line."""
+    props = torch.cuda.get_device_properties(device)
+    me = {"rank": rank, "local_device": device.index, "device_name": props.name, "device_uuid": str(getattr(props, "uuid", "")),
+          "pci_bus_id": getattr(props, "pci_bus_id", None), "pid": os.getpid(), "host": socket.gethostname()}
+    everyone = [None] * world
+    dist.all_gather_object(everyone, me)
+    ids = torch.empty(world, dtype=torch.int32, device=device)
+    dist.all_gather_into_tensor(ids, torch.tensor([rank], dtype=torch.int32, device=device))
+    ver = None
+    if backend == "nccl":
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as e:
+            ver = f"unavailable: {type(e).__name__}"
+    return {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "rccl_version": ver,
+            "rank_ids_allgathered": [int(v) for v in ids.cpu().tolist()],
+            "distinct_devices": len({(r["host"], r["device_uuid"] or r["local_device"]) for r in everyone}), "ranks": everyone,
+            "what": "dist.get_world_size() / torch.cuda.nccl.version() / one int32 all-gather of the rank ids on the device / all_gather_object of "
+                    "each rank's GPU: the communication library's own view of the job"}
+
+
+LEG_FIELDS = ("value", "unit", "ms_per_step", "ms_per_step_min", "ms_per_step_max", "ms_per_step_repeats", "n_gpus", "ranks", "backend", "launch", "dtype",
+              "scaling", "comm_exposed_us", "allreduce_bytes_per_step", "comm", "exchange", "roofline_step")
+
+
+def run_legs(args, world, rank, device, watchdog):
+    """N > 1: BASELINE.json configs[3] (c4: history 50, trainable table, dense all-reduce of table + bucket) and configs[4] (c5: the
+    c2 table row-sharded over the ranks, all-to-all lookup) at their own per-rank shapes, measured by the SAME driver command as
+    the c2 headline -- the driver passes no --config.  Each leg is a fresh set of N processes (every rank of this job starts its
+    own child `bench.py --leg --config cX` with this rank's RANK / LOCAL_RANK and a new rendezvous port), under its own
+    timeout: a hang or a crash in one leg becomes an `error` entry and cannot lose the headline or the other leg."""
+    out = {}
+    leg_timeout = float(os.environ.get("EBN_BENCH_LEG_TIMEOUT_S", "420"))
+    for cfg in [c for c in args.legs.split(",") if c]:
+        port = [None]
+        if rank == 0:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port[0] = sk.getsockname()[1]
+        watchdog.arm(f"leg {cfg}: agreeing on a rendezvous port")
+        dist.broadcast_object_list(port, src=0)
+        env = {k: v for k, v in os.environ.items() if not k.startswith(("TORCHELASTIC_", "TORCH_NCCL_ASYNC_ERROR_HANDLING"))}
+        env.update(MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=str(port[0]), EBN_BENCH_LEG="1")
+        cmd = [sys.executable, str(Path(__file__).resolve()), "--leg", "--config", cfg, "--gpus", str(world), "--steps", str(args.steps),
+               "--warmup", str(args.warmup), "--repeats", str(args.repeats), "--ids", args.ids, "--graph-collectives", args.graph_collectives,
+               "--no-roofline", "--no-probe", "--no-cpu-baseline"] + (["--no-graph"] if args.no_graph else [])
+        watchdog.arm(f"leg {cfg}: child processes (own timeout {leg_timeout:.0f} s)")
+        watchdog._deadline = time.monotonic() + leg_timeout + 60.0  # the child's own timeout fires first
+        t0 = time.perf_counter()
+        rec = {}
+        try:
+            r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=leg_timeout, cwd=str(ROOT))
+            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode != 0:
+                rec = {"error": f"rank {rank}'s child exited {r.returncode}", "stderr_tail": r.stderr[-1500:]}
+            elif rank == 0 and len(lines) != 1:
+                rec = {"error": f"expected one JSON line from the leg, got {len(lines)}", "stderr_tail": r.stderr[-1500:]}
+            elif rank == 0:
+                d = json.loads(lines[0])
+                rec = {k: d[k] for k in LEG_FIELDS if k in d}
+                rec["config"] = d["config"]
+        except subprocess.TimeoutExpired as e:
+            rec = {"error": f"rank {rank}'s child did not finish within {leg_timeout:.0f} s (killed)",
+                   "stderr_tail": (e.stderr.decode(errors="replace") if isinstance(e.stderr, bytes) else (e.stderr or ""))[-1500:]}
+        rec["wall_s"] = time.perf_counter() - t0
+        # every rank's verdict to rank 0 (a leg is good only if every rank's child was)
+        watchdog.arm(f"leg {cfg}: collecting the ranks' verdicts")
+        verdicts = [None] * world
+        dist.all_gather_object(verdicts, rec.get("error"))
+        bad = {r: v for r, v in enumerate(verdicts) if v}
+        if bad and "error" not in rec:
+            rec = {"error": "; ".join(f"rank {r}: {v}" for r, v in bad.items()), "wall_s": rec["wall_s"]}
+        out[cfg] = rec
+    watchdog.disarm()
+    return out
+
+
+def oracle_pin_status():
+    """Whether anything reference-held pins the oracle's MODEL math (tools/dump_tf_golden.py writes the file where TensorFlow
+    exists; it cannot run in this image).  Travels with every number."""
+    f = ROOT / "tests" / "golden" / "nrms_tf_golden.npz"
+    return f"pinned by {f.relative_to(ROOT)}" if f.exists() else \
+        "unpinned (no tests/golden/nrms_tf_golden.npz: TensorFlow is not installable here; evaluator metrics ARE pinned against the imported reference)"
+
+
+def nondefault_env():
+    """the EBN_* switches this run was started under (every one changes a default somewhere: the number of record must say so)"""
+    return {k: v for k, v in sorted(os.environ.items()) if k.startswith("EBN_") and k not in ("EBN_BENCH_LEG",)}
 
 
 def self_launch(args):
@@ -557,6 +684,12 @@ def main():
     ap.add_argument("--atomic-table-grad", action="store_true",
                     help="trainable table: one 64-bit atomic per gradient element instead of combining the duplicate ids of every 64 consecutive "
                          "tokens first (same bits; the A/B behind DESIGN's choice, see --ids zipf)")
+    ap.add_argument("--legs", default="c4,c5", help="N > 1 on the default config: also measure these configs (BASELINE.json configs[3] / configs[4]) as sub-records "
+                                                     "of the line, each in its own set of child processes under its own timeout ('' = none)")
+    ap.add_argument("--leg", action="store_true", help="internal: this process is one rank of a leg started by run_legs()")
+    ap.add_argument("--fault-skip-collectives-on-rank", type=int, default=-1,
+                    help="test hook: this rank skips its collectives in the timed region (its peers then wait for it forever): the hang "
+                         "watchdog must turn that into exit code 124 within EBN_COLLECTIVE_TIMEOUT_S")
     ap.add_argument("--kernel-probe", action="store_true", help="internal: launch the two roofline kernels a few times on the step's "
                                                                 "buffers and exit (what probe_kernels() wraps rocprofv3 around)")
     args = ap.parse_args()
@@ -580,6 +713,19 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     dfields = dist_fields(world, backend, n_dev)
+    trace = watchdog = None
+    if world > 1:
+        from ebrec.models.newsrec._dist import SegmentTrace
+
+        trace = SegmentTrace()
+        watchdog = HangWatchdog(rank, trace.where)
+        watchdog.arm("first collectives of the job (communicator set-up, the library's view of the ranks)")
+        dfields["rccl_view"] = rccl_view(world, rank, device, backend)
+        watchdog.disarm()
+
+    def phase(what):  # N > 1: (re)start the hang watchdog's clock for the next stretch of the run
+        if watchdog is not None:
+            watchdog.arm(what)
 
     c = dict(CONFIGS[args.config])
     if args.batch:
@@ -592,6 +738,7 @@ def main():
             torch.cuda.synchronize()
 
     if args.config == "c3":
+        phase("c3: the whole DocVec benchmark")
         bench_docvec(args, c, world, rank, device, sync, dfields)
         if world > 1:
             dist.destroy_process_group()
@@ -622,9 +769,18 @@ def main():
 
     eng.atomic_table_grad = bool(args.atomic_table_grad)
     eng.enable_graphs(not args.no_graph)
+    eng.trace = trace  # N > 1: an event behind every segment of every step, so that a hang can be named (None at N = 1: nothing recorded)
+    if world > 1:
+        dfields["guard"] = eng.guard.status() if eng.guard is not None else "disabled: the engine built none"
     eng.graph_collectives = bool(args.graph_collectives == "on" and backend == "nccl")
     if args.graph_collectives == "auto" and world > 1 and not args.no_graph:
+        phase("start-up self-check of the one-graph step (engine.verify_graph_collectives)")
         eng.verify_graph_collectives(*batches[0])
+    if args.fault_skip_collectives_on_rank == rank:  # test hook: this rank leaves its peers alone in every collective of the step
+        eng.skip_collectives = True
+        if eng.exchange is not None:
+            eng.exchange.skip = True
+    phase(f"{args.config}: warm-up + timed region ({args.warmup} + {args.repeats} x {args.steps} steps)")
     times = timed_repeats(lambda k: eng.train_step(*batches[k % len(batches)]), args, sync, world, device)
     # Kernel-level rooflines: the Q|K|V projection GEMM and the embedding gather of THIS step (same buffers, same
     # arguments), each captured into a hipGraph of 10 launches and timed with HIP events on the launch stream.
@@ -637,6 +793,7 @@ def main():
     loss = float(eng.loss_dev.item())
     comm = None
     if world > 1:
+        phase(f"{args.config}: the same steps re-timed without collectives (comm_exposed_us)")
         # what the collectives cost the step: the same steps timed again with every collective skipped (the results of those
         # steps are wrong and thrown away; all ranks skip together) -- exposed = with - without, after whatever the overlap hid
         eng.skip_collectives = True
@@ -653,7 +810,13 @@ def main():
             eng.exchange.skip = False
         ms_no = float(np.median([t / args.steps * 1e3 for t in t_no]))
         comm = {"ms_per_step_without_collectives": ms_no, "overlap": bool(eng.overlap_collectives), "collectives_in_graph": bool(eng.graph_collectives), "graph_collectives_mode": args.graph_collectives}
+    phase(f"{args.config}: closing flag check (a collective)")
     eng.check_oob()  # sticky device flags of the whole run (ids out of range, exchange overflow, accumulator range): raise, don't report
+    legs = None
+    if world > 1 and not args.leg and args.config == "c2" and args.legs:
+        legs = run_legs(args, world, rank, device, watchdog)
+    if watchdog is not None:
+        watchdog.disarm()
 
     if rank == 0:
         n_tok = c["B"] * (c["H"] + c["C"]) * c["T"]
@@ -756,6 +919,13 @@ def main():
                 rg["table_residency"] += ("; Zipf ids: the hot rows are re-read from L2 / the memory-side cache, `achieved` counts ALGORITHMIC bytes "
                                           "(every token reads its row), so it may exceed what HBM alone delivers")
         line.update(dfields)
+        line["oracle_pin"] = oracle_pin_status()
+        line["env"] = nondefault_env()
+        if legs is not None:
+            line["legs"] = legs
+            line["legs_note"] = ("BASELINE.json configs[3] (c4) and configs[4] (c5) at their own per-rank shapes, each measured by its own set of "
+                                 f"{world} child processes of this job (same ranks, same GPUs, new rendezvous) under its own timeout; `value` of the "
+                                 "line stays the c2 headline")
         if sharded:
             line["exchange"] = eng.exchange.stats()
         if world > 1:
@@ -771,7 +941,7 @@ def main():
             line["fit_loop"]["frac_of_value"] = line["fit_loop"]["value"] / line["value"]
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(c, steps=args.cpu_steps, ids=args.ids)
-        print(json.dumps(line), flush=True)
+        print("\n" + json.dumps(line), flush=True)  # (own line even when a library -- gloo -- has left an unterminated one on stdout)
     if world > 1:
         dist.destroy_process_group()
 

@@ -31,10 +31,14 @@ from __future__ import annotations
 
 import os
 from dataclasses import dataclass
-from datetime import timedelta
 
 import torch
 import torch.distributed as dist
+
+
+def _named(kind, fn, what):
+    fn.what = what
+    return kind, fn
 
 
 def world_info(group=None) -> tuple[int, int]:
@@ -52,38 +56,167 @@ def allreduce_sum_(tensors, group=None) -> None:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
 
 
+def group_timeout_s(group=None) -> float:
+    """The process group's own collective timeout in seconds (what its watchdog aborts a stuck collective after): the
+    backend options' timeout when readable, else torch's default for the backend (RCCL 600 s, gloo 1800 s)."""
+    from torch.distributed import distributed_c10d as c10d
+
+    try:
+        pg = group if group is not None else c10d._get_default_group()
+        backend = dist.get_backend(pg)
+        try:
+            dev = torch.device("cuda") if backend == "nccl" else torch.device("cpu")
+            return float(pg._get_backend(dev).options._timeout.total_seconds())
+        except Exception:
+            return float(c10d._get_default_timeout(backend).total_seconds())
+    except Exception:
+        return 600.0
+
+
 class LockStepGuard:
     """Turns "a collective API entered by only some ranks" from a hang into an error.
 
     `save_weights`, `evaluate` and `fit` are collectives when world > 1 (gradient / log / flag reductions, the table
     all-gather of a row-sharded engine).  A caller that enters one on rank 0 only -- the natural thing to write after
-    `if rank == 0:` -- would block in RCCL until the watchdog aborts the job.  `enter(what)` runs a gloo
-    `monitored_barrier` first: when a peer does not arrive within `timeout_s` (EBN_COLLECTIVE_TIMEOUT_S, default 120 s)
-    it raises a RuntimeError naming the call and the missing ranks, on every rank that did arrive.
+    `if rank == 0:` -- would block in RCCL until the watchdog aborts the job.  `enter(what)` runs a rendezvous with a
+    deadline first: when a peer does not arrive within `timeout_s` it raises a RuntimeError naming the call and the
+    missing ranks, on every rank that did arrive.
 
-    The barrier runs on a gloo SIDE group over the same ranks, made at construction (the engine is constructed by every rank of
-    its group; `use_local_synchronization` keeps other processes out of it): RCCL has no monitored barrier, and a gloo group
-    whose barrier timed out closes its connection pairs -- on a side group the caller's own group stays usable after the error."""
+    The rendezvous lives on the job's c10d STORE (the TCP store behind `init_process_group`), not on a process group:
+      * nothing is built at construction -- an engine made on only some ranks (a rank-0-only inference model while
+        `torch.distributed` is initialised) costs nothing and never blocks; the first `enter()` does the first store access;
+      * a rendezvous that timed out leaves no broken state behind: the ranks that gave up WITHDRAW their arrival marks and do
+        not advance their call counter, so the next `enter()` made by every rank passes (round 4's gloo side group closed its
+        connection pairs after one failed `monitored_barrier`, so every later guarded call raised too);
+      * the caller's RCCL / gloo group is never touched.
+    `timeout_s`: the argument, else EBN_COLLECTIVE_TIMEOUT_S, else the process group's OWN collective timeout (RCCL: 600 s) --
+    the guard never fires earlier than the watchdog it pre-empts would have, so a rank that tokenizes for minutes before
+    `fit()` does not turn a job that used to run into one that raises.  `disabled` holds the reason when no store is reachable
+    (bench.py prints it as the `guard` field); a disabled guard lets every call through."""
+
+    _calls = {}  # ranks of the group -> guarded calls passed so far.  Shared by every guard (= engine) of this process over that group:
+    # what must be lock-step is the SEQUENCE of collective API calls, whichever model makes them; an engine built on one rank
+    # only never enters a collective API, so it cannot put the ranks' counters out of step
 
     def __init__(self, group=None, timeout_s: float | None = None):
         self.rank, self.world = world_info(group)
-        self.timeout_s = float(os.environ.get("EBN_COLLECTIVE_TIMEOUT_S", "120")) if timeout_s is None else float(timeout_s)
-        self.group = None
-        if self.world > 1:
-            self.group = dist.new_group(ranks=dist.get_process_group_ranks(group if group is not None else dist.group.WORLD),
-                                        backend="gloo", timeout=timedelta(seconds=max(self.timeout_s, 30.0)),
-                                        use_local_synchronization=True)
+        self.pg = group
+        env = os.environ.get("EBN_COLLECTIVE_TIMEOUT_S")
+        self.timeout_s = float(timeout_s) if timeout_s is not None else (float(env) if env else None)
+        self.disabled = None
+        self.poll_s = 0.02
+        self._store = None
+
+    def _resolve_timeout(self) -> float:
+        if self.timeout_s is None:
+            self.timeout_s = group_timeout_s(self.pg)
+        return self.timeout_s
+
+    def ensure(self) -> bool:
+        """First use: find the store and this guard's key prefix.  Returns whether the guard is active."""
+        if self.world <= 1 or self.disabled is not None:
+            return False
+        if self._store is None:
+            try:
+                from torch.distributed import distributed_c10d as c10d
+
+                ranks = dist.get_process_group_ranks(self.pg if self.pg is not None else dist.group.WORLD)
+                self._ranks = list(ranks)
+                self._gkey = tuple(ranks)
+                self._prefix = f"ebn_guard/{'-'.join(map(str, ranks))}"
+                store = c10d._get_default_store()
+                store.add(f"{self._prefix}/probe", 0)  # a store that cannot be reached fails here, not in the first fit()
+                self._store = store
+            except Exception as e:  # a diagnostics aid must never keep a job from starting
+                self.disabled = f"{type(e).__name__}: {e}"
+                return False
+        return True
+
+    def status(self) -> str:
+        if self.world <= 1:
+            return "not needed (one rank)"
+        if not self.ensure():
+            return f"disabled: {self.disabled}"
+        return f"active (c10d store rendezvous, timeout {self._resolve_timeout():.0f} s)"
 
     def enter(self, what: str) -> None:
-        if self.world <= 1:
+        if not self.ensure():
             return
-        try:
-            dist.monitored_barrier(group=self.group, timeout=timedelta(seconds=self.timeout_s), wait_all_ranks=True)
-        except RuntimeError as e:
-            raise RuntimeError(f"{what} is a COLLECTIVE when world > 1 ({self.world} ranks): every rank of the group must call it at the "
-                               f"same point.  Rank {self.rank} entered it, but not every peer did within {self.timeout_s:.0f} s -- a call "
-                               f"guarded by `if rank == 0:`?  (rank-local inference: predict / scorer.predict / encode_news on a "
-                               f"replicated table are not collectives.)  [{str(e).splitlines()[0]}]") from e
+        import time
+
+        timeout = self._resolve_timeout()
+        n = LockStepGuard._calls.get(self._gkey, 0)
+        key = f"{self._prefix}/{n}"
+        mine = f"{key}/r{self.rank}"
+        marks = [f"{key}/r{r}" for r in self._ranks]
+        st = self._store
+        st.add(mine, 1)
+        deadline = time.monotonic() + timeout
+        while True:
+            here = [int(st.add(m, 0)) > 0 for m in marks]
+            if all(here):
+                if n:  # everyone is at call n, so everyone has left call n-1: its mark can go
+                    try:
+                        st.delete_key(f"{self._prefix}/{n - 1}/r{self.rank}")
+                    except Exception:
+                        pass
+                LockStepGuard._calls[self._gkey] = n + 1
+                return
+            if time.monotonic() >= deadline:
+                break
+            time.sleep(self.poll_s)
+        st.add(mine, -1)  # withdraw: the next enter() every rank makes starts from a clean slate
+        missing = [r for r, h in zip(self._ranks, here) if not h]
+        raise RuntimeError(f"{what} is a COLLECTIVE when world > 1 ({self.world} ranks): every rank of the group must call it at the "
+                           f"same point.  Rank {self.rank} entered it, but rank(s) {missing} did not within {timeout:.0f} s -- a call "
+                           f"guarded by `if rank == 0:`?  (rank-local inference: predict / scorer.predict / encode_news on a "
+                           f"replicated table are not collectives.)")
+
+
+class SegmentTrace:
+    """Where a multi-rank training step is when it stops making progress (bench.py's hang watchdog, debugging).
+
+    A step is a list of segments -- hipGraph replays of kernel runs and the collectives between them (`NRMSEngine._segments`).
+    With a trace attached the engine records a HIP event behind every segment of every step; `where()` -- callable from another
+    thread while the main one is blocked in a synchronize or a host-side collective -- reports the segment the HOST was
+    launching and the first segment whose event the DEVICE has not reached.  (An RCCL collective that a peer never joins does
+    not block the host at its launch: the host runs ahead and blocks at the next synchronize, so only the device-side position
+    names the segment that hangs.)  Costs one event record per segment; off unless attached."""
+
+    def __init__(self, keep: int = 4096):
+        self.keep, self.step, self.host, self.desc, self.events = int(keep), 0, None, [], {}
+
+    def run(self, fns, desc) -> None:
+        self.desc, s = desc, self.step
+        for i, fn in enumerate(fns):
+            self.host = (s, i, "launching")
+            fn()
+            ev = torch.cuda.Event()
+            ev.record()
+            self.events[(s, i)] = ev
+            self.host = (s, i, "launched")
+        self.step += 1
+        if len(self.events) > self.keep:
+            for k in sorted(self.events)[: len(self.events) - self.keep]:
+                del self.events[k]
+
+    def _name(self, i) -> str:
+        return self.desc[i] if i < len(self.desc) else "?"
+
+    def where(self) -> str:
+        host = "no step launched yet" if self.host is None else \
+            f"host: step {self.host[0]}, segment {self.host[1]} [{self._name(self.host[1])}] {self.host[2]}"
+        dev = "device: every launched segment has completed"
+        for k in sorted(self.events):
+            try:
+                done = self.events[k].query()
+            except Exception as e:  # a device in an error state: say so instead of dying in the watchdog
+                dev = f"device: event query failed at step {k[0]}, segment {k[1]} [{self._name(k[1])}]: {type(e).__name__}: {e}"
+                break
+            if not done:
+                dev = f"device: waiting in step {k[0]}, segment {k[1]} [{self._name(k[1])}] (first segment not completed)"
+                break
+        return f"{host}; {dev}"
 
 
 def rows_per_rank(V: int, world: int) -> int:
@@ -197,10 +330,10 @@ class ShardedTableExchange:
 
         segs = [("k", lambda: plan_fn(ids, n_tok, cap, b.ws, b.slot_rows, b.inv, b.counts))]
         if W > 1:
-            segs.append(("c", lambda: (self._a2a(b.recv_rows[:n], b.slot_rows[:n]), note())))
+            segs.append(_named("c", lambda: (self._a2a(b.recv_rows[:n], b.slot_rows[:n]), note()), "all-to-all of the requested row numbers (row-sharded lookup)"))
         segs.append(("k", lambda: gather_fn(b.recv_rows[:n], b.served[:n])))
         if W > 1:
-            segs.append(("c", lambda: self._a2a(b.rows[:n], b.served[:n])))
+            segs.append(_named("c", lambda: self._a2a(b.rows[:n], b.served[:n]), "all-to-all of the served table rows (row-sharded lookup)"))
         return segs
 
     def grad_segments(self, n_tok: int, b: PlannedBuffers, reduce_fn, scatter_fn) -> list:
@@ -211,7 +344,8 @@ class ShardedTableExchange:
         n = W * cap
         segs = [("k", lambda: reduce_fn(b.inv[:n_tok], b.d_slot[:n]))]
         if W > 1:
-            segs.append(("c", lambda: (self._a2a(b.d_recv[:n], b.d_slot[:n]), self.bytes_sent.update(grads=(W - 1) * cap * self.D * 4))))
+            segs.append(_named("c", lambda: (self._a2a(b.d_recv[:n], b.d_slot[:n]), self.bytes_sent.update(grads=(W - 1) * cap * self.D * 4)),
+                               "all-to-all of the row gradients to their owners (row-sharded table)"))
         segs.append(("k", lambda: scatter_fn(b.recv_rows[:n], b.d_recv[:n])))
         return segs
 

@@ -41,6 +41,12 @@ def loss_kind_of(loss: str, bce_on: str) -> int:
     return 0 if loss == "cross_entropy_loss" else (1 if bce_on == "logits" else 2)
 
 
+def _named(kind, fn, what):
+    """a step segment (kind, fn) whose fn carries a description (`SegmentTrace` / the hang watchdog name it)"""
+    fn.what = what
+    return kind, fn
+
+
 def require_gpu() -> torch.device:
     if not torch.cuda.is_available():
         raise RuntimeError("the MI355X NRMS path needs a visible GPU (no CPU fallback); "
@@ -218,19 +224,17 @@ class NRMSEngine:
         self.overlap_collectives = True  # multi-rank: start the dense-gradient buckets under the rest of the backward (see _segments)
         self.skip_collectives = False    # bench.py only: time the step without its collectives (-> comm_exposed_us); results are wrong
         self._pending = []
+        self.trace = None  # a _dist.SegmentTrace: event behind every segment of every step (bench.py's hang watchdog); None = off
         self.world = 1
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
-        self.guard = None  # world > 1: save_weights / evaluate / fit raise instead of hanging when only some ranks call them
+        # world > 1: save_weights / evaluate / fit raise instead of hanging when only some ranks call them (nothing is built here: the
+        # guard's store rendezvous starts at its first enter(); `guard.status()` says "disabled: ..." when no store is reachable)
+        self.guard = None
         if self.world > 1:
             from ._dist import LockStepGuard
 
-            try:
-                self.guard = LockStepGuard(process_group)
-            except Exception as e:  # a diagnostics aid must never keep a job from starting (e.g. no usable gloo interface on the box)
-                import warnings
-
-                warnings.warn(f"lock-step guard of the collective model APIs disabled: {type(e).__name__}: {e}")
+            self.guard = LockStepGuard(process_group)
 
     @property
     def loss_kind(self) -> int:
@@ -876,6 +880,12 @@ class NRMSEngine:
         range-checked on the host), bench.py after its timed region."""
         self._check_oob(collective=True)
 
+    def sync_moving_statistics(self) -> None:
+        """world > 1 with BatchNormalization layers: average the moving mean / variance over the ranks (a COLLECTIVE; fit() calls it
+        at the end of every epoch, evaluate() and save_weights() on entry -- see MLPStack.sync_moving_statistics for the contract)."""
+        if self.world > 1 and self.mlp is not None:
+            self.mlp.sync_moving_statistics(self.pg)
+
     def l2_penalty(self) -> float:
         """lambda * sum(W^2) over the regularised Dense kernels (0 without the optional per-token stack)."""
         return self.mlp.l2_penalty() if self.mlp is not None else 0.0
@@ -986,8 +996,14 @@ class NRMSEngine:
             run = self._graphs.get((B, C, advanced))
             if run is None:
                 run = self._capture(B, C, advanced)
-            for fn in run:
-                fn()
+            if self.trace is not None:
+                self.trace.run(run, self._graph_desc.get((B, C, advanced), []))
+            else:
+                for fn in run:
+                    fn()
+        elif self.trace is not None:
+            segs = self._segments(B, C, advanced)
+            self.trace.run([fn for _kind, fn in segs], [self.SEG_KINDS.get(kind, kind) + (f": {fn.what}" if hasattr(fn, "what") else "") for kind, fn in segs])
         else:
             for _kind, fn in self._segments(B, C, advanced):
                 fn()
@@ -1067,10 +1083,14 @@ class NRMSEngine:
             ub.head_partials = torch.empty(max(int(_hip.lib().ebn_user_head_partials_len(ub.n_seq, self.A)), 1), device=self.device)
         return nb, ub
 
+    SEG_KINDS = {"k": "kernels", "c": "collective", "a": "collective started asynchronously", "w": "wait for the started collectives"}
+
     def _capture(self, B, C, advanced=False):
         """Runs of kernel-only segments become hipGraphs; collectives stay eager launches between the replays."""
         torch.cuda.synchronize()
         segs, run, pool, i = self._segments(B, C, advanced), [], None, 0
+        desc = self.__dict__.setdefault("_graph_desc", {}).setdefault((B, C, advanced), [])
+        desc.clear()
         if self.graph_collectives and self.world > 1:
             # the collectives are captured too (RCCL supports stream capture): the whole multi-rank step is ONE graph, no
             # eager launches and no cross-stream joins between replays
@@ -1080,10 +1100,12 @@ class NRMSEngine:
                     fn()
             self._graph_objs = getattr(self, "_graph_objs", []) + [g]
             self._graphs[(B, C, advanced)] = [g.replay]
+            desc.append("ONE hipGraph: " + " | ".join(self.SEG_KINDS[k] for k, _fn in segs))
             return self._graphs[(B, C, advanced)]
         while i < len(segs):
             if segs[i][0] != "k":  # "c" | "a" | "w": collectives (and the wait for them) stay eager launches between the replays
                 run.append(segs[i][1])
+                desc.append(f"{self.SEG_KINDS[segs[i][0]]}: {getattr(segs[i][1], 'what', 'unnamed')} (segment {i} of the step's {len(segs)})")
                 i += 1
                 continue
             j = i
@@ -1095,6 +1117,7 @@ class NRMSEngine:
                     fn()
             pool = pool or g.pool()
             run.append(g.replay)
+            desc.append(f"hipGraph replay of kernel segments {i}..{j - 1} of the step's {len(segs)}")
             self._graph_objs = getattr(self, "_graph_objs", []) + [g]
             i = j
         self._graphs[(B, C, advanced)] = run
@@ -1124,12 +1147,12 @@ class NRMSEngine:
             # the gradients finished before the attention backward under it -- as much as that 2.6 MB all-reduce is expected to
             # take.  With a frozen table nothing follows dWqkv, so the step stays graph | bucket | graph.
             segs.append(("k", lambda: (self._fwd_bwd_kernels(B, C, sparse, part="a"), self._fwd_bwd_kernels(B, C, sparse, part="b"))))
-            segs.append(("a", lambda: self._allreduce_async(self.params.grad)))  # the one flat bucket of every dense gradient
+            segs.append(_named("a", lambda: self._allreduce_async(self.params.grad), "all-reduce of the flat dense-gradient bucket"))
             segs.append(("k", lambda: self._fwd_bwd_kernels(B, C, sparse, part="c")))
             if self._planned:
                 segs += self._table_grad_segments(nb, N)
             if self.exchange is None and not sparse:
-                segs.append(("c", lambda: self._allreduce_table_grad()))
+                segs.append(_named("c", lambda: self._allreduce_table_grad(), "all-reduce of the dense (V, D) table gradient"))
             if sparse:
                 segs += self._sparse_table_grad_segments(nb, N)
             segs.append(("w", self._wait_collectives))
@@ -1138,7 +1161,8 @@ class NRMSEngine:
             if self._planned and self.train_embedding:
                 segs += self._table_grad_segments(nb, N)
             if multi:
-                segs.append(("c", lambda: self._allreduce_grads(dense_table=not sparse)))
+                segs.append(_named("c", lambda: self._allreduce_grads(dense_table=not sparse),
+                                   "all-reduce of the flat dense-gradient bucket" + (" and of the dense table gradient" if (self.train_embedding and self.exchange is None and not sparse) else "")))
             if sparse:
                 segs += self._sparse_table_grad_segments(nb, N)
         segs.append(("k", lambda: self._optimizer_kernels(from_acc=self._adam_from_acc or sparse)))
@@ -1175,7 +1199,7 @@ class NRMSEngine:
             for r in range(W):
                 self._accumulate_fixed(ids_all[r * n_tok:], dX_all[r * n_tok:], n_tok, _hip.ptr(self.state), site, p)
 
-        return [("c", gather), ("k", accumulate)]
+        return [_named("c", gather, "all-gather of the per-token (id, gradient row) pairs (sparse table-gradient exchange)"), ("k", accumulate)]
 
     def _fwd_bwd_kernels(self, B, C, sparse_table_grads=False, part="all"):
         """part: "all" = the whole forward + backward (one rank: the stage calls run the news backward as one C call);

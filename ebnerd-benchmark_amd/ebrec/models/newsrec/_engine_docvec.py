@@ -54,16 +54,13 @@ class DocVecEngine:
         self.world = 1
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
-        self.guard = None  # world > 1: save_weights / evaluate / fit raise instead of hanging when only some ranks call them
+        # world > 1: save_weights / evaluate / fit raise instead of hanging when only some ranks call them (nothing is built here: the
+        # guard's store rendezvous starts at its first enter(); `guard.status()` says "disabled: ..." when no store is reachable)
+        self.guard = None
         if self.world > 1:
             from ._dist import LockStepGuard
 
-            try:
-                self.guard = LockStepGuard(process_group)
-            except Exception as e:  # a diagnostics aid must never keep a job from starting (e.g. no usable gloo interface on the box)
-                import warnings
-
-                warnings.warn(f"lock-step guard of the collective model APIs disabled: {type(e).__name__}: {e}")
+            self.guard = LockStepGuard(process_group)
 
     @property
     def loss_kind(self) -> int:
@@ -447,6 +444,12 @@ class DocVecEngine:
         if oob is not None and int(oob.item()) != 0:
             oob.zero_()
             raise IndexError(f"article row out of range [0, {self.article_matrix.shape[0]}) for the document-vector matrix")
+
+    def sync_moving_statistics(self) -> None:
+        """world > 1 with BatchNormalization layers: average the moving mean / variance over the ranks (a COLLECTIVE; fit() calls it
+        at the end of every epoch, evaluate() and save_weights() on entry -- see MLPStack.sync_moving_statistics for the contract)."""
+        if self.world > 1 and True:
+            self.mlp.sync_moving_statistics(self.pg)
 
     def l2_penalty(self) -> float:
         return self.mlp.l2_penalty()

@@ -44,6 +44,12 @@ def _enter_collective(eng, what: str) -> None:
         guard.enter(what)
 
 
+def _sync_moving_statistics(eng) -> None:
+    fn = getattr(eng, "sync_moving_statistics", None)
+    if fn is not None and int(getattr(eng, "world", 1)) > 1:
+        fn()
+
+
 def _full_batches(data) -> int:
     """number of leading batches of `data` that have the full batch size (all but possibly the last one)"""
     bs = getattr(data, "batch_size", None) or getattr(data, "bs", None)
@@ -164,6 +170,7 @@ class TrainModel:
         EBN_COLLECTIVE_TIMEOUT_S (`_dist.LockStepGuard`) instead of hanging."""
         rank, world, group = _dist_of(self._engine)
         _enter_collective(self._engine, "model.save_weights()")
+        _sync_moving_statistics(self._engine)  # BatchNormalization moving averages: the checkpoint carries the mean over the ranks
         # get_weights() is a collective when the table is row-sharded: every rank calls it, rank 0 writes the file
         state = {n: torch.from_numpy(np.ascontiguousarray(w)) for n, w in zip(self._names, self._engine.get_weights())}
         extra = getattr(self._engine, "extra_state", lambda: {})()
@@ -246,6 +253,7 @@ class TrainModel:
             logs = {"loss": ls / max(nr, 1)}
             if hasattr(eng, "check_oob"):
                 eng.check_oob()  # ids outside the table raise (as TF-CPU's Embedding does) at the epoch's one host sync
+            _sync_moving_statistics(eng)  # data parallel: once per epoch the replicas' BatchNormalization moving averages are averaged
             if want_auc:
                 logs["auc"] = auc.result(eng)
             if val is not None:
@@ -275,6 +283,7 @@ class TrainModel:
         data = x if _is_loader(x) else _ArrayBatches(x, y, batch_size)
         eng = self._engine
         _enter_collective(eng, "model.evaluate()")
+        _sync_moving_statistics(eng)  # every rank scores with the same BatchNormalization moving averages
         auc = StreamingAUC() if "auc" in self.metrics_names else None
         loss_sum, n_rows = torch.zeros(1, device=eng.device), 0
         # loaders of this repo: encode every article of the lookup matrix ONCE (the weights are fixed during evaluate) and

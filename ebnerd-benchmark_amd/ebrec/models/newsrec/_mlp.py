@@ -25,8 +25,17 @@ class MLPStack:
         self.params, self.prefix, self.din, self.units, self.device, self.l2 = params, prefix, int(din), [int(u) for u in units], device, float(l2)
         if len(self.units) > 4:
             raise ValueError("at most 4 hidden Dense layers (dropout sites 8..11 of ebn_step_state)")
-        self.bn_mean = [torch.zeros(u, device=device) for u in self.units]
-        self.bn_var = [torch.ones(u, device=device) for u in self.units]
+        # BatchNormalization moving statistics: ONE flat buffer (mean_0 | var_0 | mean_1 | ...; 256-byte aligned segments) so that the
+        # data-parallel synchronisation below is a single collective; bn_mean[l] / bn_var[l] are views the kernels update in place
+        off, spans = 0, []
+        for u in self.units:
+            spans.append((off, off + (-(-u // 64) * 64)))
+            off = spans[-1][1] + (-(-u // 64) * 64)
+        self.bn_stats = torch.zeros(max(off, 1), device=device)
+        self.bn_mean = [self.bn_stats[a: a + u] for (a, _b), u in zip(spans, self.units)]
+        self.bn_var = [self.bn_stats[b: b + u] for (_a, b), u in zip(spans, self.units)]
+        for v in self.bn_var:
+            v.fill_(1.0)
         self._b = None
 
     @staticmethod
@@ -143,6 +152,24 @@ class MLPStack:
             seg += [None, None, 0] * (4 - len(self.units))
             _hip.call("ebn_l2_reg4_f32", *seg, ctypes.c_float(self.l2), _hip.ptr(b["partials"]), _hip.ptr(loss_dev), S())
         return b["dX0"] if (need_dx0 and self.units) else (d_last if need_dx0 else None)
+
+    def sync_moving_statistics(self, group=None) -> None:
+        """Data parallel: replace every rank's BatchNormalization moving mean / variance by their MEAN over the ranks (a collective).
+
+        The contract under data parallel [KERAS-SEMANTICS: tf.keras BatchNormalization is not synchronised across replicas either]:
+        each rank normalises ITS half-batch with ITS batch statistics, per TimeDistributed call site (nrms_docvec.py:116-124,
+        nrms.py:143-152), the gradients of gamma / beta / the Dense kernels are all-reduced with every other gradient, and the
+        moving statistics -- which only inference reads -- drift apart by each rank's data.  Averaging them (each is an exponential
+        average of per-batch statistics: the mean over ranks is the same average taken over all ranks' batches) once per epoch and
+        in front of every evaluate / checkpoint makes the replicas score identically and rank 0's checkpoint carry everyone's data."""
+        import torch.distributed as dist
+
+        if not self.units or not (dist.is_available() and dist.is_initialized()):
+            return
+        world = dist.get_world_size(group)
+        if world > 1:
+            dist.all_reduce(self.bn_stats, group=group)
+            self.bn_stats.mul_(1.0 / world)
 
     def l2_penalty(self) -> float:
         """lambda * sum(W^2) of every regularised kernel (host readback; evaluate() only)."""

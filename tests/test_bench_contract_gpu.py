@@ -56,3 +56,52 @@ def test_bench_line_carries_the_contract_fields(cfg):
         st = d["roofline_step"]
         assert st["bound"] == "mfma" and abs(st["frac"] - st["achieved"] / st["peak"]) < 1e-9 and 0 < st["frac"] < d["roofline"]["frac"]
         assert abs(st["achieved"] * 1e12 - st["algorithmic_flops_per_step"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * st["achieved"] * 1e12
+
+
+def _bench(argv, timeout, env=None):
+    import os
+    import time
+
+    t0 = time.time()
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py")] + argv, capture_output=True, text=True, timeout=timeout, cwd=str(ROOT),
+                         env=dict(os.environ, **(env or {})))
+    return out, time.time() - t0
+
+
+@pytest.mark.gpu
+def test_multi_rank_line_carries_the_c4_and_c5_legs_and_the_communication_librarys_view():
+    """Verdict r4 item 1: the driver's ONE command (`bench.py --gpus N`, no --config) must yield all the multi-GPU evidence.  Two ranks
+    sharing this box's GPU over gloo (RCCL refuses two ranks on one device): a functional dry run of exactly that command."""
+    out, _ = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--repeats", "2"], 1500)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks"] == 2 and "configs[1]" in d["config"]["workload"] and d["value"] > 0
+    v = d["rccl_view"]
+    assert v["world_size"] == 2 and v["rank_ids_allgathered"] == [0, 1] and [r["rank"] for r in v["ranks"]] == [0, 1]
+    assert v["backend"] in ("gloo", "nccl") and (v["backend"] == "gloo" or v["distinct_devices"] == 2)
+    assert d["guard"].startswith("active") and d["oracle_pin"].startswith(("unpinned", "pinned")) and isinstance(d["env"], dict)
+    assert "comm_exposed_us" in d and d["allreduce_bytes_per_step"] > 0
+    legs = d["legs"]
+    assert set(legs) == {"c4", "c5"}
+    for name, idx in (("c4", 3), ("c5", 4)):
+        leg = legs[name]
+        assert "error" not in leg, leg
+        assert leg["value"] > 0 and leg["n_gpus"] == 2 and f"configs[{idx}]" in leg["config"]["workload"]
+        assert abs(leg["value"] - 2 * leg["config"]["per_gpu_batch"] / (leg["ms_per_step"] * 1e-3)) < 1e-6 * leg["value"]
+        assert "comm_exposed_us" in leg and leg["allreduce_bytes_per_step"] > 0
+    assert legs["c4"]["config"]["per_gpu_batch"] == 32 and "history_size=50" in legs["c4"]["config"]["workload"]
+    assert legs["c5"]["config"]["per_gpu_batch"] == 64 and legs["c5"]["exchange"]["world"] == 2 and "row-sharded" in legs["c5"]["config"]["workload"]
+
+
+@pytest.mark.gpu
+def test_a_rank_that_skips_its_collectives_ends_the_benchmark_non_zero_and_names_the_segment():
+    """The hang watchdog: rank 1 leaves rank 0 alone in the gradient all-reduce.  Without it the run would sit in the collective
+    until the driver's own limit; with it the job exits non-zero within EBN_COLLECTIVE_TIMEOUT_S and says where."""
+    out, dt = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--repeats", "2", "--legs", "", "--fault-skip-collectives-on-rank", "1"], 900,
+                     env={"EBN_COLLECTIVE_TIMEOUT_S": "20"})
+    assert out.returncode != 0, out.stdout[-2000:]
+    assert dt < 400, dt
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]  # no line of record from a broken run
+    assert "HUNG" in out.stderr and "segment" in out.stderr and "phase [c2: warm-up + timed region" in out.stderr, out.stderr[-3000:]

@@ -243,21 +243,48 @@ def _guard_worker(rank, world):
 
     from ebrec.models.newsrec._dist import LockStepGuard
 
+    t0 = time.time()
     g = LockStepGuard(timeout_s=2.0)
-    assert (g.rank, g.world) == (rank, world)
+    assert (g.rank, g.world) == (rank, world) and time.time() - t0 < 1.0  # construction builds nothing and talks to nobody
+    if rank == 0:
+        LockStepGuard()  # an engine (hence a guard) made on ONE rank only -- a rank-0 inference model -- must not disturb the others'
+    assert g.status().startswith("active")
     g.enter("model.evaluate()")  # everyone arrives: passes
     g.enter("model.save_weights()")
-    if rank == 0:  # the `if rank == 0: model.save_weights(...)` mistake: an error naming the call, not a hang
+    if rank == 0:  # the `if rank == 0: model.save_weights(...)` mistake: an error naming the call and the absent rank, not a hang
         t0 = time.time()
-        with pytest.raises(RuntimeError, match=r"model\.save_weights\(\) is a COLLECTIVE"):
+        with pytest.raises(RuntimeError, match=r"model\.save_weights\(\) is a COLLECTIVE.*rank\(s\) \[1\] did not"):
             g.enter("model.save_weights()")
         assert time.time() - t0 < 30
     else:
         time.sleep(4.0)
-    # the barrier that timed out ran on the guard's own side group: the caller's group is still usable after the error
+    # the failed rendezvous ran on the store: the caller's group is still usable after the error ...
     t = torch.ones(1) * (rank + 1)
     dist.all_reduce(t)
     assert float(t) == 3.0
+    # ... and so is the guard (round-4 ADVICE: a gloo side group stayed broken after one timed-out barrier): the rank that gave
+    # up withdrew its arrival mark, the next call every rank makes passes -- also through a second guard over the same group
+    g.enter("model.fit()")
+    LockStepGuard(timeout_s=2.0).enter("model.evaluate()")
+    dist.barrier()
+
+
+def _guard_default_timeout_worker(rank, world):
+    from datetime import timedelta
+
+    from ebrec.models.newsrec._dist import LockStepGuard, group_timeout_s
+
+    os.environ.pop("EBN_COLLECTIVE_TIMEOUT_S", None)
+    g = LockStepGuard()
+    g.enter("model.fit()")
+    # never stricter than the process group's own watchdog (gloo here: 30 min by default)
+    assert g.timeout_s == group_timeout_s() >= 600.0
+    sub = dist.new_group(ranks=[0, 1], backend="gloo", timeout=timedelta(seconds=77))
+    assert group_timeout_s(sub) == 77.0
+
+
+def test_lock_step_guard_default_timeout_is_the_process_groups_own():
+    _run(_guard_default_timeout_worker, 2)
 
 
 def test_collective_api_entered_by_one_rank_raises_instead_of_hanging():
@@ -268,5 +295,38 @@ def test_lock_step_guard_is_a_no_op_without_a_process_group():
     from ebrec.models.newsrec._dist import LockStepGuard
 
     g = LockStepGuard()
-    assert g.world == 1 and g.group is None
+    assert g.world == 1 and g.status().startswith("not needed")
     g.enter("anything")
+
+
+# ---------------------------------------------------------------- BatchNormalization moving statistics under data parallel
+def _bn_sync_worker(rank, world):
+    from ebrec.models.newsrec._mlp import MLPStack
+
+    units = [24, 20, 7]
+    mlp = MLPStack(None, "", 16, units, torch.device("cpu"), 0.0)
+    assert all(float(m.abs().max()) == 0 for m in mlp.bn_mean) and all(float((v - 1).abs().max()) == 0 for v in mlp.bn_var)  # Keras' initial values
+    def drifted(r):  # every rank's moving averages have drifted by ITS data
+        rng = np.random.default_rng(1000 + r)
+        return [(rng.standard_normal(u).astype(np.float32), (1 + rng.random(u)).astype(np.float32)) for u in units]
+
+    for l, (m, v) in enumerate(drifted(rank)):
+        mlp.bn_mean[l].copy_(torch.from_numpy(m))
+        mlp.bn_var[l].copy_(torch.from_numpy(v))
+    everyone = [drifted(r) for r in range(world)]
+    mlp.sync_moving_statistics()
+    for l, u in enumerate(units):
+        for k, got in ((0, mlp.bn_mean[l]), (1, mlp.bn_var[l])):
+            want = np.mean([everyone[r][l][k].astype(np.float64) for r in range(world)], axis=0)
+            assert np.allclose(got.numpy(), want, rtol=1e-6, atol=1e-7)
+    # the replicas now hold the SAME statistics (bit for bit: one all-reduce result, one scaling), and they are views of one flat buffer
+    flat = mlp.bn_stats.clone()
+    got = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(got, flat)
+    assert all(torch.equal(g, got[0]) for g in got)
+    assert mlp.bn_mean[1].data_ptr() - mlp.bn_stats.data_ptr() == 4 * (64 + 64) and mlp.bn_var[2].numel() == 7
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_batchnorm_moving_statistics_are_averaged_over_the_ranks(world):
+    _run(_bn_sync_worker, world)
