@@ -8,13 +8,11 @@ side effect of the threshold metrics.  Beyond-accuracy metrics are out of scope 
 from __future__ import annotations
 
 import json
-from itertools import compress
-from typing import Iterable
 
 import numpy as np
 
 from .metrics import accuracy_score, f1_score, log_loss, mean_squared_error, mrr_score, ndcg_score, roc_auc_score
-from .protocols import Metric
+from .protocols import Metric, MetricBase  # noqa: F401  (Metric: the structural type, re-exported)
 from .utils import convert_to_binary
 
 
@@ -22,7 +20,7 @@ def _mean_over_impressions(fn, y_true, y_pred) -> float:
     return float(np.mean([fn(labels, preds) for labels, preds in zip(y_true, y_pred)]))
 
 
-class AccuracyScore(Metric):
+class AccuracyScore(MetricBase):
     def __init__(self, threshold: float = 0.5):
         self.threshold = threshold
         self.name = "accuracy"
@@ -31,7 +29,7 @@ class AccuracyScore(Metric):
         return _mean_over_impressions(lambda l, p: accuracy_score(l, convert_to_binary(p, self.threshold)), y_true, y_pred)
 
 
-class F1Score(Metric):
+class F1Score(MetricBase):
     def __init__(self, threshold: float = 0.5):
         self.threshold = threshold
         self.name = "f1"
@@ -40,7 +38,7 @@ class F1Score(Metric):
         return _mean_over_impressions(lambda l, p: f1_score(l, convert_to_binary(p, self.threshold)), y_true, y_pred)
 
 
-class RootMeanSquaredError(Metric):
+class RootMeanSquaredError(MetricBase):
     def __init__(self):
         self.name = "rmse"
 
@@ -48,7 +46,7 @@ class RootMeanSquaredError(Metric):
         return _mean_over_impressions(lambda l, p: np.sqrt(mean_squared_error(l, p)), y_true, y_pred)
 
 
-class AucScore(Metric):
+class AucScore(MetricBase):
     def __init__(self):
         self.name = "auc"
 
@@ -56,7 +54,7 @@ class AucScore(Metric):
         return _mean_over_impressions(roc_auc_score, y_true, y_pred)
 
 
-class LogLossScore(Metric):
+class LogLossScore(MetricBase):
     def __init__(self):
         self.name = "logloss"
 
@@ -65,7 +63,7 @@ class LogLossScore(Metric):
         return _mean_over_impressions(lambda l, p: log_loss(l, clip(p)), y_true, y_pred)
 
 
-class MrrScore(Metric):
+class MrrScore(MetricBase):
     def __init__(self):
         self.name = "mrr"
 
@@ -73,7 +71,7 @@ class MrrScore(Metric):
         return _mean_over_impressions(mrr_score, y_true, y_pred)
 
 
-class NdcgScore(Metric):
+class NdcgScore(MetricBase):
     def __init__(self, k: int):
         self.k = k
         self.name = f"ndcg@{k}"
@@ -82,36 +80,45 @@ class NdcgScore(Metric):
         return _mean_over_impressions(lambda l, p: ndcg_score(l, p, self.k), y_true, y_pred)
 
 
+def _reject_non_callables(candidates) -> list:
+    """The reference's acceptance rule for `metric_functions` (metrics_protocols.py:191-203): a non-empty collection whose
+    members can all be called; anything else is a TypeError that lists the types of the offending members."""
+    candidates = list(candidates) if not isinstance(candidates, (list, tuple)) else candidates
+    offenders = [type(c) for c in candidates if not callable(c)]
+    if offenders or len(candidates) == 0:
+        raise TypeError(f"Following object(s) are not callable: {offenders}")
+    return candidates
+
+
 class MetricEvaluator:
-    """``MetricEvaluator(labels, predictions, metric_functions).evaluate()`` fills ``.evaluations`` and returns
-    the evaluator itself (metrics_protocols.py:184-189)."""
+    """Runs a list of metrics over per-impression labels and predictions (metrics_protocols.py:141-217).
+
+    ``MetricEvaluator(labels, predictions, metric_functions).evaluate()`` stores ``{metric.name: metric(labels, predictions)}``
+    in ``.evaluations`` and returns the evaluator itself, so that ``.evaluate().evaluations`` chains.  Assigning to
+    ``metric_functions`` -- in the constructor or later -- is checked by `_reject_non_callables`.  Printed, an evaluator shows
+    its results as indented JSON (``{}`` before ``evaluate()`` has run)."""
+
+    _HEAD = "<MetricEvaluator class>:"
 
     def __init__(self, labels, predictions, metric_functions):
-        self.labels = labels
-        self.predictions = predictions
+        self.labels, self.predictions = labels, predictions
         self.metric_functions = metric_functions
-        self.evaluations = dict()
+        self.evaluations = {}
+
+    def __setattr__(self, attr, value):
+        if attr == "metric_functions":
+            value = _reject_non_callables(value)
+        object.__setattr__(self, attr, value)
 
     def evaluate(self):
-        self.evaluations = {m.name: m(self.labels, self.predictions) for m in self.metric_functions}
+        results = {}
+        for metric in self.metric_functions:
+            results[metric.name] = metric(self.labels, self.predictions)
+        self.evaluations = results
         return self
 
-    @property
-    def metric_functions(self):
-        return self.__metric_functions
-
-    @metric_functions.setter
-    def metric_functions(self, values):
-        invalid = [not callable(item) for item in values]
-        if not any(invalid) and invalid:
-            self.__metric_functions = values
-        else:
-            raise TypeError(f"Following object(s) are not callable: {[type(i) for i in compress(values, invalid)]}")
-
-    def __str__(self):
-        if self.evaluations:
-            return f"<MetricEvaluator class>: \n {json.dumps(self.evaluations, indent=4)}"
-        return f"<MetricEvaluator class>: {self.evaluations}"
-
     def __repr__(self):
-        return str(self)
+        body = f" \n {json.dumps(self.evaluations, indent=4)}" if self.evaluations else f" {self.evaluations}"
+        return self._HEAD + body
+
+    __str__ = __repr__

@@ -66,3 +66,25 @@ def test_auc_needs_both_classes_and_evaluator_rejects_non_callables():
         MetricEvaluator([[1, 0]], [[0.3, 0.2]], metric_functions=[AucScore(), "mrr"])
     ev = MetricEvaluator([[1, 0]], [[0.3, 0.2]], metric_functions=[AucScore()])
     assert "{}" in str(ev) and ev.evaluate() is ev and "auc" in str(ev)
+
+
+def test_metric_is_a_structural_type_and_prints_like_the_reference():
+    """protocols.py:5-17: `name` + `calculate` make a metric; the call forwarding and the printed form are not part of the type."""
+    from ebrec.evaluation.protocols import Metric, MetricBase
+
+    class Mine:  # a third-party metric object: no base class
+        name = "mine"
+
+        def calculate(self, y_true, y_score):
+            return 1.0
+
+    assert isinstance(Mine(), Metric) and isinstance(NdcgScore(5), Metric) and not isinstance(object(), Metric)
+    assert isinstance(AucScore(), MetricBase)
+    assert str(NdcgScore(k=5)) == "<Callable Metric: ndcg@5>: params: {'k': 5, 'name': 'ndcg@5'}" == repr(NdcgScore(k=5))
+    with pytest.raises(TypeError, match=r"not callable: \[\]"):
+        MetricEvaluator([[1, 0]], [[0.3, 0.2]], metric_functions=[])  # the reference refuses an empty list too
+    with pytest.raises(TypeError, match="not callable: .*str"):
+        MetricEvaluator([[1, 0]], [[0.3, 0.2]], metric_functions=[AucScore()]).metric_functions = [AucScore(), "mrr"]
+    ev = MetricEvaluator([[1, 0]], [[0.3, 0.2]], metric_functions=[AucScore()])
+    assert str(ev) == "<MetricEvaluator class>: {}"
+    assert str(ev.evaluate()) == '<MetricEvaluator class>: \n {\n    "auc": 1.0\n}'

@@ -155,6 +155,34 @@ def test_oracle_matches_tensorflow_docvec_forward_and_one_training_step():
 
 
 @needs_gold
+def test_oracle_two_replica_docvec_step_follows_tensorflows_batchnorm_contract():
+    """Round 5: the data-parallel BatchNormalization contract (per-replica batch statistics, moving statistics = the MEAN over
+    the replicas' updates, gradients averaged) against a tf.distribute.MirroredStrategy step on two logical devices."""
+    z, _, _, _ = _load()
+    if "docvec_dp2_loss" not in z.files:
+        pytest.skip("golden file has no two-replica NRMSDocVec step")
+    P = _docvec_params(z, "docvec_w")
+    _, h, d, _, _ = (int(v) for v in z["docvec_dims"])
+    his, pred, y = z["docvec_dp2_his"].astype(np.float64), z["docvec_dp2_pred"].astype(np.float64), z["docvec_dp2_y"]
+    B = his.shape[0] // 2
+    after = _docvec_params(z, "docvec_dp2_w")
+    losses, moved = [], []
+    for r in range(2):
+        sl = slice(r * B, (r + 1) * B)
+        L, _, g, stats = on.docvec_loss_and_grads(his[sl], pred[sl], y[sl], P, h, d, l2=float(z["docvec_l2"]), training=True, drop=None)
+        Pn = dict(P)
+        on.bn_update_moving(Pn, stats)
+        losses.append(L)
+        moved.append(Pn)
+    assert abs(np.mean(losses) - float(z["docvec_dp2_loss"])) < TOL
+    for l in range(len(P["units"])):
+        for nm in ("mean", "var"):
+            want = after[f"bn{l}_{nm}"]
+            got = (moved[0][f"bn{l}_{nm}"] + moved[1][f"bn{l}_{nm}"]) / 2
+            np.testing.assert_allclose(got, want, atol=1e-5, rtol=1e-5, err_msg=f"bn{l}_{nm}: mean over the replicas")
+
+
+@needs_gold
 @pytest.mark.gpu
 def test_hip_path_matches_tensorflow_forward(hip):
     from ebrec.models.newsrec import NRMSModel

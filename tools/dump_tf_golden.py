@@ -16,6 +16,10 @@ ONE run pins everything the oracle tags [KERAS-SEMANTICS]:
     the L2 term, weights and BatchNorm moving statistics afterwards                            -> per-call-site batch
     statistics and two moving-average updates per step
   * NRMS with ``newsencoder_units_per_layer``: ``get_weights()`` order + names and a forward pass
+  * NRMSDocVec under ``tf.distribute.MirroredStrategy`` on TWO logical CPU devices (round 5): one ``fit`` step of a global batch
+    of 2 x B rows -- the loss and the BatchNorm moving statistics afterwards                    -> the data-parallel BatchNorm
+    contract of this build (per-replica batch statistics, moving statistics read as the MEAN over the replicas:
+    ``MLPStack.sync_moving_statistics``); skipped (fields absent) where the logical-device split is refused
 ``tests/test_tf_golden.py`` checks the float64 oracle (CPU) and the HIP path (GPU) against every field at 1e-4 -- the
 forward-parity experiment of BASELINE.json's north_star, widened to training.  Only data is written; no reference
 source travels.
@@ -100,6 +104,24 @@ def main(out_path):
     out["docvec_train1_loss"] = np.array(float(np.ravel(dv.model.train_on_batch((dhis, dpred), y))[0]))
     for i, a in enumerate(dv.model.get_weights()):
         out[f"docvec_train1_w{i:02d}"] = a
+    # ---- NRMSDocVec, two replicas (data parallel): what do the BatchNorm moving statistics hold after one step?
+    try:
+        cpus = tf.config.list_physical_devices("CPU")
+        tf.config.set_logical_device_configuration(cpus[0], [tf.config.LogicalDeviceConfiguration(), tf.config.LogicalDeviceConfiguration()])
+        strategy = tf.distribute.MirroredStrategy(["CPU:0", "CPU:1"])
+        with strategy.scope():
+            dv2 = NRMSDocVec(hparams=hd, seed=42)
+        dv2.model.set_weights(wd)
+        his2 = np.concatenate([dhis, rng.standard_normal(dhis.shape).astype(np.float32)])
+        pred2 = np.concatenate([dpred, rng.standard_normal(dpred.shape).astype(np.float32)])
+        y2 = np.concatenate([y, np.eye(C, dtype=np.float32)[rng.integers(0, C, B)]])
+        ds = tf.data.Dataset.from_tensor_slices(((his2, pred2), y2)).batch(2 * B)  # one global batch: B rows per replica, in order
+        h2 = dv2.model.fit(ds, epochs=1, verbose=0)
+        out.update({"docvec_dp2_his": his2, "docvec_dp2_pred": pred2, "docvec_dp2_y": y2, "docvec_dp2_loss": np.array(h2.history["loss"][0])})
+        for i, a in enumerate(dv2.model.get_weights()):
+            out[f"docvec_dp2_w{i:02d}"] = a
+    except Exception as e:  # logical devices must be configured before TF initialises its runtime: run this script in a fresh process
+        print("two-replica NRMSDocVec step skipped:", type(e).__name__, e)
     np.savez_compressed(out_path, **out)
     print("wrote", out_path, {k: v.shape for k, v in out.items() if hasattr(v, "shape")})
 
