@@ -224,6 +224,7 @@ class NRMSEngine:
         self.overlap_collectives = True  # multi-rank: start the dense-gradient buckets under the rest of the backward (see _segments)
         self.skip_collectives = False    # bench.py only: time the step without its collectives (-> comm_exposed_us); results are wrong
         self._pending = []
+        self.defer_flag_checks = False  # set by the lock-step callers around their inference calls (see _check_oob)
         self.trace = None  # a _dist.SegmentTrace: event behind every segment of every step (bench.py's hang watchdog); None = off
         self.world = 1
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
@@ -851,6 +852,12 @@ class NRMSEngine:
         have returned: examples/reproducibility_scripts/ebnerd_nrms.py).  Default (None): collective exactly when the table is
         row-sharded -- there `encode_news` is itself a collective (the lookup's all-to-alls), every rank is in the call."""
         if collective is None:
+            if self.defer_flag_checks:
+                # inside a lock-step caller (evaluate() / fit() with world > 1): the sticky flags are left alone -- neither read
+                # nor cleared nor raised on -- and the caller's closing check_oob() MAX-reduces them, so every rank raises
+                # together.  A rank raising here alone (its own range_flag, say) would leave its peers in evaluate()'s closing
+                # all-reduce with nobody to meet (round-4 ADVICE)
+                return
             collective = self.exchange is not None
         collective = bool(collective) and self.world > 1
         err = None

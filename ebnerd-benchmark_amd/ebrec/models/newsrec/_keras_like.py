@@ -210,9 +210,17 @@ class TrainModel:
         if world > 1 and hasattr(eng, "pin_table_grad_exchange") and n_batches:
             # table_grad_exchange="auto" is decided ONCE, here, from the FULL-batch shape (configuration: the same on every rank) --
             # never per step from a rank's local, possibly short, batch
-            (h0, p0), _y0 = data[0]
+            # (round-4 ADVICE: a rank whose loader has no batch_size and whose first batch is short must not pin a different
+            # collective than its peers -> the count is MAX-reduced over the group; a later fit() with another batch size must
+            # not keep a stale verdict -> the pin is reset here)
+            (h0, p0), _y0 = data.index_batch(0) if hasattr(data, "index_batch") and not getattr(data, "eval_mode", False) else data[0]
             bs = int(getattr(data, "batch_size", None) or getattr(data, "bs", None) or len(h0))
-            eng.pin_table_grad_exchange(bs * (np.shape(h0)[1] + np.shape(p0)[1]) * eng.T)
+            n_tok_full = bs * (np.shape(h0)[1] + np.shape(p0)[1]) * eng.T
+            t = torch.tensor([float(n_tok_full)], dtype=torch.float64, device=eng.device)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=_group)
+            before, eng._sparse_pin = eng._sparse_pin, None
+            if eng.pin_table_grad_exchange(int(t.item())) != before and before is not None:
+                eng._graphs.clear()  # the step's collectives changed: captured segment lists are stale
         if world > 1 and getattr(eng, "needs_equal_batches", getattr(eng, "exchange", None) is not None):
             # row-sharded table / sparse table-gradient exchange: the step's collectives are sized by the batch SHAPE, which
             # must therefore be the same on every rank in every step -- a shard's short last batch is left out (it is always
@@ -290,18 +298,25 @@ class TrainModel:
         # run each batch from the cached news vectors -- the validation pass of fit() costs user encoders only
         cached = (self.cache_articles and hasattr(data, "index_batch") and hasattr(self._owner, "_encode_article_matrix")
                   and not getattr(data, "eval_mode", False))
-        news_all = self._owner._encode_article_matrix(data.lookup_article_matrix) if cached else None
-        for i in range(len(data)):
-            if cached:
-                (his, pred), yb = data.index_batch(i)
-                loss, probs = eval_loss_from_news(eng, news_all, his, pred, yb)
-            else:
-                (his, pred), yb = data[i]
-                loss, probs = eng.eval_loss(his, pred, yb)
-            loss_sum += loss * len(his)  # stays on the device: one host sync per evaluate(), not per batch
-            n_rows += len(his)
-            if auc is not None:
-                auc.update_device(torch.as_tensor(np.asarray(yb, dtype=np.float32)).to(eng.device).reshape(probs.shape).contiguous(), probs)
+        lockstep = int(getattr(eng, "world", 1)) > 1 and hasattr(eng, "defer_flag_checks")
+        if lockstep:  # the inference calls below must not raise on one rank alone: the closing check_oob() reports for everyone
+            eng.defer_flag_checks = True
+        try:
+            news_all = self._owner._encode_article_matrix(data.lookup_article_matrix) if cached else None
+            for i in range(len(data)):
+                if cached:
+                    (his, pred), yb = data.index_batch(i)
+                    loss, probs = eval_loss_from_news(eng, news_all, his, pred, yb)
+                else:
+                    (his, pred), yb = data[i]
+                    loss, probs = eng.eval_loss(his, pred, yb)
+                loss_sum += loss * len(his)  # stays on the device: one host sync per evaluate(), not per batch
+                n_rows += len(his)
+                if auc is not None:
+                    auc.update_device(torch.as_tensor(np.asarray(yb, dtype=np.float32)).to(eng.device).reshape(probs.shape).contiguous(), probs)
+        finally:
+            if lockstep:
+                eng.defer_flag_checks = False
         ls, nr = _allreduce_host([float(loss_sum.item()), n_rows], eng)  # every rank evaluates its shard; the result is global
         out = {"loss": ls / max(nr, 1)}
         if hasattr(eng, "check_oob"):
