@@ -175,6 +175,11 @@ struct GemmEpi {
   int64_t ldcv;
   int32_t L;
   const float* bias;  // EPI = 2: C = max(acc + bias[col], 0) -- Dense(units, activation="relu") forward
+  // small-output tiles only (ebn_gemm_tn_group_f32): column sums of a [K][N] B operand, written by the first row of tiles;
+  // C += two_lambda * l2w[row][col] (leading dimension ldc)
+  float* colsum = nullptr;
+  const float* l2w = nullptr;
+  float two_lambda = 0.f;
 };
 
 // TA: A stored [K,M]; TB: B stored [N,K].
@@ -904,6 +909,10 @@ __device__ __forceinline__ void small_vec_body(int64_t M, int64_t N, int64_t K, 
   // dependent MFMAs per slab ran at less than half the matrix rate.  (Deterministic: the order of the sums is fixed.)
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
   float4 ra[2][SPT], rb[2][SPT];
+  // column sums of a [K][N] B operand (the bias gradient next to a Dense kernel gradient): the first row of tiles adds up the
+  // pieces it stages anyway -- thread t holds columns 4 (t % (T/4)) .. + 3 of the k rows t / (T/4) + i THREADS / (T/4)
+  const bool do_colsum = !B_KC && epi.colsum != nullptr && tile_y == 0;
+  float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
   // slab KT -> register set SET; a piece at k >= K (partial last slab only) reads offset 0 and is replaced by zero
 #define EBN_SM_LOAD(SET, KT)                                                                              \
   do {                                                                                                    \
@@ -928,6 +937,14 @@ __device__ __forceinline__ void small_vec_body(int64_t M, int64_t N, int64_t K, 
   do {                                                                    \
     small_store_t<A_KC, T>(smem_small + (BUF) * 2 * TILE, ra[SET], tid);       \
     small_store_t<B_KC, T>(smem_small + (BUF) * 2 * TILE + TILE, rb[SET], tid); \
+    if (do_colsum) {                                                      \
+      _Pragma("unroll") for (int i = 0; i < SPT; ++i) {                   \
+        csum.x += rb[SET][i].x;                                           \
+        csum.y += rb[SET][i].y;                                           \
+        csum.z += rb[SET][i].z;                                           \
+        csum.w += rb[SET][i].w;                                           \
+      }                                                                   \
+    }                                                                     \
   } while (0)
   const int r16 = lane & 15, kq = lane >> 4;
   // swizzled columns of a lane's two float4 per 32-deep group (ca: row wm * 16 + r16 of A's image, cb: row wn * 16 + r16 of B's)
@@ -1006,6 +1023,17 @@ __device__ __forceinline__ void small_vec_body(int64_t M, int64_t N, int64_t K, 
 #undef EBN_SM_READ
 #undef EBN_SM_MUL
   const f32x4 acc = (acc0 + acc1) + (acc2 + acc3);
+  if (do_colsum) {  // (block-uniform) fixed-order sum over the THREADS / (T/4) threads that share a column group; the tile
+    constexpr int CG = T / 4, KR = THREADS / CG;  // buffers are free: the slab loop ends behind a barrier
+    float* sc = smem_small;
+    *reinterpret_cast<float4*>(&sc[(tid / CG) * (T + 4) + (tid % CG) * 4]) = csum;
+    __syncthreads();
+    if (tid < T && n0 + tid < N) {
+      float t = 0.f;
+      for (int r = 0; r < KR; ++r) t += sc[r * (T + 4) + tid];
+      epi.colsum[n0 + tid] = t;
+    }
+  }
   // C/D map of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + r
   const int64_t col = n0 + wn * 16 + r16;
   if (col >= N) return;
@@ -1018,6 +1046,7 @@ __device__ __forceinline__ void small_vec_body(int64_t M, int64_t N, int64_t K, 
     if (epi.rs != nullptr)
       v = fmaf(epi.rs[row], epi.cv[static_cast<int64_t>(static_cast<uint32_t>(row) / static_cast<uint32_t>(epi.L)) * epi.ldcv + col], v);
     if (epi.bias != nullptr) v = fmaxf(v + epi.bias[col], 0.f);
+    if (epi.l2w != nullptr) v = fmaf(epi.two_lambda, epi.l2w[row * ldc + col], v);
     C[row * ldc + col] = v;
   }
 }
@@ -1056,6 +1085,30 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_small_pair_kernel(SmallProb
   else
     small_vec_body<false, true, 32>(p1.M, p1.N, p1.K, p1.alpha, p1.A, p1.lda, p1.B, p1.ldb, p1.beta, p1.C, p1.ldc, none,
                                     (b - p0.tiles) % p1.tiles_x, (b - p0.tiles) / p1.tiles_x);
+}
+
+// Up to EBN_TN_GROUP_MAX weight-gradient products C_i = A_i^T . B_i in one launch (ebn_gemm_tn_group_f32): every workgroup finds
+// its problem from the running tile counts (scalar loop) and runs the TN body; optional bias-gradient column sums and L2 term.
+struct SmallGroup {
+  SmallProblem p[EBN_TN_GROUP_MAX];
+  float* colsum[EBN_TN_GROUP_MAX];
+  const float* l2w[EBN_TN_GROUP_MAX];
+  float two_lambda[EBN_TN_GROUP_MAX];
+  int32_t first[EBN_TN_GROUP_MAX + 1];  // first workgroup of problem i; first[n] = total
+  int32_t n;
+};
+
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_small_tn_group_kernel(SmallGroup g) {
+  const int b = blockIdx.x;
+  int i = 0;
+  while (i + 1 < g.n && b >= g.first[i + 1]) ++i;
+  const SmallProblem& p = g.p[i];
+  GemmEpi epi{nullptr, nullptr, 0, 1, nullptr};
+  epi.colsum = g.colsum[i];
+  epi.l2w = g.l2w[i];
+  epi.two_lambda = g.two_lambda[i];
+  const int t = b - g.first[i];
+  small_vec_body<true, false, 32>(p.M, p.N, p.K, p.alpha, p.A, p.lda, p.B, p.ldb, p.beta, p.C, p.ldc, epi, t % p.tiles_x, t / p.tiles_x);
 }
 
 int launch_gemm_small(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda,
@@ -1437,6 +1490,41 @@ extern "C" int ebn_dense_bwd_pair_f32(int64_t R, int64_t K_in, int64_t N_out, co
   const int rc = gemm_dispatch(1, 0, K_in, N_out, R, 1.0f, X, ldx, dY, lddy, beta_w, dW, lddw, workspace, workspace_floats, 0, none, s);
   if (rc != EBN_OK) return rc;
   return gemm_dispatch(0, 1, R, K_in, N_out, 1.0f, dY, lddy, W, ldw, 0.0f, dX, lddx, workspace, workspace_floats, 0, none, s);
+}
+
+extern "C" int ebn_gemm_tn_group_f32(const ebn_tn_problem* problems, int32_t n, ebn_stream_t stream) {
+  EBN_REQUIRE(problems != nullptr && n >= 1 && n <= EBN_TN_GROUP_MAX, EBN_ERR_BAD_ARG);
+  SmallGroup g{};
+  int64_t total = 0;
+  g.n = 0;
+  for (int i = 0; i < n; ++i) {
+    const ebn_tn_problem& q = problems[i];
+    EBN_REQUIRE(ebn_dim_ok(q.M, q.N, q.K) && q.K >= 1, EBN_ERR_BAD_ARG);
+    if (q.M == 0 || q.N == 0) continue;
+    EBN_REQUIRE(q.A && q.B && q.C, EBN_ERR_BAD_ARG);
+    EBN_REQUIRE(q.lda >= q.M && q.ldb >= q.N && q.ldc >= q.N, EBN_ERR_BAD_ARG);
+    EBN_REQUIRE((q.lda % 4) == 0 && (q.ldb % 4) == 0 && (q.M % 4) == 0 && (q.N % 4) == 0 && ebn_aligned16(q.A) && ebn_aligned16(q.B),
+                EBN_ERR_UNSUPPORTED);
+    EBN_REQUIRE((q.K + SBK) * (q.lda > q.ldb ? q.lda : q.ldb) * 4 + 64 * 4 < (int64_t{1} << 31), EBN_ERR_UNSUPPORTED);
+    const int j = g.n++;
+    g.p[j] = SmallProblem{q.M, q.N, q.K, 1.0f, q.A, q.lda, q.B, q.ldb, 0.0f, q.C, q.ldc, static_cast<int32_t>(ebn_ceil_div(q.N, SBN)), 0};
+    g.p[j].tiles = g.p[j].tiles_x * static_cast<int32_t>(ebn_ceil_div(q.M, SBM));
+    g.colsum[j] = q.colsum;
+    g.l2w[j] = q.l2_W;
+    g.two_lambda[j] = q.two_lambda;
+    g.first[j] = static_cast<int32_t>(total);
+    total += g.p[j].tiles;
+    EBN_REQUIRE(total < (int64_t{1} << 30), EBN_ERR_UNSUPPORTED);
+  }
+  if (g.n == 0) return EBN_OK;
+  g.first[g.n] = static_cast<int32_t>(total);
+  constexpr size_t lds = static_cast<size_t>(2) * 2 * SBM * SLV * sizeof(float);
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_small_tn_group_kernel),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+  if (attr != hipSuccess) return static_cast<int>(attr);
+  hipLaunchKernelGGL(gemm_small_tn_group_kernel, dim3(static_cast<unsigned>(total)), dim3(GEMM_THREADS), lds, ebn_stream(stream), g);
+  EBN_CHECK_LAUNCH();
+  return EBN_OK;
 }
 
 extern "C" int ebn_gemm_f32(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K, float alpha,

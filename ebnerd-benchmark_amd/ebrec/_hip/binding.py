@@ -64,6 +64,29 @@ class FinishJob(ctypes.Structure):
 
 FINISH_SPLITK, FINISH_COLRED, FINISH_HEAD, FINISH_MAX_JOBS = 0, 1, 2, 6
 
+DVN_MAX_LAYERS, TN_GROUP_MAX = 4, 8
+
+
+class DvnArgs(ctypes.Structure):
+    """ebn_dvn_args: the fused training step of the NRMSDocVec news encoder (csrc/ebn_docvec.hip)."""
+    _fields_ = ([("n_layers", ctypes.c_int32), ("din", ctypes.c_int32), ("e_out", ctypes.c_int32),
+                 ("units", ctypes.c_int32 * DVN_MAX_LAYERS), ("n0", ctypes.c_int32), ("n1", ctypes.c_int32),
+                 ("drop_p", ctypes.c_float), ("l2", ctypes.c_float),
+                 ("W", ctypes.c_void_p * (DVN_MAX_LAYERS + 1)), ("b", ctypes.c_void_p * (DVN_MAX_LAYERS + 1))] +
+                [(n, ctypes.c_void_p * DVN_MAX_LAYERS) for n in ("gamma", "beta", "moving_mean", "moving_var")] +
+                [("X0", ctypes.c_void_p), ("R", ctypes.c_void_p * DVN_MAX_LAYERS), ("Xn", ctypes.c_void_p * DVN_MAX_LAYERS),
+                 ("NE", ctypes.c_void_p), ("stat", ctypes.c_void_p), ("dNE", ctypes.c_void_p),
+                 ("dY", ctypes.c_void_p * DVN_MAX_LAYERS), ("dP", ctypes.c_void_p * (DVN_MAX_LAYERS + 1)),
+                 ("ggamma", ctypes.c_void_p * DVN_MAX_LAYERS), ("gbeta", ctypes.c_void_p * DVN_MAX_LAYERS),
+                 ("loss", ctypes.c_void_p)])
+
+
+class TnProblem(ctypes.Structure):
+    """ebn_tn_problem: one weight-gradient product C = A^T . B of ebn_gemm_tn_group_f32."""
+    _fields_ = [("M", ctypes.c_int64), ("N", ctypes.c_int64), ("K", ctypes.c_int64), ("A", ctypes.c_void_p),
+                ("lda", ctypes.c_int64), ("B", ctypes.c_void_p), ("ldb", ctypes.c_int64), ("C", ctypes.c_void_p),
+                ("ldc", ctypes.c_int64), ("colsum", ctypes.c_void_p), ("l2_W", ctypes.c_void_p), ("two_lambda", ctypes.c_float)]
+
 
 # ---- header parser -------------------------------------------------------
 _PROTO = re.compile(r"^(int64_t|int|const char\*)\s+(ebn_\w+)\s*\(([^;{}]*?)\)\s*;", re.M | re.S)

@@ -41,6 +41,9 @@ class DocVecEngine:
         self.params = FlatParams(shapes, self.device)
         self.use_graph, self._graphs = False, {}
         self.fuse_user_head = True  # False: the per-impression head of a step as its six separate launches (validation)
+        # True: BatchNormalization / Dropout / ReLU-backward of the news encoder ride in the Dense matmuls of a training step
+        # (csrc/ebn_docvec.hip: one launch per layer and direction); False: the separate passes of csrc/ebn_dense.hip (validation form)
+        self.fuse_news_mlp = True
         self.mlp = MLPStack(self.params, "", self.Din, self.units, self.device, self.l2, on_realloc=lambda: self._graphs.clear())
         self.bn_mean, self.bn_var = self.mlp.bn_mean, self.mlp.bn_var
         self._init_weights(seed)
@@ -156,10 +159,71 @@ class DocVecEngine:
         _hip.call("ebn_gemm_f32_ws", tA, tB, M, N, K, ctypes.c_float(1.0), _hip.ptr(A), lda, _hip.ptr(B), ldb,
                   ctypes.c_float(beta), _hip.ptr(C), ldc, _hip.ptr(ws), 0 if ws is None else ws.numel(), _hip.stream_handle())
 
+    def _dvn(self, mb, n_hist, n_cand):
+        """ebn_dvn_args of the fused news-encoder step over this buffer set, or None when the shape is outside what the fused
+        launches take (then the per-pass kernels run)."""
+        if not (self.fuse_news_mlp and self.units):
+            return None
+        key = ("dvn", n_hist, n_cand)
+        a = mb.get(key)
+        if a is None:
+            L, N, pv, g, b = len(self.units), mb["N"], self.params.view, self.params.g, self.mlp.bufs(mb["N"])
+            a = _hip.DvnArgs()
+            a.n_layers, a.din, a.e_out, a.n0, a.n1, a.drop_p, a.l2 = L, self.Din, self.E, n_hist, n_cand, self.p, self.l2
+            for l, u in enumerate(self.units):
+                a.units[l] = u
+            if not _hip.lib().ebn_dvn_supported(ctypes.byref(a)):
+                mb[key] = False
+                return None
+            f = lambda *s: torch.empty(*s, device=self.device)
+            if "dvn_dY" not in mb:
+                mb["dvn_dY"] = [f(N, u) for u in self.units]
+                mb["dvn_dP"] = [f(N, u) for u in self.units] + [f(N, self.E)]
+            # the scratch is sized by the row tiling of (n_hist, n_cand): one per shape
+            mb[("dvn_stat", n_hist, n_cand)] = stat = torch.zeros(int(_hip.lib().ebn_dvn_stat_floats(ctypes.byref(a))), device=self.device)
+            for l in range(L):
+                a.W[l], a.b[l] = pv(f"d{l}_W").data_ptr(), pv(f"d{l}_b").data_ptr()
+                a.gamma[l], a.beta[l] = pv(f"bn{l}_g").data_ptr(), pv(f"bn{l}_b").data_ptr()
+                a.moving_mean[l], a.moving_var[l] = self.bn_mean[l].data_ptr(), self.bn_var[l].data_ptr()
+                a.R[l], a.Xn[l] = b["R"][l].data_ptr(), b["Xn"][l].data_ptr()
+                a.dY[l], a.dP[l] = mb["dvn_dY"][l].data_ptr(), mb["dvn_dP"][l].data_ptr()
+                a.ggamma[l], a.gbeta[l] = g(f"bn{l}_g").data_ptr(), g(f"bn{l}_b").data_ptr()
+            a.W[L], a.b[L], a.dP[L] = pv("out_W").data_ptr(), pv("out_b").data_ptr(), mb["dvn_dP"][L].data_ptr()
+            a.X0, a.NE, a.dNE, a.stat, a.loss = mb["X0"].data_ptr(), mb["NE"].data_ptr(), mb["dNE"].data_ptr(), stat.data_ptr(), self.loss_dev.data_ptr()
+            # weight gradients of all L + 1 Dense kernels as ONE launch: dW_l = Xn_{l-1}^T . dP_l, bias gradient = column sums
+            # of dP_l, + 2 l2 W_l for the regularised (hidden) kernels
+            probs = (_hip.TnProblem * (L + 1))()
+            dims = [self.Din] + self.units + [self.E]
+            for l in range(L + 1):
+                q = probs[l]
+                q.M, q.N, q.K = dims[l], dims[l + 1], n_hist + n_cand
+                x = mb["X0"] if l == 0 else b["Xn"][l - 1]
+                q.A, q.lda, q.B, q.ldb = x.data_ptr(), dims[l], mb["dvn_dP"][l].data_ptr(), dims[l + 1]
+                wn, bn = (f"d{l}_W", f"d{l}_b") if l < L else ("out_W", "out_b")
+                q.C, q.ldc, q.colsum = g(wn).data_ptr(), dims[l + 1], g(bn).data_ptr()
+                if l < L and self.l2 > 0:
+                    q.l2_W, q.two_lambda = pv(wn).data_ptr(), 2.0 * self.l2
+            a._probs, a._stat = probs, stat
+            mb[key] = a
+        if a and getattr(self, "_dvn_dirty", False):
+            # a step that ran only half way (an exception between its forward and its backward) left the fixed-point accumulators
+            # of the fused launches dirty: the contract of ebn_dvn_fwd_train_f32 is a zero scratch
+            for k, v in mb.items():
+                if isinstance(k, tuple) and k[0] == "dvn_stat":
+                    v.zero_()
+            self._dvn_dirty = False
+        return a or None
+
     def _news_forward(self, mb, n_hist, n_cand, train):
         """MLP over the N = n_hist + n_cand rows already in mb['X0'] -> mb['NE'][:N]."""
         N = n_hist + n_cand
         pv = self.params.view
+        a = self._dvn(mb, n_hist, n_cand) if train else None
+        mb["dvn_live"] = a
+        if a is not None:
+            self._dvn_dirty = True  # until the backward call of this step has been issued
+            _hip.call("ebn_dvn_fwd_train_f32", ctypes.byref(a), _hip.ptr(self.state), _hip.stream_handle())
+            return
         x = self.mlp.forward(mb["X0"], n_hist, n_cand, train, self.state, self.p)
         mb["x_last"] = x
         ws = mb.get("ws")  # Dense(E, relu): bias and ReLU ride in the GEMM epilogue
@@ -169,6 +233,12 @@ class DocVecEngine:
     def _news_backward(self, mb, n_hist, n_cand):
         N = n_hist + n_cand
         pv, g = self.params.view, self.params.g
+        a = mb.get("dvn_live")
+        if a is not None:
+            _hip.call("ebn_dvn_bwd_f32", ctypes.byref(a), _hip.ptr(self.state), _hip.stream_handle())
+            _hip.call("ebn_gemm_tn_group_f32", a._probs, len(a._probs), _hip.stream_handle())
+            self._dvn_dirty = False
+            return
         prev, x_last = self.mlp.out_dim, mb["x_last"]
         dpre = mb["dNE"]  # relu backward in place
         _hip.call("ebn_bias_relu_bwd_f32", _hip.ptr(mb["NE"]), _hip.ptr(mb["dNE"]), _hip.ptr(dpre), _hip.ptr(g("out_b")),
@@ -344,6 +414,7 @@ class DocVecEngine:
             raise ValueError(f"indexed batches must be (B, {self.H}) and (B, C), got {tuple(his.shape)} {tuple(pred.shape)}")
         B, C = his.shape[0], pred.shape[1]
         mb, ub = self._mlp_bufs(B * (self.H + C)), self._user_bufs(B)  # (re)allocation clears the captured graphs
+        self._dvn(mb, B * self.H, B * C)  # buffers of the fused news-encoder launches: allocated outside any capture
         self._advanced = False
         if indexed:
             y = self._stage_indexed(mb, his, pred, y)

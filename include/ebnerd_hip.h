@@ -467,6 +467,79 @@ int ebn_batchnorm2_relu_bwd_f32(const float* dY, const float* xhat, const float*
                                 float* dbias, int64_t R0, int64_t R1, int32_t Ccols, const ebn_step_state* st, int32_t site,
                                 float drop_p, ebn_stream_t stream);
 
+/* ---- a11 as ONE launch per Dense layer and direction (nrms_docvec.py:113-135, training step) ------------------------
+ * x -> [Dense(u_l, relu, l2) -> BatchNormalization -> Dropout] x n_layers -> Dense(e_out, relu) over the rows of the two
+ * TimeDistributed call sites (rows [0,n0) = history block, [n0,n0+n1) = candidate block: own batch statistics and one
+ * moving-average update each, history first; nrms_docvec.py:88-90,176-178).  BatchNormalization, Dropout and the ReLU
+ * backward never run as passes of their own: the matmul in front leaves per-tile column partials, the matmul behind
+ * combines them and transforms its A operand on the way into LDS (csrc/ebn_docvec.hip).  Same arithmetic as
+ * ebn_dense_relu_fwd_f32 + ebn_batchnorm2_fwd_f32 / ebn_batchnorm2_relu_bwd_f32 + ebn_bias_relu_bwd_f32 up to fp32
+ * rounding (the column sums are order-independent 64-bit fixed-point accumulations of per-tile sums, the batch variance
+ * is E[x^2] - mean^2 in float64 from them, not two-pass over the block): bitwise reproducible run to run.
+ *
+ * All pointers device, 16-byte aligned, matrices dense row-major.  W[l] is (d_l, u_l) with d_0 = din, W[n_layers] the
+ * output kernel (u_last, e_out); b[l] likewise.  Forward writes R[l] = relu(Dense_l), Xn[l] = Dropout(BN(R[l])), NE, the
+ * batch statistics (inside `stat`) and the moving statistics.  Backward reads dNE and writes dY[l] = d(Xn[l]) with the
+ * dropout mask applied, dP[l] = d(pre-activation of Dense l) for l = 0..n_layers (the B operands of the weight gradients
+ * W[l]' = Xn[l-1]^T . dP[l], bias gradient = column sums of dP[l]: ebn_gemm_tn_group_f32), ggamma / gbeta, and adds
+ * l2 * sum_l sum(W[l]^2), l < n_layers, to loss[0] (loss may be NULL; the 2*l2*W term of the kernel gradients is the
+ * l2_W option of ebn_gemm_tn_group_f32).
+ * ebn_dvn_supported: 1 <= n_layers <= 4, widths multiples of 4, hidden widths <= 1024.
+ * `stat`: ebn_dvn_stat_floats(args) floats, 16-byte aligned, ZERO before the first forward call, then owned by the two
+ * calls: it must survive from the forward to the backward call of a step, and every forward call must be followed by the
+ * backward call of the same step before the next forward (the accumulators inside are re-zeroed by the step's own
+ * launches: the backward ones by the first forward launch, the forward ones by the last backward launch).  After a step
+ * that ran only half way the caller zeroes `stat` again.                                                               */
+#define EBN_DVN_MAX_LAYERS 4
+typedef struct ebn_dvn_args {
+  int32_t n_layers, din, e_out;
+  int32_t units[EBN_DVN_MAX_LAYERS];
+  int32_t n0, n1;
+  float drop_p, l2;
+  const float* W[EBN_DVN_MAX_LAYERS + 1];
+  const float* b[EBN_DVN_MAX_LAYERS + 1];
+  const float* gamma[EBN_DVN_MAX_LAYERS];
+  const float* beta[EBN_DVN_MAX_LAYERS];
+  float* moving_mean[EBN_DVN_MAX_LAYERS];
+  float* moving_var[EBN_DVN_MAX_LAYERS];
+  const float* X0;
+  float* R[EBN_DVN_MAX_LAYERS];
+  float* Xn[EBN_DVN_MAX_LAYERS];
+  float* NE;
+  float* stat;
+  const float* dNE;
+  float* dY[EBN_DVN_MAX_LAYERS];
+  float* dP[EBN_DVN_MAX_LAYERS + 1];
+  float* ggamma[EBN_DVN_MAX_LAYERS];
+  float* gbeta[EBN_DVN_MAX_LAYERS];
+  float* loss;
+} ebn_dvn_args;
+int ebn_dvn_supported(const ebn_dvn_args* args);
+int64_t ebn_dvn_stat_floats(const ebn_dvn_args* args);
+int ebn_dvn_fwd_train_f32(const ebn_dvn_args* args, const ebn_step_state* st, ebn_stream_t stream);
+int ebn_dvn_bwd_f32(const ebn_dvn_args* args, const ebn_step_state* st, ebn_stream_t stream);
+
+/* Up to EBN_TN_GROUP_MAX independent weight-gradient products C_i (M_i, N_i) = A_i^T . B_i (A_i (K_i, M_i), B_i (K_i, N_i),
+ * all row-major) in ONE launch of 32x32 small-output tiles -- the Dense kernel gradients of a step (nrms_docvec.py:116-134
+ * backward; the user encoder's K.dot gradients of layers.py:65,214-226), each too small to fill the chip alone.  Options per
+ * problem: colsum (N_i floats) = column sums of B_i over K_i (the bias gradient of the same Dense layer, taken from the B
+ * tiles as they pass); l2_W (M_i, N_i, leading dimension ldc) adds two_lambda * l2_W to C_i (kernel_regularizer=l2).
+ * 16-byte aligned operands, extents and leading dimensions multiples of 4; EBN_ERR_UNSUPPORTED otherwise.              */
+#define EBN_TN_GROUP_MAX 8
+typedef struct ebn_tn_problem {
+  int64_t M, N, K;
+  const float* A;
+  int64_t lda;
+  const float* B;
+  int64_t ldb;
+  float* C;
+  int64_t ldc;
+  float* colsum;
+  const float* l2_W;
+  float two_lambda;
+} ebn_tn_problem;
+int ebn_gemm_tn_group_f32(const ebn_tn_problem* problems, int32_t n, ebn_stream_t stream);
+
 /* Step prologue: copy up to three device buffers (history ids, candidate ids, labels of a batch handed over as device
  * tensors -- the inputs of nrms.py:170-176) into the step's static buffers with ONE launch; n_i in bytes, multiples
  * of 4; a NULL source or n_i = 0 skips that pair.                                                                   */

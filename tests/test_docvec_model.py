@@ -67,30 +67,37 @@ def test_forward_eval_mode_uses_moving_statistics(docvec, cfg):
     assert_close(ne, want, rtol=2e-5, atol=2e-5, what="docvec newsencoder")
 
 
+@pytest.mark.parametrize("fused", [True, False], ids=["fused_launches", "separate_passes"])
+@pytest.mark.parametrize("units,din,B", [([48, 40], 64, 8), ([200, 136, 72], 300, 24), ([36], 20, 3)])
 @pytest.mark.parametrize("p,l2", [(0.0, 0.0), (0.2, 1e-4)])
-def test_train_step_gradients_loss_and_moving_stats(docvec, p, l2):
-    hp = make_hp(title_size=64, newsencoder_units_per_layer=[48, 40], head_num=4, head_dim=8, attention_hidden_dim=12,
+def test_train_step_gradients_loss_and_moving_stats(docvec, p, l2, units, din, B, fused):
+    """Both forms of the news encoder's training step -- BatchNormalization / Dropout / ReLU-backward inside the Dense launches
+    (csrc/ebn_docvec.hip; partial row tiles, partial and multiple 128-deep slabs, 1-3 hidden layers) and as separate passes."""
+    hp = make_hp(title_size=din, newsencoder_units_per_layer=units, head_num=4, head_dim=8, attention_hidden_dim=12,
                  history_size=7, dropout=p, newsencoder_l2_regularization=l2)
     seed = 5
     P = oracle_params(hp, 9)
     m = docvec(hp, seed=seed)
+    m._engine.fuse_news_mlp = fused
     m.model.set_weights(weight_list(P))
     rng = np.random.default_rng(2)
-    his, pred, y = data(rng, 8, hp.history_size, 5, hp.title_size)
+    his, pred, y = data(rng, B, hp.history_size, 5, hp.title_size)
     L, _, g, stats = on.docvec_loss_and_grads(his.astype(np.float64), pred.astype(np.float64), y, P, hp.head_num, hp.head_dim,
                                               l2=l2, training=True, drop=on.Drop(p, seed, 1) if p > 0 else None)
     got = float(m.train_step(his, pred, y).item())
     assert abs(got - L) <= 3e-5 * max(1.0, abs(L)), (got, L)
     eng = m._engine
     E = eng.E
-    for k in [f"d{l}_{s}" for l in range(2) for s in ("W", "b")] + [f"bn{l}_{s}" for l in range(2) for s in ("g", "b")] + ["out_W", "out_b", "u_W", "u_b"]:
+    assert (eng._bufs["mlp"].get("dvn_live") is not None) == fused
+    nl = len(units)
+    for k in [f"d{l}_{s}" for l in range(nl) for s in ("W", "b")] + [f"bn{l}_{s}" for l in range(nl) for s in ("g", "b")] + ["out_W", "out_b", "u_W", "u_b"]:
         want = g[k].reshape(eng.params.shapes[k])
         assert_close(eng.params.g(k).cpu().numpy(), want, rtol=2e-4, atol=1e-6 + 2e-4 * np.abs(want).max(), what=f"d{k}")
     want = np.concatenate([g["u_WQ"], g["u_WK"], g["u_WV"]], 1)
     assert_close(eng.params.g("u_Wqkv").cpu().numpy(), want, rtol=2e-4, atol=1e-6 + 2e-4 * np.abs(want).max(), what="du_Wqkv")
     Pn = dict(P)
     on.bn_update_moving(Pn, stats)  # history call site first, then candidates: two updates per step
-    for l in range(2):
+    for l in range(nl):
         assert_close(eng.bn_mean[l].cpu().numpy(), Pn[f"bn{l}_mean"], rtol=1e-5, atol=1e-6, what=f"moving mean {l}")
         assert_close(eng.bn_var[l].cpu().numpy(), Pn[f"bn{l}_var"], rtol=1e-5, atol=1e-6, what=f"moving var {l}")
 
