@@ -381,7 +381,7 @@ def being_profiled() -> bool:
     return any(k.startswith(("ROCP_", "ROCPROF", "ROCPROFILER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
 
 
-def probe_kernels(config, batch, precision="exact", ids="uniform"):
+def probe_kernels(config, batch, precision="exact", ids="uniform", pick=None):
     """Kernel names and HBM traffic of the two roofline kernels, observed IN THIS RUN: three rocprofv3 passes over
     `bench.py --kernel-probe` (a subprocess that builds the same engine and launches the Q|K|V projection and the gather
     eagerly on the step's buffers): (1) --kernel-trace --stats -> the names as the profiler sees them, (2) --pmc FETCH_SIZE
@@ -407,7 +407,7 @@ def probe_kernels(config, batch, precision="exact", ids="uniform"):
                                cwd=tmp, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=150)  # a pass takes ~15 s; a hung profiler (seen: 15 min after an aborted pass) falls back to the static labels
             if r.returncode != 0:
                 return None
-        pick = lambda name: "gather" if "gather" in name else ("qkv_gemm" if "gemm" in name else None)
+        pick = pick or (lambda name: "gather" if "gather" in name else ("qkv_gemm" if "gemm" in name else None))
         stats = next(Path(tmp, "stats").rglob("*kernel_stats.csv"))
         for row in csv.DictReader(open(stats)):
             k = pick(row["Name"])
@@ -481,16 +481,33 @@ def bench_docvec(args, c, world, rank, device, sync, dfields):
         y = torch.zeros(c["B"], c["C"])
         y[torch.arange(c["B"]), torch.randint(0, c["C"], (c["B"],), generator=g)] = 1.0
         batches.append((his, pred, y.to(device)))
+    if args.kernel_probe:  # the two roofline kernels, eagerly, on the step's own buffers (what probe_kernels() wraps rocprofv3 around)
+        eng.train_step(*batches[0], indexed=True)
+        rk = eng.roofline_kernels(c["B"], c["C"])
+        for h_, p_, _ in batches[:4]:
+            rk["gather"](torch.cat([h_.reshape(-1), p_.reshape(-1)]).contiguous())()
+            if "dw_group" in rk:
+                rk["dw_group"]()
+        sync()
+        return
     eng.enable_graphs(not args.no_graph)
     times = timed_repeats(lambda k: eng.train_step(*batches[k % 8], indexed=True), args, sync, world, device)
-    # kernel-level rooflines on the step's own buffers: the document-vector gather (HBM) and the widest Dense GEMM (MFMA)
+    # kernel-level rooflines on the step's own buffers: the document-vector gather (HBM) and the time-dominant launch of the step,
+    # the grouped weight-gradient product of all Dense kernels (MFMA)
     rk = eng.roofline_kernels(c["B"], c["C"])
     id_sets = [torch.cat([h.reshape(-1), p.reshape(-1)]).contiguous() for h, p, _ in batches]  # the 8 batches' row numbers
     kt = {"gather": time_kernel([rk["gather"](ids) for ids in id_sets], sync)}
-    if "dense0" in rk:
-        kt["dense0"] = time_kernel(rk["dense0"], sync)
+    if "dw_group" in rk:
+        kt["dw_group"] = time_kernel(rk["dw_group"], sync)
     if rank == 0:
         n_rows = c["B"] * (c["H"] + c["C"])
+        E, A, H, B, C = c["h"] * c["d"], c["A"], c["H"], c["B"], c["C"]
+        dims = [c["doc"]] + list(c["units"]) + [E]
+        # exact matmul FLOPs of one step: the MLP's Dense products forward, weight gradient and input gradient (none for the
+        # document vectors themselves), the user encoder (as in step_flops) and the scorer
+        fl_step = sum(2.0 * n_rows * dims[i] * dims[i + 1] * (3 if i else 2) for i in range(len(dims) - 1))
+        fl_step += 3 * 2.0 * B * H * E * 3 * E + B * c["h"] * 12.0 * H * H * c["d"] + 3 * 2.0 * B * H * E * A + 3 * 2.0 * B * C * E
+        probe = None if (args.no_probe or args.no_roofline or world > 1) else probe_kernels("c3", 0, pick=lambda n: "gather" if "gather" in n else ("dw_group" if "tn_group" in n else None))
         line = {"metric": "training impressions/sec", **timing_fields(times, args, world, c["B"]), "unit": "impressions/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup,
                 "launch": "eager" if args.no_graph else "hipGraph replay", "higher_is_better": True, "scaling": "weak",
@@ -500,19 +517,81 @@ def bench_docvec(args, c, world, rank, device, sync, dfields):
                            "global_batch": world * c["B"], "per_gpu_batch": c["B"], "parallelism": f"dp{world}",
                            "final_loss": float(eng.loss_dev.item())}, **dfields, "oracle_pin": oracle_pin_status(), "env": nondefault_env()}
         gather_bytes = n_rows * (4 + 2 * c["doc"] * 4)
-        if "dense0" in kt:
-            fl = 2.0 * n_rows * c["doc"] * c["units"][0]
-            line["roofline"] = {"kernel": f"gemm_small_vec_kernel<false, false, 32> (Dense({c['units'][0]}, relu) over the {n_rows} document vectors of a "
-                                          f"step: {n_rows}x{c['units'][0]}x{c['doc']}; the largest kernel of a step that is launch/latency-bound as a whole: "
-                                          "~0.19 GFLOP and 2.5 MB per step)", "bound": "mfma",
-                                "achieved": fl / kt["dense0"] / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                "frac": fl / kt["dense0"] / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None,
-                                "avg_launch_us": kt["dense0"] * 1e6, "algorithmic_flops_per_launch": fl}
-        line["roofline_gather"] = {"kernel": "gather_rows_vec4_kernel (document-vector gather)", "bound": "hbm",
+        src = "measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over `bench.py --config c3 --kernel-probe`, (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch" \
+            if probe else "not measured (no rocprofv3 passes in this run)"
+        if "dw_group" in kt:
+            fl = rk["dw_group_flops"]
+            line["roofline"] = {"kernel": (probe or {}).get("dw_group", {}).get("name", "gemm_small_tn_group_kernel<64>") +
+                                          f" (the weight gradients of the {len(dims) - 1} Dense kernels of the news encoder as ONE grouped launch, "
+                                          f"K = {n_rows} rows: the time-dominant launch of a step that is latency-bound as a whole)", "bound": "mfma",
+                                "achieved": fl / kt["dw_group"] / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": fl / kt["dw_group"] / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": (probe or {}).get("dw_group", {}).get("traffic"),
+                                "traffic_source": src, "avg_launch_us": kt["dw_group"] * 1e6, "algorithmic_flops_per_launch": fl,
+                                "algorithmic_bytes_per_launch": rk["dw_group_bytes"]}
+        line["roofline_gather"] = {"kernel": (probe or {}).get("gather", {}).get("name", "gather_rows_vec4_kernel") + " (document-vector gather)", "bound": "hbm",
                                    "achieved": gather_bytes / kt["gather"] / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "frac": gather_bytes / kt["gather"] / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                                   "avg_launch_us": kt["gather"] * 1e6, "algorithmic_bytes_per_launch": gather_bytes}
+                                   "frac": gather_bytes / kt["gather"] / 1e9 / HBM_PEAK_GBS, "traffic": (probe or {}).get("gather", {}).get("traffic"),
+                                   "traffic_source": src, "avg_launch_us": kt["gather"] * 1e6, "algorithmic_bytes_per_launch": gather_bytes}
+        ms = line["ms_per_step"]
+        line["roofline_step"] = {"what": "the whole training step against the exact-fp32 MFMA peak: exact matmul FLOPs of one step (every Dense product of the "
+                                         "news encoder forward / weight gradient / input gradient, the user encoder, the scorer) / ms_per_step",
+                                 "bound": "mfma", "achieved": fl_step / (ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": fl_step / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, "flops_per_step": fl_step,
+                                 "launches_per_step": "20 (r4: 27): staging, gather, 4 + 4 fused Dense launches, the weight-gradient group, 8 of the user stage, Adam"}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline_docvec(c)
         print("\n" + json.dumps(line), flush=True)  # (own line even when a library -- gloo -- has left an unterminated one on stdout)
+
+
+def cpu_baseline_docvec(c, steps=20, warmup=5, sweep=(1, 2, 4, 8, 16, 32)):
+    """configs[2] on the host cores: oracle/nrms_torch.py:CpuDocVecTrainer (fp32 torch eager, kind "port"), the protocol of
+    cpu_baseline(): thread sweep, then `warmup` untimed and `steps` timed steps at the best count (median)."""
+    from oracle import nrms_numpy as on
+    from oracle.nrms_torch import CpuDocVecTrainer
+
+    rng = np.random.default_rng(123)
+    P = on.init_docvec_params(c["doc"], c["units"], c["h"], c["d"], c["A"], seed=1, dtype=np.float32)
+    tr = CpuDocVecTrainer(P, c["units"], c["h"], c["d"], lr=1e-4, dropout=0.2, l2=1e-4, seed=0)
+    matrix = rng.standard_normal((4096, c["doc"]), dtype=np.float32)
+
+    def batch():
+        his = matrix[rng.integers(0, len(matrix), (c["B"], c["H"]))]
+        pred = matrix[rng.integers(0, len(matrix), (c["B"], c["C"]))]
+        y = np.zeros((c["B"], c["C"]), np.float32)
+        y[np.arange(c["B"]), rng.integers(0, c["C"], c["B"])] = 1
+        return his, pred, y
+
+    default_threads, n_cpu = int(torch.get_num_threads()), os.cpu_count() or 1
+    tr.step(*batch())
+    sweep_ms = {}
+    for nt in sorted({n for n in sweep if n <= n_cpu} | {default_threads}):
+        torch.set_num_threads(nt)
+        tr.step(*batch())
+        ts = []
+        for _ in range(3):
+            t1 = time.perf_counter()
+            tr.step(*batch())
+            ts.append(time.perf_counter() - t1)
+        sweep_ms[nt] = min(ts) * 1e3
+    best = min(sweep_ms, key=sweep_ms.get)
+    torch.set_num_threads(best)
+    for _ in range(warmup):
+        tr.step(*batch())
+    times = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        t1 = time.perf_counter()
+        tr.step(*batch())
+        times.append(time.perf_counter() - t1)
+    el = time.perf_counter() - t0
+    torch.set_num_threads(default_threads)
+    med = float(np.median(times))
+    return {"value": c["B"] / med, "unit": "impressions/s", "cores": int(best), "kind": "port", "timed_steps": steps,
+            "thread_sweep_ms_per_step": {str(k): round(v, 2) for k, v in sorted(sweep_ms.items())},
+            "sample": f"median of {steps} timed NRMSDocVec train steps of batch {c['B']} ({c['H']}+{c['C']} document vectors x {c['doc']}, MLP {c['units']}, "
+                      f"dropout 0.2, l2 1e-4) after the sweep and {warmup} untimed steps, {el:.2f}s of CPU work (step min/max {min(times) * 1e3:.1f}/{max(times) * 1e3:.1f} ms), "
+                      f"oracle/nrms_torch.py:CpuDocVecTrainer fp32 eager at the best of a sweep over {sorted(sweep_ms)} intra-op threads (= {best}; "
+                      f"torch's default here {default_threads}, {n_cpu} logical CPUs).  An untuned eager port: a stated baseline, not a target"}
 
 
 class HangWatchdog:

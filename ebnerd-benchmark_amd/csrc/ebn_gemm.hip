@@ -1098,7 +1098,11 @@ struct SmallGroup {
   int32_t n;
 };
 
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_small_tn_group_kernel(SmallGroup g) {
+// T = 32: 256 threads per 32 x 32 tile; T = 64: 1024 threads (sixteen waves, one 16 x 16 block each) per 64 x 64 tile -- half the
+// operand re-streaming (a group of Dense kernel gradients with K = 800 reads 210 MB through L2 on 32 x 32 tiles, 105 MB on 64 x 64),
+// taken when the group's 64 x 64 tiles alone fill the chip.
+template <int T>
+__global__ __launch_bounds__(T * T / 4) void gemm_small_tn_group_kernel(SmallGroup g) {
   const int b = blockIdx.x;
   int i = 0;
   while (i + 1 < g.n && b >= g.first[i + 1]) ++i;
@@ -1108,7 +1112,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_small_tn_group_kernel(Small
   epi.l2w = g.l2w[i];
   epi.two_lambda = g.two_lambda[i];
   const int t = b - g.first[i];
-  small_vec_body<true, false, 32>(p.M, p.N, p.K, p.alpha, p.A, p.lda, p.B, p.ldb, p.beta, p.C, p.ldc, epi, t % p.tiles_x, t / p.tiles_x);
+  small_vec_body<true, false, T>(p.M, p.N, p.K, p.alpha, p.A, p.lda, p.B, p.ldb, p.beta, p.C, p.ldc, epi, t % p.tiles_x, t / p.tiles_x);
 }
 
 int launch_gemm_small(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda,
@@ -1494,9 +1498,7 @@ extern "C" int ebn_dense_bwd_pair_f32(int64_t R, int64_t K_in, int64_t N_out, co
 
 extern "C" int ebn_gemm_tn_group_f32(const ebn_tn_problem* problems, int32_t n, ebn_stream_t stream) {
   EBN_REQUIRE(problems != nullptr && n >= 1 && n <= EBN_TN_GROUP_MAX, EBN_ERR_BAD_ARG);
-  SmallGroup g{};
-  int64_t total = 0;
-  g.n = 0;
+  int64_t tiles64 = 0;
   for (int i = 0; i < n; ++i) {
     const ebn_tn_problem& q = problems[i];
     EBN_REQUIRE(ebn_dim_ok(q.M, q.N, q.K) && q.K >= 1, EBN_ERR_BAD_ARG);
@@ -1506,9 +1508,18 @@ extern "C" int ebn_gemm_tn_group_f32(const ebn_tn_problem* problems, int32_t n, 
     EBN_REQUIRE((q.lda % 4) == 0 && (q.ldb % 4) == 0 && (q.M % 4) == 0 && (q.N % 4) == 0 && ebn_aligned16(q.A) && ebn_aligned16(q.B),
                 EBN_ERR_UNSUPPORTED);
     EBN_REQUIRE((q.K + SBK) * (q.lda > q.ldb ? q.lda : q.ldb) * 4 + 64 * 4 < (int64_t{1} << 31), EBN_ERR_UNSUPPORTED);
+    tiles64 += ebn_ceil_div(q.M, 64) * ebn_ceil_div(q.N, 64);
+  }
+  const int T = tiles64 >= 192 ? 64 : 32;  // 64 x 64 tiles once they occupy most of the 256 CUs on their own
+  SmallGroup g{};
+  int64_t total = 0;
+  g.n = 0;
+  for (int i = 0; i < n; ++i) {
+    const ebn_tn_problem& q = problems[i];
+    if (q.M == 0 || q.N == 0) continue;
     const int j = g.n++;
-    g.p[j] = SmallProblem{q.M, q.N, q.K, 1.0f, q.A, q.lda, q.B, q.ldb, 0.0f, q.C, q.ldc, static_cast<int32_t>(ebn_ceil_div(q.N, SBN)), 0};
-    g.p[j].tiles = g.p[j].tiles_x * static_cast<int32_t>(ebn_ceil_div(q.M, SBM));
+    g.p[j] = SmallProblem{q.M, q.N, q.K, 1.0f, q.A, q.lda, q.B, q.ldb, 0.0f, q.C, q.ldc, static_cast<int32_t>(ebn_ceil_div(q.N, T)), 0};
+    g.p[j].tiles = g.p[j].tiles_x * static_cast<int32_t>(ebn_ceil_div(q.M, T));
     g.colsum[j] = q.colsum;
     g.l2w[j] = q.l2_W;
     g.two_lambda[j] = q.two_lambda;
@@ -1518,11 +1529,17 @@ extern "C" int ebn_gemm_tn_group_f32(const ebn_tn_problem* problems, int32_t n, 
   }
   if (g.n == 0) return EBN_OK;
   g.first[g.n] = static_cast<int32_t>(total);
-  constexpr size_t lds = static_cast<size_t>(2) * 2 * SBM * SLV * sizeof(float);
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_small_tn_group_kernel),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-  if (attr != hipSuccess) return static_cast<int>(attr);
-  hipLaunchKernelGGL(gemm_small_tn_group_kernel, dim3(static_cast<unsigned>(total)), dim3(GEMM_THREADS), lds, ebn_stream(stream), g);
+#define EBN_TN_GROUP(TT)                                                                                                          \
+  do {                                                                                                                            \
+    constexpr size_t lds = static_cast<size_t>(2) * 2 * (TT) * SLV * sizeof(float);                                               \
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_small_tn_group_kernel<TT>),            \
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));        \
+    if (attr != hipSuccess) return static_cast<int>(attr);                                                                        \
+    hipLaunchKernelGGL(gemm_small_tn_group_kernel<TT>, dim3(static_cast<unsigned>(total)), dim3((TT) * (TT) / 4), lds, ebn_stream(stream), g); \
+  } while (0)
+  if (T == 64) EBN_TN_GROUP(64);
+  else EBN_TN_GROUP(32);
+#undef EBN_TN_GROUP
   EBN_CHECK_LAUNCH();
   return EBN_OK;
 }

@@ -497,15 +497,12 @@ class DocVecEngine:
             return gather
 
         out = {"gather": make_gather}
-        if self.units:
-            u, b = self.units[0], self.mlp.bufs(n)
-            pv = self.params.view
-
-            def dense0():
-                _hip.call("ebn_dense_relu_fwd_f32", n, u, self.Din, _hip.ptr(mb["X0"]), self.Din, _hip.ptr(pv("d0_W")), u, _hip.ptr(pv("d0_b")),
-                          _hip.ptr(b["R"][0]), u, _hip.ptr(b["ws"]), b["ws"].numel(), S())
-
-            out["dense0"] = dense0
+        a = self._dvn(mb, B * self.H, B * C)
+        if a is not None:
+            # the time-dominant launch of the fused step: the weight gradients of all Dense kernels as one grouped TN product
+            out["dw_group"] = lambda: _hip.call("ebn_gemm_tn_group_f32", a._probs, len(a._probs), S())
+            out["dw_group_flops"] = float(sum(2.0 * q.M * q.N * q.K for q in a._probs))
+            out["dw_group_bytes"] = float(sum(4.0 * (q.K * (q.M + q.N) + q.M * q.N) for q in a._probs))
         return out
 
     def check_oob(self):

@@ -146,3 +146,71 @@ class CpuNRMSTrainer:
             for k, g in zip(self.train_names, grads):
                 adam_keras_(self.P[k], g, self.m[k], self.v[k], self.t, self.lr)
         return float(L)
+
+
+def docvec_news_encoder(X, P, units, training=True, masks=None, stats_out=None):
+    """nrms_docvec.py:113-135 on the rows of ONE TimeDistributed call site: [Dense(u, relu) -> BatchNormalization (batch statistics
+    of this call site when training, eps 1e-3 [KERAS-SEMANTICS]) -> Dropout] x len(units) -> Dense(E, relu)."""
+    x = X
+    for l in range(len(units)):
+        r = torch.relu(x @ P[f"d{l}_W"] + P[f"d{l}_b"])
+        if training:
+            mu, var = r.mean(0), r.var(0, unbiased=False)
+            if stats_out is not None:
+                stats_out.append((l, mu.detach(), var.detach()))
+        else:
+            mu, var = P[f"bn{l}_mean"], P[f"bn{l}_var"]
+        x = (r - mu) / torch.sqrt(var + 1e-3) * P[f"bn{l}_g"] + P[f"bn{l}_b"]
+        if masks is not None:
+            x = x * masks[l]
+    return torch.relu(x @ P["out_W"] + P["out_b"])
+
+
+class CpuDocVecTrainer:
+    """fp32 CPU train step of NRMSDocVec (nrms_docvec.py:75-188) -- the cpu_baseline 'port' of configs[2]: two call sites with their
+    own batch statistics and moving-average updates (history first), dropout after every BatchNormalization, l2 on the hidden Dense
+    kernels, the NRMS user encoder and scorer, Keras-form Adam."""
+
+    def __init__(self, P_np: dict, units, h, d, loss="cross_entropy_loss", lr=1e-4, dropout=0.2, l2=1e-4, seed=0):
+        self.units, self.h, self.d, self.loss, self.lr, self.p, self.l2 = list(units), h, d, loss, lr, dropout, l2
+        self.P = {k: torch.tensor(v, dtype=torch.float32) for k, v in P_np.items() if k != "units"}
+        self.moving = [k for k in self.P if k.endswith("_mean") or k.endswith("_var")]
+        self.train_names = [k for k in self.P if k not in self.moving]
+        for k in self.train_names:
+            self.P[k].requires_grad_(True)
+        self.m = {k: torch.zeros_like(self.P[k]) for k in self.train_names}
+        self.v = {k: torch.zeros_like(self.P[k]) for k in self.train_names}
+        self.t = 0
+        self.gen = torch.Generator().manual_seed(seed)
+
+    def loss_and_grads(self, his, pred, y, masks_h=None, masks_c=None):
+        his, pred, y = (torch.as_tensor(a) for a in (his, pred, y))
+        B, H, Din = his.shape
+        C = pred.shape[1]
+        stats, dt = [], self.P["out_W"].dtype
+        NEh = docvec_news_encoder(his.reshape(B * H, Din).to(dt), self.P, self.units, True, masks_h, stats)
+        NEc = docvec_news_encoder(pred.reshape(B * C, Din).to(dt), self.P, self.units, True, masks_c, stats)
+        user = user_from_news(NEh.view(B, H, -1), self.P, self.h, self.d)
+        s = torch.einsum("bce,be->bc", NEc.view(B, C, -1), user)
+        L = loss_from_scores(s, y, self.loss)
+        for l in range(len(self.units)):
+            L = L + self.l2 * (self.P[f"d{l}_W"] ** 2).sum()
+        grads = torch.autograd.grad(L, [self.P[k] for k in self.train_names])
+        return L, dict(zip(self.train_names, grads)), stats
+
+    def step(self, his, pred, y):
+        B, H, C = his.shape[0], his.shape[1], pred.shape[1]
+        masks_h = masks_c = None
+        if self.p > 0:
+            sc = 1.0 / (1.0 - self.p)
+            masks_h = [(torch.rand(B * H, u, generator=self.gen) >= self.p).float() * sc for u in self.units]
+            masks_c = [(torch.rand(B * C, u, generator=self.gen) >= self.p).float() * sc for u in self.units]
+        L, grads, stats = self.loss_and_grads(his, pred, y, masks_h, masks_c)
+        self.t += 1
+        with torch.no_grad():
+            for l, mu, var in stats:  # history call site first, then the candidates: two moving-average updates per layer and step
+                self.P[f"bn{l}_mean"].mul_(0.99).add_(0.01 * mu)
+                self.P[f"bn{l}_var"].mul_(0.99).add_(0.01 * var)
+            for k in self.train_names:
+                adam_keras_(self.P[k], grads[k], self.m[k], self.v[k], self.t, self.lr)
+        return float(L)

@@ -257,3 +257,29 @@ def test_docvec_backward_against_finite_differences():
         Lm = on.docvec_loss_and_grads(his, pred, y, P, h, d, l2=1e-3, training=True, drop=drop)[0]
         P[k][idx] += eps
         assert (Lp - Lm) / (2 * eps) == pytest.approx(g[k][idx], rel=5e-5, abs=1e-9), k
+
+
+def test_torch_docvec_port_agrees_with_the_numpy_oracle():
+    """oracle/nrms_torch.py:CpuDocVecTrainer (autograd; the cpu_baseline port of configs[2]) against the hand-derived float64
+    restatement: loss, every gradient, and the batch statistics both call sites feed into the moving averages."""
+    import torch
+
+    from oracle import nrms_numpy as on
+    from oracle.nrms_torch import CpuDocVecTrainer
+
+    units, h, d, A, Din, B, H, C, l2 = [24, 16], 2, 4, 6, 12, 5, 3, 4, 1e-3
+    P = on.init_docvec_params(Din, units, h, d, A, seed=3, randomize_bn=True)
+    P = {k: (v.astype(np.float32).astype(np.float64) if isinstance(v, np.ndarray) else v) for k, v in P.items()}  # fp32-exact values
+    rng = np.random.default_rng(0)
+    his, pred = rng.standard_normal((B, H, Din)), rng.standard_normal((B, C, Din))
+    y = np.zeros((B, C)); y[np.arange(B), rng.integers(0, C, B)] = 1
+    L, _, g, (st_h, st_c) = on.docvec_loss_and_grads(his, pred, y, P, h, d, l2=l2, training=True, drop=None)
+    tr = CpuDocVecTrainer(P, units, h, d, dropout=0.0, l2=l2)
+    tr.P = {k: v.detach().double().requires_grad_(v.requires_grad) for k, v in tr.P.items()}
+    Lt, gt, stats = tr.loss_and_grads(torch.tensor(his), torch.tensor(pred), torch.tensor(y))
+    assert float(Lt) == pytest.approx(L, rel=1e-10)
+    for k in ("d0_W", "d1_b", "bn0_g", "bn1_b", "out_W", "out_b", "u_WQ", "u_W", "u_q"):
+        np.testing.assert_allclose(gt[k].numpy().reshape(g[k].shape), g[k], rtol=1e-8, atol=1e-10)
+    for (l, mu, var), (mu_o, var_o) in zip(stats, list(st_h) + list(st_c)):
+        np.testing.assert_allclose(mu.numpy(), mu_o, rtol=1e-10)
+        np.testing.assert_allclose(var.numpy(), var_o, rtol=1e-10)
