@@ -625,6 +625,65 @@ __global__ __launch_bounds__(ATHR) void dvn_dbn_apply_kernel(ApplyArgs p) {
   }
 }
 
+// The prologue of a step on a device-resident batch of article-row numbers (dataloader.py:169-179: lookup_article_matrix[rows]):
+// step-state advance + label copy + document-vector gather as ONE launch -- the rows are read straight from the (up to two)
+// staged index segments, never unpacked.
+struct StageArgs {
+  const int32_t* s0;
+  const int32_t* s1;
+  int n0, n1;
+  const uint32_t* lab_src;
+  uint32_t* lab_dst;
+  int n_lab;
+  const float4* matrix;
+  float4* X0;
+  int vpr;  // float4 per row
+  int64_t n_rows;
+  int32_t* oob;
+  ebn_step_state* st;
+  double beta1, beta2;
+};
+__global__ __launch_bounds__(256) void dvn_stage_gather_kernel(StageArgs a) {
+  if (a.st != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {  // ebn_step_advance
+    ebn_step_state* st = a.st;
+    const uint32_t t = st->step + 1u;
+    st->step = t;
+    const double b1t = pow(a.beta1, static_cast<double>(t));
+    const double b2t = pow(a.beta2, static_cast<double>(t));
+    st->adam_alpha = static_cast<float>(static_cast<double>(st->lr) * sqrt(1.0 - b2t) / (1.0 - b1t));
+    for (uint32_t s = 0; s < EBN_N_SITES; ++s) st->drop_key[s] = ebn_dropout_key(st->seed, t, s);
+  }
+  const int gtid = blockIdx.x * 256 + threadIdx.x;
+  if (gtid < a.n_lab) a.lab_dst[gtid] = a.lab_src[gtid];
+  const int items = (a.n0 + a.n1) * a.vpr;
+  // two items per thread, ids first, then the rows: unconditional loads with clamped addresses
+  int it[2], row[2];
+  int64_t id[2];
+  bool ok[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    it[u] = gtid + u * gridDim.x * 256;
+    ok[u] = it[u] < items;
+    const int itc = ok[u] ? it[u] : 0;
+    row[u] = itc / a.vpr;
+    id[u] = row[u] < a.n0 ? a.s0[row[u]] : a.s1[row[u] - a.n0];
+  }
+  float4 v[2];
+  bool bad = false;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const bool in = id[u] >= 0 && id[u] < a.n_rows;
+    bad |= ok[u] && !in;
+    const int itc = ok[u] ? it[u] : 0;
+    const float4 t = a.matrix[(in ? id[u] : 0) * a.vpr + (itc - row[u] * a.vpr)];
+    v[u] = in ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (bad && a.oob != nullptr) *a.oob = 1;
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+    if (ok[u]) a.X0[it[u]] = v[u];
+}
+
 inline int row_tiles(const ebn_dvn_args* a) { return (a->n0 + TM - 1) / TM + (a->n1 + TM - 1) / TM; }
 
 // stat layout (floats; 64-bit words 8-byte aligned because every block is a multiple of 8 floats -- widths are multiples of 4):
@@ -804,5 +863,24 @@ extern "C" int ebn_dvn_bwd_f32(const ebn_dvn_args* a, const ebn_step_state* st, 
     hipLaunchKernelGGL(dvn_dbn_apply_kernel, grid, dim3(ATHR), 0, s, q);
     EBN_CHECK_LAUNCH();
   }
+  return EBN_OK;
+}
+
+extern "C" int ebn_docvec_stage_gather_f32(const int32_t* idx0, int64_t n0, const int32_t* idx1, int64_t n1, const float* labels_src,
+                                           float* labels_dst, int64_t n_labels, const float* matrix, int64_t n_rows, int32_t din, float* X0,
+                                           int32_t* oob_flag, ebn_step_state* st, double beta1, double beta2, ebn_stream_t stream) {
+  EBN_REQUIRE(n0 >= 0 && n1 >= 0 && n_labels >= 0 && n_rows > 0 && din > 0, EBN_ERR_BAD_ARG);
+  EBN_REQUIRE((n0 == 0 || idx0) && (n1 == 0 || idx1) && (n_labels == 0 || (labels_src && labels_dst)) && matrix && X0, EBN_ERR_BAD_ARG);
+  EBN_REQUIRE((din % 4) == 0 && ebn_aligned16(matrix) && ebn_aligned16(X0), EBN_ERR_ALIGN);
+  EBN_REQUIRE((n0 + n1) * (din / 4) < (int64_t{1} << 30) && n_labels < (int64_t{1} << 30), EBN_ERR_UNSUPPORTED);
+  StageArgs a{idx0, idx1, static_cast<int>(n0), static_cast<int>(n1), reinterpret_cast<const uint32_t*>(labels_src),
+              reinterpret_cast<uint32_t*>(labels_dst), static_cast<int>(n_labels), reinterpret_cast<const float4*>(matrix),
+              reinterpret_cast<float4*>(X0), din / 4, n_rows, oob_flag, st, beta1, beta2};
+  const int64_t items = (n0 + n1) * (din / 4);
+  int64_t blocks = ebn_ceil_div(items, 512);
+  if (blocks * 256 < n_labels) blocks = ebn_ceil_div(n_labels, 256);
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(dvn_stage_gather_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, ebn_stream(stream), a);
+  EBN_CHECK_LAUNCH();
   return EBN_OK;
 }

@@ -366,11 +366,12 @@ class DocVecEngine:
         same_dev = lambda t: t.is_cuda and (self.device.index is None or t.device.index == self.device.index)
         ok = lambda t, dt: isinstance(t, torch.Tensor) and same_dev(t) and t.dtype == dt and t.is_contiguous()
         if ok(his_idx, torch.int32) and ok(pred_idx, torch.int32) and ok(y, torch.float32):
-            nh = his_idx.numel()
-            _hip.call("ebn_copy3_advance", _hip.ptr(his_idx), _hip.ptr(mb["art_idx"]), nh * 4, _hip.ptr(pred_idx), _hip.ptr(mb["art_idx"][nh:]),
-                      pred_idx.numel() * 4, _hip.ptr(y), _hip.ptr(mb["labels"]), y.numel() * 4, _hip.ptr(self.state), BETA1, BETA2,
-                      _hip.stream_handle())
-            y, self._advanced = None, True  # the step-state advance rode in the staging launch
+            # ONE launch: step-state advance + label copy + the gather, reading the row numbers from the two tensors as they are
+            _hip.call("ebn_docvec_stage_gather_f32", _hip.ptr(his_idx), his_idx.numel(), _hip.ptr(pred_idx), pred_idx.numel(), _hip.ptr(y),
+                      _hip.ptr(mb["labels"]), y.numel(), _hip.ptr(self.article_matrix), self.article_matrix.shape[0], self.Din,
+                      _hip.ptr(mb["X0"]), _hip.ptr(self._oob), _hip.ptr(self.state), BETA1, BETA2, _hip.stream_handle())
+            self._advanced = True
+            return None
         elif not isinstance(his_idx, torch.Tensor) and not isinstance(pred_idx, torch.Tensor) and y is not None and not isinstance(y, torch.Tensor):
             # host batch (what the loaders hand over): ONE asynchronous copy out of a pinned, double-buffered staging area; the
             # kernel that unpacks it also advances the step state -- the host never waits for the GPU
@@ -391,9 +392,11 @@ class DocVecEngine:
             st["dev"][:tot].copy_(st["pinned"][k][:tot], non_blocking=True)
             st["ev"][k] = torch.cuda.Event()
             st["ev"][k].record()
-            _hip.call("ebn_copy3_advance", _hip.ptr(st["dev"]), _hip.ptr(mb["art_idx"]), n * 4, None, None, 0, _hip.ptr(st["dev"][n:]),
-                      _hip.ptr(mb["labels"]), n_lab * 4, _hip.ptr(self.state), BETA1, BETA2, _hip.stream_handle())
-            y, self._advanced = None, True
+            _hip.call("ebn_docvec_stage_gather_f32", _hip.ptr(st["dev"]), n, None, 0, _hip.ptr(st["dev"][n:]), _hip.ptr(mb["labels"]), n_lab,
+                      _hip.ptr(self.article_matrix), self.article_matrix.shape[0], self.Din, _hip.ptr(mb["X0"]), _hip.ptr(self._oob),
+                      _hip.ptr(self.state), BETA1, BETA2, _hip.stream_handle())
+            self._advanced = True
+            return None
         else:
             off = 0
             for a in (his_idx, pred_idx):

@@ -519,6 +519,14 @@ int64_t ebn_dvn_stat_floats(const ebn_dvn_args* args);
 int ebn_dvn_fwd_train_f32(const ebn_dvn_args* args, const ebn_step_state* st, ebn_stream_t stream);
 int ebn_dvn_bwd_f32(const ebn_dvn_args* args, const ebn_step_state* st, ebn_stream_t stream);
 
+/* The prologue of an NRMSDocVec training step on a device-resident batch of article-row numbers (dataloader.py:169-179,
+ * lookup_article_matrix[rows]) as ONE launch: ebn_step_advance (st may be NULL: no advance) + the label copy (n_labels floats) +
+ * X0[r,:] = matrix[idx[r],:] for the n0 + n1 rows of the (up to two) index segments idx0 | idx1 -- what ebn_copy3_advance +
+ * ebn_gather_rows_f32 do in two.  Rows outside [0, n_rows) write zeros and set *oob_flag (may be NULL).  din % 4 == 0.    */
+int ebn_docvec_stage_gather_f32(const int32_t* idx0, int64_t n0, const int32_t* idx1, int64_t n1, const float* labels_src,
+                                float* labels_dst, int64_t n_labels, const float* matrix, int64_t n_rows, int32_t din, float* X0,
+                                int32_t* oob_flag, ebn_step_state* st, double beta1, double beta2, ebn_stream_t stream);
+
 /* Up to EBN_TN_GROUP_MAX independent weight-gradient products C_i (M_i, N_i) = A_i^T . B_i (A_i (K_i, M_i), B_i (K_i, N_i),
  * all row-major) in ONE launch of 32x32 small-output tiles -- the Dense kernel gradients of a step (nrms_docvec.py:116-134
  * backward; the user encoder's K.dot gradients of layers.py:65,214-226), each too small to fill the chip alone.  Options per

@@ -145,7 +145,7 @@ class CpuNRMSTrainer:
         with torch.no_grad():
             for k, g in zip(self.train_names, grads):
                 adam_keras_(self.P[k], g, self.m[k], self.v[k], self.t, self.lr)
-        return float(L)
+        return float(L.detach())
 
 
 def docvec_news_encoder(X, P, units, training=True, masks=None, stats_out=None):
@@ -213,4 +213,4 @@ class CpuDocVecTrainer:
                 self.P[f"bn{l}_var"].mul_(0.99).add_(0.01 * var)
             for k in self.train_names:
                 adam_keras_(self.P[k], grads[k], self.m[k], self.v[k], self.t, self.lr)
-        return float(L)
+        return float(L.detach())
