@@ -28,10 +28,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#ifndef EBN_ATTN_WAVES
-#define EBN_ATTN_WAVES 4  // independent (sequence, head) problems per workgroup, one wave each
-#endif
-constexpr int ATT_WAVES = EBN_ATTN_WAVES;
+constexpr int ATT_WAVES = 4;  // independent (sequence, head) problems per workgroup, one wave each
 
 struct MfmaAttnArgs {
   const float* qkv;
@@ -343,17 +340,6 @@ __device__ __forceinline__ void tile_transpose(f32x16& t, float* __restrict__ bu
   }
 }
 
-// Wave priority over a problem's phases (tuning switch EBN_ATTN_PRIO: 0 off, 1 rising with progress, 2 static per workgroup).
-#ifndef EBN_ATTN_PRIO
-#define EBN_ATTN_PRIO 0
-#endif
-#if EBN_ATTN_PRIO == 1
-#define EBN_ATTN_PRIO_AT(n) __builtin_amdgcn_s_setprio(n)
-#elif EBN_ATTN_PRIO == 2
-#define EBN_ATTN_PRIO_AT(n) do { if ((n) == 0) { switch ((blockIdx.x >> 8) & 3) { case 0: __builtin_amdgcn_s_setprio(0); break; case 1: __builtin_amdgcn_s_setprio(1); break; case 2: __builtin_amdgcn_s_setprio(2); break; default: __builtin_amdgcn_s_setprio(3); } } } while (0)
-#else
-#define EBN_ATTN_PRIO_AT(n) do { } while (0)
-#endif
 
 // LC: sequence length known at compile time (0 = use a.L).  title_size = 30 and history_size = 20 are what every
 // BASELINE config runs: with L a constant most of the row / column validity masks of a 32-wide tile fold away (only
@@ -374,18 +360,11 @@ struct AttnProb {
 // of a title are neighbours in memory: head k's 80-byte row pieces share 128-byte lines with heads k - 1 / k + 1.  With the
 // dispatch order as the problem order those neighbours sit on DIFFERENT XCDs, every shared line is fetched by two L2s and --
 // what costs -- written as two partial lines from two L2s.  Remapped so that each XCD walks one contiguous run of problems
-// (bijective for any grid size; the same formula as the GEMM's tile order).  EBN_ATTN_XCD=0 switches it off (tuning).
-#ifndef EBN_ATTN_XCD
-#define EBN_ATTN_XCD 1
-#endif
+// (bijective for any grid size; the same formula as the GEMM's tile order).
 __device__ __forceinline__ uint32_t xcd_chunked_block() {
-#if EBN_ATTN_XCD
   const uint32_t nwg = gridDim.x, orig = blockIdx.x;
   const uint32_t q = nwg >> 3, r = nwg & 7u, xcd = orig & 7u, idx = orig >> 3;
   return ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-#else
-  return blockIdx.x;
-#endif
 }
 
 // The workgroups of a launch's FIRST dispatch round start together, and a workgroup of the group-form backward is three phases
@@ -398,7 +377,7 @@ __device__ __forceinline__ uint32_t xcd_chunked_block() {
 // (Measured instead of this and NOT kept, profiles/r04_tuning_notes.md: a persistent, software-pipelined form of the kernel that
 // requests the next group's Q | K | dO pieces into 36 registers before it computes -- 128 VGPRs, bit-identical, 66.6 us.)
 __device__ __forceinline__ void stagger_first_round(const MfmaAttnArgs& a) {
-  if (a.stagger_units != 0u && blockIdx.x < (a.stagger_mod << 8)) {
+  if (a.stagger_units != 0u && blockIdx.x < (a.stagger_mod << a.stagger_shift)) {
     const uint32_t n = ((blockIdx.x >> a.stagger_shift) % a.stagger_mod) * a.stagger_units;
     for (uint32_t i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(8);
   }
@@ -590,30 +569,15 @@ __global__ __launch_bounds__(64 * ATT_WAVES) void attn_mfma_bwd_kernel(MfmaAttnA
   const bool drop = a.key_ptr != nullptr, pooled = a.pool_w != nullptr;  // wave-uniform
   const uint32_t key = drop ? *a.key_ptr : 0u;
 
-  EBN_ATTN_PRIO_AT(0);
   const AttnProb p = attn_prob(prob, a.h, L);
   const float* qb = a.qkv + p.row0 * a.ld_qkv + p.head * D;
   float vr[KH];  // row form of V (lane = row), the only form V is needed in: straight from global memory
-#if defined(EBN_ATTN_BWD_PROBE) && (EBN_ATTN_BWD_PROBE == 2 || EBN_ATTN_BWD_PROBE >= 6)  // tuning probe: no global loads
-  {
-    for (int i = lane; i < 3 * region; i += 64) sq[i] = 0.001f * static_cast<float>((i * 7 + lane) & 63);
-#pragma unroll
-    for (int s = 0; s < KH; ++s) vr[s] = 0.01f * static_cast<float>(lane + s);
-  }
-#else
   {
     Staged<D> tq, tk, tg;
     stage_load<D>(tq, qb, a.ld_qkv, L, lane);
     stage_load<D>(tk, qb + E, a.ld_qkv, L, lane);
     stage_load<D>(tg, a.dout + p.row0 * a.ld_dout + p.head * D, a.ld_dout, L, lane);
-#if defined(EBN_ATTN_BWD_PROBE) && EBN_ATTN_BWD_PROBE == 5  // loads alone, V as a fourth float4 tile instead of 8-byte pieces
-    Staged<D> tv;
-    stage_load<D>(tv, qb + 2 * E, a.ld_qkv, L, lane);
-#pragma unroll
-    for (int s_ = 0; s_ < KH; ++s_) vr[s_] = tv.v[s_ % Tile<D>::ROUNDS].x;
-#else
     global_row_form<D>(vr, qb + 2 * E, a.ld_qkv, L, row, hi);
-#endif
     if (pooled) {
       PoolTerm<D> pt;
       pool_load<D>(pt, a.pool_w + p.row0, a.pool_d + p.seq * a.ld_pool + p.head * D, L, lane);
@@ -624,54 +588,9 @@ __global__ __launch_bounds__(64 * ATT_WAVES) void attn_mfma_bwd_kernel(MfmaAttnA
     if (drop) stage_store<D, true>(sg, tg, L, lane, key, static_cast<uint64_t>(p.row0) * E + p.head * D, E, a.thresh, a.scale);
     else stage_store<D, false>(sg, tg, L, lane, 0u, 0u, 0, 0u, 0.f);
   }
-#endif
   wave_lds_sync();
 
   float* ob = a.out + p.row0 * a.ld_out + p.head * D;
-#if defined(EBN_ATTN_BWD_PROBE) && (EBN_ATTN_BWD_PROBE == 3 || EBN_ATTN_BWD_PROBE == 5)  // tuning probe: the loads alone (one never-taken store)
-  {
-    float c[16], acc = vr[0] + vr[KH - 1];
-    lds_col_form<D>(c, sg, L, row, hi);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc += c[r];
-    lds_col_form<D>(c, sk, L, row, hi);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc += c[r];
-    lds_col_form<D>(c, sq, L, row, hi);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc += c[r];
-    if (acc == 123456.789f) ob[lane] = acc;
-    return;
-  }
-#endif
-#if defined(EBN_ATTN_BWD_PROBE) && EBN_ATTN_BWD_PROBE == 7  // tuning probe: the stores alone, as 80-byte row pieces out of LDS
-  {
-    wave_lds_sync();
-    stage_out<D, false>(sg, ob + 2 * E, a.ld_out, L, lane, 0u, 0u, 0, 0u, 0.f);
-    stage_out<D, false>(sk, ob, a.ld_out, L, lane, 0u, 0u, 0, 0u, 0.f);
-    stage_out<D, false>(sq, ob + E, a.ld_out, L, lane, 0u, 0u, 0, 0u, 0.f);
-    return;
-  }
-#endif
-#if defined(EBN_ATTN_BWD_PROBE) && (EBN_ATTN_BWD_PROBE == 1 || EBN_ATTN_BWD_PROBE == 6)  // the memory pattern alone (no MFMA, no softmax); 6: stores alone
-  {
-    f32x16 t;
-    float c[16];
-    lds_col_form<D>(c, sg, L, row, hi);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) t[r] = c[r] + vr[r % KH];
-    tile_rows_to_global<D, false>(ob + 2 * E, a.ld_out, t, L, row, hi, 1.0f, 0u, 0u, 0, 0u, 0.f);
-    lds_col_form<D>(c, sk, L, row, hi);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) t[r] = c[r];
-    tile_rows_to_global<D, false>(ob, a.ld_out, t, L, row, hi, inv, 0u, 0u, 0, 0u, 0.f);
-    lds_col_form<D>(c, sq, L, row, hi);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) t[r] = c[r];
-    tile_rows_to_global<D, false>(ob + E, a.ld_out, t, L, row, hi, inv, 0u, 0u, 0, 0u, 0.f);
-    return;
-  }
-#endif
   f32x16 P, dP;
   {
     float qr[KH], kr[KH];
@@ -679,7 +598,6 @@ __global__ __launch_bounds__(64 * ATT_WAVES) void attn_mfma_bwd_kernel(MfmaAttnA
     lds_row_form<D>(kr, sk, L, row, hi);
     P = mm_rows<KH>(kr, qr);  // T[j][i]: lane i, regs j
   }
-  EBN_ATTN_PRIO_AT(1);
   softmax_in_lane(P, L, hi, inv2);  // P[i][j]: lane i, regs j
   {
     float gr[KH];
@@ -691,7 +609,6 @@ __global__ __launch_bounds__(64 * ATT_WAVES) void attn_mfma_bwd_kernel(MfmaAttnA
   for (int r = 0; r < 16; ++r) rowdot = fmaf(P[r], dP[r], rowdot);
   rowdot += __shfl_xor(rowdot, 32, 64);  // sum_j P[i][j] dP[i][j] for i = lane&31
 
-  EBN_ATTN_PRIO_AT(2);
   float col[16];
   lds_col_form<D>(col, sg, L, row, hi);
   {  // dV^T[c][i] = sum_j dO[j][c] P[i][j]
@@ -705,7 +622,6 @@ __global__ __launch_bounds__(64 * ATT_WAVES) void attn_mfma_bwd_kernel(MfmaAttnA
     const f32x16 dQ = mm_col_tile(col, P);
     tile_rows_to_global<D, false>(ob, a.ld_out, dQ, L, row, hi, inv, 0u, 0u, 0, 0u, 0.f);
   }
-  EBN_ATTN_PRIO_AT(3);
   wave_lds_sync();                    // K and dO have been read for the last time: their regions become the transpose buffer
   tile_transpose(P, sk, L, row, hi);  // dS[i][j]: lane j, regs i
   lds_col_form<D>(col, sq, L, row, hi);
@@ -813,7 +729,6 @@ __global__ __launch_bounds__(64 * G) void attn_mfma_bwd_group_kernel(MfmaAttnArg
     }
   }
   __syncthreads();
-  EBN_ATTN_PRIO_AT(1);
 
   float* sq = smem + wv * wave_floats;
   float* sk = sq + region;
@@ -836,7 +751,6 @@ __global__ __launch_bounds__(64 * G) void attn_mfma_bwd_group_kernel(MfmaAttnArg
   for (int r = 0; r < 16; ++r) rowdot = fmaf(P[r], dP[r], rowdot);
   rowdot += __shfl_xor(rowdot, 32, 64);
 
-  EBN_ATTN_PRIO_AT(2);
   float col[16], colq[16];
   lds_col_form<D>(col, sg, L, row, hi);
   lds_col_form<D>(colq, sq, L, row, hi);
@@ -849,7 +763,6 @@ __global__ __launch_bounds__(64 * G) void attn_mfma_bwd_group_kernel(MfmaAttnArg
   for (int r = 0; r < 16; ++r) P[r] = P[r] * (dP[r] - rowdot);  // dS[i][j]: lane i, regs j
   lds_col_form<D>(col, sk, L, row, hi);
   const f32x16 dQ = mm_col_tile(col, P);  // dQ^T[c][i] = inv * sum_j K[j][c] dS[i][j]; stays in registers over the transpose
-  EBN_ATTN_PRIO_AT(3);
   wave_lds_sync();                    // Q and K have been read for the last time: their tiles become the transpose buffer
   tile_transpose(P, sq, L, row, hi);  // dS[i][j]: lane j, regs i
   wave_lds_sync();
@@ -1161,18 +1074,21 @@ __global__ __launch_bounds__(64 * ATT2_WAVES) void attn_mfma2_bwd_kernel(MfmaAtt
 
 }  // namespace
 
-#ifndef EBN_ATTN_BWD_GROUP
-#define EBN_ATTN_BWD_GROUP 4  // heads per workgroup of the group-form backward: one wave per SIMD (5 or 10 measured slower)
-#endif
-constexpr int BWD_GROUP = EBN_ATTN_BWD_GROUP;
-#ifndef EBN_ATTN_FWD_GROUP_MIN_BYTES
-#define EBN_ATTN_FWD_GROUP_MIN_BYTES 200'000'000
-#endif
-constexpr int64_t FWD_GROUP_MIN_QKV_BYTES = EBN_ATTN_FWD_GROUP_MIN_BYTES;
+constexpr int BWD_GROUP = 4;  // heads per workgroup of the group-form backward: one wave per SIMD (5 or 10 measured slower)
+constexpr int64_t FWD_GROUP_MIN_QKV_BYTES = 200'000'000;
 constexpr int64_t BWD_GROUP_MIN_PROBLEMS = 4096;  // about one resident round of waves on 256 CUs
-static uint32_t env_u32(const char* name, uint32_t dflt) {  // tuning switches: read on every launch (a getenv per launch)
-  const char* e = getenv(name);
-  return e != nullptr ? static_cast<uint32_t>(strtoul(e, nullptr, 10)) : dflt;
+// The start-up stagger of the group backward de-phases the workgroups that share a CU: it needs the number of CUs the first
+// dispatch round is dealt over (a power of two: the shift) -- read once from the device; any other topology runs without it.
+static uint32_t stagger_shift_of_device() {
+  static const uint32_t shift = [] {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0u;
+    if (cus < 16 || (cus & (cus - 1)) != 0) return 0u;
+    uint32_t s = 0;
+    while ((1 << s) < cus) ++s;
+    return s;
+  }();
+  return shift;
 }
 
 static bool bwd_group_off() {  // EBN_ATTN_BWD_PER_WAVE=1: the one-wave-per-head backward everywhere (validation / tuning)
@@ -1280,10 +1196,9 @@ int ebn_attn_mfma_bwd(const float* qkv, int64_t ld_qkv, const float* dout, int64
   if (d == 20 && (h % BWD_GROUP) == 0 && a.n_prob >= BWD_GROUP_MIN_PROBLEMS && !bwd_group_off()) {
     const size_t lds = static_cast<size_t>(BWD_GROUP) * bwd_group_wave_floats<20>(L) * sizeof(float);
     const dim3 grid(static_cast<unsigned>(a.n_prob / BWD_GROUP)), block(64 * BWD_GROUP);
-    a.stagger_units = env_u32("EBN_ATTN_STAGGER", 7u);  // x 512 cycles per step; 0 = off (tuning switches)
-    a.stagger_shift = env_u32("EBN_ATTN_STAGGER_SHIFT", 8u);
-    a.stagger_mod = env_u32("EBN_ATTN_STAGGER_MOD", 5u);  // workgroups per CU: 28.8 KB of LDS each
-    if (a.stagger_mod == 0u) a.stagger_mod = 1u;
+    a.stagger_shift = stagger_shift_of_device();  // 8 on the 256 CUs of an MI355X; 0 = unknown topology: no stagger
+    a.stagger_units = a.stagger_shift != 0u ? 7u : 0u;  // x 512 cycles per step
+    a.stagger_mod = 5u;  // workgroups per CU: 28.8 KB of LDS each
     if (L == 30) {
       allow_lds(attn_mfma_bwd_group_kernel<20, 30, BWD_GROUP>, lds);
       hipLaunchKernelGGL((attn_mfma_bwd_group_kernel<20, 30, BWD_GROUP>), grid, block, lds, s, a);

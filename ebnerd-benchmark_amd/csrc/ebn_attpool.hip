@@ -300,83 +300,6 @@ __global__ __launch_bounds__(POOL_THREADS) void attpool_bwd_dpre_kernel(float* _
   }
 }
 
-// AttLayer2 backward in ONE pass per sequence: attpool_bwd_pool_vec_kernel (de = w (dw - sum w dw), dw_l = dout . x_l) followed by
-// attpool_bwd_dpre_kernel's element-wise part on the sequence's own L rows of U (d(pre-tanh) = de q (1 - U^2), written over U) with
-// the sequence's partial column sums of d(q), d(b) -- de never leaves the workgroup before it is used, and the two launches
-// (both HBM-bound row streams of the step's dependent chain) become one.  Same formulas; partials[n][0][k] = d(q), [n][1][k] = d(b)
-// of sequence n, reduced over the sequences by ebn_reduce_partials in a fixed order.
-__global__ __launch_bounds__(POOL_THREADS) void attpool_bwd_fused_kernel(const float* __restrict__ X, const float* __restrict__ w,
-                                                                         const float* __restrict__ dout, float* __restrict__ U,
-                                                                         const float* __restrict__ q, float* __restrict__ de,
-                                                                         float* __restrict__ partials, int L, int E, int A) {
-  extern __shared__ float sm[];  // dw[L] -> de[L]
-  const int64_t n = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int E4 = E >> 2;
-  const float* g = dout + n * E;
-  constexpr int VL = 4;  // float4 per lane per row: E <= 1024
-  float4 gg[VL];
-#pragma unroll
-  for (int v = 0; v < VL; ++v) gg[v] = ld4_or_zero(g, (lane + 64 * v) * 4, lane + 64 * v < E4);
-  for (int l0 = wave; l0 < L; l0 += POOL_WAVES * POOL_RB) {
-    float part[POOL_RB];
-#pragma unroll
-    for (int j = 0; j < POOL_RB; ++j) part[j] = 0.f;
-#pragma unroll
-    for (int v = 0; v < VL; ++v) {
-      if (64 * v >= E4) break;  // uniform
-      float4 x[POOL_RB];
-#pragma unroll
-      for (int j = 0; j < POOL_RB; ++j) {
-        const int l = l0 + POOL_WAVES * j;
-        x[j] = ld4_clamped(X, (n * L + l) * E + (lane + 64 * v) * 4, l < L && lane + 64 * v < E4);
-      }
-#pragma unroll
-      for (int j = 0; j < POOL_RB; ++j)
-        part[j] = fmaf(gg[v].w, x[j].w, fmaf(gg[v].z, x[j].z, fmaf(gg[v].y, x[j].y, fmaf(gg[v].x, x[j].x, part[j]))));
-    }
-#pragma unroll
-    for (int j = 0; j < POOL_RB; ++j) {
-      const int l = l0 + POOL_WAVES * j;
-      const float t = ebn_wave_sum(part[j]);
-      if (lane == 0 && l < L) sm[l] = t;
-    }
-  }
-  __syncthreads();
-  if (wave == 0) {
-    float s = 0.f;
-    for (int l = lane; l < L; l += 64) s = fmaf(w[n * L + l], sm[l], s);
-    s = ebn_wave_sum(s);
-    for (int l = lane; l < L; l += 64) {
-      const float d = w[n * L + l] * (sm[l] - s);
-      sm[l] = d;
-      de[n * L + l] = d;
-    }
-  }
-  __syncthreads();
-  // d(pre-tanh) over this sequence's rows: thread = column (coalesced rows), 8 rows of loads in flight before the first store
-  for (int k = tid; k < A; k += POOL_THREADS) {
-    const float qk = q[k];
-    float dq = 0.f, db = 0.f;
-    for (int rb = 0; rb < L; rb += 8) {
-      float u[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) u[j] = U[(n * L + (rb + j < L ? rb + j : L - 1)) * A + k];  // clamped, unconditional
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        if (rb + j >= L) break;
-        const float d = sm[rb + j];
-        dq = fmaf(d, u[j], dq);
-        const float dp = d * qk * (1.0f - u[j] * u[j]);
-        U[(n * L + rb + j) * A + k] = dp;
-        db += dp;
-      }
-    }
-    partials[(n * 2 + 0) * A + k] = dq;
-    partials[(n * 2 + 1) * A + k] = db;
-  }
-}
-
 }  // namespace
 
 extern "C" int64_t ebn_attpool_partials_len(int64_t R, int32_t A) { return ebn_dim_ok(R, A) ? ebn_colred_blocks(R) * 2 * A : 0; }
@@ -435,22 +358,3 @@ extern "C" int ebn_attpool_bwd_dpre_f32(float* U, const float* q, const float* d
   return EBN_OK;
 }
 
-extern "C" int64_t ebn_attpool_bwd_fused_partials_len(int64_t n_seq, int32_t A) {
-  return ebn_dim_ok(n_seq, A) ? n_seq * 2 * static_cast<int64_t>(A) : 0;
-}
-
-extern "C" int ebn_attpool_bwd_fused_f32(const float* X, const float* w, const float* dout, float* U, const float* q, float* de,
-                                         float* dq, float* db, float* partials, int64_t n_seq, int32_t L, int32_t E, int32_t A,
-                                         int32_t accumulate, ebn_stream_t stream) {
-  EBN_REQUIRE(X && w && dout && U && q && de && dq && db && partials, EBN_ERR_BAD_ARG);
-  EBN_REQUIRE(n_seq >= 0 && L > 0 && E > 0 && A > 0, EBN_ERR_BAD_ARG);
-  EBN_REQUIRE(L <= 8192 && (E % 4) == 0 && E <= 1024 && n_seq < (int64_t{1} << 30), EBN_ERR_UNSUPPORTED);
-  EBN_REQUIRE(ebn_aligned16(X) && ebn_aligned16(dout), EBN_ERR_ALIGN);
-  if (n_seq == 0) return EBN_OK;
-  hipLaunchKernelGGL(attpool_bwd_fused_kernel, dim3(static_cast<unsigned>(n_seq)), dim3(POOL_THREADS), L * sizeof(float), ebn_stream(stream), X, w,
-                     dout, U, q, de, partials, L, E, A);
-  EBN_CHECK_LAUNCH();
-  ebn_reduce_partials(partials, n_seq, 2, A, 1.0f, dq, db, accumulate, nullptr, nullptr, ebn_stream(stream));
-  EBN_CHECK_LAUNCH();
-  return EBN_OK;
-}

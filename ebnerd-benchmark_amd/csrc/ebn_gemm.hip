@@ -32,11 +32,6 @@ __device__ ebn_f32x4 ebn_raw_buffer_load_x4(ebn_i32x4 rsrc, int voffset, int sof
 __device__ void ebn_raw_buffer_load_lds(ebn_i32x4 rsrc, __attribute__((address_space(3))) void* lds, int size, int voffset,
                                         int soffset, int offset, int aux) __asm("llvm.amdgcn.raw.buffer.load.lds");
 
-// ebn_gemm_tall.hip
-bool ebn_gemm_tall_wanted(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K, const float* C, int64_t ldc);
-int ebn_gemm_tall_launch(int32_t transB, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda, const float* B,
-                         int64_t ldb, float* C, int64_t ldc, hipStream_t s);
-
 // ebn_gemm_direct.hip
 int ebn_gemm_direct_tn_slices(int64_t M, int64_t N, int64_t K);
 int ebn_gemm_direct_tn_launch(int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda, const float* B, int64_t ldb,
@@ -49,12 +44,6 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#ifndef EBN_GEMM_XCD
-#define EBN_GEMM_XCD 1
-#endif
-#ifndef EBN_GEMM_GLDS
-#define EBN_GEMM_GLDS 3  // direct global->LDS tile fetch, see GLDS_A / GLDS_B in the kernel
-#endif
 
 typedef float f32x4n __attribute__((ext_vector_type(4)));
 // 16-byte load through an explicitly GLOBAL pointer (global_load_dwordx4, never flat_load)
@@ -81,12 +70,10 @@ __device__ __forceinline__ float4 bload4(i32x4n r, uint32_t lane_bytes, uint32_t
   return make_float4(t.x, t.y, t.z, t.w);
 }
 
-#ifndef EBN_GEMM_WPE
 // Waves per SIMD the register allocation must allow (LDS admits three 41.5 KB workgroups per CU).  It also selects the
 // VGPR form of the MFMAs (accumulators in ordinary registers): without it the compiler picks the AGPR form and, around
 // the two-slab loop body, copies all 64 accumulators between the two register files every iteration.
-#define EBN_GEMM_WPE 3
-#endif
+constexpr int GEMM_WPE = 3;
 constexpr int BK = 16;
 constexpr int PAD = 4;
 constexpr int GEMM_THREADS = 256;
@@ -185,17 +172,11 @@ struct GemmEpi {
 // TA: A stored [K,M]; TB: B stored [N,K].
 // gridDim.z = split-K factor; when > 1 each z-slice writes alpha*partial to
 // Cpart + z*M*N (dense ld = N) and a reduce kernel finishes; else writes C directly.
-// SITE only labels the instantiation (0 = generic, 1 = the encoders' Q|K|V projection) so that per-kernel profiler
-// summaries separate the roofline kernel of bench.py from the other GEMM call sites of the same shape class.
-// PERSIST: the launch holds only as many workgroups as the chip keeps resident (vgx x vgy x vgz is the VIRTUAL grid of tiles x K
-// splits); a workgroup walks the tiles blockIdx.x, blockIdx.x + gridDim.x, ... of the same XCD-contiguous order, and requests the
-// first slab of its NEXT tile before it stores the current one -- the fetch latency of a tile's prologue then lies under the C
-// stores of the tile before it instead of in front of its first MFMA (it matters for short contractions: K = 300 is 19 slabs).
-template <int BM, int BN, int WAVES_M, bool TA, bool TB, bool VEC, int SITE, int EPI = 0, bool PERSIST = false>
-__global__ __launch_bounds__(GEMM_THREADS, EBN_GEMM_WPE) void gemm_f32_kernel(
+template <int BM, int BN, int WAVES_M, bool TA, bool TB, bool VEC, int EPI = 0>
+__global__ __launch_bounds__(GEMM_THREADS, GEMM_WPE) void gemm_f32_kernel(
     int64_t M, int64_t N, int64_t K, float alpha, const float* __restrict__ A, int64_t lda,
     const float* __restrict__ B, int64_t ldb, float beta, float* __restrict__ C, int64_t ldc,
-    int64_t k_per_split, float* __restrict__ Cpart, GemmEpi epi, int32_t vgx, int32_t vgy, int32_t vgz) {
+    int64_t k_per_split, float* __restrict__ Cpart, GemmEpi epi) {
   constexpr int WAVES_N = 4 / WAVES_M;    // the 4 waves form a WAVES_M x WAVES_N grid over the block tile
   constexpr int WTM = BM / WAVES_M;       // rows / columns owned by one wave
   constexpr int WTN = BN / WAVES_N;
@@ -211,8 +192,7 @@ __global__ __launch_bounds__(GEMM_THREADS, EBN_GEMM_WPE) void gemm_f32_kernel(
   // Used for every layout of 16-byte-aligned operands.  (While the k-contiguous images were read through float4-typed
   // loads the NT GEMMs lost with it -- the compiler then waits vmcnt(0) in front of the first LDS read of every slab --
   // and were kept on the register path; with float-typed reads the NT input-gradient GEMM of c1 went 169 -> 156 us.)
-  // EBN_GEMM_GLDS: 0 never, 1 TN only, 2 NN + TN, 3 every layout (tuning).
-  constexpr bool GLDS_A = VEC && ((EBN_GEMM_GLDS == 3) || (EBN_GEMM_GLDS == 2 && !TB) || (EBN_GEMM_GLDS == 1 && TA && !TB));
+  constexpr bool GLDS_A = VEC;
   constexpr bool GLDS_B = GLDS_A;
   constexpr int PADA = GLDS_A ? 0 : PAD, PADB = GLDS_B ? 0 : PAD;
   constexpr int LDA_S = BM + PADA;
@@ -236,11 +216,10 @@ __global__ __launch_bounds__(GEMM_THREADS, EBN_GEMM_WPE) void gemm_f32_kernel(
   // XCD-aware tile order: hardware deals consecutive workgroups round-robin to the 8 XCDs (private
   // L2s); remap so that each XCD walks a CONTIGUOUS run of tiles (neighbouring tiles share their A
   // row-panel / B column-panel in one L2).  Bijective for any grid size; speed only, never correctness.
-  const int64_t GX = PERSIST ? vgx : gridDim.x, GY = PERSIST ? vgy : gridDim.y, GZ = PERSIST ? vgz : gridDim.z;
+  const int64_t GX = gridDim.x, GY = gridDim.y, GZ = gridDim.z;
   const int64_t per_z = GX * GY, nwg = per_z * GZ;
-  // position in the hardware dispatch order (PERSIST: of the virtual grid)
-  int64_t vb = PERSIST ? static_cast<int64_t>(blockIdx.x)
-                       : static_cast<int64_t>(blockIdx.y) * gridDim.x + blockIdx.x + per_z * blockIdx.z;
+  // position in the hardware dispatch order
+  const int64_t vb = static_cast<int64_t>(blockIdx.y) * gridDim.x + blockIdx.x + per_z * blockIdx.z;
   int64_t m0 = 0, n0 = 0, kbeg = 0, kend = 0, zsplit = 0;
   int nk = 0, nk_full = 0, nk_main = 0;
 
@@ -275,12 +254,10 @@ __global__ __launch_bounds__(GEMM_THREADS, EBN_GEMM_WPE) void gemm_f32_kernel(
   // Everything that depends on WHICH tile (and K split) this is: origin, K range, buffer resources, lane offsets.
   auto tile_setup = [&](int64_t v) {
     int64_t lin = v;
-#if EBN_GEMM_XCD
     {
       const int64_t q = nwg / 8, r = nwg % 8, xcd = v % 8, idx = v / 8;
       lin = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-#endif
     zsplit = lin / per_z;  // tiles of one K-split share their A/B K-range: keep them on one XCD too
     const int64_t tile_id = lin - zsplit * per_z;
     m0 = (tile_id / GX) * BM;
@@ -437,8 +414,7 @@ __global__ __launch_bounds__(GEMM_THREADS, EBN_GEMM_WPE) void gemm_f32_kernel(
   // or every slab of a non-VEC kernel, through registers with a run-time buffer index.
   const int kl = lane >> 5;
   const int il = lane & 31;
-  bool fetched = false;  // PERSIST: slab 0 of this tile was requested under the previous tile's stores
-  while (true) {
+  {
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -446,10 +422,8 @@ __global__ __launch_bounds__(GEMM_THREADS, EBN_GEMM_WPE) void gemm_f32_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   if (nk_main > 0) {
-    if (!fetched) {
-      EBN_FETCH_FULL(0);
-      EBN_STORE_FULL(0);
-    }
+    EBN_FETCH_FULL(0);
+    EBN_STORE_FULL(0);
     __syncthreads();
   }
   // The MFMAs of one slab out of LDS buffer CUR.  MFMA contraction index = (instruction, lane half); the slab's 16 k are
@@ -527,18 +501,7 @@ _Pragma("unroll")  \
       cur ^= 1;
     }
   }
-  // the tile just multiplied: what its epilogue needs, saved before the NEXT tile's setup overwrites the working set
   const int64_t em0 = m0, en0 = n0, ezs = zsplit;
-  bool has_next = false;
-  if (PERSIST) {
-    vb += gridDim.x;
-    has_next = vb < nwg;
-    if (has_next) {
-      tile_setup(vb);
-      fetched = GLDS_A && GLDS_B && nk_main > 0;
-      if (fetched) EBN_FETCH_FULL(0);  // both LDS buffers are free (the last slab's barrier has passed): slab 0 of the next tile
-    }                                  // travels while this tile's results are stored
-  }
 
   // epilogue. C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
   if constexpr (EPI != 0) {
@@ -616,8 +579,7 @@ _Pragma("unroll")  \
     }
 
   }
-  if (!has_next) break;
-  }  // while (true): next tile of a persistent workgroup
+  }
 #undef EBN_MMA
 #undef EBN_FETCH_FULL
 #undef EBN_FETCH_PART
@@ -640,11 +602,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
                       beta, C, ldc, epi.rs, epi.cv, epi.ldcv, epi.L, epi.bias);
 }
 
-static int persist_mode() {  // EBN_GEMM_PERSIST = 0: one workgroup per tile (hardware dispatch); 1: persistent workgroups with the next tile's
-  static const int m = [] { const char* e = getenv("EBN_GEMM_PERSIST"); return e ? atoi(e) : 0; }();  // first slab requested under the stores
-  return m;
-}
-
 template <int BM, int BN, int WAVES_M>
 int launch_gemm(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha, const float* A,
                 int64_t lda, const float* B, int64_t ldb, float beta, float* C, int64_t ldc, int vecA,
@@ -652,36 +609,23 @@ int launch_gemm(int transA, int transB, int64_t M, int64_t N, int64_t K, float a
   dim3 grid(static_cast<unsigned>(ebn_ceil_div(N, BN)), static_cast<unsigned>(ebn_ceil_div(M, BM)),
             static_cast<unsigned>(splits));
   dim3 block(GEMM_THREADS);
-  const int64_t total = static_cast<int64_t>(grid.x) * grid.y * grid.z;
-  // persistent form: as many workgroups as stay resident (three per CU by registers and LDS; four of the 64 x 64 tile)
-  const int64_t slots = 256 * (BM == 64 ? 4 : 3);
-  const bool persist = persist_mode() != 0 && vecA && vecB && epi.bias == nullptr && epi.rs == nullptr && total > slots;
-  const dim3 pgrid(static_cast<unsigned>(total < slots ? total : slots));
-  const int32_t gx = static_cast<int32_t>(grid.x), gy = static_cast<int32_t>(grid.y), gz = static_cast<int32_t>(grid.z);
 #define EBN_GEMM_LAUNCH(TA, TB)                                                                            \
   do {                                                                                                    \
-    if (persist)                                                                                          \
-      hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WAVES_M, TA, TB, true, 0, 0, true>), pgrid, block, 0, s, M, N, K, alpha, A, lda, \
-                         B, ldb, beta, C, ldc, k_per_split, part, epi, gx, gy, gz);                       \
-    else if (vecA && vecB)                                                                                \
-      hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WAVES_M, TA, TB, true, 0>), grid, block, 0, s, M, N, K, alpha, A, lda, \
-                         B, ldb, beta, C, ldc, k_per_split, part, epi, gx, gy, gz);                       \
+    if (vecA && vecB)                                                                                     \
+      hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WAVES_M, TA, TB, true>), grid, block, 0, s, M, N, K, alpha, A, lda, \
+                         B, ldb, beta, C, ldc, k_per_split, part, epi);                       \
+    else if constexpr (BM == 64 && BN == 64) /* unaligned operands: the scalar-load form exists for the 64 x 64 tile only */ \
+      hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WAVES_M, TA, TB, false>), grid, block, 0, s, M, N, K, alpha, A,  \
+                         lda, B, ldb, beta, C, ldc, k_per_split, part, epi);                  \
     else                                                                                                  \
-      hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WAVES_M, TA, TB, false, 0>), grid, block, 0, s, M, N, K, alpha, A,  \
-                         lda, B, ldb, beta, C, ldc, k_per_split, part, epi, gx, gy, gz);                  \
+      return EBN_ERR_UNSUPPORTED;                                                                         \
   } while (0)
   if (epi.bias != nullptr)  // caller guarantees !transA && !transB && vecA && vecB
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WAVES_M, false, false, true, 0, 2>), grid, block, 0, s, M, N, K, alpha, A, lda,
-                       B, ldb, beta, C, ldc, k_per_split, part, epi, gx, gy, gz);
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WAVES_M, false, false, true, 2>), grid, block, 0, s, M, N, K, alpha, A, lda,
+                       B, ldb, beta, C, ldc, k_per_split, part, epi);
   else if (epi.rs != nullptr)  // caller guarantees !transA && transB && vecA && vecB
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WAVES_M, false, true, true, 0, 1>), grid, block, 0, s, M, N, K, alpha, A, lda,
-                       B, ldb, beta, C, ldc, k_per_split, part, epi, gx, gy, gz);
-  else if (!transA && !transB && site == 1 && vecA && vecB && persist)
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WAVES_M, false, false, true, 1, 0, true>), pgrid, block, 0, s, M, N, K, alpha, A, lda, B,
-                       ldb, beta, C, ldc, k_per_split, part, epi, gx, gy, gz);
-  else if (!transA && !transB && site == 1 && vecA && vecB)
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WAVES_M, false, false, true, 1>), grid, block, 0, s, M, N, K, alpha, A, lda, B,
-                       ldb, beta, C, ldc, k_per_split, part, epi, gx, gy, gz);
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WAVES_M, false, true, true, 1>), grid, block, 0, s, M, N, K, alpha, A, lda,
+                       B, ldb, beta, C, ldc, k_per_split, part, epi);
   else if (!transA && !transB) EBN_GEMM_LAUNCH(false, false);
   else if (!transA && transB) EBN_GEMM_LAUNCH(false, true);
   else if (transA && !transB) EBN_GEMM_LAUNCH(true, false);
@@ -1144,7 +1088,6 @@ int launch_gemm_small(int transA, int transB, int64_t M, int64_t N, int64_t K, f
 #define EBN_SMALL(TA, TB)                              \
   do {                                                 \
     if (vecA && vecB && fits32) EBN_SMALL_VEC(TA, TB); \
-    else if (vecA && vecB) EBN_SMALL_ONE(TA, TB, true, true); \
     else EBN_SMALL_ONE(TA, TB, false, false);          \
   } while (0)
   if (!transA && !transB) EBN_SMALL(false, false);
@@ -1179,19 +1122,6 @@ struct GemmPlan {
   double cost;
 };
 
-static int forced_tile_bm() {  // EBN_GEMM_FORCE_TILE = 64 | 128 | 256: restrict the planner to one family -- tuning only
-  static const int bm = [] {
-    const char* e = getenv("EBN_GEMM_FORCE_TILE");
-    return e ? atoi(e) : 0;
-  }();
-  return bm;
-}
-
-static bool tile_128x64_on() {  // EBN_GEMM_TILE_128X64=0: the planner without the 128x64 family (tuning)
-  static const bool on = [] { const char* e = getenv("EBN_GEMM_TILE_128X64"); return !(e && e[0] == '0'); }();
-  return on;
-}
-
 static GemmPlan gemm_plan(int64_t M, int64_t N, int64_t K, int64_t ws_floats) {
   int64_t max_split = K / (4 * BK);  // keep >= 4 slabs per split
   if (max_split > 64) max_split = 64;
@@ -1213,7 +1143,7 @@ static GemmPlan gemm_plan(int64_t M, int64_t N, int64_t K, int64_t ws_floats) {
     // Only for outputs that leave the big tiles under-filled and K ranges a single workgroup can walk (no split-K here).
     const int64_t wgs = ebn_ceil_div(M, SBM) * ebn_ceil_div(N, SBN);
     const int64_t tiles64 = ebn_ceil_div(M, 64) * ebn_ceil_div(N, 64);
-    if (forced_tile_bm() == 32 || (forced_tile_bm() == 0 && tiles64 <= 256 && K <= 4096)) {
+    if (tiles64 <= 256 && K <= 4096) {
       const int64_t W = ebn_ceil_div(wgs, 256);
       // two workgroups fit a CU (LDS): a pair shares it at ~1.6 us per 128-deep slab, a lone one takes ~1.1 us; from the
       // third workgroup of a CU on (a second round) the measured cost grows faster than that (1600x400x1200: 3.7 us)
@@ -1228,14 +1158,12 @@ static GemmPlan gemm_plan(int64_t M, int64_t N, int64_t K, int64_t ws_floats) {
       // there it competes with the big tiles on modelled cost, with the same in-step bias (x 0.8) in its favour.
       // EBN_GEMM_FORCE_TILE = 32 | 64 | 128 | 256 still overrides.
       const bool measured = K <= 1536 && W <= 3;
-      best = GemmPlan{32, 32, 1, ebn_ceil_div(K > 0 ? K : 1, SBK) * SBK, (forced_tile_bm() == 32 || measured) ? cost : 0.8 * cost};
-      if (forced_tile_bm() == 32 || measured) return best;
+      best = GemmPlan{32, 32, 1, ebn_ceil_div(K > 0 ? K : 1, SBK) * SBK, measured ? cost : 0.8 * cost};
+      if (measured) return best;
     }
   }
   for (int t = 0; t < 4; ++t) {
     if (kTiles[t].bm == 256 && M < 256) continue;
-    if (forced_tile_bm() == 0 && kTiles[t].family == 96 && !tile_128x64_on()) continue;
-    if (forced_tile_bm() != 0 && forced_tile_bm() != kTiles[t].family && !(kTiles[t].bm == 64 && M < 256 && forced_tile_bm() == 256)) continue;
     const int64_t tiles = ebn_ceil_div(M, kTiles[t].bm) * ebn_ceil_div(N, kTiles[t].bn);
     int64_t prev_s = 0;
     for (int64_t c = 1; c <= max_split; ++c) {
@@ -1298,20 +1226,14 @@ static int gemm_dispatch(int32_t transA, int32_t transB, int64_t M, int64_t N, i
   if ((epi.bias != nullptr || epi.rs != nullptr) && !(vecA && vecB)) return EBN_ERR_UNSUPPORTED;  // epilogue kernels are VEC only
   // tall output x small second operand: the LDS-free 16 x 16-block kernel, operand fragments straight from global memory
   // (ebn_gemm_direct.hip): A [M][K] by float4 (vecA), B [N][K] by float4 (vecB) or B [K][N] by dwords (no alignment needed)
-  if (epi.bias == nullptr && epi.rs == nullptr && beta == 0.f && vecA && (vecB || !transB) && forced_tile_bm() == 0 &&
+  if (epi.bias == nullptr && epi.rs == nullptr && beta == 0.f && vecA && (vecB || !transB) &&
       ebn_gemm_direct_wanted(transA, transB, M, N, K)) {
     const int rc_dir = ebn_gemm_direct_launch(transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, s);
     if (rc_dir != EBN_ERR_UNSUPPORTED) return rc_dir;
   }
-  // tall outputs with a narrow N that 64-wide tiles pad badly: 16 x 16 MFMA blocks (ebn_gemm_tall.hip)
-  if (epi.bias == nullptr && epi.rs == nullptr && beta == 0.f && vecA && vecB && forced_tile_bm() == 0 &&
-      ebn_gemm_tall_wanted(transA, transB, M, N, K, C, ldc)) {
-    const int rc_tall = ebn_gemm_tall_launch(transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, s);
-    if (rc_tall != EBN_ERR_UNSUPPORTED) return rc_tall;
-  }
   // weight gradient of a tall product with a small, awkward output (AttLayer2 dW = Y^T.dpre): 16 x 16 blocks, K chunks across
   // workgroups, dense slices like any split-K product (ebn_gemm_direct.hip) -- combined below or left to ebn_grad_finish_f32
-  if (transA && !transB && epi.bias == nullptr && epi.rs == nullptr && forced_tile_bm() == 0 && workspace != nullptr &&
+  if (transA && !transB && epi.bias == nullptr && epi.rs == nullptr && workspace != nullptr &&
       M * N < (int64_t{1} << 31)) {
     const int z = ebn_gemm_direct_tn_slices(M, N, K);
     if (z >= 2 && workspace_floats >= static_cast<int64_t>(z) * M * N) {
@@ -1336,7 +1258,9 @@ static int gemm_dispatch(int32_t transA, int32_t transB, int64_t M, int64_t N, i
   int rc;
   if (plan.bm == 32)
     return launch_gemm_small(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, vecA, vecB, s, epi);
-  if (plan.bm == 256)
+  if (!(vecA && vecB))  // unaligned operands (no call site of the hot path): the scalar-load kernels are built for the 64 x 64 tile only
+    rc = launch_gemm<64, 64, 2>(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, vecA, vecB, splits, kps, workspace, s, site, epi);
+  else if (plan.bm == 256)
     rc = launch_gemm<256, 64, 4>(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, vecA, vecB, splits, kps,
                                  workspace, s, site, epi);
   else if (plan.bm == 128 && plan.bn == 64)
@@ -1473,7 +1397,7 @@ extern "C" int ebn_dense_bwd_pair_f32(int64_t R, int64_t K_in, int64_t N_out, co
                        ebn_aligned16(W) && (K_in % 4) == 0 && (N_out % 4) == 0;
   const int64_t span = (R + SBK) * (ldx > lddy ? ldx : lddy) * 4 + 64 * ((ldx > lddy ? ldx : lddy) > ldw ? (ldx > lddy ? ldx : lddy) : ldw) * 4;
   const bool small = R > 0 && gemm_plan(K_in, N_out, R, workspace ? workspace_floats : 0).bm == 32 &&
-                     gemm_plan(R, K_in, N_out, workspace ? workspace_floats : 0).bm == 32 && forced_tile_bm() == 0;
+                     gemm_plan(R, K_in, N_out, workspace ? workspace_floats : 0).bm == 32;
   if (aligned && small && span < (int64_t{1} << 31)) {
     SmallProblem p0{K_in, N_out, R, 1.0f, X, ldx, dY, lddy, beta_w, dW, lddw, static_cast<int32_t>(ebn_ceil_div(N_out, SBN)), 0};
     p0.tiles = p0.tiles_x * static_cast<int32_t>(ebn_ceil_div(K_in, SBM));

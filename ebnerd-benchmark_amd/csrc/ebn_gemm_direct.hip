@@ -26,13 +26,9 @@ typedef int ebn_dir_i32x4 __attribute__((ext_vector_type(4)));
 __device__ ebn_dir_f32x4 ebn_dir_buffer_load_x4(ebn_dir_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
 __device__ float ebn_dir_buffer_load_x1(ebn_dir_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
 
-#ifndef EBN_DIRECT_INTERLEAVE
-#define EBN_DIRECT_INTERLEAVE 1  // 0: all requests of a k group in front of the previous group's MFMAs (tuning / A-B)
-#endif
-
 namespace {
 
-constexpr bool INTERLEAVE = EBN_DIRECT_INTERLEAVE != 0;
+constexpr bool INTERLEAVE = true;  // the requests of k group g + 1 between the MFMAs of group g (all of them in front: measured slower)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ ebn_dir_i32x4 dir_rsrc(const float* base) {
@@ -472,14 +468,11 @@ TnDirectPlan tn_direct_plan(int64_t M, int64_t N, int64_t K) {
   TnDirectPlan best{0, 0, 0, 0, 0, 0, 0};
   double best_cost = 1e300;
   static const int kR[3] = {5, 4, 3}, kC[2] = {5, 4};
-  static const int wgs = [] { const char* e = getenv("EBN_GEMM_DIRECT_TN_WGS"); const int v = e ? atoi(e) : 256; return v > 0 ? v : 256; }();  // tuning
-  static const int force_r = [] { const char* e = getenv("EBN_GEMM_DIRECT_TN_R"); return e ? atoi(e) : 0; }();
-  static const int force_c = [] { const char* e = getenv("EBN_GEMM_DIRECT_TN_C"); return e ? atoi(e) : 0; }();
+  constexpr int wgs = 256;  // tiles x chunks fill the CUs once
   for (int ci = 0; ci < 2; ++ci) {
     const int64_t cw = kC[ci], G = ebn_ceil_div(NB, cw), n_wide = NB - G * (cw - 1);
-    if (n_wide < 0 || n_wide > G || (force_c != 0 && force_c != cw)) continue;
+    if (n_wide < 0 || n_wide > G) continue;
     for (int ri = 0; ri < 3; ++ri) {
-      if (force_r != 0 && force_r != kR[ri]) continue;
       const int64_t tiles = ebn_ceil_div(MB, kR[ri]) * G;
       if (tiles > wgs) continue;
       int64_t Z = wgs / tiles;
@@ -499,11 +492,6 @@ TnDirectPlan tn_direct_plan(int64_t M, int64_t N, int64_t K) {
   return best;
 }
 
-int direct_mode() {  // EBN_GEMM_DIRECT = 0: never (validation / tuning: the LDS-staged kernels take these shapes again); default 1
-  static const int mode = [] { const char* e = getenv("EBN_GEMM_DIRECT"); return e ? atoi(e) : 1; }();
-  return mode;
-}
-
 struct DirectPlan {
   int R, CW, G, n_wide;
   int64_t tasks;
@@ -516,19 +504,16 @@ struct DirectPlan {
 DirectPlan direct_plan(int64_t M, int64_t N, bool b_kc) {
   const int64_t MB = ebn_ceil_div(M, 16), NB = ebn_ceil_div(N, 16);
   DirectPlan best{0, 0, 0, 0, 0, 1e300};
-  static const int force_r = [] { const char* e = getenv("EBN_GEMM_DIRECT_R"); return e ? atoi(e) : 0; }();   // tuning: restrict the
-  static const int force_c = [] { const char* e = getenv("EBN_GEMM_DIRECT_C"); return e ? atoi(e) : 0; }();   // plan to one R / CW
   static const int kR[4] = {4, 3, 2, 1}, kC[3] = {7, 5, 4};
   for (int ci = 0; ci < 3; ++ci) {
     const int64_t cw = kC[ci], G = ebn_ceil_div(NB, cw), n_wide = NB - G * (cw - 1);
-    if (n_wide < 0 || n_wide > G || (force_c != 0 && force_c != cw)) continue;
+    if (n_wide < 0 || n_wide > G) continue;
     const int64_t width = n_wide > 0 ? cw : cw - 1;  // blocks of the widest task
     for (int ri = 0; ri < 4; ++ri) {
-      if (force_r != 0 && force_r != kR[ri]) continue;
       // one row block per wave with a [N][K] B: 6 float4 fragments (6 KB) per 20 MFMAs -- the fetch path, not the matrix pipe, sets
       // the pace (52800 x 400 x 200: 114 us against 90 us for two or three row blocks); with a [K][N] B the dword rows come out of
       // L1 and one row block per wave is the best-filling split (52800 x 200 x 400: 82 us)
-      if (b_kc && kR[ri] == 1 && force_r == 0) continue;
+      if (b_kc && kR[ri] == 1) continue;
       const int64_t tasks = ebn_ceil_div(MB, kR[ri]) * G;
       const double rounds = static_cast<double>(ebn_ceil_div(tasks, 1024));
       // a task's issue time ~ R * width blocks; fewer, fatter tasks fetch less per MFMA (R + width fragments for R * width blocks):
@@ -540,24 +525,17 @@ DirectPlan direct_plan(int64_t M, int64_t N, bool b_kc) {
   return best;
 }
 
-int direct_depth() {  // EBN_GEMM_DIRECT_DEPTH = 2 | 3: register sets of operand fragments (groups requested ahead + 1); tuning
-  static const int d = [] { const char* e = getenv("EBN_GEMM_DIRECT_DEPTH"); const int v = e ? atoi(e) : 2; return v == 3 ? 3 : 2; }();
-  return d;
-}
-
 template <int R, int CW>
 int direct_launch_rc(bool b_kc, const DirectPlan& pl, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda, const float* B,
                      int64_t ldb, float* C, int64_t ldc, hipStream_t s) {
   const dim3 grid(static_cast<unsigned>(ebn_ceil_div(pl.tasks, 4))), block(256);
 #define EBN_DIR_GO(KC, DP) \
   hipLaunchKernelGGL((gemm_direct16_kernel<R, CW, KC, DP>), grid, block, 0, s, M, N, K, alpha, A, lda, B, ldb, C, ldc, pl.G, pl.n_wide, pl.tasks)
-  if (direct_depth() == 2) {
-    if (b_kc) EBN_DIR_GO(true, 2);
-    else EBN_DIR_GO(false, 2);
-  } else {
-    if (b_kc) EBN_DIR_GO(true, 3);
-    else EBN_DIR_GO(false, 3);
-  }
+  if constexpr (R == 1) {  // (the planner never gives one row block per wave to a [N][K] B: the fetch path sets the pace there)
+    if (b_kc) return EBN_ERR_UNSUPPORTED;
+    EBN_DIR_GO(false, 2);
+  } else if (b_kc) EBN_DIR_GO(true, 2);  // two register sets of fragments (a third, two groups ahead, measured slower: load latency is not what is left)
+  else EBN_DIR_GO(false, 2);
 #undef EBN_DIR_GO
   EBN_CHECK_LAUNCH();
   return EBN_OK;
@@ -570,9 +548,9 @@ int direct_launch_rc(bool b_kc, const DirectPlan& pl, int64_t M, int64_t N, int6
 // operand small enough to stay cache-resident while every wave re-reads it, over a contraction short enough that the A panel of a
 // row group is walked once.
 bool ebn_gemm_direct_wanted(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K) {
-  if (transA || direct_mode() == 0) return false;
+  if (transA) return false;
   if (M < 4096 || N < 48 || N > 512 || K < 32 || K > 2048 || (K % 4)) return false;
-  static const int64_t max_b = [] { const char* e = getenv("EBN_GEMM_DIRECT_MAXB"); return e ? static_cast<int64_t>(atoll(e)) : (int64_t{2} << 20); }();  // tuning
+  constexpr int64_t max_b = int64_t{2} << 20;
   if (N * K * 4 > max_b) return false;  // a larger B streams from L2 / MALL for every wave
   const DirectPlan pl = direct_plan(M, N, transB != 0);
   if (pl.R == 0) return false;
@@ -604,12 +582,9 @@ int ebn_gemm_direct_launch(int32_t transB, int64_t M, int64_t N, int64_t K, floa
 // `part`), 0 when the shape is not this kernel's: an output of at most 512 rows (32 row blocks) and 1280 columns under a long
 // contraction.  Measured envelope (MI355X, GEMM + combining pass, against the 64 x 64 split-K tiles): 400 x 200 x 24000 47.6 vs 55.0 us,
 // x 52800 82 vs 105 us (43 % tile padding removed); 300 x 1200 x 24000 152.6 vs 170.7 us, x 52800 308.5 vs 345.0 us (only 8 %
-// padding there: the gain is the barrier-free, wave-private pipeline).  EBN_GEMM_DIRECT_TN_MAXN / _PADONLY: tuning.
+// padding there: the gain is the barrier-free, wave-private pipeline).
 int ebn_gemm_direct_tn_slices(int64_t M, int64_t N, int64_t K) {
-  static const int64_t max_n = [] { const char* e = getenv("EBN_GEMM_DIRECT_TN_MAXN"); return e ? static_cast<int64_t>(atoi(e)) : int64_t{1280}; }();
-  static const bool pad_only = getenv("EBN_GEMM_DIRECT_TN_PADONLY") != nullptr;  // only outputs the 64 x 64 tiles pad by >= 20 %
-  if (direct_mode() == 0 || M < 48 || N < 48 || M > 512 || N > max_n || K < 4096) return 0;
-  if (pad_only && ebn_ceil_div(M, 64) * ebn_ceil_div(N, 64) * 64 * 64 * 10 < M * N * 12) return 0;
+  if (M < 48 || N < 48 || M > 512 || N > 1280 || K < 4096) return 0;
   return tn_direct_plan(M, N, K).Z;
 }
 

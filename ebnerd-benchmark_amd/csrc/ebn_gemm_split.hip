@@ -37,13 +37,8 @@ constexpr int SP_THREADS = 256;
 
 // round-to-nearest-even bf16 of an fp32: the hardware conversion of gfx950 (v_cvt_pk_bf16_f32)
 __device__ __forceinline__ uint32_t bf16_rne_bits(float x) {
-#ifdef EBN_SPLIT_SW_RNE  // tuning: integer rounding instead of the conversion instruction
-  const uint32_t u = __float_as_uint(x);
-  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
-#else
   const __bf16 h = static_cast<__bf16>(x);
   return static_cast<uint32_t>(__builtin_bit_cast(unsigned short, h));
-#endif
 }
 __device__ __forceinline__ void split3(float x, uint16_t& p0, uint16_t& p1, uint16_t& p2) {
   const uint32_t b0 = bf16_rne_bits(x);
@@ -387,11 +382,7 @@ __global__ __launch_bounds__(256) void split_planes_t_rows_kernel(const float* _
 // wave reads 1 KB contiguous of one table row, all of a thread's loads in flight).  The 64 x 64-tile kernel above reads every
 // 4 KB table row as sixteen 256-byte pieces from sixteen workgroups at different times -- random 256-byte reads run at half
 // the HBM rate of random 4 KB reads.  LDS tile [16][GS_CHUNK + 4] fp32 (the +4 makes both read patterns conflict-free).
-#ifndef EBN_GS_TOK
-#define EBN_GS_TOK 16
-#define EBN_GS_CHUNK 1024
-#endif
-constexpr int GS_TOK = EBN_GS_TOK, GS_CHUNK = EBN_GS_CHUNK, GS_PITCH = GS_CHUNK + 4;  // (tuning: 16 x 1024 | 32 x 512 | 64 x 256)
+constexpr int GS_TOK = 16, GS_CHUNK = 1024, GS_PITCH = GS_CHUNK + 4;  // (32 x 512 and 64 x 256 measured slower)
 __global__ __launch_bounds__(256) void gather_split_rows_kernel(const int32_t* __restrict__ ids, const float4* __restrict__ table,
                                                                 int64_t R, int64_t D, int64_t V, const uint32_t* __restrict__ key_ptr,
                                                                 uint32_t thresh, float scale, int32_t* __restrict__ oob_flag,
@@ -513,13 +504,9 @@ extern "C" int ebn_split_planes_f32(const float* src, int64_t ld, int64_t rows, 
   EBN_REQUIRE(ebn_aligned16(planes), EBN_ERR_ALIGN);
   const int64_t rows_p = pad_rows(rows), Kp = pad_k(K);
   const dim3 grid(static_cast<unsigned>(rows_p / 64), static_cast<unsigned>(ebn_ceil_div(Kp, 64)));
-  static const bool split_t_tile = getenv("EBN_SPLIT_T_TILE") != nullptr;  // read once (tuning switch)
   if (!trans) hipLaunchKernelGGL((split_planes_kernel<false>), grid, dim3(256), 0, ebn_stream(stream), src, ld, rows, K,
                                  static_cast<uint16_t*>(planes), rows_p, Kp);
-  else if (split_t_tile)  // tuning: the 64 x 64-tile transpose through LDS
-    hipLaunchKernelGGL((split_planes_kernel<true>), grid, dim3(256), 0, ebn_stream(stream), src, ld, rows, K,
-                       static_cast<uint16_t*>(planes), rows_p, Kp);
-  else
+  else  // transposing source: whole rows in order (the 64 x 64-tile transpose through LDS straddled three lines per 256-byte tile row)
     hipLaunchKernelGGL(split_planes_t_rows_kernel, dim3(static_cast<unsigned>(Kp / 8)), dim3(256), 0, ebn_stream(stream), src, ld, rows, K,
                        static_cast<uint16_t*>(planes), rows_p, Kp);
   EBN_CHECK_LAUNCH();
@@ -534,8 +521,7 @@ extern "C" int ebn_gather_split_planes_f32(const int32_t* ids, const float* tabl
   const EbnDrop d = ebn_make_drop(st, site, drop_p);
   const int64_t n_rows_p = pad_rows(n_rows), n_Kp = pad_k(D), t_rows_p = pad_rows(D), t_Kp = pad_k(n_rows);
   const int64_t tok_ext = n_rows_p > t_Kp ? n_rows_p : t_Kp, col_ext = t_rows_p > n_Kp ? t_rows_p : n_Kp;
-  static const bool gather_tile = getenv("EBN_GATHER_SPLIT_TILE") != nullptr;  // read once (tuning: the 64 x 64-tile kernel)
-  if ((D % 4) == 0 && ebn_aligned16(table) && !gather_tile) {  // whole table rows at a time
+  if ((D % 4) == 0 && ebn_aligned16(table)) {  // whole table rows at a time
     constexpr size_t lds = static_cast<size_t>(GS_TOK) * GS_PITCH * sizeof(float);  // 65,792 bytes: above the 64 KB default limit
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_split_rows_kernel),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));

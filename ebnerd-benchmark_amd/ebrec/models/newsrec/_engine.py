@@ -125,7 +125,7 @@ class EncoderBuffers:
         self.QKV, self.Y, self.U, self.w = f(R, 3 * E), f(R, E), f(R, A), f(R)
         self.out = f(n_seq, E)
         self.dY, self.dQKV, self.de = f(R, E), f(R, 3 * E), f(R)
-        self.partials = f(max(int(_hip.lib().ebn_attpool_partials_len(R, A)), int(_hip.lib().ebn_attpool_bwd_fused_partials_len(n_seq, A))))
+        self.partials = f(int(_hip.lib().ebn_attpool_partials_len(R, A)))
         wsf = _hip.lib().ebn_gemm_workspace_floats  # split-K scratch for every GEMM shape of the stage (fwd and bwd)
         ws = max(int(wsf(Din, 3 * E, R)), int(wsf(E, A, R)), int(wsf(R, 3 * E, Din)), int(wsf(R, A, E)), int(wsf(R, E, A)),
                  int(wsf(R, Din, 3 * E)), 1)
@@ -209,10 +209,6 @@ class NRMSEngine:
         self.range_flag = torch.zeros(1, dtype=torch.int32, device=self.device)  # fixed-point gradient accumulator left its range
         self.loss_dev = torch.zeros(1, device=self.device)
         self.use_graph = False  # capture the per-shape kernel sequence into hipGraphs (enable_graphs())
-        # True: the news AttLayer2 backward (de, dpre, dq, db) as ONE pass per title instead of two launches.  Measured slower in the
-        # step (c2 1.2965 vs 1.2938 ms, c1 0.979 vs 0.9725): the per-title pass has 200 of 256 threads walking 30 rows each, the two
-        # streaming kernels it replaces fill the chip better -- kept for validation, off by default
-        self.fuse_attpool_bwd = False
         self.fuse_user_head = True  # False: the per-impression head of a step as its six separate launches (validation)
         # True: the four small finishing passes of the backward (split-K sums of dW and dWqkv, AttLayer2 d(q) / d(b) column sums, the
         # per-impression head's d(q) / d(b) / loss sums) run as ONE launch at the end of the backward (ebn_grad_finish_f32) instead
@@ -555,13 +551,9 @@ class NRMSEngine:
         pv, g = self.params.view, self.params.g
         ws, wsn = _hip.ptr(b.ws), b.ws.numel()
         one, zero = ctypes.c_float(1.0), ctypes.c_float(0.0)
-        if self.fuse_attpool_bwd and E % 4 == 0 and E <= 1024:  # de, d(pre-tanh), dq, db in one pass per sequence
-            _hip.call("ebn_attpool_bwd_fused_f32", _hip.ptr(b.Y), _hip.ptr(b.w), _hip.ptr(dout), _hip.ptr(b.U), _hip.ptr(pv("n_q")), _hip.ptr(b.de),
-                      _hip.ptr(g("n_q")), _hip.ptr(g("n_b")), _hip.ptr(b.partials), n_seq, T, E, A, 0, S())
-        else:
-            _hip.call("ebn_attpool_bwd_pool_f32", _hip.ptr(b.Y), _hip.ptr(b.w), _hip.ptr(dout), None, _hip.ptr(b.de), n_seq, T, E, S())
-            _hip.call("ebn_attpool_bwd_dpre_f32", _hip.ptr(b.U), _hip.ptr(pv("n_q")), _hip.ptr(b.de), _hip.ptr(g("n_q")), _hip.ptr(g("n_b")),
-                      _hip.ptr(b.partials), R, A, 0, S())
+        _hip.call("ebn_attpool_bwd_pool_f32", _hip.ptr(b.Y), _hip.ptr(b.w), _hip.ptr(dout), None, _hip.ptr(b.de), n_seq, T, E, S())
+        _hip.call("ebn_attpool_bwd_dpre_f32", _hip.ptr(b.U), _hip.ptr(pv("n_q")), _hip.ptr(b.de), _hip.ptr(g("n_q")), _hip.ptr(g("n_b")),
+                  _hip.ptr(b.partials), R, A, 0, S())
         if self._fold_pooling(T):
             _hip.call("ebn_dense_bwd_pair_f32", R, E, A, _hip.ptr(b.Y), E, _hip.ptr(b.U), A, _hip.ptr(pv("n_W")), A, zero, _hip.ptr(g("n_W")), A,
                       _hip.ptr(b.dY), E, ws, wsn, S())
@@ -1248,7 +1240,7 @@ class NRMSEngine:
         """whether this step leaves its finishing passes to ONE ebn_grad_finish_f32 launch (the standard configuration: no
         per-token Dense stack, exact precision, the one-launch head and the pooling term folded into the attention backward)"""
         L = _hip.lib()
-        return bool(self.defer_finish and self.mlp is None and self.precision == "exact" and self.fuse_user_head and not self.fuse_attpool_bwd
+        return bool(self.defer_finish and self.mlp is None and self.precision == "exact" and self.fuse_user_head
                     and self._fold_pooling(self.T) and self._fold_pooling(self.H)
                     and int(L.ebn_user_head_supported(self.H, C, self.E, self.A)) != 0)
 

@@ -212,8 +212,8 @@ typedef struct {
 } ebn_finish_job;
 int ebn_grad_finish_f32(const ebn_finish_job* jobs, int32_t n_jobs, ebn_stream_t stream);
 
-/* Same again; `site` only labels the kernel instantiation (0 generic, 1 = Q|K|V projection of an encoder) so that
- * per-kernel profiler summaries keep the roofline kernel of bench.py apart from other call sites.               */
+/* Same again; `site` is accepted and ignored (rounds 1-4 used it to label the kernel instantiation of the encoders' Q|K|V
+ * projection for per-kernel profiler summaries; the instantiations it doubled are gone).                        */
 int ebn_gemm_f32_site(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K, float alpha,
                       const float* A, int64_t lda, const float* B, int64_t ldb, float beta, float* C,
                       int64_t ldc, float* workspace, int64_t workspace_floats, int32_t site,
@@ -287,14 +287,6 @@ int64_t ebn_attpool_partials_len(int64_t R, int32_t A);
 int ebn_attpool_bwd_dpre_f32(float* U, const float* q, const float* de, float* dq, float* db,
                              float* partials, int64_t R, int32_t A, int32_t accumulate,
                              ebn_stream_t stream);
-/* ebn_attpool_bwd_pool_f32 (without the dX part) + ebn_attpool_bwd_dpre_f32 in ONE pass per sequence: de, U <- d(pre-tanh),
- * dq, db (layers.py:65-81 backward).  E % 4 == 0, E <= 1024, 16-byte aligned X / dout; partials:
- * ebn_attpool_bwd_fused_partials_len(n_seq, A) floats.  Same formulas, one launch less on the step's dependent chain.   */
-int64_t ebn_attpool_bwd_fused_partials_len(int64_t n_seq, int32_t A);
-int ebn_attpool_bwd_fused_f32(const float* X, const float* w, const float* dout, float* U, const float* q, float* de,
-                              float* dq, float* db, float* partials, int64_t n_seq, int32_t L, int32_t E, int32_t A,
-                              int32_t accumulate, ebn_stream_t stream);
-
 /* ---- stage level: SelfAttention + AttLayer2 over a batch of sequences -----------------
  * The news encoder after its embedding gather (nrms.py:137-156, L = title_size,
  * Din = word_emb_dim) and the user encoder after TimeDistributed(news encoder)

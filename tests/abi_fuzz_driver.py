@@ -16,7 +16,8 @@ sys.path.insert(0, str(ROOT / "ebnerd-benchmark_amd"))
 from ebrec._hip import binding as B  # noqa: E402  (header parser + struct mirrors; does not load the product library)
 
 HOST_STRUCTS = {"ebn_encoder_dims": B.EncoderDims, "ebn_encoder_params": B.EncoderParams, "ebn_encoder_acts": B.EncoderActs,
-                "ebn_encoder_grads": B.EncoderGrads, "ebn_encoder_scratch": B.EncoderScratch, "ebn_finish_job": B.FinishJob * B.FINISH_MAX_JOBS}
+                "ebn_encoder_grads": B.EncoderGrads, "ebn_encoder_scratch": B.EncoderScratch, "ebn_finish_job": B.FinishJob * B.FINISH_MAX_JOBS,
+                "ebn_dvn_args": B.DvnArgs, "ebn_tn_problem": B.TnProblem * B.TN_GROUP_MAX}
 FAKE_DEV = 0x7E0000000000  # a 16-byte-aligned address no host mapping uses: device pointers are never dereferenced on the host
 SIZES = [0, 1, 2, 3, 5, 7, 16, 20, 30, 31, 32, 33, 50, 63, 64, 65, 100, 127, 128, 200, 255, 256, 257, 300, 400, 512, 768, 1000, 1024, 1200,
          4096, 24000, 32000, 52800, 250002, 1 << 20, (1 << 24) + 1, (1 << 31) - 1, 1 << 31, (1 << 31) + 7, 1 << 33, 1 << 40, (1 << 62) + 3]
@@ -50,7 +51,14 @@ def value(decl, rng, mode, keep):
                 keep.append(s)
                 return ctypes.cast(s, ctypes.c_void_p)
             for fname, ftype in s._fields_:
-                if ftype is ctypes.c_void_p:
+                if isinstance(ftype, type) and issubclass(ftype, ctypes.Array):  # fixed arrays inside a struct (ebn_dvn_args)
+                    arr = getattr(s, fname)
+                    for i in range(len(arr)):
+                        if ftype._type_ is ctypes.c_void_p:
+                            arr[i] = None if rng.random() < 0.05 else FAKE_DEV + 4096 * rng.randrange(1 << 16)
+                        else:
+                            arr[i] = rng.choice([v for v in SIZES + [-1] if v < (1 << 31)])
+                elif ftype is ctypes.c_void_p:
                     setattr(s, fname, None if rng.random() < 0.05 else FAKE_DEV + 4096 * rng.randrange(1 << 16))
                 elif ftype is ctypes.c_float:
                     setattr(s, fname, rng.choice([0.0, 0.2, -1.0, 1.5]))

@@ -107,45 +107,13 @@ GEMM_SHAPES = [(1, 1, 1), (5, 7, 3), (64, 64, 16), (130, 70, 33), (257, 129, 300
                (800, 512, 768), (640, 1200, 400), (250, 768, 640),
                # the edges of the planner's small-tile envelope (K = 1536 | 1537, tiles64 = 256 at K = 4096)
                (640, 1200, 1536), (640, 1200, 1537), (1024, 1024, 4096),
-               # tall outputs with an N the 64-wide tiles pad by > 10 %: the 16x16-block kernel (ebn_gemm_tall.hip) for A not
+               # tall outputs with an N the 64-wide tiles pad by > 10 %: the LDS-free 16x16-block kernels (ebn_gemm_direct.hip) for A not
                # transposed and beta = 0 -- AttLayer2's two shapes (short), ragged M / N / K with a partial last slab, two column panels
                (4096, 200, 400), (4100, 400, 200), (4099, 68, 72), (4500, 416, 100), (5000, 100, 64),
                # small, awkward outputs under a long contraction (AttLayer2's weight gradient and ragged relatives): the transposed-A layout
                # takes the 16x16-block K-chunked kernel of ebn_gemm_direct.hip -- partial last group (K % 16 != 0), partial last chunk,
                # M / N not multiples of 16, every (R, CW) instantiation the plan can pick
                (400, 200, 24000), (416, 208, 9000), (100, 500, 5003), (500, 60, 4100), (72, 72, 30001), (330, 330, 7777), (300, 1200, 9000), (512, 1280, 4100)]
-
-
-_TALL_SCRIPT = r'''
-import ctypes, sys
-sys.path.insert(0, "{root}/ebnerd-benchmark_amd")
-import torch
-from ebrec import _hip
-P, S = _hip.ptr, _hip.stream_handle
-g = torch.Generator(device="cuda").manual_seed(3)
-worst = 0.0
-for M, N, K in ((4096, 200, 400), (4100, 400, 200), (4099, 68, 72), (4500, 416, 100)):
-    for tB in (0, 1):
-        A = torch.randn(M, K, device="cuda", generator=g)
-        B = torch.randn((N, K) if tB else (K, N), device="cuda", generator=g)
-        C = torch.full((M, N), float("nan"), device="cuda")
-        _hip.call("ebn_gemm_f32", 0, tB, M, N, K, ctypes.c_float(0.5), P(A), K, P(B), B.shape[1], ctypes.c_float(0.0), P(C), N, S())
-        ref = 0.5 * (A.double() @ (B.double().t() if tB else B.double()))
-        worst = max(worst, float((C.double() - ref).abs().max() / ref.abs().max()))
-print("TALL_WORST", worst)
-'''
-
-
-def test_tall_gemm_kernel_in_both_b_layouts(hip, tmp_path):
-    """EBN_GEMM_TALL=2 sends the [N][K] layouts to the 16x16-block kernel as well (by default only B stored [K][N] takes it)."""
-    import os
-    import subprocess
-    import sys
-    script = tmp_path / "tall.py"
-    script.write_text(_TALL_SCRIPT.format(root=str(ROOT)))
-    out = subprocess.run([sys.executable, str(script)], env=dict(os.environ, EBN_GEMM_TALL="2"), capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0 and "TALL_WORST" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
-    assert float(out.stdout.split("TALL_WORST", 1)[1].split()[0]) < 2e-6
 
 
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
@@ -464,18 +432,7 @@ def test_attpool_forward_and_backward(hip, n_seq, L, E, A):
     part = torch.empty(int(hip.lib().ebn_attpool_partials_len(R, A)), device="cuda")
     dqd = torch.full((A,), 5.0, device="cuda")
     dbd = torch.full((A,), 5.0, device="cuda")
-    # the one-pass form (ebn_attpool_bwd_fused_f32) on a copy of U: same de and d(pre-tanh) bit for bit, dq / db summed per
-    # sequence first
-    Uf, def_, dqf, dbf = U.clone(), torch.empty(R, device="cuda"), torch.full((A,), 5.0, device="cuda"), torch.full((A,), 5.0, device="cuda")
-    partf = torch.empty(int(hip.lib().ebn_attpool_bwd_fused_partials_len(n_seq, A)), device="cuda")
-    hip.call("ebn_attpool_bwd_fused_f32", P(Xd), P(w), P(dev(dout)), P(Uf), P(dev(q)), P(def_), P(dqf), P(dbf), P(partf), n_seq, L, E, A, 0, S())
     hip.call("ebn_attpool_bwd_dpre_f32", P(U), P(dev(q)), P(de), P(dqd), P(dbd), P(part), R, A, 0, S())
-    assert np.array_equal(host(def_), host(de)) and np.array_equal(host(Uf), host(U)), "fused AttLayer2 backward: de / d(pre-tanh)"
-    assert_close(host(dqf), dq[:, 0], rtol=3e-5, atol=2e-5, what="dq (fused)")
-    assert_close(host(dbf), db, rtol=3e-5, atol=2e-5, what="db (fused)")
-    hip.call("ebn_attpool_bwd_fused_f32", P(Xd), P(w), P(dev(np.zeros((n_seq, E)))), P(Uf.copy_(U)), P(dev(q)), P(def_), P(dqf), P(dbf), P(partf),
-             n_seq, L, E, A, 1, S())
-    assert_close(host(dqf), dq[:, 0], rtol=3e-5, atol=2e-5, what="dq (fused) accumulate(0)")
     assert_close(host(dqd), dq[:, 0], rtol=3e-5, atol=2e-5, what="dq")
     assert_close(host(dbd), db, rtol=3e-5, atol=2e-5, what="db")
     dWd = torch.empty(E, A, device="cuda")

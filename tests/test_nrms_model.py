@@ -194,28 +194,6 @@ def test_fused_user_head_step_equals_the_step_with_separate_kernels(nrms, H):
     assert abs(l0 - L) <= 2e-5 * max(1.0, abs(L))
 
 
-@pytest.mark.parametrize("precision", ["exact", "split"])
-def test_one_pass_news_attlayer2_backward_equals_the_two_launch_form(nrms, precision):
-    """`fuse_attpool_bwd` (off by default: measured slower in the step): de, d(pre-tanh), dq, db of the news encoder's AttLayer2 in one pass per title
-    (ebn_attpool_bwd_fused_f32) against the two launches it replaces -- the same loss, gradients to summation-order noise."""
-    hp = make_hp(dropout=0.2)
-    V, D, seed = 300, 64, 4
-    rng = np.random.default_rng(22)
-    P = on.random_nrms_params(V, D, hp.head_num, hp.head_dim, hp.attention_hidden_dim, seed=9)
-    his, pred, y = batch(rng, 5, hp.history_size, 5, hp.title_size, V)
-    out = []
-    for fuse in (True, False):
-        m = nrms(hp, word2vec_embedding=P["emb"], seed=seed, precision=precision).from_keras_weight_list(weight_list(P))
-        m._engine.fuse_attpool_bwd = fuse
-        m._engine.keep_table_grad = True
-        loss = float(m.train_step(his, pred, y).item())
-        out.append((loss, m._engine.params.grad.cpu().numpy().astype(np.float64), m._engine.table_grad.cpu().numpy().astype(np.float64)))
-    (l0, g0, t0), (l1, g1, t1) = out
-    assert l0 == l1
-    assert_close(g0, g1, rtol=1e-4, atol=1e-7 + 2e-5 * np.abs(g1).max(), what="dense gradients, one pass vs two launches")
-    assert_close(t0, t1, rtol=1e-4, atol=1e-7 + 2e-5 * np.abs(t1).max(), what="table gradient, one pass vs two launches")
-
-
 @pytest.mark.parametrize("train_embedding", [False, True])
 def test_split_precision_model_holds_the_exact_model_tolerances(nrms, train_embedding):
     """NRMSModel(precision="split"): the news encoder's projection GEMMs as bf16x6 split products on the bf16 matrix pipe.
