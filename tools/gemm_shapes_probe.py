@@ -1,6 +1,6 @@
 """Times every GEMM shape of a training step in isolation (HIP events, graph-captured batch of launches to exclude launch
 gaps) under the planner's choice, and torch.matmul (hipBLASLt) on the same data for scale.
-usage: gemm_shapes_probe.py [c1|c2]      (EBN_GEMM_FORCE_TILE=64|128|256 restricts the planner to one tile family)"""
+usage: gemm_shapes_probe.py [c1|c2]"""
 import ctypes
 import os
 import sys
@@ -29,7 +29,7 @@ if cfg == "c3":  # NRMSDocVec: 800 document vectors per step through Dense 768-5
               ("u QKV fwd", 0, 0, 640, 3 * E3, E3), ("u dWqkv", 1, 0, E3, 3 * E3, 640), ("u U", 0, 0, 640, A, E3),
               ("u dW", 1, 0, E3, A, 640), ("u dY", 0, 1, 640, E3, A), ("u dX", 0, 1, 640, E3, 3 * E3)]
 g = torch.Generator(device="cuda").manual_seed(0)
-print(f"config {cfg}, EBN_GEMM_FORCE_TILE={os.environ.get('EBN_GEMM_FORCE_TILE', '-')}")
+print(f"config {cfg}")
 tot = 0.0
 for name, tA, tB, M, N, K in SHAPES:
     Am = torch.randn((K, M) if tA else (M, K), device="cuda", generator=g)
