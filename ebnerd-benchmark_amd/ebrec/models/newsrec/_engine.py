@@ -27,6 +27,9 @@ from ebrec import _hip
 BETA1, BETA2, ADAM_EPS = 0.9, 0.999, 1e-7  # tf.keras.optimizers.Adam defaults (nrms.py:77)
 _ALIGN = 64  # floats; keeps every parameter 256-byte aligned inside the flat buffer
 
+from ._engine_segments import SegmentsMixin  # noqa: E402  (the multi-rank step: segments, collectives, the one-graph self-check)
+from ._engine_staging import StagingMixin  # noqa: E402  (device-side batch assembly: article rows -> token ids, pinned staging)
+
 LOSS_KIND = {"cross_entropy_loss": 0, "log_loss": 1}
 BCE_ON = ("logits", "probs")
 
@@ -39,12 +42,6 @@ def loss_kind_of(loss: str, bce_on: str) -> int:
     if bce_on not in BCE_ON:
         raise ValueError(f"bce_on must be one of {BCE_ON}, got {bce_on}")
     return 0 if loss == "cross_entropy_loss" else (1 if bce_on == "logits" else 2)
-
-
-def _named(kind, fn, what):
-    """a step segment (kind, fn) whose fn carries a description (`SegmentTrace` / the hang watchdog name it)"""
-    fn.what = what
-    return kind, fn
 
 
 def require_gpu() -> torch.device:
@@ -134,7 +131,7 @@ class EncoderBuffers:
         self.dX = f(R, Din) if need_dx else None
 
 
-class NRMSEngine:
+class NRMSEngine(StagingMixin, SegmentsMixin):
     def __init__(self, table: np.ndarray, title_size: int, history_size: int, head_num: int, head_dim: int,
                  attention_hidden_dim: int, dropout: float, learning_rate: float, loss: str, seed=None,
                  train_embedding: bool = True, device=None, process_group=None, shard_table: bool = False,
@@ -646,26 +643,6 @@ class NRMSEngine:
                   ctypes.byref(grads), ctypes.byref(scratch), _hip.ptr(dX), 0, _hip.ptr(self.state),
                   _hip.stream_handle())
 
-    def _device_batch(self, his, pred, y) -> bool:
-        same_dev = lambda t: t.is_cuda and (self.device.index is None or t.device.index == self.device.index)
-        ok = lambda t, dt: isinstance(t, torch.Tensor) and same_dev(t) and t.dtype == dt and t.is_contiguous()
-        return ok(his, torch.int32) and ok(pred, torch.int32) and ok(y, torch.float32)
-
-    def _upload_ids(self, dst, *arrays):
-        """Token ids -> int32 device buffer; ids outside [0,V) raise like TF-CPU's Embedding does."""
-        off = 0
-        for a in arrays:
-            if isinstance(a, torch.Tensor):
-                t = a.reshape(-1).to(device=self.device, dtype=torch.int32)
-            else:
-                a = np.asarray(a)
-                if a.size and (a.min() < 0 or a.max() >= self.V):
-                    raise IndexError(f"token id out of range [0, {self.V}) for the embedding table")
-                t = torch.from_numpy(np.ascontiguousarray(a.reshape(-1).astype(np.int32, copy=False)))
-            dst[off: off + t.numel()].copy_(t, non_blocking=True)
-            off += t.numel()
-        return off
-
     def _news_forward(self, b, N, train, n_first=None, looked_up=False):
         """a1..a4 for N titles whose ids are already in b.ids -> b.out[:N].  n_first = titles of the first
         TimeDistributed call site (history); only the BatchNorm of the optional Dense stack cares.
@@ -705,51 +682,6 @@ class NRMSEngine:
         b.planes_rows = -1
         _hip.call("ebn_gather_rows_f32", _hip.ptr(ids), _hip.ptr(table), _hip.ptr(b.X), n_tok, self.D, table_rows, st, site,
                   ctypes.c_float(p), _hip.ptr(self.oob_flag), _hip.stream_handle())
-
-    # ---- device-planned row-sharded lookup, as ("k" kernels | "c" collective, fn) segments -------------------------
-    def _lookup_segments(self, b, N):
-        ex, n_tok = self.exchange, N * self.T
-
-        def plan(ids, n, cap, ws, slot_rows, inv, counts):
-            _hip.call("ebn_shard_plan_i32", _hip.ptr(ids), n, self.V, ex.world, 1 if ex.cyclic else 0, cap, _hip.ptr(ws),
-                      _hip.ptr(slot_rows), _hip.ptr(inv), _hip.ptr(counts), _hip.stream_handle())
-
-        def serve(local_rows, out):  # rows other ranks (and this one) asked of my shard; -1 padding gathers a zero row, no flag
-            _hip.call("ebn_gather_rows_f32", _hip.ptr(local_rows), _hip.ptr(self.table), _hip.ptr(out), local_rows.numel(), self.D,
-                      self.table.shape[0], None, -1, ctypes.c_float(0.0), None, _hip.stream_handle())
-
-        return ex.lookup_segments(b.ids, n_tok, b.xb, plan, serve)
-
-    def _table_grad_segments(self, b, N):
-        """d(rows): one gradient row per requested slot locally, each slab sent to its owner, owners accumulate."""
-        ex, n_tok = self.exchange, N * self.T
-        site, p = (0, self.p) if self.p > 0 else (-1, 0.0)
-
-        def reduce_local(inv, d_slot):
-            d_slot.zero_()
-            _hip.call("ebn_embedding_grad_scatter_f32", _hip.ptr(inv), _hip.ptr(b.dX), _hip.ptr(d_slot), n_tok, self.D,
-                      d_slot.shape[0], _hip.ptr(self.state), site, ctypes.c_float(p), _hip.stream_handle())
-
-        def accumulate(local_rows, grads):
-            self.table_grad.zero_()
-            _hip.call("ebn_embedding_grad_scatter_f32", _hip.ptr(local_rows), _hip.ptr(grads), _hip.ptr(self.table_grad),
-                      local_rows.numel(), self.D, self.table.shape[0], None, -1, ctypes.c_float(0.0), _hip.stream_handle())
-
-        return ex.grad_segments(n_tok, b.xb, reduce_local, accumulate)
-
-    def _local_gather(self, local_rows: torch.Tensor) -> torch.Tensor:
-        m = local_rows.numel()
-        out = torch.empty(m, self.D, device=self.device)
-        if m:
-            _hip.call("ebn_gather_rows_f32", _hip.ptr(local_rows), _hip.ptr(self.table), _hip.ptr(out), m, self.D,
-                      self.table.shape[0], None, -1, ctypes.c_float(0.0), _hip.ptr(self.oob_flag), _hip.stream_handle())
-        return out
-
-    def _local_scatter_add(self, local_rows: torch.Tensor, grads: torch.Tensor) -> None:
-        m = local_rows.numel()
-        if m:
-            _hip.call("ebn_embedding_grad_scatter_f32", _hip.ptr(local_rows), _hip.ptr(grads), _hip.ptr(self.table_grad),
-                      m, self.D, self.table.shape[0], None, -1, ctypes.c_float(0.0), _hip.stream_handle())
 
     # ------------------------------------------------------------------ public compute
     def encode_news(self, ids, chunk=8192) -> torch.Tensor:
@@ -889,72 +821,6 @@ class NRMSEngine:
         """lambda * sum(W^2) over the regularised Dense kernels (0 without the optional per-token stack)."""
         return self.mlp.l2_penalty() if self.mlp is not None else 0.0
 
-    # ------------------------------------------------------------------ training
-    # ------------------------------------------------------------------ device-side batch assembly (a13)
-    def set_article_matrix(self, matrix) -> None:
-        """Keep the loader's (n_articles+1, T) token matrix in HBM; batches can then be given as article-row
-        numbers (``train_step(..., indexed=True)``) and expanded to token ids on the device."""
-        m = np.asarray(matrix)
-        if m.ndim != 2 or m.shape[1] != self.T or not np.issubdtype(m.dtype, np.integer):
-            raise ValueError(f"article matrix must be integer (n_articles+1, {self.T}), got {m.dtype} {m.shape}")
-        if m.size and (m.min() < 0 or m.max() >= self.V):
-            raise IndexError(f"token id out of range [0, {self.V}) for the embedding table")
-        self.article_matrix = torch.from_numpy(np.ascontiguousarray(m.astype(np.int32))).to(self.device)
-        self._article_matrix_src = matrix
-
-    def _stage_host(self, int_arrays, dst_int: torch.Tensor, y, dst_lab: torch.Tensor) -> None:
-        """Host integers (token ids or article-row numbers) + labels -> device in ONE asynchronous copy out of a pinned,
-        double-buffered staging area; the kernel that unpacks it into `dst_int` / `dst_lab` also advances the step state.
-        The host never waits for the GPU and runs up to two steps ahead."""
-        flat = [np.asarray(a).reshape(-1) for a in int_arrays]
-        n_int = sum(a.size for a in flat)
-        lab = np.asarray(y, dtype=np.float32).reshape(-1)
-        n = n_int + lab.size
-        st = getattr(self, "_host_stage", None)
-        if st is None or st["pinned"][0].numel() < n:
-            st = self._host_stage = {"pinned": [torch.empty(2 * n, dtype=torch.int32).pin_memory() for _ in range(2)],
-                                     "dev": torch.empty(2 * n, dtype=torch.int32, device=self.device), "ev": [None, None], "k": 0}
-        k = st["k"] = st["k"] ^ 1
-        if st["ev"][k] is not None:
-            st["ev"][k].synchronize()  # the copy that last read this pinned buffer (two steps ago) has long finished
-        hs = st["pinned"][k].numpy()
-        off = 0
-        for a in flat:
-            hs[off: off + a.size] = a
-            off += a.size
-        hs[n_int:n].view(np.float32)[:] = lab
-        st["dev"][:n].copy_(st["pinned"][k][:n], non_blocking=True)
-        st["ev"][k] = torch.cuda.Event()
-        st["ev"][k].record()
-        _hip.call("ebn_copy3_advance", _hip.ptr(st["dev"]), _hip.ptr(dst_int), n_int * 4, None, None, 0, _hip.ptr(st["dev"][n_int:]),
-                  _hip.ptr(dst_lab), lab.size * 4, _hip.ptr(self.state), BETA1, BETA2, _hip.stream_handle())
-
-    def _stage_indexed(self, nb, his_idx, pred_idx, y=None):
-        """Article-row numbers (+ labels) of a batch -> device, then the token ids are expanded on the device.  Host batches
-        (what the loaders hand over) travel as ONE asynchronous copy out of a pinned, double-buffered staging area, and the
-        step-state advance rides in the kernel that unpacks it: the host never waits for the GPU and runs a step ahead.
-        Returns (y still to be uploaded or None, whether the step state has been advanced)."""
-        B, C = his_idx.shape[0], pred_idx.shape[1]
-        n_titles, n_lab = B * (self.H + C), B * C
-        if not hasattr(nb, "art_idx") or nb.art_idx.numel() < n_titles:
-            nb.art_idx = torch.empty(nb.n_seq, dtype=torch.int32, device=self.device)
-        advanced = False
-        host = not isinstance(his_idx, torch.Tensor) and not isinstance(pred_idx, torch.Tensor) and y is not None and \
-            not isinstance(y, torch.Tensor)
-        if host:
-            self._stage_host([his_idx, pred_idx], nb.art_idx, y, nb.labels)
-            y, advanced = None, True
-        else:
-            off = 0
-            for a in (his_idx, pred_idx):
-                t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(a).reshape(-1).astype(np.int32, copy=False)))
-                t = t.reshape(-1)
-                nb.art_idx[off: off + t.numel()].copy_(t.to(device=self.device, dtype=torch.int32), non_blocking=True)
-                off += t.numel()
-        _hip.call("ebn_expand_titles_i32", _hip.ptr(nb.art_idx), _hip.ptr(self.article_matrix), _hip.ptr(nb.ids), n_titles,
-                  self.T, self.article_matrix.shape[0], _hip.ptr(self.oob_flag), _hip.stream_handle())
-        return y, advanced
-
     def train_step(self, his, pred, y, return_probs=False, indexed=False):
         """One optimizer step (forward, loss, backward, gradient all-reduce, Keras Adam).
         Returns the batch loss as a 1-element device tensor (no host sync).  With
@@ -1010,61 +876,6 @@ class NRMSEngine:
             return self.loss_dev, nb.probs[: B * C].view(B, C), nb.labels[: B * C].view(B, C)
         return self.loss_dev
 
-    # ------------------------------------------------------------------ one-graph multi-rank step: self-check
-    def _state_tensors(self):
-        ts = [self.params.data, self.params.grad, self.params.m, self.params.v, self.state, self.loss_dev]
-        if self.train_embedding:
-            ts += [self.table, self.table_grad, self.table_m, self.table_v] + ([self.table_acc] if self.deterministic else [])
-        return ts
-
-    def verify_graph_collectives(self, his, pred, y) -> bool:
-        """Multi-rank: decide whether the WHOLE step -- kernels and collectives -- may run as one hipGraph (`graph_collectives`).
-        Runs ONE training step from the current state twice, as the default form (hipGraph segments with eager collectives between
-        the replays) and as the one-graph form (collectives captured: no eager launches, no cross-stream fork / join between
-        replays), and compares every parameter, Adam moment, gradient and the loss BIT FOR BIT; the state (weights, moments, step
-        counter, dropout keys) is restored in between and afterwards, so the check leaves no trace.  The verdict is MIN-reduced
-        over the group: every rank adopts the one-graph form or none does.  Any exception while capturing or replaying the
-        one-graph form counts as a failed check.  A collective (all ranks call it with their own batch of the same shape)."""
-        if not (self.use_graph and self.graph_capable and self.world > 1):
-            self.graph_collectives = False
-            return False
-        if torch.distributed.get_backend(self.pg) != "nccl":
-            # only RCCL's collectives are stream operations that a hipGraph can hold; gloo's run on the host (attempting to capture
-            # one invalidates the capture and leaves the stream unusable) -- nothing to try, the segment form stays
-            self.graph_collectives = False
-            return False
-        torch.cuda.synchronize()
-        snap = [t.clone() for t in self._state_tensors()]
-
-        def restore():
-            for t, s in zip(self._state_tensors(), snap):
-                t.copy_(s)
-
-        def one_step(flag):
-            self.graph_collectives = flag
-            self._graphs.clear()
-            self.train_step(his, pred, y)   # captures
-            restore()
-            self.train_step(his, pred, y)   # replays from the same state
-            torch.cuda.synchronize()
-            out = [t.clone() for t in self._state_tensors()]
-            restore()
-            return out
-
-        ok = True
-        try:
-            ref = one_step(False)
-            got = one_step(True)
-            ok = all(torch.equal(a, b) for a, b in zip(ref, got))
-        except Exception:  # capture of a collective refused, a replay failed: keep the segment form
-            ok = False
-            restore()
-        verdict = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device)
-        torch.distributed.all_reduce(verdict, op=torch.distributed.ReduceOp.MIN, group=self.pg)
-        self.graph_collectives = bool(int(verdict.item()))
-        self._graphs.clear()
-        return self.graph_collectives
-
     def _train_bufs(self, B, C):
         N, E = B * (self.H + C), self.E
         nb = self._news_bufs(N, True)
@@ -1083,122 +894,6 @@ class NRMSEngine:
         return nb, ub
 
     SEG_KINDS = {"k": "kernels", "c": "collective", "a": "collective started asynchronously", "w": "wait for the started collectives"}
-
-    def _capture(self, B, C, advanced=False):
-        """Runs of kernel-only segments become hipGraphs; collectives stay eager launches between the replays."""
-        torch.cuda.synchronize()
-        segs, run, pool, i = self._segments(B, C, advanced), [], None, 0
-        desc = self.__dict__.setdefault("_graph_desc", {}).setdefault((B, C, advanced), [])
-        desc.clear()
-        if self.graph_collectives and self.world > 1:
-            # the collectives are captured too (RCCL supports stream capture): the whole multi-rank step is ONE graph, no
-            # eager launches and no cross-stream joins between replays
-            g = torch.cuda.CUDAGraph()
-            with _hip.capture(g):
-                for _kind, fn in segs:
-                    fn()
-            self._graph_objs = getattr(self, "_graph_objs", []) + [g]
-            self._graphs[(B, C, advanced)] = [g.replay]
-            desc.append("ONE hipGraph: " + " | ".join(self.SEG_KINDS[k] for k, _fn in segs))
-            return self._graphs[(B, C, advanced)]
-        while i < len(segs):
-            if segs[i][0] != "k":  # "c" | "a" | "w": collectives (and the wait for them) stay eager launches between the replays
-                run.append(segs[i][1])
-                desc.append(f"{self.SEG_KINDS[segs[i][0]]}: {getattr(segs[i][1], 'what', 'unnamed')} (segment {i} of the step's {len(segs)})")
-                i += 1
-                continue
-            j = i
-            while j < len(segs) and segs[j][0] == "k":
-                j += 1
-            g = torch.cuda.CUDAGraph()
-            with _hip.capture(g, pool=pool):  # (thread_local error mode, garbage collector held off: see _hip.capture)
-                for _kind, fn in segs[i:j]:
-                    fn()
-            pool = pool or g.pool()
-            run.append(g.replay)
-            desc.append(f"hipGraph replay of kernel segments {i}..{j - 1} of the step's {len(segs)}")
-            self._graph_objs = getattr(self, "_graph_objs", []) + [g]
-            i = j
-        self._graphs[(B, C, advanced)] = run
-        return run
-
-    def _segments(self, B, C, advanced=False):
-        """One training step as an ordered list of (kind, fn): "k" = kernels only (captured into hipGraphs), "c" = collective the
-        step waits for, "a" = collective started asynchronously (RCCL runs it on its own stream after everything enqueued so far;
-        the following kernels do not wait), "w" = wait for every started collective.
-
-        Multi-rank data parallel: the dense gradients travel as ONE flat bucket.  With a trainable table it is started
-        asynchronously after the dWqkv GEMM and runs under the dX GEMM and the table-gradient accumulation; with a frozen table
-        nothing follows dWqkv and it is issued in place.  The same collective on the same buffer either way: the overlapped step
-        is bit-identical to the serial one."""
-        N = B * (self.H + C)
-        nb, _ub = self._train_bufs(B, C)
-        multi = self.world > 1
-        segs = [] if advanced else [("k", lambda: _hip.call("ebn_step_advance", _hip.ptr(self.state), BETA1, BETA2, _hip.stream_handle()))]
-        if self._planned:
-            segs += self._lookup_segments(nb, N)
-        sparse = self._sparse_dp(N * self.T)
-        if multi and self.mlp is None and self.overlap_collectives and self.train_embedding:
-            # trainable table: the flat bucket of dense gradients is complete after the dWqkv GEMM and travels under the dX GEMM and the
-            # table-gradient accumulation (~430 us at c4).  ONE extra graph boundary: every asynchronous collective costs a
-            # cross-stream fork / join between graph replays -- measured with identity collectives on a 1-rank RCCL group
-            # (tools/overlap_split_probe.py): +24 us at c4 for this cut, +30-35 us more for a finer one that would also start
-            # the gradients finished before the attention backward under it -- as much as that 2.6 MB all-reduce is expected to
-            # take.  With a frozen table nothing follows dWqkv, so the step stays graph | bucket | graph.
-            segs.append(("k", lambda: (self._fwd_bwd_kernels(B, C, sparse, part="a"), self._fwd_bwd_kernels(B, C, sparse, part="b"))))
-            segs.append(_named("a", lambda: self._allreduce_async(self.params.grad), "all-reduce of the flat dense-gradient bucket"))
-            segs.append(("k", lambda: self._fwd_bwd_kernels(B, C, sparse, part="c")))
-            if self._planned:
-                segs += self._table_grad_segments(nb, N)
-            if self.exchange is None and not sparse:
-                segs.append(_named("c", lambda: self._allreduce_table_grad(), "all-reduce of the dense (V, D) table gradient"))
-            if sparse:
-                segs += self._sparse_table_grad_segments(nb, N)
-            segs.append(("w", self._wait_collectives))
-        else:
-            segs.append(("k", lambda: self._fwd_bwd_kernels(B, C, sparse)))
-            if self._planned and self.train_embedding:
-                segs += self._table_grad_segments(nb, N)
-            if multi:
-                segs.append(_named("c", lambda: self._allreduce_grads(dense_table=not sparse),
-                                   "all-reduce of the flat dense-gradient bucket" + (" and of the dense table gradient" if (self.train_embedding and self.exchange is None and not sparse) else "")))
-            if sparse:
-                segs += self._sparse_table_grad_segments(nb, N)
-        segs.append(("k", lambda: self._optimizer_kernels(from_acc=self._adam_from_acc or sparse)))
-        return segs
-
-    def _allreduce_async(self, t):
-        if self.world > 1 and not self.skip_collectives:
-            self._pending.append(torch.distributed.all_reduce(t, group=self.pg, async_op=True))
-
-    def _wait_collectives(self):
-        for w in self._pending:
-            w.wait()  # RCCL: the compute stream waits for the collective's stream (no host block); gloo: the host waits
-        self._pending = []
-
-    def _allreduce_table_grad(self):
-        if self.world > 1 and not self.skip_collectives:
-            torch.distributed.all_reduce(self.table_grad, group=self.pg)
-
-    def _sparse_table_grad_segments(self, nb, N):
-        n_tok, W = N * self.T, self.world
-        if getattr(nb, "ids_all", None) is None or nb.ids_all.numel() < W * n_tok:
-            nb.ids_all = torch.empty(W * nb.n_seq * self.T, dtype=torch.int32, device=self.device)
-            nb.dX_all = torch.empty(W * nb.n_seq * self.T, self.D, device=self.device)
-        ids_all, dX_all = nb.ids_all[: W * n_tok], nb.dX_all[: W * n_tok]
-        site, p = (0, self.p) if self.p > 0 else (-1, 0.0)
-
-        def gather():
-            if self.skip_collectives:
-                return
-            torch.distributed.all_gather_into_tensor(ids_all, nb.ids[:n_tok], group=self.pg)
-            torch.distributed.all_gather_into_tensor(dX_all, nb.dX[:n_tok], group=self.pg)
-
-        def accumulate():  # one launch per rank's slab: the dropout mask of d(X) is indexed by the position in THAT rank's batch
-            for r in range(W):
-                self._accumulate_fixed(ids_all[r * n_tok:], dX_all[r * n_tok:], n_tok, _hip.ptr(self.state), site, p)
-
-        return [_named("c", gather, "all-gather of the per-token (id, gradient row) pairs (sparse table-gradient exchange)"), ("k", accumulate)]
 
     def _fwd_bwd_kernels(self, B, C, sparse_table_grads=False, part="all"):
         """part: "all" = the whole forward + backward (one rank: the stage calls run the news backward as one C call);
@@ -1363,14 +1058,6 @@ class NRMSEngine:
             else:
                 _hip.call("ebn_embedding_grad_scatter_f32", _hip.ptr(nb.ids), _hip.ptr(nb.dX), _hip.ptr(self.table_grad),
                           N * self.T, self.D, self.V, st, site, ctypes.c_float(p), S())
-
-    def _allreduce_grads(self, dense_table=True):
-        """Data-parallel gradient all-reduce over RCCL (SUM; the 1/world is folded into Adam): one flat bucket."""
-        if self.world > 1 and not self.skip_collectives:
-            torch.distributed.all_reduce(self.params.grad, group=self.pg)
-            # (a sharded table's gradients already sit at their owner; the sparse exchange all-gathers token rows instead)
-            if self.train_embedding and self.exchange is None and dense_table:
-                torch.distributed.all_reduce(self.table_grad, group=self.pg)
 
     def _optimizer_kernels(self, from_acc=None):
         from_acc = self._adam_from_acc if from_acc is None else from_acc
