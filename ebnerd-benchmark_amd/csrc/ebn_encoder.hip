@@ -39,6 +39,26 @@ extern "C" int ebn_encoder_fwd_f32(const ebn_encoder_dims* dims, const ebn_encod
   return EBN_OK;
 }
 
+extern "C" int ebn_encoder_fwd_gather_f32(const ebn_encoder_dims* dims, const ebn_encoder_params* p, const ebn_encoder_acts* a,
+                                          const ebn_encoder_scratch* s, const int32_t* ids, const float* table, int64_t table_rows,
+                                          int32_t* oob_flag, ebn_stream_t stream) {
+  EBN_TRY(check_dims(dims));
+  EBN_REQUIRE(p && a && ids && table && p->Wqkv && p->W && p->b && p->q, EBN_ERR_BAD_ARG);
+  EBN_REQUIRE(a->QKV && a->Y && a->U && a->w && a->out, EBN_ERR_BAD_ARG);
+  EBN_REQUIRE(dims->drop_p <= 0.0f, EBN_ERR_UNSUPPORTED);  // a dropout between gather and projection needs the rows materialised
+  const int64_t R = dims->n_seq * dims->L;
+  const int E = dims->h * dims->d;
+  if (R == 0) return EBN_OK;
+  float* ws = s ? s->gemm_ws : nullptr;
+  const int64_t ws_n = s ? s->gemm_ws_floats : 0;
+  // Q|K|V = table[ids].Wqkv: the rows go table -> LDS -> MFMA, X is never written (nrms.py:125-139 in inference mode)
+  EBN_TRY(ebn_gemm_f32_rowmap(ids, table_rows, R, 3 * E, dims->Din, table, dims->Din, p->Wqkv, 3 * E, a->QKV, 3 * E, oob_flag, stream));
+  EBN_TRY(ebn_attn_fwd_f32(a->QKV, 3 * E, a->Y, E, dims->n_seq, dims->L, dims->h, dims->d, nullptr, -1, 0.0f, stream));
+  EBN_TRY(ebn_gemm_f32_ws(0, 0, R, dims->A, E, 1.0f, a->Y, E, p->W, dims->A, 0.0f, a->U, dims->A, ws, ws_n, stream));
+  EBN_TRY(ebn_attpool_fwd_f32(a->U, p->b, p->q, a->Y, a->out, a->w, dims->n_seq, dims->L, E, dims->A, stream));
+  return EBN_OK;
+}
+
 extern "C" int ebn_encoder_bwd_f32(const ebn_encoder_dims* dims, const ebn_encoder_params* p,
                                    const ebn_encoder_acts* a, const float* dout, const ebn_encoder_grads* g,
                                    const ebn_encoder_scratch* s, float* dX, int32_t accumulate,

@@ -167,6 +167,12 @@ struct GemmEpi {
   float* colsum = nullptr;
   const float* l2w = nullptr;
   float two_lambda = 0.f;
+  // EPI = 3 (ebn_gemm_f32_rowmap): row r of the A operand is row rowmap[r] of a (rowmap_rows, K) table -- the embedding gather of
+  // nrms.py:125-134 fused into the projection's A-operand fetch (inference: no dropout between them); ids outside the table read
+  // row 0 and raise *oob
+  const int32_t* rowmap = nullptr;
+  int64_t rowmap_rows = 0;
+  int32_t* oob = nullptr;
 };
 
 // TA: A stored [K,M]; TB: B stored [N,K].
@@ -252,6 +258,13 @@ __global__ __launch_bounds__(GEMM_THREADS, GEMM_WPE) void gemm_f32_kernel(
   static_assert(BM <= 256 && BN <= 256 && A_IPW >= 1 && B_IPW >= 1, "glds tiling");
   uint32_t gao[GLDS_A ? A_IPW : 1], gbo[GLDS_B ? B_IPW : 1];  // lane byte offsets into arsrc / brsrc
   // Everything that depends on WHICH tile (and K split) this is: origin, K range, buffer resources, lane offsets.
+  constexpr bool ROWMAP = EPI == 3;
+  auto mapped_row = [&](int64_t row) -> int64_t {  // table row of operand row `row` (clamped into the table; the flag tells)
+    const int64_t id = epi.rowmap[row];
+    const bool in = id >= 0 && id < epi.rowmap_rows;
+    if (!in && epi.oob != nullptr) *epi.oob = 1;
+    return in ? id : 0;
+  };
   auto tile_setup = [&](int64_t v) {
     int64_t lin = v;
     {
@@ -267,7 +280,7 @@ __global__ __launch_bounds__(GEMM_THREADS, GEMM_WPE) void gemm_f32_kernel(
     nk = static_cast<int>((kend - kbeg + BK - 1) / BK);
     nk_full = static_cast<int>((kend - kbeg) / BK);  // slabs that lie completely inside [kbeg, kend)
     nk_main = VEC ? nk_full : 0;
-      arsrc = make_rsrc(TA ? A + kbeg * lda + m0 : A + m0 * lda + kbeg);
+      arsrc = make_rsrc(ROWMAP ? A + kbeg : (TA ? A + kbeg * lda + m0 : A + m0 * lda + kbeg));
       brsrc = make_rsrc(TB ? B + n0 * ldb + kbeg : B + kbeg * ldb + n0);
       sa = 0;
       sb = 0;
@@ -278,7 +291,7 @@ __global__ __launch_bounds__(GEMM_THREADS, GEMM_WPE) void gemm_f32_kernel(
         if (!TA) {  // A is [M][K]
           int64_t row = m0 + v / (BK / 4);
           row = row < M ? row : M - 1;
-          oa[i] = static_cast<uint32_t>(((row - m0) * lda + (v % (BK / 4)) * 4) * 4);
+          oa[i] = static_cast<uint32_t>(((ROWMAP ? mapped_row(row) : row - m0) * lda + (v % (BK / 4)) * 4) * 4);
         } else {  // A is [K][M]
           int64_t col = m0 + (v % (BM / 4)) * 4;
           col = col < M ? col : M - 4;
@@ -307,7 +320,7 @@ __global__ __launch_bounds__(GEMM_THREADS, GEMM_WPE) void gemm_f32_kernel(
           const int r = ((q * 4 + wave) * 64 + lane) >> 2, kq = (lane & 3) ^ ((r >> 2) & 3);
           int64_t row = m0 + r;
           row = row < M ? row : M - 1;
-          gao[q] = static_cast<uint32_t>(((row - m0) * lda + kq * 4) * 4);
+          gao[q] = static_cast<uint32_t>(((ROWMAP ? mapped_row(row) : row - m0) * lda + kq * 4) * 4);
         } else {
           const int krow = (wave * A_IPW + q) * A_RPI + lane / A_LPR;
           int64_t col = m0 + (lane % A_LPR) * 4;
@@ -504,7 +517,7 @@ _Pragma("unroll")  \
   const int64_t em0 = m0, en0 = n0, ezs = zsplit;
 
   // epilogue. C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-  if constexpr (EPI != 0) {
+  if constexpr (EPI == 1 || EPI == 2) {
     // Epilogues that READ (the rank-1 operands, the bias): all reads of the 16 elements of a 32x32 tile are issued first,
     // unconditionally and with clamped indices; validity only guards the stores.  Reads placed next to the per-element
     // guards are serialised -- one global round trip per element, 128 per lane for the rank-1 form.  (The plain
@@ -620,7 +633,13 @@ int launch_gemm(int transA, int transB, int64_t M, int64_t N, int64_t K, float a
     else                                                                                                  \
       return EBN_ERR_UNSUPPORTED;                                                                         \
   } while (0)
-  if (epi.bias != nullptr)  // caller guarantees !transA && !transB && vecA && vecB
+  if (epi.rowmap != nullptr) {  // caller guarantees !transA && !transB && vecA && vecB, no split-K; the 256 x 64 tile only
+    if constexpr (BM == 256)
+      hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WAVES_M, false, false, true, 3>), grid, block, 0, s, M, N, K, alpha, A, lda, B, ldb, beta,
+                         C, ldc, k_per_split, part, epi);
+    else
+      return EBN_ERR_UNSUPPORTED;
+  } else if (epi.bias != nullptr)  // caller guarantees !transA && !transB && vecA && vecB
     hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WAVES_M, false, false, true, 2>), grid, block, 0, s, M, N, K, alpha, A, lda,
                        B, ldb, beta, C, ldc, k_per_split, part, epi);
   else if (epi.rs != nullptr)  // caller guarantees !transA && transB && vecA && vecB
@@ -1418,6 +1437,23 @@ extern "C" int ebn_dense_bwd_pair_f32(int64_t R, int64_t K_in, int64_t N_out, co
   const int rc = gemm_dispatch(1, 0, K_in, N_out, R, 1.0f, X, ldx, dY, lddy, beta_w, dW, lddw, workspace, workspace_floats, 0, none, s);
   if (rc != EBN_OK) return rc;
   return gemm_dispatch(0, 1, R, K_in, N_out, 1.0f, dY, lddy, W, ldw, 0.0f, dX, lddx, workspace, workspace_floats, 0, none, s);
+}
+
+extern "C" int ebn_gemm_f32_rowmap(const int32_t* ids, int64_t table_rows, int64_t M, int64_t N, int64_t K, const float* table,
+                                   int64_t ldt, const float* B, int64_t ldb, float* C, int64_t ldc, int32_t* oob_flag, ebn_stream_t stream) {
+  EBN_REQUIRE(ebn_dim_ok(M, N, K) && table_rows > 0, EBN_ERR_BAD_ARG);
+  if (M == 0 || N == 0) return EBN_OK;
+  EBN_REQUIRE(ids && table && B && C && ldt >= K && ldb >= N && ldc >= N && K > 0, EBN_ERR_BAD_ARG);
+  // the 256 x 64 tile with both operands fetched straight into LDS: aligned operands, whole tiles of rows, table offsets in 32 bits
+  const bool ok = M >= 256 && (ldt % 4) == 0 && (ldb % 4) == 0 && (K % 4) == 0 && (N % 4) == 0 && ebn_aligned16(table) && ebn_aligned16(B) &&
+                  (table_rows * ldt + K + 16) * 4 < (int64_t{1} << 32) && ((K + 16) * ldb + 256) * 4 < (int64_t{1} << 32);
+  if (!ok) return EBN_ERR_UNSUPPORTED;
+  GemmEpi epi{nullptr, nullptr, 0, 1, nullptr};
+  epi.rowmap = ids;
+  epi.rowmap_rows = table_rows;
+  epi.oob = oob_flag;
+  return launch_gemm<256, 64, 4>(0, 0, M, N, K, 1.0f, table, ldt, B, ldb, 0.0f, C, ldc, 1, 1, 1, ebn_ceil_div(K, BK) * BK, nullptr,
+                                 ebn_stream(stream), 0, epi);
 }
 
 extern "C" int ebn_gemm_tn_group_f32(const ebn_tn_problem* problems, int32_t n, ebn_stream_t stream) {

@@ -207,6 +207,7 @@ class NRMSEngine(StagingMixin, SegmentsMixin):
         self.loss_dev = torch.zeros(1, device=self.device)
         self.use_graph = False  # capture the per-shape kernel sequence into hipGraphs (enable_graphs())
         self.fuse_user_head = True  # False: the per-impression head of a step as its six separate launches (validation)
+        self.fuse_eval_gather = True  # False: inference gathers the token rows into X first, like a training step (validation / A-B)
         # True: the four small finishing passes of the backward (split-K sums of dW and dWqkv, AttLayer2 d(q) / d(b) column sums, the
         # per-impression head's d(q) / d(b) / loss sums) run as ONE launch at the end of the backward (ebn_grad_finish_f32) instead
         # of four launches of the dependent chain; same summation orders, same bits (False: the stand-alone passes -- validation)
@@ -666,6 +667,16 @@ class NRMSEngine(StagingMixin, SegmentsMixin):
             b.rows_uniq = self.exchange.lookup(b.plan, self._local_gather)
             self._gather_tokens(b, b.plan.inv, b.rows_uniq, b.rows_uniq.shape[0], n_tok, st, site, p, train)
             return self._encoder_fwd("n", b, N, b.X, train, n_first)
+        if not train and self.fuse_eval_gather and self.mlp is None and self.precision == "exact":
+            # inference: no Dropout between Embedding and the projection (nrms.py:136 is training-only), so the gather rides in the
+            # projection's A-operand fetch -- table rows -> LDS -> MFMA, the (n_tok, D) activations are never written or re-read
+            dims, params, acts = self._enc_structs("n", b, N, b.X, -1, 0.0)
+            rc = _hip.lib().ebn_encoder_fwd_gather_f32(ctypes.byref(dims), ctypes.byref(params), ctypes.byref(acts), ctypes.byref(self._fwd_scratch(b)),
+                                                       _hip.ptr(b.ids), _hip.ptr(self.table), self.V, _hip.ptr(self.oob_flag), _hip.stream_handle())
+            if rc == 0:
+                return
+            if rc != -2:  # EBN_ERR_UNSUPPORTED: a shape the fused kernel does not take (fewer than 256 token rows, ...): two steps
+                raise _hip.HipError(f"ebn_encoder_fwd_gather_f32 failed with code {rc}")
         self._gather_tokens(b, b.ids, self.table, self.V, n_tok, st, site, p, train)
         self._encoder_fwd("n", b, N, b.X, train, n_first)
 

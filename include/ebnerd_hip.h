@@ -341,6 +341,18 @@ typedef struct ebn_encoder_scratch {
 int ebn_encoder_fwd_f32(const ebn_encoder_dims* dims, const ebn_encoder_params* params,
                         const ebn_encoder_acts* acts, const ebn_encoder_scratch* scratch,
                         const ebn_step_state* st, ebn_stream_t stream);
+/* ebn_encoder_fwd_f32 of the news encoder in INFERENCE mode with the embedding gather fused into the projection
+ * (nrms.py:125-139 without the training-only Dropout of :136): row r of the projection's A operand is table[ids[r], :],
+ * fetched table -> LDS -> MFMA; X (a->X) is neither read nor written.  ids outside [0, table_rows) read row 0 and set
+ * *oob_flag (may be NULL).  EBN_ERR_UNSUPPORTED (nothing launched) when the shape is outside the fused kernel's
+ * (fewer than 256 token rows, unaligned operands, a table of 4 GB or more): the caller gathers and calls ebn_encoder_fwd_f32. */
+int ebn_encoder_fwd_gather_f32(const ebn_encoder_dims* dims, const ebn_encoder_params* params, const ebn_encoder_acts* acts,
+                               const ebn_encoder_scratch* scratch, const int32_t* ids, const float* table, int64_t table_rows,
+                               int32_t* oob_flag, ebn_stream_t stream);
+/* The fused product by itself: C (M, N) = table[ids[0..M), :] (K columns, leading dimension ldt) . B (K, N).  Same contract. */
+int ebn_gemm_f32_rowmap(const int32_t* ids, int64_t table_rows, int64_t M, int64_t N, int64_t K, const float* table,
+                        int64_t ldt, const float* B, int64_t ldb, float* C, int64_t ldc, int32_t* oob_flag, ebn_stream_t stream);
+
 /* dout [n_seq, E] -> parameter gradients (accumulated when accumulate != 0) and, when dX is
  * non-NULL, dX [R, Din] (overwritten).  acts->U is consumed (overwritten with d(pre-tanh)). */
 int ebn_encoder_bwd_f32(const ebn_encoder_dims* dims, const ebn_encoder_params* params,

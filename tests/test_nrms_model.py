@@ -91,6 +91,40 @@ def test_forward_matches_oracle_on_identical_weights(nrms, cfg):
     assert_close(ue, want_u, rtol=1e-5, atol=1e-5, what="userencoder")
 
 
+@pytest.mark.parametrize("D", [300, 64])
+def test_inference_with_the_gather_fused_into_the_projection_changes_no_bit(nrms, D):
+    """encode_news / predict in inference mode fetch the projection's A operand straight from the table (table rows -> LDS -> MFMA,
+    ebn_encoder_fwd_gather_f32: no Dropout between Embedding and K.dot at inference, nrms.py:125-139); against the two-step form
+    (gather into X, then the same GEMM) the news vectors are bit-identical wherever both run the same block tile -- the same fma
+    chains over the same operands -- for D with a partial last 16-deep slab (300) and without; at 270 token rows the planner gives
+    the two-step form another tile (other summation order: rounding-level differences); fewer than 256 rows fall back to it; an
+    out-of-range id raises either way."""
+    hp = make_hp()
+    V, seed = 777, 3
+    rng = np.random.default_rng(5)
+    P = on.random_nrms_params(V, D, hp.head_num, hp.head_dim, hp.attention_hidden_dim, seed=2)
+    m = nrms(hp, word2vec_embedding=P["emb"], seed=seed).from_keras_weight_list(weight_list(P))
+    eng = m._engine
+    for n_titles in (700, 9, 3):  # 21000 / 270 token rows: fused; 90: the two-step fallback inside the same call
+        ids = rng.integers(0, V, (n_titles, hp.title_size))
+        ids[0] = 0
+        eng.fuse_eval_gather = True
+        a = eng.encode_news(ids).cpu().numpy()
+        eng.fuse_eval_gather = False
+        b = eng.encode_news(ids).cpu().numpy()
+        if n_titles == 9:
+            assert_close(a, b, rtol=2e-5, atol=1e-6, what="fused vs two-step news vectors, different block tiles")
+        else:
+            assert np.array_equal(a, b), n_titles
+    ne = on.news_encoder_fwd(ids, P, hp.head_num, hp.head_dim)[0]
+    assert_close(a, ne, rtol=1e-4, atol=1e-5, what="fused-gather news vectors vs oracle")
+    eng.fuse_eval_gather = True
+    bad = rng.integers(0, V, (40, hp.title_size))
+    bad[7, 3] = V + 5
+    with pytest.raises(IndexError):
+        eng.encode_news(bad)
+
+
 def test_one_model_scores_every_history_length_from_1_to_50(nrms):
     """The reference's history-length sweep (ebnerd_nrms_doc_hist.py:270-300) feeds ONE trained model histories truncated to
     1 ... 50 entries: no weight of the user encoder depends on H (layers.py:200-254, 55-81), so scorer / userencoder take H
