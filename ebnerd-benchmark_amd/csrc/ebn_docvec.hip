@@ -801,14 +801,16 @@ extern "C" int ebn_dvn_fwd_train_f32(const ebn_dvn_args* a, const ebn_step_state
   return EBN_OK;
 }
 
-extern "C" int ebn_dvn_bwd_f32(const ebn_dvn_args* a, const ebn_step_state* st, ebn_stream_t stream) {
+// one launch of the backward: l = n_layers (output Dense) ... 1: dy_{l-1} = dropout-backward(dP_l . W_l^T), dP_l formed on the A operand
+// and written out; l = 0: dP_0 element-wise (+ the L2 term of the loss, + re-zeroing of the forward accumulators)
+static int dvn_bwd_layer(const ebn_dvn_args* a, int32_t l, const ebn_step_state* st, ebn_stream_t stream) {
   const int rc = check_args(a);
   if (rc != EBN_OK) return rc;
   EBN_REQUIRE(a->dNE != nullptr && a->NE != nullptr && a->stat != nullptr, EBN_ERR_BAD_ARG);
   hipStream_t s = ebn_stream(stream);
   const int L = a->n_layers;
-  // l = L (output Dense), L-1, ..., 1: dy_{l-1} = dropout-backward(dP_l . W_l^T); dP_l is formed on the A operand
-  for (int l = L; l >= 1; --l) {
+  EBN_REQUIRE(l >= 0 && l <= L, EBN_ERR_BAD_ARG);
+  if (l >= 1) {
     const StatView so = stat_view(a, l - 1);
     const EbnDrop d_out = ebn_make_drop(st, EBN_SITE_MLP0 + (l - 1), a->drop_p);
     PanelArgs p{};
@@ -828,40 +830,45 @@ extern "C" int ebn_dvn_bwd_f32(const ebn_dvn_args* a, const ebn_step_state* st, 
     p.thresh = d_out.thresh;
     p.scale = d_out.scale;
     EBN_REQUIRE(p.B && p.C && p.Aout && p.Rout, EBN_ERR_BAD_ARG);
-    int r;
     if (l == L) {
       p.A = a->dNE;
       p.A2 = a->NE;
-      r = launch_panel<AX_RELU, true, EPI_DY>(p, s);
-    } else {
-      const StatView si = stat_view(a, l);
-      EBN_REQUIRE(a->dY[l] && a->R[l] && a->gamma[l] && a->ggamma[l] && a->gbeta[l], EBN_ERR_BAD_ARG);
-      p.A = a->dY[l];
-      p.A2 = a->R[l];
-      p.in_acc = si.bwd;
-      p.gamma = a->gamma[l];
-      p.mean_io = si.mean;
-      p.istd_io = si.istd;
-      p.ggamma = a->ggamma[l];
-      p.gbeta = a->gbeta[l];
-      r = launch_panel<AX_DBN, true, EPI_DY>(p, s);
+      return launch_panel<AX_RELU, true, EPI_DY>(p, s);
     }
-    if (r != EBN_OK) return r;
+    const StatView si = stat_view(a, l);
+    EBN_REQUIRE(a->dY[l] && a->R[l] && a->gamma[l] && a->ggamma[l] && a->gbeta[l], EBN_ERR_BAD_ARG);
+    p.A = a->dY[l];
+    p.A2 = a->R[l];
+    p.in_acc = si.bwd;
+    p.gamma = a->gamma[l];
+    p.mean_io = si.mean;
+    p.istd_io = si.istd;
+    p.ggamma = a->ggamma[l];
+    p.gbeta = a->gbeta[l];
+    return launch_panel<AX_DBN, true, EPI_DY>(p, s);
   }
-  {  // dP_0 element-wise
-    const StatView s0 = stat_view(a, 0);
-    EBN_REQUIRE(a->dY[0] && a->R[0] && a->gamma[0] && a->ggamma[0] && a->gbeta[0] && a->dP[0], EBN_ERR_BAD_ARG);
-    ApplyArgs q{a->n0, a->n1, a->units[0], a->dY[0], a->R[0], s0.bwd, a->gamma[0], s0.mean, s0.istd, a->dP[0], a->ggamma[0], a->gbeta[0]};
-    q.zero = reinterpret_cast<float*>(s0.fwd);  // the forward accumulators of all layers, for the next step
-    q.zero_n = static_cast<int>(8 * sum_units(a, L));
-    q.l2_part = l2_view(a);
-    q.n_l2 = a->l2 > 0.f ? L : 0;
-    for (int l = 0; l < L; ++l) q.l2_tiles[l] = (a->units[l] + TN - 1) / TN;
-    q.l2 = a->l2;
-    q.loss = a->loss;
-    const dim3 grid(static_cast<unsigned>((a->units[0] + 255) / 256), static_cast<unsigned>(row_tiles(a)));
-    hipLaunchKernelGGL(dvn_dbn_apply_kernel, grid, dim3(ATHR), 0, s, q);
-    EBN_CHECK_LAUNCH();
+  const StatView s0 = stat_view(a, 0);
+  EBN_REQUIRE(a->dY[0] && a->R[0] && a->gamma[0] && a->ggamma[0] && a->gbeta[0] && a->dP[0], EBN_ERR_BAD_ARG);
+  ApplyArgs q{a->n0, a->n1, a->units[0], a->dY[0], a->R[0], s0.bwd, a->gamma[0], s0.mean, s0.istd, a->dP[0], a->ggamma[0], a->gbeta[0]};
+  q.zero = reinterpret_cast<float*>(s0.fwd);  // the forward accumulators of all layers, for the next step
+  q.zero_n = static_cast<int>(8 * sum_units(a, L));
+  q.l2_part = l2_view(a);
+  q.n_l2 = a->l2 > 0.f ? L : 0;
+  for (int i = 0; i < L; ++i) q.l2_tiles[i] = (a->units[i] + TN - 1) / TN;
+  q.l2 = a->l2;
+  q.loss = a->loss;
+  const dim3 grid(static_cast<unsigned>((a->units[0] + 255) / 256), static_cast<unsigned>(row_tiles(a)));
+  hipLaunchKernelGGL(dvn_dbn_apply_kernel, grid, dim3(ATHR), 0, s, q);
+  EBN_CHECK_LAUNCH();
+  return EBN_OK;
+}
+
+extern "C" int ebn_dvn_bwd_f32(const ebn_dvn_args* a, const ebn_step_state* st, ebn_stream_t stream) {
+  const int rc = check_args(a);
+  if (rc != EBN_OK) return rc;
+  for (int l = a->n_layers; l >= 0; --l) {
+    const int r = dvn_bwd_layer(a, l, st, stream);
+    if (r != EBN_OK) return r;
   }
   return EBN_OK;
 }
