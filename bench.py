@@ -903,7 +903,7 @@ def main():
         gemm_flops = 2.0 * n_tok * c["D"] * 3 * E
         bm, bn, sp = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
         _hip.call("ebn_gemm_plan", n_tok, 3 * E, c["D"], 0, ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(sp))
-        gemm_name = (f"gemm_f32_kernel<{bm.value}, {bn.value}, {4 if bm.value == 256 else 2}, false, false, true, 1, 0>" if bm.value != 32
+        gemm_name = (f"gemm_f32_kernel<{bm.value}, {bn.value}, {4 if bm.value == 256 else 2}, false, false, true, 0>" if bm.value != 32
                      else "gemm_small_vec_kernel<false, false, 32>") + f" (ebn_gemm_plan: tile {bm.value}x{bn.value}, split-K {sp.value})"
         gather_bytes = n_tok * (4 + 2 * c["D"] * 4)  # id + row read + row write (materialising gather)
         probed = None if (args.no_probe or args.no_roofline or world > 1) else probe_kernels(args.config, args.batch, args.precision, args.ids)

@@ -5,14 +5,15 @@
 # --pmc passes are separate runs with --kernel-trace only (no sys/hip/hsa trace domains), as the pool requires.
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
-tag=${1:-r04}
+tag=${1:-r05}
 out=gpurun_out/$tag
 mkdir -p $out
 timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -5 > $out/pytest_gpu.log
 # the driver's command first (c2, CPU baseline included), then every other config
 python bench.py --steps 20 --warmup 5 > $out/bench_c2.json 2> $out/bench_c2.err
 for c in c1 c3 c4 c5 c5h50; do
-  python bench.py --config $c --steps 20 --warmup 5 --no-cpu-baseline --no-split-leg > $out/bench_$c.json 2> $out/bench_$c.err
+  nocpu=--no-cpu-baseline; [ $c = c3 ] && nocpu=   # c3 carries its own cpu_baseline leg (a second of CPU work)
+  python bench.py --config $c --steps 20 --warmup 5 $nocpu --no-split-leg > $out/bench_$c.json 2> $out/bench_$c.err
 done
 # SURVEY.md 8(d) "Z" inputs (Zipf ids + 15 % padded history slots): every trainable / sharded config, and the A/B of the table-gradient
 # accumulation on them (duplicate-combining default vs one atomic per element)
@@ -48,6 +49,6 @@ rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-
 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $out/pmc_mfma_b -o b -- \
   python bench.py --no-graph --no-roofline --no-probe --no-fit-loop --no-split-leg --no-cpu-baseline --steps 10 --warmup 2 --repeats 1 > /dev/null 2> $out/pmc_mfma_b.err
 rm -f $out/pmc_mfma_*/*kernel_trace.csv $out/pmc_mfma_*/*agent_info.csv
-bash tools/trace_kernel.sh c2 "256, 64, 4, false, false, true, 1" > $out/gemm_launch_trace.txt 2>&1
+bash tools/trace_kernel.sh c2 "256, 64, 4, false, false, true, 0" > $out/gemm_launch_trace.txt 2>&1
 cat $out/pytest_gpu.log
 ls $out

@@ -13,7 +13,7 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
 # the Q|K|V projection is the SITE = 1 instantiation of the GEMM template (SITE template argument), whatever its tile
-KERNELS = {"gather": (r"gather_rows_vec4_kernel", None), "qkv_gemm": (r"gemm_f32_kernel<\d+, \d+, \d+, false, false, true, 1\b", None)}
+KERNELS = {"gather": (r"gather_rows_vec4_kernel", None), "qkv_gemm": (r"gemm_f32_kernel<\d+, \d+, \d+, false, false, true, 0\b", None)}
 
 
 def per_kernel(path, counter):
