@@ -47,7 +47,9 @@ constexpr int SB = TN * TK / 4 / NTHR;  // ... of the B tile (4)
 constexpr int TILE_A = TM * LD, TILE_B = TN * LD;
 constexpr int MAX_K = 1024;     // widest layer whose per-column constants fit next to the tiles in LDS
 constexpr int MAX_TILES = 4096;  // row tiles of both sites together (131 072 rows: only the launch geometry bounds it)
-// fixed-point scales of the accumulators: forward sums of relu outputs / of their squares, backward sums of gradients
+// fixed-point scales of the accumulators: forward sums of relu outputs / of their squares, backward sums of gradients.  Ranges: |sum x| <
+// 2^31, sum x^2 < 2^35, |sum dy| < 2^23 per call site and column -- orders of magnitude beyond a model that has not diverged (a diverged one
+// shows in the activations themselves: NaN / Inf travel through the data path, only the statistics are formed from the integer sums)
 constexpr float FIX_SUM = 4294967296.0f /* 2^32 */, FIX_SQ = 268435456.0f /* 2^28 */, FIX_GRAD = 1099511627776.0f /* 2^40 */;
 constexpr int L2_SLOTS = MAX_K / 64;  // column tiles of the widest regularised kernel
 

@@ -1176,3 +1176,88 @@ def test_one_finishing_launch_equals_the_four_stand_alone_passes(hip):
     bad = (hip.FinishJob * 1)(_finish_job(hip, 7, 1, 4, 4, w1, dW_b, ld=4))
     with pytest.raises(hip.HipError):
         hip.call("ebn_grad_finish_f32", bad, 1, S())
+
+
+# ---------------------------------------------------------------- round 5: grouped TN products, row-mapped A, the DocVec prologue
+@pytest.mark.parametrize("shapes", [[(48, 40, 96), (20, 36, 96)],                                  # 32 x 32 tiles, partial tiles, one slab
+                                    [(768, 512, 800), (512, 512, 800), (512, 512, 800), (512, 256, 800)],  # the c3 group: 64 x 64 tiles
+                                    [(132, 68, 1000), (8, 4, 5), (64, 64, 128)]])
+def test_tn_group_products_column_sums_and_l2_term(hip, shapes):
+    """ebn_gemm_tn_group_f32: C_i = A_i^T . B_i for every problem of the group in one launch, colsum_i = column sums of B_i (the bias
+    gradient of a Dense layer), C_i += two_lambda * W_i (kernel_regularizer=l2) -- against float64."""
+    from ebrec import _hip
+
+    rng = np.random.default_rng(len(shapes) * 7 + shapes[0][0])
+    probs = (_hip.TnProblem * len(shapes))()
+    keep, want = [], []
+    for i, (M, N, K) in enumerate(shapes):
+        A, B, W = (rng.standard_normal(s).astype(np.float32) for s in ((K, M), (K, N), (M, N)))
+        dA, dB, dW = dev(A), dev(B), dev(W)
+        C, cs = torch.full((M, N), float("nan"), device="cuda"), torch.full((N,), float("nan"), device="cuda")
+        q = probs[i]
+        q.M, q.N, q.K, q.A, q.lda, q.B, q.ldb, q.C, q.ldc = M, N, K, dA.data_ptr(), M, dB.data_ptr(), N, C.data_ptr(), N
+        lam = 0.25 if i % 2 == 0 else 0.0
+        if i != 1:
+            q.colsum = cs.data_ptr()
+        if lam:
+            q.l2_W, q.two_lambda = dW.data_ptr(), lam
+        keep += [dA, dB, dW, C, cs]
+        want.append((A.astype(np.float64).T @ B.astype(np.float64) + lam * W, B.astype(np.float64).sum(0), i != 1))
+    hip.call("ebn_gemm_tn_group_f32", probs, len(shapes), S())
+    for i, (c_ref, cs_ref, has_cs) in enumerate(want):
+        C, cs = keep[5 * i + 3], keep[5 * i + 4]
+        assert_close(host(C), c_ref, rtol=2e-5, atol=2e-5 * np.abs(c_ref).max(), what=f"C of problem {i}")
+        if has_cs:
+            assert_close(host(cs), cs_ref, rtol=2e-5, atol=2e-5 * max(1.0, np.abs(cs_ref).max()), what=f"column sums of problem {i}")
+    bad = (_hip.TnProblem * 1)()
+    bad[0].M, bad[0].N, bad[0].K = 6, 8, 16  # M % 4 != 0: the group takes aligned problems only
+    bad[0].A = bad[0].B = bad[0].C = keep[0].data_ptr()
+    bad[0].lda, bad[0].ldb, bad[0].ldc = 6, 8, 8
+    assert hip.lib().ebn_gemm_tn_group_f32(bad, 1, S()) == -2
+
+
+@pytest.mark.parametrize("M,N,K,V", [(270, 1200, 300, 500), (1000, 64, 1024, 77), (256, 132, 40, 1000)])
+def test_row_mapped_projection_equals_gather_then_gemm(hip, M, N, K, V):
+    """ebn_gemm_f32_rowmap: C = table[ids] . B with the rows fetched table -> LDS inside the GEMM -- against float64, with a partial
+    last 16-deep slab (K = 300, 40), ragged M / N, repeated and boundary ids; an id outside the table raises the flag; fewer than
+    256 rows are EBN_ERR_UNSUPPORTED (the caller gathers first)."""
+    rng = np.random.default_rng(M + N)
+    table, B = rng.standard_normal((V, K)).astype(np.float32), rng.standard_normal((K, N)).astype(np.float32)
+    ids = rng.integers(0, V, M).astype(np.int32)
+    ids[0], ids[1], ids[-1] = 0, V - 1, ids[2]
+    C = torch.full((M, N), float("nan"), device="cuda")
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    dt, dB, di = dev(table), dev(B), dev(ids, torch.int32)
+    hip.call("ebn_gemm_f32_rowmap", P(di), V, M, N, K, P(dt), K, P(dB), N, P(C), N, P(flag), S())
+    ref = table[ids].astype(np.float64) @ B.astype(np.float64)
+    assert_close(host(C), ref, rtol=2e-5, atol=2e-5 * np.abs(ref).max(), what="row-mapped product")
+    assert int(flag.item()) == 0
+    ids[5] = V + 3
+    hip.call("ebn_gemm_f32_rowmap", P(dev(ids, torch.int32)), V, M, N, K, P(dt), K, P(dB), N, P(C), N, P(flag), S())
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 1
+    assert hip.lib().ebn_gemm_f32_rowmap(P(di), V, 255, N, K, P(dt), K, P(dB), N, P(C), N, P(flag), S()) == -2
+
+
+def test_docvec_step_prologue_in_one_launch(hip):
+    """ebn_docvec_stage_gather_f32 = ebn_step_advance + label copy + ebn_gather_rows_f32 over two index segments, bit for bit."""
+    rng = np.random.default_rng(3)
+    n_rows, din, n0, n1 = 300, 768, 37, 11
+    matrix = rng.standard_normal((n_rows, din)).astype(np.float32)
+    i0, i1 = rng.integers(0, n_rows, n0).astype(np.int32), rng.integers(0, n_rows, n1).astype(np.int32)
+    i0[0], i1[-1] = 0, n_rows - 1
+    lab = rng.random(n1).astype(np.float32)
+    st = make_state(seed=9, step=4, lr=1e-3)
+    X0, lab_d = torch.full((n0 + n1, din), float("nan"), device="cuda"), torch.zeros(n1, device="cuda")
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    dm = dev(matrix)
+    hip.call("ebn_docvec_stage_gather_f32", P(dev(i0, torch.int32)), n0, P(dev(i1, torch.int32)), n1, P(dev(lab)), P(lab_d), n1, P(dm), n_rows, din,
+             P(X0), P(flag), P(st), 0.9, 0.999, S())
+    assert np.array_equal(host(X0), matrix[np.concatenate([i0, i1])]) and np.array_equal(host(lab_d), lab) and int(flag.item()) == 0
+    got = read_state(st)
+    assert got.step == 5 and got.drop_key[8] == on.dropout_key(9, 5, 8)
+    i1[3] = n_rows
+    hip.call("ebn_docvec_stage_gather_f32", P(dev(i0, torch.int32)), n0, P(dev(i1, torch.int32)), n1, None, None, 0, P(dm), n_rows, din, P(X0), P(flag),
+             None, 0.9, 0.999, S())
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 1 and not host(X0)[n0 + 3].any()
