@@ -302,6 +302,64 @@ __global__ __launch_bounds__(POOL_THREADS) void attpool_bwd_dpre_kernel(float* _
 
 }  // namespace
 
+// The same for A % 4 == 0, A <= 1024 and 16-byte aligned U: thread = (4 columns, row stripe); a thread's rows of a batch are requested
+// together as 16-byte pieces (eight rows = 128 bytes in flight per thread where the kernel above has 32), the stripes are combined
+// through LDS in a fixed order.
+__global__ __launch_bounds__(POOL_THREADS) void attpool_bwd_dpre_vec_kernel(float* __restrict__ U, const float* __restrict__ q,
+                                                                             const float* __restrict__ de, float* __restrict__ partials,
+                                                                             int64_t R, int A, int64_t rpb) {
+  extern __shared__ float sm[];  // [2][RS][A]
+  const int A4 = A >> 2, RS = POOL_THREADS / A4;
+  const int tid = threadIdx.x, c4 = tid % A4, rs = tid / A4;
+  const bool active = rs < RS;
+  const int64_t r0 = static_cast<int64_t>(blockIdx.x) * rpb;
+  const int64_t r1 = (r0 + rpb < R) ? r0 + rpb : R;
+  float4 dq = make_float4(0.f, 0.f, 0.f, 0.f), db = dq;
+  if (active) {
+    const float4 qk = *reinterpret_cast<const float4*>(q + c4 * 4);
+    for (int64_t rb = r0 + rs; rb < r1; rb += static_cast<int64_t>(8) * RS) {
+      float4 u[8];
+      float der[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        int64_t r = rb + static_cast<int64_t>(j) * RS;
+        r = r < r1 ? r : r1 - 1;  // clamped, unconditional
+        u[j] = *reinterpret_cast<const float4*>(U + r * A + c4 * 4);
+        der[j] = de[r];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int64_t r = rb + static_cast<int64_t>(j) * RS;
+        if (r >= r1) break;
+        const float d = der[j];
+        dq.x = fmaf(d, u[j].x, dq.x);
+        dq.y = fmaf(d, u[j].y, dq.y);
+        dq.z = fmaf(d, u[j].z, dq.z);
+        dq.w = fmaf(d, u[j].w, dq.w);
+        const float4 dp = make_float4(d * qk.x * (1.0f - u[j].x * u[j].x), d * qk.y * (1.0f - u[j].y * u[j].y),
+                                      d * qk.z * (1.0f - u[j].z * u[j].z), d * qk.w * (1.0f - u[j].w * u[j].w));
+        *reinterpret_cast<float4*>(U + r * A + c4 * 4) = dp;
+        db.x += dp.x;
+        db.y += dp.y;
+        db.z += dp.z;
+        db.w += dp.w;
+      }
+    }
+    *reinterpret_cast<float4*>(&sm[rs * A + c4 * 4]) = dq;
+    *reinterpret_cast<float4*>(&sm[(RS + rs) * A + c4 * 4]) = db;
+  }
+  __syncthreads();
+  for (int k = tid; k < A; k += POOL_THREADS) {
+    float tq = 0.f, tb = 0.f;
+    for (int i = 0; i < RS; ++i) {
+      tq += sm[i * A + k];
+      tb += sm[(RS + i) * A + k];
+    }
+    partials[(static_cast<int64_t>(blockIdx.x) * 2 + 0) * A + k] = tq;
+    partials[(static_cast<int64_t>(blockIdx.x) * 2 + 1) * A + k] = tb;
+  }
+}
+
 extern "C" int64_t ebn_attpool_partials_len(int64_t R, int32_t A) { return ebn_dim_ok(R, A) ? ebn_colred_blocks(R) * 2 * A : 0; }
 
 extern "C" int ebn_attpool_fwd_f32(float* U, const float* b, const float* q, const float* X, float* out,
@@ -349,8 +407,14 @@ extern "C" int ebn_attpool_bwd_dpre_f32(float* U, const float* q, const float* d
   if (R == 0) return EBN_OK;
   const int64_t nb = ebn_colred_blocks(R);
   const int64_t rpb = ebn_ceil_div(R, nb);
-  hipLaunchKernelGGL(attpool_bwd_dpre_kernel, dim3(static_cast<unsigned>(nb)), dim3(POOL_THREADS), 0,
-                     ebn_stream(stream), U, q, de, partials, R, A, rpb);
+  if ((A % 4) == 0 && A >= 4 && A <= 1024 && ebn_aligned16(U) && ebn_aligned16(q)) {
+    const size_t lds = static_cast<size_t>(2) * (POOL_THREADS / (A / 4)) * A * sizeof(float);  // <= 2 x 256 x 4 floats = 8 KB
+    hipLaunchKernelGGL(attpool_bwd_dpre_vec_kernel, dim3(static_cast<unsigned>(nb)), dim3(POOL_THREADS), lds, ebn_stream(stream), U, q, de, partials,
+                       R, A, rpb);
+  } else {
+    hipLaunchKernelGGL(attpool_bwd_dpre_kernel, dim3(static_cast<unsigned>(nb)), dim3(POOL_THREADS), 0,
+                       ebn_stream(stream), U, q, de, partials, R, A, rpb);
+  }
   EBN_CHECK_LAUNCH();
   if (dq == nullptr) return EBN_OK;  // the sum over the row blocks is left to ebn_grad_finish_f32 (EBN_FINISH_COLRED job over `partials`)
   ebn_reduce_partials(partials, nb, 2, A, 1.0f, dq, db, accumulate, nullptr, nullptr, ebn_stream(stream));
