@@ -166,7 +166,11 @@ int ebn_gemm_f32(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K
                  int64_t ldc, ebn_stream_t stream);
 /* Same, with a caller-owned scratch buffer that enables deterministic split-K for skinny
  * outputs (weight gradients: M,N ~ 1e3, K = all tokens of the batch).
- * ebn_gemm_workspace_floats() returns the size the planner can use for (M,N,K).        */
+ * ebn_gemm_workspace_floats() returns the size the planner can use for (M,N,K).
+ * NOTE: which kernel family runs DEPENDS on the scratch given: with no / too little of it a skinny product runs unsplit on
+ * the block tiles (or the 32 x 32 small-output tiles), with enough of it as split-K slices or -- transposed-A, small output,
+ * K >= 4096 -- as the K-chunked 16 x 16-block kernel (csrc/ebn_gemm_direct.hip), whose slices ebn_gemm_workspace_floats()
+ * already covers.  Results agree to fp32 summation order; callers that need bit-identical reruns keep the size fixed.  */
 int64_t ebn_gemm_workspace_floats(int64_t M, int64_t N, int64_t K);
 /* The plan the launcher will use for (M,N,K) with `workspace_floats` of scratch: block tile bm x bn (128x128, 64x64 or
  * the tall 256x64 that removes column padding / last-turn idling, e.g. N = 1200) and the split-K factor.  Diagnostic:
