@@ -537,7 +537,7 @@ def bench_docvec(args, c, world, rank, device, sync, dfields):
                                          "news encoder forward / weight gradient / input gradient, the user encoder, the scorer) / ms_per_step",
                                  "bound": "mfma", "achieved": fl_step / (ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                  "frac": fl_step / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, "flops_per_step": fl_step,
-                                 "launches_per_step": "20 (r4: 27): staging, gather, 4 + 4 fused Dense launches, the weight-gradient group, 8 of the user stage, Adam"}
+                                 "launches_per_step": "19 (r4: 27): one-launch prologue (state advance + labels + gather), 4 + 4 fused Dense launches, the weight-gradient group, 8 of the user stage, Adam"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_docvec(c)
         print("\n" + json.dumps(line), flush=True)  # (own line even when a library -- gloo -- has left an unterminated one on stdout)
