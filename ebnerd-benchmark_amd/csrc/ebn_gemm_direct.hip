@@ -144,7 +144,7 @@ __device__ __forceinline__ void dir_task(int64_t M, int64_t N, int64_t K, float 
 
   const int nkf = static_cast<int>(K / 16);         // full k groups
   const int krem = static_cast<int>(K - 16 * static_cast<int64_t>(nkf));  // 0, 4, 8 or 12 (K % 4 == 0)
-  DirFrags<R, NC> f0, f1, f2;
+  DirFrags<R, NC> f0, f1;
   uint32_t sa = 0, sb = 0;
   // A wave issues in order and a VMEM instruction holds its issue slot for tens of cycles (address + data path hand-off): a clump
   // of 31 loads in front of 84 MFMAs leaves the matrix pipe idle for the length of the clump -- with one wave per SIMD nobody
@@ -182,7 +182,7 @@ __device__ __forceinline__ void dir_task(int64_t M, int64_t N, int64_t K, float 
   // The sched_barriers keep the requests in front of the multiplies (the scheduler sinks loads to their uses).  The loops hold
   // ONLY unconditional fetches: a conditional one merging into them makes the compiler wait vmcnt(0), i.e. for the group it has
   // just requested.  Register sets alternate with literal names.
-  if (DEPTH == 2) {  // one group ahead
+  {  // one group ahead (a third register set, two groups ahead, measured slower: load latency is not what is left)
     if (nkf > 0) {
       EBN_DIR_FETCH(f0);
       int g = 0;
@@ -194,36 +194,6 @@ __device__ __forceinline__ void dir_task(int64_t M, int64_t N, int64_t K, float 
         EBN_DIR_STEP(f1, f0);
         EBN_DIR_MMA(f1);
       } else {
-        EBN_DIR_MMA(f0);
-      }
-    }
-  } else {  // two groups ahead: a group's operands have two groups' worth of MFMAs (2 x R*NC*128 cycles) to arrive
-    if (nkf > 0) {
-      EBN_DIR_FETCH(f0);
-      if (nkf > 1) EBN_DIR_FETCH(f1);
-      int g = 0;
-      for (; g + 4 < nkf; g += 3) {  // top: f0 = group g, f1 = group g + 1 requested, f2 free
-        EBN_DIR_STEP(f2, f0);
-        EBN_DIR_STEP(f0, f1);
-        EBN_DIR_STEP(f1, f2);
-      }
-      const int left = nkf - g;  // 1..4 groups left, f0 (and f1 when left > 1) requested
-      if (left == 1) {
-        EBN_DIR_MMA(f0);
-      } else if (left == 2) {
-        EBN_DIR_MMA(f0);
-        EBN_DIR_MMA(f1);
-      } else if (left == 3) {
-        EBN_DIR_FETCH(f2);
-        EBN_DIR_MMA(f0);
-        EBN_DIR_MMA(f1);
-        EBN_DIR_MMA(f2);
-      } else {
-        EBN_DIR_FETCH(f2);
-        EBN_DIR_MMA(f0);
-        EBN_DIR_FETCH(f0);
-        EBN_DIR_MMA(f1);
-        EBN_DIR_MMA(f2);
         EBN_DIR_MMA(f0);
       }
     }
@@ -256,7 +226,7 @@ __device__ __forceinline__ void dir_task(int64_t M, int64_t N, int64_t K, float 
 // blocks of its share: the first n_wide groups hold CW of them, the others CW - 1 (the two block counts an instantiation carries;
 // the host plan only offers splits of that form).
 template <int R, int CW, bool B_KC, int DEPTH>
-__global__ __launch_bounds__(256, (DEPTH == 3 && R * CW >= 14) ? 1 : 2) void gemm_direct16_kernel(int64_t M, int64_t N, int64_t K, float alpha, const float* __restrict__ A,
+__global__ __launch_bounds__(256, 2) void gemm_direct16_kernel(int64_t M, int64_t N, int64_t K, float alpha, const float* __restrict__ A,
                                                                int64_t lda, const float* __restrict__ B, int64_t ldb,
                                                                float* __restrict__ C, int64_t ldc, int32_t G, int32_t n_wide, int64_t n_tasks) {
   const int lane = threadIdx.x & 63;
