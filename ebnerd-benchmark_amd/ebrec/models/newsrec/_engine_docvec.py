@@ -44,6 +44,7 @@ class DocVecEngine:
         # True: BatchNormalization / Dropout / ReLU-backward of the news encoder ride in the Dense matmuls of a training step
         # (csrc/ebn_docvec.hip: one launch per layer and direction); False: the separate passes of csrc/ebn_dense.hip (validation form)
         self.fuse_news_mlp = True
+        self._dvn_dirty = False  # a fused forward whose backward has not been issued yet (see _dvn)
         self.mlp = MLPStack(self.params, "", self.Din, self.units, self.device, self.l2, on_realloc=lambda: self._graphs.clear())
         self.bn_mean, self.bn_var = self.mlp.bn_mean, self.mlp.bn_var
         self._init_weights(seed)
@@ -205,7 +206,7 @@ class DocVecEngine:
                     q.l2_W, q.two_lambda = pv(wn).data_ptr(), 2.0 * self.l2
             a._probs, a._stat = probs, stat
             mb[key] = a
-        if a and getattr(self, "_dvn_dirty", False):
+        if a and self._dvn_dirty:
             # a step that ran only half way (an exception between its forward and its backward) left the fixed-point accumulators
             # of the fused launches dirty: the contract of ebn_dvn_fwd_train_f32 is a zero scratch
             for k, v in mb.items():
@@ -519,7 +520,7 @@ class DocVecEngine:
     def sync_moving_statistics(self) -> None:
         """world > 1 with BatchNormalization layers: average the moving mean / variance over the ranks (a COLLECTIVE; fit() calls it
         at the end of every epoch, evaluate() and save_weights() on entry -- see MLPStack.sync_moving_statistics for the contract)."""
-        if self.world > 1 and True:
+        if self.world > 1:
             self.mlp.sync_moving_statistics(self.pg)
 
     def l2_penalty(self) -> float:
