@@ -47,7 +47,7 @@ static inline void ebn_colred_stage1(F f, float* partials, int64_t R, int C, hip
 // Stage 2: v_s[k] = scale * sum_b partials[b][s][k]; out_s[k] = (accumulate ? out_s[k] : 0) + v_s[k];
 // optional copies site_s[k] = v_s[k] (per-call-site values kept next to an accumulated total).
 // One 1024-thread block per 32 flattened (s,k) outputs: thread (col = t%32, part = t/32) sums every 32nd block
-// (coalesced 128-byte rows of partials; 4 independent loads in flight), then the 32 parts are combined in a fixed
+// (coalesced 128-byte rows of partials; 8 independent loads in flight), then the 32 parts are combined in a fixed
 // order through LDS.  (With 8 parts the ~94 dependent iterations of a 24,000-row call site cost 15 us.)
 // (the body, shared with the merged finishing pass of a training step: ebn_grad_finish_f32 in ebn_finish.hip; `blk` = index of the
 // 1024-thread block among the blocks of THIS reduction, `sm` = 32 x 33 floats of LDS)
@@ -61,12 +61,18 @@ static __device__ __forceinline__ void ebn_reduce_partials_body(float (*sm)[33],
   if (ok) {
     const float* p = partials + idx;
     const int64_t stride = 2 * static_cast<int64_t>(A);
-    int bk = part;
-    for (; bk + 96 < nblk; bk += 128) {
-      const float v0 = p[bk * stride], v1 = p[(bk + 32) * stride], v2 = p[(bk + 64) * stride], v3 = p[(bk + 96) * stride];
-      acc += (v0 + v1) + (v2 + v3);
+    // eight row blocks per round trip, unconditional loads with clamped indices (a 24 000-row call site leaves 750 row blocks = 24 per
+    // thread: four at a time plus a scalar tail were eight or nine dependent round trips -- the critical path of the step's finishing launch)
+    for (int bk = part; bk < nblk; bk += 256) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int b = bk + 32 * j;
+        v[j] = p[(b < nblk ? b : part) * stride];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc += (bk + 32 * j < nblk) ? v[j] : 0.f;
     }
-    for (; bk < nblk; bk += 32) acc += p[bk * stride];
   }
   sm[part][col] = acc;
   __syncthreads();
