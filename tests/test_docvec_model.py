@@ -193,3 +193,30 @@ def test_docvec_out_of_range_article_rows_raise_at_the_epoch_check_and_val_loss_
     penalty = 1e-2 * (float((w[0].astype(np.float64) ** 2).sum()) + float((w[6].astype(np.float64) ** 2).sum()))  # the two hidden Dense kernels
     got = m.model.evaluate((his, pred), yy, batch_size=6, return_dict=True)["loss"]
     assert abs(got - (plain + penalty)) <= 1e-5 * max(1.0, abs(got)), (got, plain, penalty)
+
+
+def test_a_step_that_stopped_between_forward_and_backward_does_not_poison_the_next_one(docvec):
+    """The fused launches keep their column sums in accumulators that the step itself re-zeroes (backward ones by the first forward launch,
+    forward ones by the last backward launch).  A step that ran only its forward -- an exception in between -- leaves them dirty: the engine
+    notices (`_dvn_dirty`) and clears the scratch, so the next step is the step a fresh model would take."""
+    hp = make_hp(title_size=64, newsencoder_units_per_layer=[48, 40], head_num=4, head_dim=8, attention_hidden_dim=12, history_size=7, dropout=0.0)
+    P = oracle_params(hp, 9)
+    rng = np.random.default_rng(2)
+    his, pred, y = data(rng, 8, hp.history_size, 5, hp.title_size)
+    grads = []
+    for interrupted in (False, True):
+        m = docvec(hp, seed=5)
+        m.model.set_weights(weight_list(P))
+        eng = m._engine
+        if interrupted:  # forward of a training step on other data, no backward
+            h2, p2, _ = data(np.random.default_rng(7), 8, hp.history_size, 5, hp.title_size)
+            mb = eng._mlp_bufs(8 * (hp.history_size + 5))
+            eng._dvn(mb, 8 * hp.history_size, 8 * 5)
+            eng._upload(mb, h2, p2)
+            eng._news_forward(mb, 8 * hp.history_size, 8 * 5, True)
+            assert eng._dvn_dirty
+            m.model.set_weights(weight_list(P))  # (the moving statistics the lone forward pass updated)
+        eng.train_step(his, pred, y)
+        assert not eng._dvn_dirty
+        grads.append(eng.params.grad.cpu().numpy().copy())
+    assert np.array_equal(grads[0], grads[1])
