@@ -13,7 +13,7 @@
 //   * the matmul that CONSUMES the normalised activations turns the accumulators into per-site batch statistics in its
 //     prologue (float64 for E[x^2] - mean^2) -- every workgroup redundantly, so there is no cross-workgroup dependency inside
 //     a launch -- and applies gamma * (x - mean) * istd + beta and the dropout mask to its A operand on the way from
-//     registers to LDS.  The workgroups of the first column tile also write the transformed operand out once
+//     registers to LDS.  The workgroups of a row tile also write the transformed operand out once, slab by slab in turns
 //     (it is the A operand of the weight gradient in backward); workgroup (0, 0) writes the statistics and updates the
 //     moving averages (history site first, then the candidate site: two TimeDistributed call sites, nrms_docvec.py:88-90,
 //     176-178).
@@ -78,7 +78,7 @@ struct PanelArgs {
   const float* B;      // B_KC ? [Nout][K] : [K][Nout]
   int ldb;
   float* C;            // (N, Nout)
-  float* Aout;         // transformed A operand, written by the first column tile's workgroups (may be null)
+  float* Aout;         // transformed A operand, written out once (slab kt by column tile kt mod #column tiles); may be null
   const long long* in_acc;  // accumulators of the A-side layer: [2 sums][2 sites][K]
   const float* gamma;  // of the A-side BatchNormalization
   const float* beta;
@@ -290,7 +290,10 @@ __global__ __launch_bounds__(NTHR) void dvn_panel_kernel(PanelArgs p) {
   }
 
   // ---- registers -> (transform) -> LDS ---------------------------------------------------------------------------------
-  const bool side = p.Aout != nullptr && tx == 0;
+  // the transformed operand is written out ONCE, slab kt by the workgroup of column tile kt mod (column tiles): spread over the row
+  // tile's workgroups instead of making the first column tile's the launch's stragglers
+  const bool side = p.Aout != nullptr;
+  const int ntx = static_cast<int>(gridDim.x);
   // kernel_regularizer=l2: the first row of tiles adds up the squares of the weight pieces it stages anyway
   const bool do_l2 = !B_KC && p.l2_part != nullptr && ty == 0 && n0c + (tid & 15) * 4 < Nout;
   float l2acc = 0.f;
@@ -327,7 +330,7 @@ __global__ __launch_bounds__(NTHR) void dvn_panel_kernel(PanelArgs p) {
       }                                                                                                    \
       const int rl__ = (tid >> 5) + (NTHR / 32) * i;                                                       \
       *reinterpret_cast<float4*>(&sa__[rl__ * LD + (k4 ^ swz(rl__))]) = v__;                               \
-      if (side && arow[i] < row_end && kk__ < K)                                                           \
+      if (side && (KT) % ntx == tx && arow[i] < row_end && kk__ < K)                                       \
         *reinterpret_cast<float4*>(p.Aout + static_cast<int64_t>(arow[i]) * K + kk__) = v__;               \
     }                                                                                                      \
     _Pragma("unroll") for (int i = 0; i < SB; ++i) {                                                       \
