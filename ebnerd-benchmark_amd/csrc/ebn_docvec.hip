@@ -295,7 +295,8 @@ __global__ __launch_bounds__(NTHR) void dvn_panel_kernel(PanelArgs p) {
   const bool side = p.Aout != nullptr;
   const int ntx = static_cast<int>(gridDim.x);
   // kernel_regularizer=l2: the first row of tiles adds up the squares of the weight pieces it stages anyway
-  const bool do_l2 = !B_KC && p.l2_part != nullptr && ty == 0 && n0c + (tid & 15) * 4 < Nout;
+  const bool l2_wg = !B_KC && p.l2_part != nullptr && ty == 0;
+  const bool do_l2 = l2_wg && n0c + (tid & 15) * 4 < Nout;
   float l2acc = 0.f;
 #define DVN_STORE(SET, BUF, KT)                                                                            \
   do {                                                                                                     \
@@ -407,6 +408,16 @@ __global__ __launch_bounds__(NTHR) void dvn_panel_kernel(PanelArgs p) {
 
   // slab kt: multiply from LDS buffer kt & 1, then move slab kt + 1 (requested three steps ago) from its register set into the
   // other buffer and request slab kt + 4 into the set slab kt left; the loop is unrolled by the four register sets
+  // the bias of the epilogue, requested before the slab loop (behind it: a memory round trip of its own).  (The relu outputs and statistics
+  // the dy epilogue needs are NOT: eight more loads in front of the loop cost the backward launches what they gain -- measured.)
+  float epre_a[2] = {0.f, 0.f};
+  if (EPI != EPI_DY && kg == 0) {
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int col = n0c + wn * 32 + b * 16 + (lane & 15);
+      epre_a[b] = p.bias[col < Nout ? col : Nout - 1];
+    }
+  }
   DVN_STORE(0, 0, 0);
   __syncthreads();
 #define DVN_STEP(J)                                                              \
@@ -430,7 +441,7 @@ __global__ __launch_bounds__(NTHR) void dvn_panel_kernel(PanelArgs p) {
 #undef DVN_READ
 #undef DVN_MUL
 
-  if (!B_KC && p.l2_part != nullptr && ty == 0) {  // block-uniform
+  if (l2_wg) {  // block-uniform
     const float w = ebn_wave_sum(l2acc);
     if (lane == 0) red[wave] = w;
     __syncthreads();
@@ -467,8 +478,7 @@ __global__ __launch_bounds__(NTHR) void dvn_panel_kernel(PanelArgs p) {
       const int col = n0c + wn * 32 + b * 16 + r16;
       const bool cok = col < Nout;
       const int colc = cok ? col : Nout - 1;
-      float bias = 0.f, mi = 0.f, is = 0.f;
-      if (EPI != EPI_DY) bias = p.bias[colc];
+      float mi = 0.f, is = 0.f;
       if (EPI == EPI_DY) {
         is = p.istd_out[site * Nout + colc];
         mi = p.mean_out[site * Nout + colc] * is;
@@ -479,7 +489,7 @@ __global__ __launch_bounds__(NTHR) void dvn_panel_kernel(PanelArgs p) {
         const bool ok = cok && row < row_end;
         float v = accb[b][r];
         if (EPI != EPI_DY) {
-          v = fmaxf(v + bias, 0.f);
+          v = fmaxf(v + epre_a[b], 0.f);
           if (ok) p.C[static_cast<int64_t>(row) * Nout + col] = v;
           val[b][r] = ok ? v : 0.f;
           s0[b] += val[b][r];
