@@ -29,6 +29,17 @@ def test_bench_line_carries_the_contract_fields(cfg):
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and 0 < r["frac"] < 1
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    if cfg == "c3":  # (round 5) the NRMSDocVec line carries the same evidence as the headline's: whole-step roofline, counter traffic, CPU leg
+        st, c = d["roofline_step"], d["cpu_baseline"]
+        assert st["bound"] == "mfma" and abs(st["frac"] - st["achieved"] / st["peak"]) < 1e-9 and 0 < st["frac"] < r["frac"]
+        assert abs(st["achieved"] * 1e12 - st["flops_per_step"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * st["achieved"] * 1e12
+        assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and "CpuDocVecTrainer" in c["sample"]
+        assert "tn_group" in r["kernel"] and r["algorithmic_flops_per_launch"] > 1e9
+        for key in ("roofline", "roofline_gather"):
+            assert d[key]["traffic_source"].startswith(("measured in this run", "not measured"))
+            if d[key]["traffic_source"].startswith("measured"):
+                assert d[key]["traffic"] > 0
+        assert d["oracle_pin"].startswith(("unpinned", "pinned")) and isinstance(d["env"], dict)
     if cfg == "c2":  # the driver's configuration: the CPU port of the same step is timed beside it
         c = d["cpu_baseline"]
         assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1 and c["sample"] and c["timed_steps"] == 3
