@@ -235,12 +235,29 @@ def timed_repeats(step_fn, args, sync, world, device):
             k += 1
         sync()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if world > 1 or dist.is_initialized():  # (a one-rank group under --force-dist: the same collective, an identity)
             t = torch.tensor([dt], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         times.append(dt)
     return times
+
+
+def launches_of_one_step(eng, step_fn, sync):
+    """Kernel launches of ONE training step, COUNTED: the library's own launch counter (ebn_launch_count: every launch site goes
+    through it) around one eager step of the same engine -- the captured graphs replay exactly these launches."""
+    from ebrec import _hip
+
+    sync()
+    was, eng.use_graph = eng.use_graph, False
+    try:
+        n0 = int(_hip.lib().ebn_launch_count())
+        step_fn()
+        n1 = int(_hip.lib().ebn_launch_count())
+    finally:
+        eng.use_graph = was
+    sync()
+    return n1 - n0
 
 
 def time_kernel(fns, sync, reps=10, replays=5):
@@ -453,15 +470,18 @@ def timing_fields(times, args, world, per_gpu_batch):
                       "~50 ms) and is the slow one the median sets aside, not an average over it"}
 
 
-def dist_fields(world, backend, n_dev):
-    if world == 1:
+def dist_fields(world, backend, n_dev, forced=False):
+    if world == 1 and not forced:
         return {}
+    if world == 1:
+        return {"ranks": 1, "backend": backend, "dist_note": f"--force-dist: the multi-rank branch on a ONE-rank {backend} group (every collective an identity) -- "
+                                                               "an execution check of that code path, not a scaling number"}
     note = "RCCL over xGMI, one rank per GPU" if backend == "nccl" else \
         f"{backend}: {world} ranks share {n_dev} GPU(s) -- functional dry run of the multi-rank path, NOT a scaling number"
     return {"ranks": world, "backend": backend, "dist_note": note}
 
 
-def bench_docvec(args, c, world, rank, device, sync, dfields):
+def bench_docvec(args, c, world, rank, device, sync, dfields, multi=False):
     """configs[2]: NRMSDocVec train step on article-row batches gathered on the device."""
     from ebrec.models.newsrec import NRMSDocVec
 
@@ -473,6 +493,8 @@ def bench_docvec(args, c, world, rank, device, sync, dfields):
     matrix = rng.standard_normal((c["n_articles"], c["doc"]), dtype=np.float32)
     matrix[0] = 0
     eng.set_article_matrix(matrix)
+    if args.force_dist and world == 1:
+        eng.force_collectives = True
     g = torch.Generator(device="cpu").manual_seed(123 + rank)
     batches = []
     for _ in range(8):
@@ -492,6 +514,7 @@ def bench_docvec(args, c, world, rank, device, sync, dfields):
         return
     eng.enable_graphs(not args.no_graph)
     times = timed_repeats(lambda k: eng.train_step(*batches[k % 8], indexed=True), args, sync, world, device)
+    n_launches = launches_of_one_step(eng, lambda: eng.train_step(*batches[0], indexed=True), sync)
     # kernel-level rooflines on the step's own buffers: the document-vector gather (HBM) and the time-dominant launch of the step,
     # the grouped weight-gradient product of all Dense kernels (MFMA)
     rk = eng.roofline_kernels(c["B"], c["C"])
@@ -507,7 +530,7 @@ def bench_docvec(args, c, world, rank, device, sync, dfields):
         # document vectors themselves), the user encoder (as in step_flops) and the scorer
         fl_step = sum(2.0 * n_rows * dims[i] * dims[i + 1] * (3 if i else 2) for i in range(len(dims) - 1))
         fl_step += 3 * 2.0 * B * H * E * 3 * E + B * c["h"] * 12.0 * H * H * c["d"] + 3 * 2.0 * B * H * E * A + 3 * 2.0 * B * C * E
-        probe = None if (args.no_probe or args.no_roofline or world > 1) else probe_kernels("c3", 0, pick=lambda n: "gather" if "gather" in n else ("dw_group" if "tn_group" in n else None))
+        probe = None if (args.no_probe or args.no_roofline or multi) else probe_kernels("c3", 0, pick=lambda n: "gather" if "gather" in n else ("dw_group" if "tn_group" in n else None))
         line = {"metric": "training impressions/sec", **timing_fields(times, args, world, c["B"]), "unit": "impressions/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup,
                 "launch": "eager" if args.no_graph else "hipGraph replay", "higher_is_better": True, "scaling": "weak",
@@ -537,8 +560,11 @@ def bench_docvec(args, c, world, rank, device, sync, dfields):
                                          "news encoder forward / weight gradient / input gradient, the user encoder, the scorer) / ms_per_step",
                                  "bound": "mfma", "achieved": fl_step / (ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                  "frac": fl_step / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, "flops_per_step": fl_step,
-                                 "launches_per_step": "19 (r4: 27): one-launch prologue (state advance + labels + gather), 4 + 4 fused Dense launches, the weight-gradient group, 8 of the user stage, Adam"}
-        if world == 1 and not args.no_cpu_baseline:
+                                 "launches_per_step": n_launches,
+                                 "launches_note": "counted (ebn_launch_count around one eager step of this engine; the hipGraphs replay the same launches): "
+                                                  f"news-encoder MLP of {len(c['units'])} hidden layers in the {'fused' if 'dw_group' in rk else 'per-pass'} form, "
+                                                  "the user stage, Adam"}
+        if not multi and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_docvec(c)
         print("\n" + json.dumps(line), flush=True)  # (own line even when a library -- gloo -- has left an unterminated one on stdout)
 
@@ -676,7 +702,7 @@ def run_legs(args, world, rank, device, watchdog):
         env.update(MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=str(port[0]), EBN_BENCH_LEG="1")
         cmd = [sys.executable, str(Path(__file__).resolve()), "--leg", "--config", cfg, "--gpus", str(world), "--steps", str(args.steps),
                "--warmup", str(args.warmup), "--repeats", str(args.repeats), "--ids", args.ids, "--graph-collectives", args.graph_collectives,
-               "--no-roofline", "--no-probe", "--no-cpu-baseline"] + (["--no-graph"] if args.no_graph else [])
+               "--no-roofline", "--no-probe", "--no-cpu-baseline"] + (["--no-graph"] if args.no_graph else []) + (["--force-dist"] if args.force_dist else [])
         watchdog.arm(f"leg {cfg}: child processes (own timeout {leg_timeout:.0f} s)")
         watchdog._deadline = time.monotonic() + leg_timeout + 60.0  # the child's own timeout fires first
         t0 = time.perf_counter()
@@ -706,6 +732,54 @@ def run_legs(args, world, rank, device, watchdog):
         out[cfg] = rec
     watchdog.disarm()
     return out
+
+
+SINGLE_LEG_FIELDS = LEG_FIELDS + ("repeats", "steps", "warmup", "roofline", "roofline_gather", "cpu_baseline")
+
+
+def run_legs_single_gpu(args):
+    """N = 1: every OTHER BASELINE.json config at its single-GPU shape, measured by the SAME driver command as the c2 headline (the
+    driver passes no --config): c1 = configs[0] (the reference script's literal configuration), c3 = configs[2] (NRMSDocVec), c4 =
+    configs[3] at its per-rank shape (history 50, batch 32), c5 = configs[4] on one rank (batch 64, the planned exchange with itself).
+    Each leg is a child `bench.py --leg --config cX` under its own timeout: its whole timed region, its kernel rooflines (HIP events
+    + the three rocprofv3 passes over its own --kernel-probe) and, for c3, its CPU baseline; a crash or a hang in one leg becomes
+    an `error` entry and cannot lose the headline or the other legs."""
+    out = {}
+    leg_timeout = float(os.environ.get("EBN_BENCH_LEG_TIMEOUT_S", "300"))
+    profiled = being_profiled()
+    for cfg in [c for c in args.legs.split(",") if c]:
+        if cfg not in CONFIGS or cfg == "c2":
+            out[cfg] = {"error": f"unknown leg config {cfg!r}"}
+            continue
+        if profiled:  # a profiler around this process would also wrap the children and mix their kernels into its summary
+            out[cfg] = {"skipped": "this process runs under a profiler: profile the leg directly with --config " + cfg}
+            continue
+        cmd = [sys.executable, str(Path(__file__).resolve()), "--leg", "--config", cfg, "--gpus", "1", "--steps", str(args.steps),
+               "--warmup", str(args.warmup), "--repeats", str(args.repeats), "--ids", args.ids, "--no-fit-loop", "--no-split-leg"] + \
+              (["--no-graph"] if args.no_graph else []) + (["--no-probe"] if args.no_probe else []) + (["--no-roofline"] if args.no_roofline else []) + \
+              ([] if (cfg == "c3" and not args.no_cpu_baseline) else ["--no-cpu-baseline"])
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=leg_timeout, cwd=str(ROOT),
+                               env=dict(os.environ, EBN_BENCH_LEG="1"))
+            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode != 0:
+                rec = {"error": f"the leg's process exited {r.returncode}", "stderr_tail": r.stderr[-1500:]}
+            elif len(lines) != 1:
+                rec = {"error": f"expected one JSON line from the leg, got {len(lines)}", "stderr_tail": r.stderr[-1500:]}
+            else:
+                d = json.loads(lines[0])
+                rec = {k: d[k] for k in SINGLE_LEG_FIELDS if k in d}
+                rec["config"] = d["config"]
+        except subprocess.TimeoutExpired as e:
+            rec = {"error": f"the leg did not finish within {leg_timeout:.0f} s (killed)",
+                   "stderr_tail": (e.stderr.decode(errors="replace") if isinstance(e.stderr, bytes) else (e.stderr or ""))[-1500:]}
+        rec["wall_s"] = time.perf_counter() - t0
+        out[cfg] = rec
+    note = ("every other BASELINE.json config on this GPU, each measured by its own child process of this command under its own timeout: c1 = "
+            "configs[0], c3 = configs[2] (NRMSDocVec, with its cpu_baseline), c4 = configs[3] at its per-rank shape, c5 = configs[4] on one rank; "
+            "same steps / warmup / repeats, same timing protocol, own kernel rooflines; `value` of the line stays the c2 headline")
+    return out, note
 
 
 def oracle_pin_status():
@@ -763,8 +837,14 @@ def main():
     ap.add_argument("--atomic-table-grad", action="store_true",
                     help="trainable table: one 64-bit atomic per gradient element instead of combining the duplicate ids of every 64 consecutive "
                          "tokens first (same bits; the A/B behind DESIGN's choice, see --ids zipf)")
-    ap.add_argument("--legs", default="c4,c5", help="N > 1 on the default config: also measure these configs (BASELINE.json configs[3] / configs[4]) as sub-records "
-                                                     "of the line, each in its own set of child processes under its own timeout ('' = none)")
+    ap.add_argument("--legs", default=None, help="on the default config: also measure these configs as sub-records of the line, each in its own (set of) child "
+                                                  "process(es) under its own timeout ('' = none).  Default: N = 1 -> c1,c3,c4,c5 (every other BASELINE.json config at "
+                                                  "its single-GPU / per-rank shape, with its own roofline objects); N > 1 -> c4,c5 (configs[3] / configs[4])")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the MULTI-RANK branch on a group of one rank: through torch.distributed.run, init_process_group('nccl', device_id=...), "
+                         "rccl_view, SegmentTrace, HangWatchdog, the engine's multi-rank launch form (collectives between the graph replays -- identities "
+                         "on one rank), run_legs with its fresh rendezvous and the closing collective flag check: what the 8-GPU node will run, executed "
+                         "on a 1-GPU box")
     ap.add_argument("--leg", action="store_true", help="internal: this process is one rank of a leg started by run_legs()")
     ap.add_argument("--fault-skip-collectives-on-rank", type=int, default=-1,
                     help="test hook: this rank skips its collectives in the timed region (its peers then wait for it forever): the hang "
@@ -773,7 +853,7 @@ def main():
                                                                 "buffers and exit (what probe_kernels() wraps rocprofv3 around)")
     args = ap.parse_args()
 
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if (args.gpus > 1 or args.force_dist) and "WORLD_SIZE" not in os.environ:
         self_launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -783,7 +863,10 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     backend = None
-    if world > 1:
+    multi = world > 1 or args.force_dist  # the multi-rank branch (a one-rank group under --force-dist)
+    if args.legs is None:
+        args.legs = "c4,c5" if multi else "c1,c3,c4,c5"
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # "nccl" = RCCL over xGMI; RCCL refuses two ranks on one GPU, so a box with fewer GPUs than ranks falls back to gloo
         backend = os.environ.get("EBN_DIST_BACKEND", "nccl" if torch.cuda.device_count() >= world else "gloo")
@@ -791,9 +874,9 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    dfields = dist_fields(world, backend, n_dev)
+    dfields = dist_fields(world, backend, n_dev, forced=args.force_dist)
     trace = watchdog = None
-    if world > 1:
+    if multi:
         from ebrec.models.newsrec._dist import SegmentTrace
 
         trace = SegmentTrace()
@@ -812,14 +895,14 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
             torch.cuda.synchronize()
 
     if args.config == "c3":
         phase("c3: the whole DocVec benchmark")
-        bench_docvec(args, c, world, rank, device, sync, dfields)
-        if world > 1:
+        bench_docvec(args, c, world, rank, device, sync, dfields, multi)
+        if multi:
             dist.destroy_process_group()
         return
     from ebrec import _hip
@@ -849,10 +932,16 @@ def main():
     eng.atomic_table_grad = bool(args.atomic_table_grad)
     eng.enable_graphs(not args.no_graph)
     eng.trace = trace  # N > 1: an event behind every segment of every step, so that a hang can be named (None at N = 1: nothing recorded)
-    if world > 1:
+    if args.force_dist and world == 1:
+        from ebrec.models.newsrec._dist import LockStepGuard
+
+        eng.force_collectives = True
+        eng.guard = LockStepGuard(force=True)
+        eng.guard.enter("bench.py --force-dist (the guard's store rendezvous on a one-rank group)")
+    if multi:
         dfields["guard"] = eng.guard.status() if eng.guard is not None else "disabled: the engine built none"
     eng.graph_collectives = bool(args.graph_collectives == "on" and backend == "nccl")
-    if args.graph_collectives == "auto" and world > 1 and not args.no_graph:
+    if args.graph_collectives == "auto" and multi and not args.no_graph:
         phase("start-up self-check of the one-graph step (engine.verify_graph_collectives)")
         eng.verify_graph_collectives(*batches[0])
     if args.fault_skip_collectives_on_rank == rank:  # test hook: this rank leaves its peers alone in every collective of the step
@@ -861,6 +950,7 @@ def main():
             eng.exchange.skip = True
     phase(f"{args.config}: warm-up + timed region ({args.warmup} + {args.repeats} x {args.steps} steps)")
     times = timed_repeats(lambda k: eng.train_step(*batches[k % len(batches)]), args, sync, world, device)
+    n_launches = launches_of_one_step(eng, lambda: eng.train_step(*batches[0]), sync) if not multi else None
     # Kernel-level rooflines: the Q|K|V projection GEMM and the embedding gather of THIS step (same buffers, same
     # arguments), each captured into a hipGraph of 10 launches and timed with HIP events on the launch stream.
     rk = eng.roofline_kernels(c["B"], c["C"])
@@ -871,7 +961,7 @@ def main():
         calib = hbm_calibration(sync, device)
     loss = float(eng.loss_dev.item())
     comm = None
-    if world > 1:
+    if multi:
         phase(f"{args.config}: the same steps re-timed without collectives (comm_exposed_us)")
         # what the collectives cost the step: the same steps timed again with every collective skipped (the results of those
         # steps are wrong and thrown away; all ranks skip together) -- exposed = with - without, after whatever the overlap hid
@@ -892,7 +982,7 @@ def main():
     phase(f"{args.config}: closing flag check (a collective)")
     eng.check_oob()  # sticky device flags of the whole run (ids out of range, exchange overflow, accumulator range): raise, don't report
     legs = None
-    if world > 1 and not args.leg and args.config == "c2" and args.legs:
+    if multi and not args.leg and args.config == "c2" and args.legs:
         legs = run_legs(args, world, rank, device, watchdog)
     if watchdog is not None:
         watchdog.disarm()
@@ -906,7 +996,7 @@ def main():
         gemm_name = (f"gemm_f32_kernel<{bm.value}, {bn.value}, {4 if bm.value == 256 else 2}, false, false, true, 0>" if bm.value != 32
                      else "gemm_small_vec_kernel<false, false, 32>") + f" (ebn_gemm_plan: tile {bm.value}x{bn.value}, split-K {sp.value})"
         gather_bytes = n_tok * (4 + 2 * c["D"] * 4)  # id + row read + row write (materialising gather)
-        probed = None if (args.no_probe or args.no_roofline or world > 1) else probe_kernels(args.config, args.batch, args.precision, args.ids)
+        probed = None if (args.no_probe or args.no_roofline or multi) else probe_kernels(args.config, args.batch, args.precision, args.ids)
         if probed and "traffic" in probed.get("qkv_gemm", {}) and "traffic" in probed.get("gather", {}):
             traffic = {k: v["traffic"] for k, v in probed.items()}
             traffic_source = ("measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over "
@@ -952,7 +1042,8 @@ def main():
                                          "(every GEMM and attention contraction, forward and backward) / ms_per_step",
                                  "bound": "mfma", "achieved": fl_step / (line["ms_per_step"] * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
                                  "unit": "TFLOP/s", "frac": fl_step / (line["ms_per_step"] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                                 "algorithmic_flops_per_step": fl_step}
+                                 "algorithmic_flops_per_step": fl_step,
+                                 **({"launches_per_step": n_launches, "launches_note": "counted: ebn_launch_count around one eager step of this engine"} if n_launches is not None else {})}
         if args.precision == "split":  # part of the step runs on the bf16 pipe: a fraction of the fp32 peak would mean nothing
             line["roofline_step"].update({"what": "fp32-equivalent matmul rate of the whole step (exact matmul FLOPs of one step / ms_per_step); the "
                                                   "projection GEMMs execute 6 bf16 MFMA products per fp32 product on the bf16 pipe, so no single peak applies",
@@ -1007,21 +1098,23 @@ def main():
                                  "line stays the c2 headline")
         if sharded:
             line["exchange"] = eng.exchange.stats()
-        if world > 1:
+        if multi:
             line["allreduce_bytes_per_step"] = eng.allreduce_bytes(c["B"] * (c["H"] + c["C"]) * c["T"])
             line["comm_exposed_us"] = (line["ms_per_step"] - comm["ms_per_step_without_collectives"]) * 1e3
             line["comm"] = {**comm, "note": "comm_exposed_us = ms_per_step - the same steps with every collective skipped (measured after the timed region, same graphs).  "
                                             "The dense gradients travel as one flat bucket: with a trainable table it is started asynchronously after the dWqkv GEMM and "
                                             "runs under the dX GEMM and the table-gradient accumulation; with a frozen table nothing follows dWqkv"}
-        if world == 1 and not args.no_split_leg and args.precision == "exact" and not sharded and not args.no_graph:
+        if not multi and not args.no_split_leg and args.precision == "exact" and not sharded and not args.no_graph:
             line["split_precision"] = split_precision_leg(c, make_model, batches, args, sync, device, line["ms_per_step"])
-        if world == 1 and not args.no_fit_loop and not sharded:
+        if not multi and not args.no_fit_loop and not sharded:
             line["fit_loop"] = fit_loop_leg(model, c)
             line["fit_loop"]["frac_of_value"] = line["fit_loop"]["value"] / line["value"]
-        if world == 1 and not args.no_cpu_baseline:
+        if not multi and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(c, steps=args.cpu_steps, ids=args.ids)
+        if not multi and not args.leg and args.config == "c2" and args.legs and not args.batch:
+            line["legs"], line["legs_note"] = run_legs_single_gpu(args)
         print("\n" + json.dumps(line), flush=True)  # (own line even when a library -- gloo -- has left an unterminated one on stdout)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

@@ -457,7 +457,7 @@ extern "C" int ebn_attn_fwd_f32(const float* qkv, int64_t ld_qkv, float* out, in
     const size_t lds = static_cast<size_t>(3 * L * d + 2 * L) * sizeof(float);
     EBN_REQUIRE(lds <= 160 * 1024 && a.n_prob <= 0x7FFFFFFF, EBN_ERR_UNSUPPORTED);
     allow_big_lds(attn_long_fwd_kernel, lds);
-    hipLaunchKernelGGL(attn_long_fwd_kernel, dim3(static_cast<unsigned>(a.n_prob)), dim3(LONG_THREADS), lds, ebn_stream(stream), a);
+    EBN_LAUNCH(attn_long_fwd_kernel, dim3(static_cast<unsigned>(a.n_prob)), dim3(LONG_THREADS), lds, ebn_stream(stream), a);
     EBN_CHECK_LAUNCH();
     return EBN_OK;
   }
@@ -466,10 +466,10 @@ extern "C" int ebn_attn_fwd_f32(const float* qkv, int64_t ld_qkv, float* out, in
   EBN_REQUIRE(static_cast<size_t>((L <= 32 ? 2 : 1) * per_group) * sizeof(float) <= 65536, EBN_ERR_UNSUPPORTED);
   if (L <= 32) {
     const int64_t grid = ebn_ceil_div(a.n_prob, 2);
-    hipLaunchKernelGGL(attn_fwd_kernel<32>, dim3(static_cast<unsigned>(grid)), dim3(64),
+    EBN_LAUNCH(attn_fwd_kernel<32>, dim3(static_cast<unsigned>(grid)), dim3(64),
                        2 * per_group * sizeof(float), ebn_stream(stream), a);
   } else {
-    hipLaunchKernelGGL(attn_fwd_kernel<64>, dim3(static_cast<unsigned>(a.n_prob)), dim3(64),
+    EBN_LAUNCH(attn_fwd_kernel<64>, dim3(static_cast<unsigned>(a.n_prob)), dim3(64),
                        per_group * sizeof(float), ebn_stream(stream), a);
   }
   EBN_CHECK_LAUNCH();
@@ -496,7 +496,7 @@ extern "C" int ebn_attn_bwd_f32(const float* qkv, int64_t ld_qkv, const float* d
     const size_t lds = static_cast<size_t>(4 * L * d + 3 * L) * sizeof(float);
     EBN_REQUIRE(lds <= 160 * 1024 && a.n_prob <= 0x7FFFFFFF, EBN_ERR_UNSUPPORTED);
     allow_big_lds(attn_long_bwd_kernel, lds);
-    hipLaunchKernelGGL(attn_long_bwd_kernel, dim3(static_cast<unsigned>(a.n_prob)), dim3(LONG_THREADS), lds, ebn_stream(stream), a);
+    EBN_LAUNCH(attn_long_bwd_kernel, dim3(static_cast<unsigned>(a.n_prob)), dim3(LONG_THREADS), lds, ebn_stream(stream), a);
     EBN_CHECK_LAUNCH();
     return EBN_OK;
   }
@@ -505,10 +505,10 @@ extern "C" int ebn_attn_bwd_f32(const float* qkv, int64_t ld_qkv, const float* d
   EBN_REQUIRE(static_cast<size_t>((L <= 32 ? 2 : 1) * per_group) * sizeof(float) <= 65536, EBN_ERR_UNSUPPORTED);
   if (L <= 32) {
     const int64_t grid = ebn_ceil_div(a.n_prob, 2);
-    hipLaunchKernelGGL(attn_bwd_kernel<32>, dim3(static_cast<unsigned>(grid)), dim3(64),
+    EBN_LAUNCH(attn_bwd_kernel<32>, dim3(static_cast<unsigned>(grid)), dim3(64),
                        2 * per_group * sizeof(float), ebn_stream(stream), a);
   } else {
-    hipLaunchKernelGGL(attn_bwd_kernel<64>, dim3(static_cast<unsigned>(a.n_prob)), dim3(64),
+    EBN_LAUNCH(attn_bwd_kernel<64>, dim3(static_cast<unsigned>(a.n_prob)), dim3(64),
                        per_group * sizeof(float), ebn_stream(stream), a);
   }
   EBN_CHECK_LAUNCH();

@@ -1114,7 +1114,7 @@ static void allow_lds(K kernel, size_t bytes) {
 template <class K>
 static void launch_waves(K kernel, size_t lds, const MfmaAttnArgs& a, hipStream_t s) {
   allow_lds(kernel, lds);
-  hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(ebn_ceil_div(a.n_prob, ATT_WAVES))), dim3(64 * ATT_WAVES), lds, s, a);
+  EBN_LAUNCH(kernel, dim3(static_cast<unsigned>(ebn_ceil_div(a.n_prob, ATT_WAVES))), dim3(64 * ATT_WAVES), lds, s, a);
 }
 
 template <int D, int LC>
@@ -1123,10 +1123,10 @@ static void launch_mfma2_lc(bool bwd, const MfmaAttnArgs& a, hipStream_t s) {
   const size_t lds = static_cast<size_t>(ATT2_WAVES) * (bwd ? 4 : 3) * a.L * Tile<D>::STRIDE * sizeof(float);
   if (bwd) {
     allow_lds(attn_mfma2_bwd_kernel<D, LC>, lds);
-    hipLaunchKernelGGL((attn_mfma2_bwd_kernel<D, LC>), grid, block, lds, s, a);
+    EBN_LAUNCH((attn_mfma2_bwd_kernel<D, LC>), grid, block, lds, s, a);
   } else {
     allow_lds(attn_mfma2_fwd_kernel<D, LC>, lds);
-    hipLaunchKernelGGL((attn_mfma2_fwd_kernel<D, LC>), grid, block, lds, s, a);
+    EBN_LAUNCH((attn_mfma2_fwd_kernel<D, LC>), grid, block, lds, s, a);
   }
 }
 
@@ -1159,10 +1159,10 @@ int ebn_attn_mfma_fwd(const float* qkv, int64_t ld_qkv, float* out, int64_t ld_o
     const dim3 grid(static_cast<unsigned>(a.n_prob / BWD_GROUP)), block(64 * BWD_GROUP);
     if (L == 30) {
       allow_lds(attn_mfma_fwd_group_kernel<20, 30, BWD_GROUP>, lds);
-      hipLaunchKernelGGL((attn_mfma_fwd_group_kernel<20, 30, BWD_GROUP>), grid, block, lds, s, a);
+      EBN_LAUNCH((attn_mfma_fwd_group_kernel<20, 30, BWD_GROUP>), grid, block, lds, s, a);
     } else {
       allow_lds(attn_mfma_fwd_group_kernel<20, 0, BWD_GROUP>, lds);
-      hipLaunchKernelGGL((attn_mfma_fwd_group_kernel<20, 0, BWD_GROUP>), grid, block, lds, s, a);
+      EBN_LAUNCH((attn_mfma_fwd_group_kernel<20, 0, BWD_GROUP>), grid, block, lds, s, a);
     }
     EBN_CHECK_LAUNCH();
     return EBN_OK;
@@ -1201,10 +1201,10 @@ int ebn_attn_mfma_bwd(const float* qkv, int64_t ld_qkv, const float* dout, int64
     a.stagger_mod = 5u;  // workgroups per CU: 28.8 KB of LDS each
     if (L == 30) {
       allow_lds(attn_mfma_bwd_group_kernel<20, 30, BWD_GROUP>, lds);
-      hipLaunchKernelGGL((attn_mfma_bwd_group_kernel<20, 30, BWD_GROUP>), grid, block, lds, s, a);
+      EBN_LAUNCH((attn_mfma_bwd_group_kernel<20, 30, BWD_GROUP>), grid, block, lds, s, a);
     } else {
       allow_lds(attn_mfma_bwd_group_kernel<20, 0, BWD_GROUP>, lds);
-      hipLaunchKernelGGL((attn_mfma_bwd_group_kernel<20, 0, BWD_GROUP>), grid, block, lds, s, a);
+      EBN_LAUNCH((attn_mfma_bwd_group_kernel<20, 0, BWD_GROUP>), grid, block, lds, s, a);
     }
     EBN_CHECK_LAUNCH();
     return EBN_OK;

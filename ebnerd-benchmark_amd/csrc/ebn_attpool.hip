@@ -372,10 +372,10 @@ extern "C" int ebn_attpool_fwd_f32(float* U, const float* b, const float* q, con
   const bool vec = (A % 4 == 0) && A <= 256 && (E % 4 == 0) && E <= 1024 && ebn_aligned16(U) && ebn_aligned16(b) &&
                    ebn_aligned16(q) && ebn_aligned16(X) && ebn_aligned16(out);
   if (vec)
-    hipLaunchKernelGGL(attpool_fwd_vec_kernel, dim3(static_cast<unsigned>(n_seq)), dim3(POOL_THREADS),
+    EBN_LAUNCH(attpool_fwd_vec_kernel, dim3(static_cast<unsigned>(n_seq)), dim3(POOL_THREADS),
                        L * sizeof(float), ebn_stream(stream), U, b, q, X, out, w, L, E, A);
   else
-    hipLaunchKernelGGL(attpool_fwd_kernel, dim3(static_cast<unsigned>(n_seq)), dim3(POOL_THREADS),
+    EBN_LAUNCH(attpool_fwd_kernel, dim3(static_cast<unsigned>(n_seq)), dim3(POOL_THREADS),
                        L * sizeof(float), ebn_stream(stream), U, b, q, X, out, w, L, E, A);
   EBN_CHECK_LAUNCH();
   return EBN_OK;
@@ -390,10 +390,10 @@ extern "C" int ebn_attpool_bwd_pool_f32(const float* X, const float* w, const fl
   if (n_seq == 0) return EBN_OK;
   const bool vec = (E % 4 == 0) && E <= 1024 && ebn_aligned16(X) && ebn_aligned16(dout) && ebn_aligned16(dX);  // NULL is aligned
   if (vec)
-    hipLaunchKernelGGL(attpool_bwd_pool_vec_kernel, dim3(static_cast<unsigned>(n_seq)), dim3(POOL_THREADS),
+    EBN_LAUNCH(attpool_bwd_pool_vec_kernel, dim3(static_cast<unsigned>(n_seq)), dim3(POOL_THREADS),
                        L * sizeof(float), ebn_stream(stream), X, w, dout, dX, de, L, E, dX != nullptr ? 1 : 0);
   else
-    hipLaunchKernelGGL(attpool_bwd_pool_kernel, dim3(static_cast<unsigned>(n_seq)), dim3(POOL_THREADS),
+    EBN_LAUNCH(attpool_bwd_pool_kernel, dim3(static_cast<unsigned>(n_seq)), dim3(POOL_THREADS),
                        L * sizeof(float), ebn_stream(stream), X, w, dout, dX, de, L, E);
   EBN_CHECK_LAUNCH();
   return EBN_OK;
@@ -409,10 +409,10 @@ extern "C" int ebn_attpool_bwd_dpre_f32(float* U, const float* q, const float* d
   const int64_t rpb = ebn_ceil_div(R, nb);
   if ((A % 4) == 0 && A >= 4 && A <= 1024 && ebn_aligned16(U) && ebn_aligned16(q)) {
     const size_t lds = static_cast<size_t>(2) * (POOL_THREADS / (A / 4)) * A * sizeof(float);  // <= 2 x 256 x 4 floats = 8 KB
-    hipLaunchKernelGGL(attpool_bwd_dpre_vec_kernel, dim3(static_cast<unsigned>(nb)), dim3(POOL_THREADS), lds, ebn_stream(stream), U, q, de, partials,
+    EBN_LAUNCH(attpool_bwd_dpre_vec_kernel, dim3(static_cast<unsigned>(nb)), dim3(POOL_THREADS), lds, ebn_stream(stream), U, q, de, partials,
                        R, A, rpb);
   } else {
-    hipLaunchKernelGGL(attpool_bwd_dpre_kernel, dim3(static_cast<unsigned>(nb)), dim3(POOL_THREADS), 0,
+    EBN_LAUNCH(attpool_bwd_dpre_kernel, dim3(static_cast<unsigned>(nb)), dim3(POOL_THREADS), 0,
                        ebn_stream(stream), U, q, de, partials, R, A, rpb);
   }
   EBN_CHECK_LAUNCH();

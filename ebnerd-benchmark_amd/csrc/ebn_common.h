@@ -13,6 +13,15 @@
     if (e__ != hipSuccess) return (int)e__;  \
   } while (0)
 
+// Every kernel launch of the library goes through EBN_LAUNCH: a process-wide count (ebn_launch_count) lets the host layer REPORT how
+// many launches a training step makes (bench.py's `launches_per_step`) instead of stating it.  One relaxed atomic add on the host.
+__attribute__((visibility("hidden"))) void ebnx_note_launch(void);
+#define EBN_LAUNCH(...)                 \
+  do {                                  \
+    ebnx_note_launch();                 \
+    hipLaunchKernelGGL(__VA_ARGS__);    \
+  } while (0)
+
 #define EBN_REQUIRE(cond, code) \
   do {                          \
     if (!(cond)) return (code); \

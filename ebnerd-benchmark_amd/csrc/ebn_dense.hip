@@ -560,7 +560,7 @@ extern "C" int ebn_bias_relu_f32(const float* X, const float* bias, float* Y, in
   EBN_REQUIRE(X && bias && Y, EBN_ERR_BAD_ARG);
   EBN_REQUIRE(R >= 0 && Ccols > 0, EBN_ERR_BAD_ARG);
   if (R == 0) return EBN_OK;
-  hipLaunchKernelGGL(bias_relu_kernel, dim3(grid_for(R * Ccols)), dim3(256), 0, ebn_stream(stream), X, bias, Y,
+  EBN_LAUNCH(bias_relu_kernel, dim3(grid_for(R * Ccols)), dim3(256), 0, ebn_stream(stream), X, bias, Y,
                      R * Ccols, Ccols);
   EBN_CHECK_LAUNCH();
   return EBN_OK;
@@ -573,7 +573,7 @@ extern "C" int ebn_bias_relu_bwd_f32(const float* Y, const float* dY, float* dX,
   if (R == 0) return EBN_OK;
   hipStream_t s = ebn_stream(stream);
   if (R <= STRIP_ROWS) {
-    hipLaunchKernelGGL(relu_bwd_strip_kernel, dim3(static_cast<unsigned>(ebn_ceil_div(Ccols, STRIP_COLS))), dim3(1024), 0, s,
+    EBN_LAUNCH(relu_bwd_strip_kernel, dim3(static_cast<unsigned>(ebn_ceil_div(Ccols, STRIP_COLS))), dim3(1024), 0, s,
                        Y, dY, dX, dbias, static_cast<int>(R), Ccols, accumulate);
     EBN_CHECK_LAUNCH();
     return EBN_OK;
@@ -600,7 +600,7 @@ extern "C" int ebn_batchnorm_fwd_f32(const float* X, const float* gamma, const f
   const unsigned cgrid = static_cast<unsigned>(ebn_ceil_div(C, 256));
   if (training && R <= STRIP_ROWS) {
     const EbnDrop dr = ebn_make_drop(st, site, drop_p);
-    hipLaunchKernelGGL(bn_fwd_strip_kernel, dim3(static_cast<unsigned>(ebn_ceil_div(C, STRIP_COLS))), dim3(1024), 0, s, X,
+    EBN_LAUNCH(bn_fwd_strip_kernel, dim3(static_cast<unsigned>(ebn_ceil_div(C, STRIP_COLS))), dim3(1024), 0, s, X,
                        gamma, beta, moving_mean, moving_var, Y, xhat, mean_out, istd_out, static_cast<int>(R), C,
                        dr.key_ptr, dr.thresh, dr.scale, elem_offset);
     EBN_CHECK_LAUNCH();
@@ -612,15 +612,15 @@ extern "C" int ebn_batchnorm_fwd_f32(const float* X, const float* gamma, const f
     ebn_colred_stage1(ColMoment<1>{X, nullptr, C}, partials, R, C, s, &nb);
     ebn_reduce_partials(partials, nb, 1, C, inv_R, mean_out, nullptr, 0, nullptr, nullptr, s);
     ebn_colred_stage1(ColMoment<2>{X, mean_out, C}, partials, R, C, s, &nb);
-    hipLaunchKernelGGL(bn_var_finalize_kernel, dim3(cgrid), dim3(256), 0, s, partials, static_cast<int>(nb), C, inv_R,
+    EBN_LAUNCH(bn_var_finalize_kernel, dim3(cgrid), dim3(256), 0, s, partials, static_cast<int>(nb), C, inv_R,
                        mean_out, istd_out, moving_mean, moving_var);
   } else {
-    hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(cgrid), dim3(256), 0, s, moving_mean, moving_var, mean_out, istd_out,
+    EBN_LAUNCH(bn_eval_stats_kernel, dim3(cgrid), dim3(256), 0, s, moving_mean, moving_var, mean_out, istd_out,
                        C);
   }
   EBN_CHECK_LAUNCH();
   const EbnDrop dr = training ? ebn_make_drop(st, site, drop_p) : ebn_make_drop(nullptr, -1, 0.f);
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(R * C)), dim3(256), 0, s, X, gamma, beta, mean_out, istd_out, Y,
+  EBN_LAUNCH(bn_apply_kernel, dim3(grid_for(R * C)), dim3(256), 0, s, X, gamma, beta, mean_out, istd_out, Y,
                      xhat, R * C, C, dr.key_ptr, dr.thresh, dr.scale, elem_offset);
   EBN_CHECK_LAUNCH();
   return EBN_OK;
@@ -637,7 +637,7 @@ extern "C" int ebn_batchnorm_bwd_f32(const float* dY, const float* xhat, const f
   const int C = Ccols;
   const EbnDrop dr = training ? ebn_make_drop(st, site, drop_p) : ebn_make_drop(nullptr, -1, 0.f);
   if (R <= STRIP_ROWS) {
-    hipLaunchKernelGGL(bn_bwd_strip_kernel, dim3(static_cast<unsigned>(ebn_ceil_div(C, STRIP_COLS))), dim3(1024), 0, s, dY,
+    EBN_LAUNCH(bn_bwd_strip_kernel, dim3(static_cast<unsigned>(ebn_ceil_div(C, STRIP_COLS))), dim3(1024), 0, s, dY,
                        xhat, gamma, istd, dX, dgamma, dbeta, static_cast<int>(R), C, training, accumulate, dr.key_ptr,
                        dr.thresh, dr.scale, elem_offset);
     EBN_CHECK_LAUNCH();
@@ -649,7 +649,7 @@ extern "C" int ebn_batchnorm_bwd_f32(const float* dY, const float* xhat, const f
   float* site_db = site_dg + C;
   ebn_reduce_partials(partials, nb, 2, C, 1.0f, dgamma, dbeta, accumulate, site_dg, site_db, s);
   EBN_CHECK_LAUNCH();
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(R * C)), dim3(256), 0, s, dY, xhat, gamma, istd, site_dg,
+  EBN_LAUNCH(bn_bwd_apply_kernel, dim3(grid_for(R * C)), dim3(256), 0, s, dY, xhat, gamma, istd, site_dg,
                      site_db, dX, R * C, C, 1.0f / static_cast<float>(R), training, dr.key_ptr, dr.thresh, dr.scale,
                      elem_offset);
   EBN_CHECK_LAUNCH();
@@ -667,7 +667,7 @@ extern "C" int ebn_batchnorm2_fwd_f32(const float* X, const float* gamma, const 
   if (R0 + R1 == 0) return EBN_OK;
   const EbnDrop dr = ebn_make_drop(st, site, drop_p);
   Bn2Sites sites{{static_cast<int>(R0), static_cast<int>(R1)}, {mean_out0, mean_out1}, {istd_out0, istd_out1}};
-  hipLaunchKernelGGL(bn2_fwd_strip_kernel, dim3(static_cast<unsigned>(ebn_ceil_div(Ccols, STRIP_COLS))), dim3(1024), 0,
+  EBN_LAUNCH(bn2_fwd_strip_kernel, dim3(static_cast<unsigned>(ebn_ceil_div(Ccols, STRIP_COLS))), dim3(1024), 0,
                      ebn_stream(stream), X, gamma, beta, moving_mean, moving_var, Y, xhat, sites, Ccols, dr.key_ptr, dr.thresh,
                      dr.scale);
   EBN_CHECK_LAUNCH();
@@ -683,7 +683,7 @@ extern "C" int ebn_batchnorm2_relu_bwd_f32(const float* dY, const float* xhat, c
   EBN_REQUIRE(R0 + R1 <= STRIP_ROWS, EBN_ERR_UNSUPPORTED);
   if (R0 + R1 == 0) return EBN_OK;
   const EbnDrop dr = ebn_make_drop(st, site, drop_p);
-  hipLaunchKernelGGL(bn2_relu_bwd_strip_kernel, dim3(static_cast<unsigned>(ebn_ceil_div(Ccols, STRIP_COLS))), dim3(1024), 0,
+  EBN_LAUNCH(bn2_relu_bwd_strip_kernel, dim3(static_cast<unsigned>(ebn_ceil_div(Ccols, STRIP_COLS))), dim3(1024), 0,
                      ebn_stream(stream), dY, xhat, relu_out, gamma, istd0, istd1, dX, dgamma, dbeta, dbias, static_cast<int>(R0),
                      static_cast<int>(R1), Ccols, dr.key_ptr, dr.thresh, dr.scale);
   EBN_CHECK_LAUNCH();
@@ -740,7 +740,7 @@ static int copy3_launch(const void* s0, void* d0, int64_t n0, const void* s1, vo
   int64_t gx = ebn_ceil_div(most, 256);
   if (gx > 1024) gx = 1024;
   if (gx < 1) gx = 1;
-  hipLaunchKernelGGL(copy3_kernel, dim3(static_cast<unsigned>(gx), 3), dim3(256), 0, ebn_stream(stream), c);
+  EBN_LAUNCH(copy3_kernel, dim3(static_cast<unsigned>(gx), 3), dim3(256), 0, ebn_stream(stream), c);
   EBN_CHECK_LAUNCH();
   return EBN_OK;
 }
@@ -760,7 +760,7 @@ extern "C" int ebn_copy3_advance(const void* s0, void* d0, int64_t n0, const voi
 extern "C" int ebn_axpy_f32(float a, const float* x, float* y, int64_t n, ebn_stream_t stream) {
   EBN_REQUIRE(x && y && n >= 0, EBN_ERR_BAD_ARG);
   if (n == 0) return EBN_OK;
-  hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n)), dim3(256), 0, ebn_stream(stream), a, x, y, n);
+  EBN_LAUNCH(axpy_kernel, dim3(grid_for(n)), dim3(256), 0, ebn_stream(stream), a, x, y, n);
   EBN_CHECK_LAUNCH();
   return EBN_OK;
 }
@@ -795,9 +795,9 @@ extern "C" int ebn_l2_reg4_f32(const float* W0, float* g0, int64_t n0, const flo
   int64_t grid = ebn_ceil_div(most, 256 * 4);
   if (grid > L2_BLOCKS) grid = L2_BLOCKS;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(l2_reg4_kernel, dim3(static_cast<unsigned>(grid), static_cast<unsigned>(nseg)), dim3(256), 0, s, sg,
+  EBN_LAUNCH(l2_reg4_kernel, dim3(static_cast<unsigned>(grid), static_cast<unsigned>(nseg)), dim3(256), 0, s, sg,
                      2.0f * lambda, partials);
-  hipLaunchKernelGGL((sum_kernel<false>), dim3(1), dim3(1024), 0, s, partials, grid * nseg, lambda, loss, 1);
+  EBN_LAUNCH((sum_kernel<false>), dim3(1), dim3(1024), 0, s, partials, grid * nseg, lambda, loss, 1);
   EBN_CHECK_LAUNCH();
   return EBN_OK;
 }
@@ -810,8 +810,8 @@ extern "C" int ebn_l2_reg_f32(const float* W, float* gW, int64_t n, float lambda
   int64_t grid = ebn_ceil_div(n, 256 * 4);
   if (grid > L2_BLOCKS) grid = L2_BLOCKS;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(l2_reg_kernel, dim3(static_cast<unsigned>(grid)), dim3(256), 0, s, W, gW, n, 2.0f * lambda, partials);
-  hipLaunchKernelGGL((sum_kernel<false>), dim3(1), dim3(1024), 0, s, partials, grid, lambda, loss, 1);
+  EBN_LAUNCH(l2_reg_kernel, dim3(static_cast<unsigned>(grid)), dim3(256), 0, s, W, gW, n, 2.0f * lambda, partials);
+  EBN_LAUNCH((sum_kernel<false>), dim3(1), dim3(1024), 0, s, partials, grid, lambda, loss, 1);
   EBN_CHECK_LAUNCH();
   return EBN_OK;
 }
@@ -819,7 +819,7 @@ extern "C" int ebn_l2_reg_f32(const float* W, float* gW, int64_t n, float lambda
 extern "C" int ebn_sum_f32(const float* x, int64_t n, float scale, float* out, int32_t accumulate,
                            ebn_stream_t stream) {
   EBN_REQUIRE(x && out && n >= 0, EBN_ERR_BAD_ARG);
-  hipLaunchKernelGGL((sum_kernel<false>), dim3(1), dim3(1024), 0, ebn_stream(stream), x, n, scale, out, accumulate);
+  EBN_LAUNCH((sum_kernel<false>), dim3(1), dim3(1024), 0, ebn_stream(stream), x, n, scale, out, accumulate);
   EBN_CHECK_LAUNCH();
   return EBN_OK;
 }
@@ -827,7 +827,7 @@ extern "C" int ebn_sum_f32(const float* x, int64_t n, float scale, float* out, i
 extern "C" int ebn_sumsq_f32(const float* x, int64_t n, float scale, float* out, int32_t accumulate,
                              ebn_stream_t stream) {
   EBN_REQUIRE(x && out && n >= 0, EBN_ERR_BAD_ARG);
-  hipLaunchKernelGGL((sum_kernel<true>), dim3(1), dim3(1024), 0, ebn_stream(stream), x, n, scale, out, accumulate);
+  EBN_LAUNCH((sum_kernel<true>), dim3(1), dim3(1024), 0, ebn_stream(stream), x, n, scale, out, accumulate);
   EBN_CHECK_LAUNCH();
   return EBN_OK;
 }

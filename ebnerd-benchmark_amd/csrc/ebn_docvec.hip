@@ -738,7 +738,7 @@ int launch_panel(const PanelArgs& p, hipStream_t s) {
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
   if (attr != hipSuccess) return static_cast<int>(attr);
   const dim3 grid(static_cast<unsigned>((p.Nout + TN - 1) / TN), static_cast<unsigned>((p.n0 + TM - 1) / TM + (p.n1 + TM - 1) / TM));
-  hipLaunchKernelGGL((dvn_panel_kernel<AX, B_KC, EPI>), grid, dim3(NTHR), panel_lds(p.K, CST), s, p);
+  EBN_LAUNCH((dvn_panel_kernel<AX, B_KC, EPI>), grid, dim3(NTHR), panel_lds(p.K, CST), s, p);
   EBN_CHECK_LAUNCH();
   return EBN_OK;
 }
@@ -873,7 +873,7 @@ static int dvn_bwd_layer(const ebn_dvn_args* a, int32_t l, const ebn_step_state*
   q.l2 = a->l2;
   q.loss = a->loss;
   const dim3 grid(static_cast<unsigned>((a->units[0] + 255) / 256), static_cast<unsigned>(row_tiles(a)));
-  hipLaunchKernelGGL(dvn_dbn_apply_kernel, grid, dim3(ATHR), 0, s, q);
+  EBN_LAUNCH(dvn_dbn_apply_kernel, grid, dim3(ATHR), 0, s, q);
   EBN_CHECK_LAUNCH();
   return EBN_OK;
 }
@@ -902,7 +902,7 @@ extern "C" int ebn_docvec_stage_gather_f32(const int32_t* idx0, int64_t n0, cons
   int64_t blocks = ebn_ceil_div(items, 512);
   if (blocks * 256 < n_labels) blocks = ebn_ceil_div(n_labels, 256);
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(dvn_stage_gather_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, ebn_stream(stream), a);
+  EBN_LAUNCH(dvn_stage_gather_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, ebn_stream(stream), a);
   EBN_CHECK_LAUNCH();
   return EBN_OK;
 }

@@ -294,10 +294,10 @@ int scatter_fixed_atomic_launch(const int32_t* ids, const float* dX, int64_t* ac
   int64_t grid = ebn_ceil_div(n_items, GATHER_THREADS);
   if (grid > 256 * 32) grid = 256 * 32;
   if (n_items + grid * GATHER_THREADS < (static_cast<int64_t>(1) << 32))
-    hipLaunchKernelGGL(scatter_add_rows_fixed_kernel<uint32_t>, dim3(static_cast<unsigned>(grid)), dim3(GATHER_THREADS), 0, s, ids, dX,
+    EBN_LAUNCH(scatter_add_rows_fixed_kernel<uint32_t>, dim3(static_cast<unsigned>(grid)), dim3(GATHER_THREADS), 0, s, ids, dX,
                        reinterpret_cast<long long*>(acc), n_items, D, V, dr.key_ptr, dr.thresh, dr.scale, range_flag);
   else
-    hipLaunchKernelGGL(scatter_add_rows_fixed_kernel<int64_t>, dim3(static_cast<unsigned>(grid)), dim3(GATHER_THREADS), 0, s, ids, dX,
+    EBN_LAUNCH(scatter_add_rows_fixed_kernel<int64_t>, dim3(static_cast<unsigned>(grid)), dim3(GATHER_THREADS), 0, s, ids, dX,
                        reinterpret_cast<long long*>(acc), n_items, D, V, dr.key_ptr, dr.thresh, dr.scale, range_flag);
   EBN_CHECK_LAUNCH();
   return EBN_OK;
@@ -316,7 +316,7 @@ extern "C" int ebn_embedding_grad_scatter_fixed(const int32_t* ids, const float*
     return scatter_fixed_atomic_launch(ids, dX, acc, n_tok, D, V, dr, range_flag, ebn_stream(stream));
   int threads = static_cast<int>(ebn_ceil_div(D, 64) * 64);
   if (threads > 1024) threads = 1024;
-  hipLaunchKernelGGL(scatter_add_rows_fixed_runs_kernel, dim3(static_cast<unsigned>(ebn_ceil_div(n_tok, RUN_CHUNK))), dim3(threads), 0,
+  EBN_LAUNCH(scatter_add_rows_fixed_runs_kernel, dim3(static_cast<unsigned>(ebn_ceil_div(n_tok, RUN_CHUNK))), dim3(threads), 0,
                      ebn_stream(stream), ids, dX, reinterpret_cast<long long*>(acc), n_tok, D, V, dr.key_ptr, dr.thresh, dr.scale, range_flag);
   EBN_CHECK_LAUNCH();
   return EBN_OK;
@@ -336,7 +336,7 @@ extern "C" int ebn_fixed_to_f32(int64_t* acc, float* out, int64_t n, int32_t* ra
   if (n == 0) return EBN_OK;
   int64_t grid = ebn_ceil_div(n, 256);
   if (grid > 256 * 16) grid = 256 * 16;
-  hipLaunchKernelGGL(fixed_to_f32_kernel, dim3(static_cast<unsigned>(grid)), dim3(256), 0, ebn_stream(stream),
+  EBN_LAUNCH(fixed_to_f32_kernel, dim3(static_cast<unsigned>(grid)), dim3(256), 0, ebn_stream(stream),
                      reinterpret_cast<long long*>(acc), out, n, range_flag);
   EBN_CHECK_LAUNCH();
   return EBN_OK;
@@ -350,7 +350,7 @@ extern "C" int ebn_adam_keras_step_fixed_f32(float* theta, int64_t* acc, float* 
   if (n == 0) return EBN_OK;
   int64_t grid = ebn_ceil_div(ebn_ceil_div(n, 4), 256);
   if (grid > 256 * 16) grid = 256 * 16;
-  hipLaunchKernelGGL(adam_keras_fixed_kernel, dim3(static_cast<unsigned>(grid)), dim3(256), 0, ebn_stream(stream), theta,
+  EBN_LAUNCH(adam_keras_fixed_kernel, dim3(static_cast<unsigned>(grid)), dim3(256), 0, ebn_stream(stream), theta,
                      reinterpret_cast<long long*>(acc), m, v, n, st, static_cast<float>(1.0 - beta1),
                      static_cast<float>(1.0 - beta2), static_cast<float>(eps_d), grad_scale, range_flag);
   EBN_CHECK_LAUNCH();
@@ -366,7 +366,7 @@ extern "C" int ebn_expand_titles_i32(const int32_t* art_idx, const int32_t* toke
   const int64_t n_items = n_titles * T;
   int64_t grid = ebn_ceil_div(n_items, GATHER_THREADS);
   if (grid > 256 * 32) grid = 256 * 32;
-  hipLaunchKernelGGL(expand_titles_kernel, dim3(static_cast<unsigned>(grid)), dim3(GATHER_THREADS), 0,
+  EBN_LAUNCH(expand_titles_kernel, dim3(static_cast<unsigned>(grid)), dim3(GATHER_THREADS), 0,
                      ebn_stream(stream), art_idx, token_matrix, ids_out, n_items, T, n_rows, oob_flag);
   EBN_CHECK_LAUNCH();
   return EBN_OK;
@@ -387,7 +387,7 @@ extern "C" int ebn_gather_rows_f32(const int32_t* ids, const float* table, float
     EBN_REQUIRE(grid <= 0x7FFFFFFF, EBN_ERR_UNSUPPORTED);
     const bool small = n_items + per_block < (static_cast<int64_t>(1) << 32);  // every item index fits 32 bits
 #define EBN_GATHER_LAUNCH(IT, SH)                                                                                     \
-  hipLaunchKernelGGL((gather_rows_vec4_kernel<IT, SH>), dim3(static_cast<unsigned>(grid)), dim3(GATHER_THREADS), 0,   \
+  EBN_LAUNCH((gather_rows_vec4_kernel<IT, SH>), dim3(static_cast<unsigned>(grid)), dim3(GATHER_THREADS), 0,   \
                      ebn_stream(stream), ids, reinterpret_cast<const float4*>(table), reinterpret_cast<float4*>(out), \
                      n_items, vpr, V, dr.key_ptr, dr.thresh, dr.scale, oob_flag)
     if (small && vpr == 256) EBN_GATHER_LAUNCH(uint32_t, 8);
@@ -399,7 +399,7 @@ extern "C" int ebn_gather_rows_f32(const int32_t* ids, const float* table, float
     const int64_t n_items = n_tok * D;
     int64_t grid = ebn_ceil_div(n_items, GATHER_THREADS);
     if (grid > 256 * 32) grid = 256 * 32;
-    hipLaunchKernelGGL(gather_rows_scalar_kernel, dim3(static_cast<unsigned>(grid)), dim3(GATHER_THREADS),
+    EBN_LAUNCH(gather_rows_scalar_kernel, dim3(static_cast<unsigned>(grid)), dim3(GATHER_THREADS),
                        0, ebn_stream(stream), ids, table, out, n_items, D, V, dr.key_ptr, dr.thresh,
                        dr.scale, oob_flag);
   }
@@ -419,10 +419,10 @@ extern "C" int ebn_embedding_grad_scatter_f32(const int32_t* ids, const float* d
   int64_t grid = ebn_ceil_div(n_items, GATHER_THREADS);
   if (grid > 256 * 32) grid = 256 * 32;
   if (n_items + grid * GATHER_THREADS < (static_cast<int64_t>(1) << 32))
-    hipLaunchKernelGGL(scatter_add_rows_kernel<uint32_t>, dim3(static_cast<unsigned>(grid)), dim3(GATHER_THREADS), 0,
+    EBN_LAUNCH(scatter_add_rows_kernel<uint32_t>, dim3(static_cast<unsigned>(grid)), dim3(GATHER_THREADS), 0,
                        ebn_stream(stream), ids, dX, dTable, n_items, D, V, dr.key_ptr, dr.thresh, dr.scale);
   else
-    hipLaunchKernelGGL(scatter_add_rows_kernel<int64_t>, dim3(static_cast<unsigned>(grid)), dim3(GATHER_THREADS), 0,
+    EBN_LAUNCH(scatter_add_rows_kernel<int64_t>, dim3(static_cast<unsigned>(grid)), dim3(GATHER_THREADS), 0,
                        ebn_stream(stream), ids, dX, dTable, n_items, D, V, dr.key_ptr, dr.thresh, dr.scale);
   EBN_CHECK_LAUNCH();
   return EBN_OK;

@@ -65,7 +65,7 @@ extern "C" int ebn_grad_finish_f32(const ebn_finish_job* jobs, int32_t n_jobs, e
     ++js.n;
   }
   if (js.n == 0) return EBN_OK;
-  hipLaunchKernelGGL(grad_finish_kernel, dim3(static_cast<unsigned>(js.first_block[js.n])), dim3(1024), 0, ebn_stream(stream), js);
+  EBN_LAUNCH(grad_finish_kernel, dim3(static_cast<unsigned>(js.first_block[js.n])), dim3(1024), 0, ebn_stream(stream), js);
   EBN_CHECK_LAUNCH();
   return EBN_OK;
 }

@@ -625,25 +625,25 @@ int launch_gemm(int transA, int transB, int64_t M, int64_t N, int64_t K, float a
 #define EBN_GEMM_LAUNCH(TA, TB)                                                                            \
   do {                                                                                                    \
     if (vecA && vecB)                                                                                     \
-      hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WAVES_M, TA, TB, true>), grid, block, 0, s, M, N, K, alpha, A, lda, \
+      EBN_LAUNCH((gemm_f32_kernel<BM, BN, WAVES_M, TA, TB, true>), grid, block, 0, s, M, N, K, alpha, A, lda, \
                          B, ldb, beta, C, ldc, k_per_split, part, epi);                       \
     else if constexpr (BM == 64 && BN == 64) /* unaligned operands: the scalar-load form exists for the 64 x 64 tile only */ \
-      hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WAVES_M, TA, TB, false>), grid, block, 0, s, M, N, K, alpha, A,  \
+      EBN_LAUNCH((gemm_f32_kernel<BM, BN, WAVES_M, TA, TB, false>), grid, block, 0, s, M, N, K, alpha, A,  \
                          lda, B, ldb, beta, C, ldc, k_per_split, part, epi);                  \
     else                                                                                                  \
       return EBN_ERR_UNSUPPORTED;                                                                         \
   } while (0)
   if (epi.rowmap != nullptr) {  // caller guarantees !transA && !transB && vecA && vecB, no split-K; the 256 x 64 tile only
     if constexpr (BM == 256)
-      hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WAVES_M, false, false, true, 3>), grid, block, 0, s, M, N, K, alpha, A, lda, B, ldb, beta,
+      EBN_LAUNCH((gemm_f32_kernel<BM, BN, WAVES_M, false, false, true, 3>), grid, block, 0, s, M, N, K, alpha, A, lda, B, ldb, beta,
                          C, ldc, k_per_split, part, epi);
     else
       return EBN_ERR_UNSUPPORTED;
   } else if (epi.bias != nullptr)  // caller guarantees !transA && !transB && vecA && vecB
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WAVES_M, false, false, true, 2>), grid, block, 0, s, M, N, K, alpha, A, lda,
+    EBN_LAUNCH((gemm_f32_kernel<BM, BN, WAVES_M, false, false, true, 2>), grid, block, 0, s, M, N, K, alpha, A, lda,
                        B, ldb, beta, C, ldc, k_per_split, part, epi);
   else if (epi.rs != nullptr)  // caller guarantees !transA && transB && vecA && vecB
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WAVES_M, false, true, true, 1>), grid, block, 0, s, M, N, K, alpha, A, lda,
+    EBN_LAUNCH((gemm_f32_kernel<BM, BN, WAVES_M, false, true, true, 1>), grid, block, 0, s, M, N, K, alpha, A, lda,
                        B, ldb, beta, C, ldc, k_per_split, part, epi);
   else if (!transA && !transB) EBN_GEMM_LAUNCH(false, false);
   else if (!transA && transB) EBN_GEMM_LAUNCH(false, true);
@@ -1088,7 +1088,7 @@ int launch_gemm_small(int transA, int transB, int64_t M, int64_t N, int64_t K, f
     static const hipError_t attr__ = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_small_kernel<TA, TB, VA, VB>), \
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)); \
     if (attr__ != hipSuccess) return static_cast<int>(attr__);                                                            \
-    hipLaunchKernelGGL((gemm_small_kernel<TA, TB, VA, VB>), grid, block, lds, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, epi); \
+    EBN_LAUNCH((gemm_small_kernel<TA, TB, VA, VB>), grid, block, lds, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, epi); \
   } while (0)
 #define EBN_SMALL_VEC_T(TA, TB, T)                                                                                         \
   do {                                                                                                                     \
@@ -1097,7 +1097,7 @@ int launch_gemm_small(int transA, int transB, int64_t M, int64_t N, int64_t K, f
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_t)); \
     if (attr__ != hipSuccess) return static_cast<int>(attr__);                                                            \
     const dim3 grid_t(static_cast<unsigned>(ebn_ceil_div(N, T)), static_cast<unsigned>(ebn_ceil_div(M, T)));               \
-    hipLaunchKernelGGL((gemm_small_vec_kernel<TA, TB, T>), grid_t, dim3((T) * (T) / 4), lds_t, s, M, N, K, alpha, A, lda, B, ldb, \
+    EBN_LAUNCH((gemm_small_vec_kernel<TA, TB, T>), grid_t, dim3((T) * (T) / 4), lds_t, s, M, N, K, alpha, A, lda, B, ldb, \
                        beta, C, ldc, epi);                                                                                 \
   } while (0)
 #define EBN_SMALL_VEC(TA, TB) EBN_SMALL_VEC_T(TA, TB, 32)
@@ -1264,7 +1264,7 @@ static int gemm_dispatch(int32_t transA, int32_t transB, int64_t M, int64_t N, i
         }
         int64_t grid = ebn_ceil_div(M * N, 256);
         if (grid > 4096) grid = 4096;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(static_cast<unsigned>(grid)), dim3(256), 0, s, workspace, z, M, N, beta, C, ldc, epi);
+        EBN_LAUNCH(splitk_reduce_kernel, dim3(static_cast<unsigned>(grid)), dim3(256), 0, s, workspace, z, M, N, beta, C, ldc, epi);
         EBN_CHECK_LAUNCH();
         return EBN_OK;
       }
@@ -1299,7 +1299,7 @@ static int gemm_dispatch(int32_t transA, int32_t transB, int64_t M, int64_t N, i
   if (splits > 1) {
     int64_t grid = ebn_ceil_div(M * N, 256);
     if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(static_cast<unsigned>(grid)), dim3(256), 0, s, workspace,
+    EBN_LAUNCH(splitk_reduce_kernel, dim3(static_cast<unsigned>(grid)), dim3(256), 0, s, workspace,
                        splits, M, N, beta, C, ldc, epi);
     EBN_CHECK_LAUNCH();
   }
@@ -1365,7 +1365,7 @@ extern "C" int ebn_gemm_f32_rank1(int64_t M, int64_t N, int64_t K, float alpha, 
   // unaligned operands: write the rank-1 term, then accumulate the product onto it with the scalar-load kernels
   int64_t grid = ebn_ceil_div(M * N, 256);
   if (grid > 4096) grid = 4096;
-  hipLaunchKernelGGL(rank1_fill_kernel, dim3(static_cast<unsigned>(grid)), dim3(256), 0, s, C, ldc, M, N, epi);
+  EBN_LAUNCH(rank1_fill_kernel, dim3(static_cast<unsigned>(grid)), dim3(256), 0, s, C, ldc, M, N, epi);
   EBN_CHECK_LAUNCH();
   return gemm_dispatch(0, 1, M, N, K, alpha, A, lda, B, ldb, 1.0f, C, ldc, workspace, workspace_floats, 0,
                        GemmEpi{nullptr, nullptr, 0, 1, nullptr}, s);
@@ -1426,7 +1426,7 @@ extern "C" int ebn_dense_bwd_pair_f32(int64_t R, int64_t K_in, int64_t N_out, co
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_small_pair_kernel),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     if (attr != hipSuccess) return static_cast<int>(attr);
-    hipLaunchKernelGGL(gemm_small_pair_kernel, dim3(static_cast<unsigned>(p0.tiles + p1.tiles)), dim3(GEMM_THREADS), lds, s, p0, p1);
+    EBN_LAUNCH(gemm_small_pair_kernel, dim3(static_cast<unsigned>(p0.tiles + p1.tiles)), dim3(GEMM_THREADS), lds, s, p0, p1);
     EBN_CHECK_LAUNCH();
     return EBN_OK;
   }
@@ -1495,7 +1495,7 @@ extern "C" int ebn_gemm_tn_group_f32(const ebn_tn_problem* problems, int32_t n, 
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_small_tn_group_kernel<TT>),            \
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));        \
     if (attr != hipSuccess) return static_cast<int>(attr);                                                                        \
-    hipLaunchKernelGGL(gemm_small_tn_group_kernel<TT>, dim3(static_cast<unsigned>(total)), dim3((TT) * (TT) / 4), lds, ebn_stream(stream), g); \
+    EBN_LAUNCH(gemm_small_tn_group_kernel<TT>, dim3(static_cast<unsigned>(total)), dim3((TT) * (TT) / 4), lds, ebn_stream(stream), g); \
   } while (0)
   if (T == 64) EBN_TN_GROUP(64);
   else EBN_TN_GROUP(32);

@@ -500,7 +500,7 @@ int direct_launch_rc(bool b_kc, const DirectPlan& pl, int64_t M, int64_t N, int6
                      int64_t ldb, float* C, int64_t ldc, hipStream_t s) {
   const dim3 grid(static_cast<unsigned>(ebn_ceil_div(pl.tasks, 4))), block(256);
 #define EBN_DIR_GO(KC, DP) \
-  hipLaunchKernelGGL((gemm_direct16_kernel<R, CW, KC, DP>), grid, block, 0, s, M, N, K, alpha, A, lda, B, ldb, C, ldc, pl.G, pl.n_wide, pl.tasks)
+  EBN_LAUNCH((gemm_direct16_kernel<R, CW, KC, DP>), grid, block, 0, s, M, N, K, alpha, A, lda, B, ldb, C, ldc, pl.G, pl.n_wide, pl.tasks)
   if constexpr (R == 1) {  // (the planner never gives one row block per wave to a [N][K] B: the fetch path sets the pace there)
     if (b_kc) return EBN_ERR_UNSUPPORTED;
     EBN_DIR_GO(false, 2);
@@ -566,7 +566,7 @@ int ebn_gemm_direct_tn_launch(int64_t M, int64_t N, int64_t K, float alpha, cons
   const dim3 grid(static_cast<unsigned>(pl.tiles * pl.Z)), block(256);
 #define EBN_TN_CASE(RR, CC)                                                                                                        \
   if (pl.R == RR && pl.CW == CC) {                                                                                                 \
-    hipLaunchKernelGGL((gemm_direct16_tn_kernel<RR, CC>), grid, block, 0, s, M, N, K, alpha, A, lda, B, ldb, part, pl.G, pl.n_wide, pl.tiles, \
+    EBN_LAUNCH((gemm_direct16_tn_kernel<RR, CC>), grid, block, 0, s, M, N, K, alpha, A, lda, B, ldb, part, pl.G, pl.n_wide, pl.tiles, \
                        pl.kps);                                                                                                    \
     EBN_CHECK_LAUNCH();                                                                                                            \
     return EBN_OK;                                                                                                                 \

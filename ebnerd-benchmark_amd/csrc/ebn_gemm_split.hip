@@ -504,10 +504,10 @@ extern "C" int ebn_split_planes_f32(const float* src, int64_t ld, int64_t rows, 
   EBN_REQUIRE(ebn_aligned16(planes), EBN_ERR_ALIGN);
   const int64_t rows_p = pad_rows(rows), Kp = pad_k(K);
   const dim3 grid(static_cast<unsigned>(rows_p / 64), static_cast<unsigned>(ebn_ceil_div(Kp, 64)));
-  if (!trans) hipLaunchKernelGGL((split_planes_kernel<false>), grid, dim3(256), 0, ebn_stream(stream), src, ld, rows, K,
+  if (!trans) EBN_LAUNCH((split_planes_kernel<false>), grid, dim3(256), 0, ebn_stream(stream), src, ld, rows, K,
                                  static_cast<uint16_t*>(planes), rows_p, Kp);
   else  // transposing source: whole rows in order (the 64 x 64-tile transpose through LDS straddled three lines per 256-byte tile row)
-    hipLaunchKernelGGL(split_planes_t_rows_kernel, dim3(static_cast<unsigned>(Kp / 8)), dim3(256), 0, ebn_stream(stream), src, ld, rows, K,
+    EBN_LAUNCH(split_planes_t_rows_kernel, dim3(static_cast<unsigned>(Kp / 8)), dim3(256), 0, ebn_stream(stream), src, ld, rows, K,
                        static_cast<uint16_t*>(planes), rows_p, Kp);
   EBN_CHECK_LAUNCH();
   return EBN_OK;
@@ -527,14 +527,14 @@ extern "C" int ebn_gather_split_planes_f32(const int32_t* ids, const float* tabl
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     if (attr != hipSuccess) return static_cast<int>(attr);
     const dim3 grid_r(static_cast<unsigned>(ebn_ceil_div(tok_ext, GS_TOK)), static_cast<unsigned>(ebn_ceil_div(col_ext, GS_CHUNK)));
-    hipLaunchKernelGGL(gather_split_rows_kernel, grid_r, dim3(256), lds, ebn_stream(stream), ids, reinterpret_cast<const float4*>(table), n_rows,
+    EBN_LAUNCH(gather_split_rows_kernel, grid_r, dim3(256), lds, ebn_stream(stream), ids, reinterpret_cast<const float4*>(table), n_rows,
                        static_cast<int64_t>(D), V, d.key_ptr, d.thresh, d.scale, oob_flag, static_cast<uint16_t*>(planes_n), n_rows_p, n_Kp,
                        static_cast<uint16_t*>(planes_t), t_rows_p, t_Kp);
     EBN_CHECK_LAUNCH();
     return EBN_OK;
   }
   const dim3 grid(static_cast<unsigned>(ebn_ceil_div(tok_ext, 64)), static_cast<unsigned>(ebn_ceil_div(col_ext, 64)));
-  hipLaunchKernelGGL(gather_split_planes_kernel, grid, dim3(256), 0, ebn_stream(stream), ids, table, n_rows, static_cast<int64_t>(D), V,
+  EBN_LAUNCH(gather_split_planes_kernel, grid, dim3(256), 0, ebn_stream(stream), ids, table, n_rows, static_cast<int64_t>(D), V,
                      d.key_ptr, d.thresh, d.scale, oob_flag, static_cast<uint16_t*>(planes_n), n_rows_p, n_Kp,
                      static_cast<uint16_t*>(planes_t), t_rows_p, t_Kp);
   EBN_CHECK_LAUNCH();
@@ -562,25 +562,25 @@ extern "C" int ebn_gemm_planes_f32(const void* a_planes, int64_t M, const void* 
   EBN_REQUIRE(direct || (workspace && workspace_floats >= static_cast<int64_t>(p.splits) * M * N), EBN_ERR_BAD_ARG);
   const dim3 grid(static_cast<unsigned>(ebn_ceil_div(N, SP_BN)), static_cast<unsigned>(a_rows / SP_BM), static_cast<unsigned>(direct ? 1 : p.splits));
   if (direct) {
-    hipLaunchKernelGGL(gemm_bf16x6_kernel, grid, dim3(SP_THREADS), 0, s, Ap, Bp, a_rows, b_rows, Kp, M, N, C, ldc, p.slabs_per_split, nullptr);
+    EBN_LAUNCH(gemm_bf16x6_kernel, grid, dim3(SP_THREADS), 0, s, Ap, Bp, a_rows, b_rows, Kp, M, N, C, ldc, p.slabs_per_split, nullptr);
     EBN_CHECK_LAUNCH();
     if (alpha != 1.0f) {
       int64_t g = ebn_ceil_div(M * N, 256);
       if (g > 4096) g = 4096;
-      hipLaunchKernelGGL(scale_inplace_kernel, dim3(static_cast<unsigned>(g)), dim3(256), 0, s, C, ldc, M, N, alpha);
+      EBN_LAUNCH(scale_inplace_kernel, dim3(static_cast<unsigned>(g)), dim3(256), 0, s, C, ldc, M, N, alpha);
       EBN_CHECK_LAUNCH();
     }
     return EBN_OK;
   }
   // split-K, or beta != 0: every z-slice writes a partial, a fixed-order combine finishes
   if (p.splits == 1)  // the kernel treats gridDim.z == 1 as "write C": C is pointed at the partial buffer (ld = N)
-    hipLaunchKernelGGL(gemm_bf16x6_kernel, grid, dim3(SP_THREADS), 0, s, Ap, Bp, a_rows, b_rows, Kp, M, N, workspace, N, p.slabs_per_split, nullptr);
+    EBN_LAUNCH(gemm_bf16x6_kernel, grid, dim3(SP_THREADS), 0, s, Ap, Bp, a_rows, b_rows, Kp, M, N, workspace, N, p.slabs_per_split, nullptr);
   else
-    hipLaunchKernelGGL(gemm_bf16x6_kernel, grid, dim3(SP_THREADS), 0, s, Ap, Bp, a_rows, b_rows, Kp, M, N, C, ldc, p.slabs_per_split, workspace);
+    EBN_LAUNCH(gemm_bf16x6_kernel, grid, dim3(SP_THREADS), 0, s, Ap, Bp, a_rows, b_rows, Kp, M, N, C, ldc, p.slabs_per_split, workspace);
   EBN_CHECK_LAUNCH();
   int64_t g = ebn_ceil_div(M * N, 256);
   if (g > 4096) g = 4096;
-  hipLaunchKernelGGL(split_reduce_kernel, dim3(static_cast<unsigned>(g)), dim3(256), 0, s, workspace, p.splits, M, N, alpha, beta, C, ldc);
+  EBN_LAUNCH(split_reduce_kernel, dim3(static_cast<unsigned>(g)), dim3(256), 0, s, workspace, p.splits, M, N, alpha, beta, C, ldc);
   EBN_CHECK_LAUNCH();
   return EBN_OK;
 }

@@ -39,7 +39,7 @@ template <class F>
 static inline void ebn_colred_stage1(F f, float* partials, int64_t R, int C, hipStream_t s, int64_t* nb_out) {
   const int64_t nb = ebn_colred_blocks(R);
   const int64_t rpb = ebn_ceil_div(R, nb);
-  hipLaunchKernelGGL((ebn_colred_stage1_kernel<F>), dim3(static_cast<unsigned>(nb), static_cast<unsigned>(ebn_ceil_div(C, 64))),
+  EBN_LAUNCH((ebn_colred_stage1_kernel<F>), dim3(static_cast<unsigned>(nb), static_cast<unsigned>(ebn_ceil_div(C, 64))),
                      dim3(256), 0, s, f, partials, R, C, rpb);
   *nb_out = nb;
 }
@@ -101,6 +101,6 @@ static __global__ __launch_bounds__(1024) void ebn_reduce_partials_kernel(const 
 
 static inline void ebn_reduce_partials(const float* partials, int64_t nb, int S, int A, float scale, float* out0,
                                        float* out1, int accumulate, float* site0, float* site1, hipStream_t s) {
-  hipLaunchKernelGGL(ebn_reduce_partials_kernel, dim3(static_cast<unsigned>(ebn_ceil_div(S * A, 32))), dim3(1024), 0, s,
+  EBN_LAUNCH(ebn_reduce_partials_kernel, dim3(static_cast<unsigned>(ebn_ceil_div(S * A, 32))), dim3(1024), 0, s,
                      partials, static_cast<int>(nb), S, A, scale, out0, out1, accumulate, site0, site1);
 }

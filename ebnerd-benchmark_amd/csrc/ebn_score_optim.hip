@@ -2,6 +2,8 @@
 // (nrms.py:56-67) with its backward into the news/user representations, the ragged pair scorer
 // of the evaluation path, and a10: the Keras-form Adam step (nrms.py:69-80) with the per-step
 // device state.  All latency- or HBM-bound elementwise/row work.
+#include <atomic>
+
 #include "ebn_common.h"
 
 namespace {
@@ -317,6 +319,10 @@ __global__ __launch_bounds__(256) void adam_keras_scalar_kernel(float* __restric
 
 extern "C" int ebn_abi_version(void) { return EBN_ABI_VERSION; }
 
+static std::atomic<int64_t> g_launches{0};
+void ebnx_note_launch(void) { g_launches.fetch_add(1, std::memory_order_relaxed); }
+extern "C" int64_t ebn_launch_count(void) { return g_launches.load(std::memory_order_relaxed); }
+
 extern "C" const char* ebn_error_string(int code) {
   switch (code) {
     case EBN_OK: return "ok";
@@ -331,7 +337,7 @@ extern "C" const char* ebn_error_string(int code) {
 
 extern "C" int ebn_step_advance(ebn_step_state* st, double beta1, double beta2, ebn_stream_t stream) {
   EBN_REQUIRE(st, EBN_ERR_BAD_ARG);
-  hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, ebn_stream(stream), st, beta1, beta2);
+  EBN_LAUNCH(step_advance_kernel, dim3(1), dim3(64), 0, ebn_stream(stream), st, beta1, beta2);
   EBN_CHECK_LAUNCH();
   return EBN_OK;
 }
@@ -342,7 +348,7 @@ extern "C" int ebn_score_fwd_f32(const float* cand, const float* user, float* sc
   EBN_REQUIRE(B >= 0 && C > 0 && E > 0, EBN_ERR_BAD_ARG);
   EBN_REQUIRE(C <= 8192, EBN_ERR_UNSUPPORTED);
   if (B == 0) return EBN_OK;
-  hipLaunchKernelGGL(score_fwd_kernel, dim3(static_cast<unsigned>(B)), dim3(256), C * sizeof(float),
+  EBN_LAUNCH(score_fwd_kernel, dim3(static_cast<unsigned>(B)), dim3(256), C * sizeof(float),
                      ebn_stream(stream), cand, user, scores, probs, C, E, mode);
   EBN_CHECK_LAUNCH();
   return EBN_OK;
@@ -356,7 +362,7 @@ extern "C" int ebn_score_loss_bwd_f32(const float* cand, const float* user, cons
   EBN_REQUIRE(B >= 0 && C > 0 && E > 0, EBN_ERR_BAD_ARG);
   EBN_REQUIRE(C <= 8192 && loss_kind >= 0 && loss_kind <= 2, EBN_ERR_UNSUPPORTED);
   if (B == 0) return EBN_OK;
-  hipLaunchKernelGGL(score_loss_bwd_kernel, dim3(static_cast<unsigned>(B)), dim3(64), C * sizeof(float),
+  EBN_LAUNCH(score_loss_bwd_kernel, dim3(static_cast<unsigned>(B)), dim3(64), C * sizeof(float),
                      ebn_stream(stream), cand, user, scores, labels, loss_rows, dcand, duser, C, E, loss_kind,
                      inv_batch);
   EBN_CHECK_LAUNCH();
@@ -371,7 +377,7 @@ extern "C" int ebn_score_loss_train_f32(const float* cand, const float* user, co
   EBN_REQUIRE(B >= 0 && C > 0 && E > 0, EBN_ERR_BAD_ARG);
   EBN_REQUIRE(C <= 8192 && loss_kind >= 0 && loss_kind <= 2, EBN_ERR_UNSUPPORTED);
   if (B == 0) return EBN_OK;
-  hipLaunchKernelGGL(score_loss_train_kernel, dim3(static_cast<unsigned>(B)), dim3(256), 2 * C * sizeof(float),
+  EBN_LAUNCH(score_loss_train_kernel, dim3(static_cast<unsigned>(B)), dim3(256), 2 * C * sizeof(float),
                      ebn_stream(stream), cand, user, labels, scores, probs, loss_rows, dcand, duser, C, E, loss_kind,
                      inv_batch);
   EBN_CHECK_LAUNCH();
@@ -385,7 +391,7 @@ extern "C" int ebn_auc_hist_f32(const float* probs, const float* labels, int64_t
   if (n == 0) return EBN_OK;
   int64_t grid = ebn_ceil_div(n, 256);
   if (grid > 1024) grid = 1024;
-  hipLaunchKernelGGL(auc_hist_kernel, dim3(static_cast<unsigned>(grid)), dim3(256), 0, ebn_stream(stream), probs, labels, n,
+  EBN_LAUNCH(auc_hist_kernel, dim3(static_cast<unsigned>(grid)), dim3(256), 0, ebn_stream(stream), probs, labels, n,
                      thresholds, n_thresholds, reinterpret_cast<unsigned long long*>(pos_hist),
                      reinterpret_cast<unsigned long long*>(neg_hist));
   EBN_CHECK_LAUNCH();
@@ -398,7 +404,7 @@ extern "C" int ebn_pair_score_f32(const float* user, const float* news, const in
   EBN_REQUIRE(user && news && u_idx && n_idx && out, EBN_ERR_BAD_ARG);
   EBN_REQUIRE(n_pairs >= 0 && E > 0, EBN_ERR_BAD_ARG);
   if (n_pairs == 0) return EBN_OK;
-  hipLaunchKernelGGL(pair_score_kernel, dim3(static_cast<unsigned>(ebn_ceil_div(n_pairs, 4))), dim3(256), 0,
+  EBN_LAUNCH(pair_score_kernel, dim3(static_cast<unsigned>(ebn_ceil_div(n_pairs, 4))), dim3(256), 0,
                      ebn_stream(stream), user, news, u_idx, n_idx, out, n_pairs, E, mode);
   EBN_CHECK_LAUNCH();
   return EBN_OK;
@@ -417,10 +423,10 @@ extern "C" int ebn_adam_keras_step_f32(float* theta, const float* g, float* m, f
   if (grid > 256 * 16) grid = 256 * 16;
   if (grid < 1) grid = 1;
   if (vec)
-    hipLaunchKernelGGL(adam_keras_kernel, dim3(static_cast<unsigned>(grid)), dim3(256), 0, ebn_stream(stream),
+    EBN_LAUNCH(adam_keras_kernel, dim3(static_cast<unsigned>(grid)), dim3(256), 0, ebn_stream(stream),
                        theta, g, m, v, n, st, omb1, omb2, eps, grad_scale);
   else
-    hipLaunchKernelGGL(adam_keras_scalar_kernel, dim3(static_cast<unsigned>(grid)), dim3(256), 0,
+    EBN_LAUNCH(adam_keras_scalar_kernel, dim3(static_cast<unsigned>(grid)), dim3(256), 0,
                        ebn_stream(stream), theta, g, m, v, n, st, omb1, omb2, eps, grad_scale);
   EBN_CHECK_LAUNCH();
   return EBN_OK;

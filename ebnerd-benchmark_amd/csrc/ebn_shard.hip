@@ -197,24 +197,24 @@ extern "C" int ebn_shard_plan_i32(const int32_t* ids, int64_t n_tok, int64_t V, 
   {
     const int64_t n_init = static_cast<int64_t>(world) * g.per + static_cast<int64_t>(world) * cap + world;
     const unsigned init_grid = static_cast<unsigned>(ebn_ceil_div(n_init, PLAN_THREADS) < 2048 ? ebn_ceil_div(n_init, PLAN_THREADS) : 2048);
-    hipLaunchKernelGGL(shard_init_kernel, dim3(init_grid), dim3(PLAN_THREADS), 0, s, mark, static_cast<int64_t>(world) * g.per,
+    EBN_LAUNCH(shard_init_kernel, dim3(init_grid), dim3(PLAN_THREADS), 0, s, mark, static_cast<int64_t>(world) * g.per,
                        slot_rows, static_cast<int64_t>(world) * cap, counts, world);
     EBN_CHECK_LAUNCH();
   }
   const unsigned tok_grid = static_cast<unsigned>(n_tok > 0 ? (ebn_ceil_div(n_tok, PLAN_THREADS) < 4096 ? ebn_ceil_div(n_tok, PLAN_THREADS) : 4096) : 1);
   const unsigned n_chunks = static_cast<unsigned>(world) * static_cast<unsigned>(g.chunks_per_owner);
   if (n_tok > 0) {
-    hipLaunchKernelGGL(shard_mark_kernel, dim3(tok_grid), dim3(PLAN_THREADS), 0, s, ids, n_tok, g, mark, counts);
+    EBN_LAUNCH(shard_mark_kernel, dim3(tok_grid), dim3(PLAN_THREADS), 0, s, ids, n_tok, g, mark, counts);
     EBN_CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(shard_chunk_count_kernel, dim3(n_chunks), dim3(PLAN_THREADS), 0, s, mark, g, chunk);
+  EBN_LAUNCH(shard_chunk_count_kernel, dim3(n_chunks), dim3(PLAN_THREADS), 0, s, mark, g, chunk);
   EBN_CHECK_LAUNCH();
-  hipLaunchKernelGGL(shard_chunk_scan_kernel, dim3(static_cast<unsigned>(ebn_ceil_div(world, 64))), dim3(64), 0, s, g, chunk, counts);
+  EBN_LAUNCH(shard_chunk_scan_kernel, dim3(static_cast<unsigned>(ebn_ceil_div(world, 64))), dim3(64), 0, s, g, chunk, counts);
   EBN_CHECK_LAUNCH();
-  hipLaunchKernelGGL(shard_assign_kernel, dim3(n_chunks), dim3(PLAN_THREADS), 0, s, mark, g, chunk, slot_rows);
+  EBN_LAUNCH(shard_assign_kernel, dim3(n_chunks), dim3(PLAN_THREADS), 0, s, mark, g, chunk, slot_rows);
   EBN_CHECK_LAUNCH();
   if (n_tok > 0) {
-    hipLaunchKernelGGL(shard_inverse_kernel, dim3(tok_grid), dim3(PLAN_THREADS), 0, s, ids, n_tok, g, mark, inv);
+    EBN_LAUNCH(shard_inverse_kernel, dim3(tok_grid), dim3(PLAN_THREADS), 0, s, ids, n_tok, g, mark, inv);
     EBN_CHECK_LAUNCH();
   }
   return EBN_OK;

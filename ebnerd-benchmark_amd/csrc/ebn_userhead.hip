@@ -317,10 +317,10 @@ extern "C" int ebn_user_head_train_f32(float* U, const float* b, const float* q,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
   if (attr != hipSuccess) return static_cast<int>(attr);
   HeadArgs a{U, b, q, X, cand, labels, w, user, scores, probs, loss_rows, dcand, duser, de, partials, L, C, E, A, loss_kind, inv_batch};
-  hipLaunchKernelGGL(user_head_train_kernel, dim3(static_cast<unsigned>(B)), dim3(HEAD_THREADS), lds, s, a);
+  EBN_LAUNCH(user_head_train_kernel, dim3(static_cast<unsigned>(B)), dim3(HEAD_THREADS), lds, s, a);
   EBN_CHECK_LAUNCH();
   if (dq == nullptr) return EBN_OK;  // d(q), d(b) and the batch loss are left to ebn_grad_finish_f32 (EBN_FINISH_HEAD job)
-  hipLaunchKernelGGL(user_head_finish_kernel, dim3(static_cast<unsigned>(ebn_ceil_div(2 * A, 256) + 1)), dim3(256), 0, s, partials, B, A,
+  EBN_LAUNCH(user_head_finish_kernel, dim3(static_cast<unsigned>(ebn_ceil_div(2 * A, 256) + 1)), dim3(256), 0, s, partials, B, A,
                      dq, db, loss_rows, loss_out);
   EBN_CHECK_LAUNCH();
   return EBN_OK;

@@ -1,14 +1,26 @@
 """What the evaluator asks of a metric (the interface the reference declares in evaluation/protocols.py:5-17).
 
-A metric object has a ``name`` (the key of its result in ``MetricEvaluator.evaluations``) and a
-``calculate(y_true, y_score)`` that takes the per-impression label and score arrays and returns one float.  That pair is
-the whole structural type: ``isinstance(x, Metric)`` holds for ANY object with those two members.  The call forwarding
-and the printed form the reference's metrics have live in ``MetricBase``, which the concrete metrics of this package
-derive from -- outside the Protocol, so that they are not requirements on third-party metric objects.
+``Metric`` is the reference's type: a ``name`` (the key of the result in ``MetricEvaluator.evaluations``), a
+``calculate(y_true, y_score)`` returning one float, and -- as DEFAULT bodies, exactly where the reference keeps them
+(protocols.py:10-17) -- the call forwarding and the printed form ``<Callable Metric: name>: params: {...}``.  A user metric
+written the reference's way, ``class Foo(Metric): def calculate(...)``, is therefore callable and accepted by
+``MetricEvaluator``.
+
+``MetricLike`` is the structural check (``isinstance(x, MetricLike)`` holds for ANY object with ``name`` + ``calculate``,
+base class or not); ``MetricBase`` is the concrete base this package's metrics derive from.
 """
 from __future__ import annotations
 
 from typing import Protocol, Sequence, runtime_checkable
+
+
+@runtime_checkable
+class MetricLike(Protocol):
+    name: str
+
+    def calculate(self, y_true: Sequence, y_score: Sequence) -> float:
+        """one float from the impressions' labels and scores"""
+        ...
 
 
 @runtime_checkable
@@ -19,20 +31,20 @@ class Metric(Protocol):
         """one float from the impressions' labels and scores"""
         ...
 
-
-class MetricBase:
-    """Shared behaviour of this package's metrics: calling the object runs ``calculate``; ``str`` / ``repr`` print the
-    reference's form ``<Callable Metric: name>: params: {...}`` (evaluation/protocols.py:10-14)."""
-
-    name: str = ""
-
-    def calculate(self, y_true: Sequence, y_score: Sequence) -> float:
-        raise NotImplementedError(f"{type(self).__name__} does not define calculate()")
-
     def __call__(self, y_true: Sequence, y_score: Sequence) -> float:
         return self.calculate(y_true, y_score)
 
     def __str__(self) -> str:
         return f"<Callable Metric: {self.name}>: params: {vars(self)}"
 
-    __repr__ = __str__
+    def __repr__(self) -> str:
+        return str(self)
+
+
+class MetricBase(Metric):
+    """Base of this package's metrics: ``Metric``'s defaults plus a ``calculate`` that says what is missing."""
+
+    name: str = ""
+
+    def calculate(self, y_true: Sequence, y_score: Sequence) -> float:
+        raise NotImplementedError(f"{type(self).__name__} does not define calculate()")

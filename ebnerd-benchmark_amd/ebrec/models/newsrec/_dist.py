@@ -98,8 +98,9 @@ class LockStepGuard:
     # what must be lock-step is the SEQUENCE of collective API calls, whichever model makes them; an engine built on one rank
     # only never enters a collective API, so it cannot put the ranks' counters out of step
 
-    def __init__(self, group=None, timeout_s: float | None = None):
+    def __init__(self, group=None, timeout_s: float | None = None, force: bool = False):
         self.rank, self.world = world_info(group)
+        self.force = bool(force)  # run the rendezvous on a ONE-rank group too (`bench.py --force-dist`: the store path, exercised)
         self.pg = group
         env = os.environ.get("EBN_COLLECTIVE_TIMEOUT_S")
         self.timeout_s = float(timeout_s) if timeout_s is not None else (float(env) if env else None)
@@ -114,7 +115,7 @@ class LockStepGuard:
 
     def ensure(self) -> bool:
         """First use: find the store and this guard's key prefix.  Returns whether the guard is active."""
-        if self.world <= 1 or self.disabled is not None:
+        if (self.world <= 1 and not self.force) or self.disabled is not None:
             return False
         if self._store is None:
             try:
@@ -133,7 +134,7 @@ class LockStepGuard:
         return True
 
     def status(self) -> str:
-        if self.world <= 1:
+        if self.world <= 1 and not self.force:
             return "not needed (one rank)"
         if not self.ensure():
             return f"disabled: {self.disabled}"

@@ -230,6 +230,14 @@ class NRMSEngine(StagingMixin, SegmentsMixin):
             from ._dist import LockStepGuard
 
             self.guard = LockStepGuard(process_group)
+        # True: launch the multi-rank form of the step (collectives between the graph replays, the multi-rank Adam inputs) on a group of
+        # ONE rank, where every collective is an identity -- `bench.py --force-dist` runs the RCCL branch end to end on a 1-GPU box
+        self.force_collectives = False
+
+    @property
+    def multi(self) -> bool:
+        """the step runs its multi-rank launch form (world > 1, or forced on a one-rank group: see `force_collectives`)"""
+        return self.world > 1 or self.force_collectives
 
     @property
     def loss_kind(self) -> int:
@@ -315,7 +323,7 @@ class NRMSEngine(StagingMixin, SegmentsMixin):
     @property
     def _adam_from_acc(self) -> bool:
         """trainable replicated table on ONE rank with the deterministic accumulator: Adam reads it directly"""
-        return (self.train_embedding and self.deterministic and self.exchange is None and self.world == 1
+        return (self.train_embedding and self.deterministic and self.exchange is None and not self.multi
                 and not self.keep_table_grad)
 
     def _sparse_dp(self, n_tok: int) -> bool:
@@ -326,7 +334,7 @@ class NRMSEngine(StagingMixin, SegmentsMixin):
         the gradient; a 32 000 x 300 table (38 MB) stays dense.  The "auto" choice is PINNED the first time it is asked
         (`pin_table_grad_exchange`: fit() asks with the loader's full-batch shape before the first step), so that a rank's
         short last batch can never pick a different collective than its peers' full ones."""
-        if not (self.world > 1 and self.train_embedding and self.exchange is None and self.deterministic and not self.keep_table_grad):
+        if not (self.multi and self.train_embedding and self.exchange is None and self.deterministic and not self.keep_table_grad):
             return False
         if self.table_grad_exchange != "auto":
             return self.table_grad_exchange == "sparse"
@@ -794,7 +802,7 @@ class NRMSEngine(StagingMixin, SegmentsMixin):
                 # all-reduce with nobody to meet (round-4 ADVICE)
                 return
             collective = self.exchange is not None
-        collective = bool(collective) and self.world > 1
+        collective = bool(collective) and self.multi
         err = None
         if self._planned:  # the plan's own flags first: an overflowed exchange also shows up as zero rows in the gather
             for key in sorted((k for k, b in self._bufs.items() if hasattr(b, "xb")), key=repr):

@@ -65,6 +65,11 @@ class DocVecEngine:
             from ._dist import LockStepGuard
 
             self.guard = LockStepGuard(process_group)
+        self.force_collectives = False  # True: the multi-rank launch form on a one-rank group (`bench.py --force-dist`; see NRMSEngine)
+
+    @property
+    def multi(self) -> bool:
+        return self.world > 1 or self.force_collectives
 
     @property
     def loss_kind(self) -> int:
@@ -163,9 +168,19 @@ class DocVecEngine:
     def _dvn(self, mb, n_hist, n_cand):
         """ebn_dvn_args of the fused news-encoder step over this buffer set, or None when the shape is outside what the fused
         launches take (then the per-pass kernels run)."""
+        if self._dvn_dirty:
+            # a step that ran only half way (an exception between its forward and its backward) left the fixed-point accumulators of
+            # the fused launches dirty: the contract of ebn_dvn_fwd_train_f32 is a zero scratch.  Every shape's scratch, whether or
+            # not the CURRENT shape takes the fused launches
+            for k, v in mb.items():
+                if isinstance(k, tuple) and k[0] == "dvn_stat":
+                    v.zero_()
+            self._dvn_dirty = False
         if not (self.fuse_news_mlp and self.units):
             return None
-        key = ("dvn", n_hist, n_cand)
+        # the cached argument block freezes raw pointers AND the scalars p / l2: they are part of the key, so that changing
+        # `eng.p` or `eng.l2` between steps reaches the fused launches as it reaches the per-pass kernels
+        key = ("dvn", n_hist, n_cand, self.p, self.l2)
         a = mb.get(key)
         if a is None:
             L, N, pv, g, b = len(self.units), mb["N"], self.params.view, self.params.g, self.mlp.bufs(mb["N"])
@@ -181,7 +196,7 @@ class DocVecEngine:
                 mb["dvn_dY"] = [f(N, u) for u in self.units]
                 mb["dvn_dP"] = [f(N, u) for u in self.units] + [f(N, self.E)]
             # the scratch is sized by the row tiling of (n_hist, n_cand): one per shape
-            mb[("dvn_stat", n_hist, n_cand)] = stat = torch.zeros(int(_hip.lib().ebn_dvn_stat_floats(ctypes.byref(a))), device=self.device)
+            mb[("dvn_stat", n_hist, n_cand, self.p, self.l2)] = stat = torch.zeros(int(_hip.lib().ebn_dvn_stat_floats(ctypes.byref(a))), device=self.device)
             for l in range(L):
                 a.W[l], a.b[l] = pv(f"d{l}_W").data_ptr(), pv(f"d{l}_b").data_ptr()
                 a.gamma[l], a.beta[l] = pv(f"bn{l}_g").data_ptr(), pv(f"bn{l}_b").data_ptr()
@@ -206,13 +221,6 @@ class DocVecEngine:
                     q.l2_W, q.two_lambda = pv(wn).data_ptr(), 2.0 * self.l2
             a._probs, a._stat = probs, stat
             mb[key] = a
-        if a and self._dvn_dirty:
-            # a step that ran only half way (an exception between its forward and its backward) left the fixed-point accumulators
-            # of the fused launches dirty: the contract of ebn_dvn_fwd_train_f32 is a zero scratch
-            for k, v in mb.items():
-                if isinstance(k, tuple) and k[0] == "dvn_stat":
-                    v.zero_()
-            self._dvn_dirty = False
         return a or None
 
     def _news_forward(self, mb, n_hist, n_cand, train):
@@ -430,7 +438,8 @@ class DocVecEngine:
         if self.use_graph:
             # graph(forward + backward) -> gradient all-reduce over RCCL (eager, data-parallel only) -> graph(Adam)
             adv = self._advanced
-            g = self._graphs.get((B, C, adv))
+            gkey = (B, C, adv, bool(self.fuse_news_mlp), self.p, self.l2)  # a captured graph freezes the launch form and its scalars
+            g = self._graphs.get(gkey)
             if g is None:
                 torch.cuda.synchronize()
                 g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
@@ -438,7 +447,7 @@ class DocVecEngine:
                     self._fwd_bwd_kernels(B, C, adv)
                 with _hip.capture(g2, pool=g1.pool()):
                     self._optimizer_kernels()
-                g = self._graphs[(B, C, adv)] = (g1, g2)
+                g = self._graphs[gkey] = (g1, g2)
             g[0].replay()
             self._allreduce_grads()
             g[1].replay()
@@ -475,7 +484,7 @@ class DocVecEngine:
         self._news_backward(mb, n_hist, n_cand)
 
     def _allreduce_grads(self):
-        if self.world > 1:
+        if self.multi:
             torch.distributed.all_reduce(self.params.grad, group=self.pg)
 
     def _optimizer_kernels(self):

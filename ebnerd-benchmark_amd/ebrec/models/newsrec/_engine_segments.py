@@ -81,7 +81,7 @@ class SegmentsMixin:
         counter, dropout keys) is restored in between and afterwards, so the check leaves no trace.  The verdict is MIN-reduced
         over the group: every rank adopts the one-graph form or none does.  Any exception while capturing or replaying the
         one-graph form counts as a failed check.  A collective (all ranks call it with their own batch of the same shape)."""
-        if not (self.use_graph and self.graph_capable and self.world > 1):
+        if not (self.use_graph and self.graph_capable and self.multi):
             self.graph_collectives = False
             return False
         if torch.distributed.get_backend(self.pg) != "nccl":
@@ -127,7 +127,7 @@ class SegmentsMixin:
         segs, run, pool, i = self._segments(B, C, advanced), [], None, 0
         desc = self.__dict__.setdefault("_graph_desc", {}).setdefault((B, C, advanced), [])
         desc.clear()
-        if self.graph_collectives and self.world > 1:
+        if self.graph_collectives and self.multi:
             # the collectives are captured too (RCCL supports stream capture): the whole multi-rank step is ONE graph, no
             # eager launches and no cross-stream joins between replays
             g = torch.cuda.CUDAGraph()
@@ -170,7 +170,7 @@ class SegmentsMixin:
         is bit-identical to the serial one."""
         N = B * (self.H + C)
         nb, _ub = self._train_bufs(B, C)
-        multi = self.world > 1
+        multi = self.multi
         segs = [] if advanced else [("k", lambda: _hip.call("ebn_step_advance", _hip.ptr(self.state), BETA1, BETA2, _hip.stream_handle()))]
         if self._planned:
             segs += self._lookup_segments(nb, N)
@@ -205,7 +205,7 @@ class SegmentsMixin:
         return segs
 
     def _allreduce_async(self, t):
-        if self.world > 1 and not self.skip_collectives:
+        if self.multi and not self.skip_collectives:
             self._pending.append(torch.distributed.all_reduce(t, group=self.pg, async_op=True))
 
     def _wait_collectives(self):
@@ -214,7 +214,7 @@ class SegmentsMixin:
         self._pending = []
 
     def _allreduce_table_grad(self):
-        if self.world > 1 and not self.skip_collectives:
+        if self.multi and not self.skip_collectives:
             torch.distributed.all_reduce(self.table_grad, group=self.pg)
 
     def _sparse_table_grad_segments(self, nb, N):
@@ -239,7 +239,7 @@ class SegmentsMixin:
 
     def _allreduce_grads(self, dense_table=True):
         """Data-parallel gradient all-reduce over RCCL (SUM; the 1/world is folded into Adam): one flat bucket."""
-        if self.world > 1 and not self.skip_collectives:
+        if self.multi and not self.skip_collectives:
             torch.distributed.all_reduce(self.params.grad, group=self.pg)
             # (a sharded table's gradients already sit at their owner; the sparse exchange all-gathers token rows instead)
             if self.train_embedding and self.exchange is None and dense_table:

@@ -54,6 +54,10 @@ typedef struct ebn_step_state {
 
 int ebn_abi_version(void);
 const char* ebn_error_string(int code);
+/* Kernel launches this library has enqueued in this process so far (captured ones included: a launch recorded into a hipGraph counts
+ * once, at capture).  Diagnostics: bench.py reports `launches_per_step` as the difference around one eager step.  No reference
+ * counterpart (Keras' train_function, nrms.py:92-99 compile + fit, hides its op launches).                                          */
+int64_t ebn_launch_count(void);
 
 /* step++ ; adam_alpha and the dropout keys for the new step. One tiny kernel. */
 int ebn_step_advance(ebn_step_state* st, double beta1, double beta2, ebn_stream_t stream);

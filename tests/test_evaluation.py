@@ -69,8 +69,20 @@ def test_auc_needs_both_classes_and_evaluator_rejects_non_callables():
 
 
 def test_metric_is_a_structural_type_and_prints_like_the_reference():
-    """protocols.py:5-17: `name` + `calculate` make a metric; the call forwarding and the printed form are not part of the type."""
-    from ebrec.evaluation.protocols import Metric, MetricBase
+    """protocols.py:5-17: `name` + `calculate` make a metric (MetricLike, structural); `Metric` carries the reference's default
+    call forwarding and printed form, so a metric written the reference's way -- `class Foo(Metric)` with only `calculate` --
+    is callable and the evaluator takes it (round-5 ADVICE: it was rejected as "not callable")."""
+    from ebrec.evaluation.protocols import Metric, MetricBase, MetricLike
+
+    class Foo(Metric):  # the reference's own idiom (metrics_protocols.py:74-86 derive from Metric and define calculate only)
+        def __init__(self):
+            self.name = "foo"
+
+        def calculate(self, y_true, y_score):
+            return 0.25
+
+    assert Foo()([[1, 0]], [[0.3, 0.2]]) == 0.25 and str(Foo()) == "<Callable Metric: foo>: params: {'name': 'foo'}" == repr(Foo())
+    assert MetricEvaluator([[1, 0]], [[0.3, 0.2]], [Foo()]).evaluate().evaluations == {"foo": 0.25}
 
     class Mine:  # a third-party metric object: no base class
         name = "mine"
@@ -78,8 +90,8 @@ def test_metric_is_a_structural_type_and_prints_like_the_reference():
         def calculate(self, y_true, y_score):
             return 1.0
 
-    assert isinstance(Mine(), Metric) and isinstance(NdcgScore(5), Metric) and not isinstance(object(), Metric)
-    assert isinstance(AucScore(), MetricBase)
+    assert isinstance(Mine(), MetricLike) and isinstance(NdcgScore(5), MetricLike) and isinstance(Foo(), MetricLike) and not isinstance(object(), MetricLike)
+    assert isinstance(AucScore(), MetricBase) and isinstance(AucScore(), Metric)
     assert str(NdcgScore(k=5)) == "<Callable Metric: ndcg@5>: params: {'k': 5, 'name': 'ndcg@5'}" == repr(NdcgScore(k=5))
     with pytest.raises(TypeError, match=r"not callable: \[\]"):
         MetricEvaluator([[1, 0]], [[0.3, 0.2]], metric_functions=[])  # the reference refuses an empty list too
