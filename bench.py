@@ -441,6 +441,15 @@ def probe_kernels(config, batch, precision="exact", ids="uniform", pick=None):
         for k, v in out.items():
             if "FETCH_SIZE_KiB" in v and "WRITE_SIZE_KiB" in v:
                 v["traffic"] = (2.0 * v["FETCH_SIZE_KiB"] + v["WRITE_SIZE_KiB"]) * 1024.0
+        keep = os.environ.get("EBN_PROBE_KEEP_DIR")
+        if keep:  # the summaries behind `roofline*.kernel` / `.traffic`, kept for profiles/: PROBE-ONLY statistics (a handful of launches
+            # of exactly the two roofline kernels on the step's buffers -- no calibration copies, no other role of the same kernel)
+            Path(keep).mkdir(parents=True, exist_ok=True)
+            tag = config + ("" if precision == "exact" else "_" + precision) + ("" if ids == "uniform" else "_" + ids)
+            shutil.copyfile(stats, Path(keep, f"probe_kernel_stats_{tag}.csv"))
+            Path(keep, f"probe_pmc_{tag}.json").write_text(json.dumps(
+                {"what": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py --kernel-probe --config " + config + "`: per-launch "
+                         "averages in KiB; traffic = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 bytes (MI355X_MICROARCH.md, HBM section)", "kernels": out}, indent=1))
         return out
     except Exception:  # a profiler that cannot run here must not take the benchmark down: fall back to the static labels
         return None

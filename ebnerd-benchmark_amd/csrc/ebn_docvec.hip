@@ -369,24 +369,35 @@ __global__ __launch_bounds__(NTHR) void dvn_panel_kernel(PanelArgs p) {
     fb1__[SET][0] = *reinterpret_cast<const float4*>(bp1__ + 32 * (g) + cb10);  \
     fb1__[SET][1] = *reinterpret_cast<const float4*>(bp1__ + 32 * (g) + cb11);  \
   } while (0)
+// -DEBN_DVN_ALT_ORDER (csrc/variants/dvn_alt_order.so, a TEST build only): every product of a block goes into ONE accumulator
+// chain instead of two alternating ones -- a different, equally correct summation order of the same matmul.  tests/
+// test_full_size_parity.py runs the full-size NRMSDocVec parity test against both builds: the comparison with the oracle must not
+// depend on which side of 0 a ReLU input's rounding falls (verdict r5 item 3).
+#ifdef EBN_DVN_ALT_ORDER
+#define DVN_ACC01 acc00
+#define DVN_ACC11 acc10
+#else
+#define DVN_ACC01 acc01
+#define DVN_ACC11 acc11
+#endif
 #define DVN_MUL(SET)                                                                                   \
   do {                                                                                                 \
     acc00 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa__[SET][0].x, fb0__[SET][0].x, acc00, 0, 0, 0);     \
     acc10 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa__[SET][0].x, fb1__[SET][0].x, acc10, 0, 0, 0);     \
-    acc01 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa__[SET][0].y, fb0__[SET][0].y, acc01, 0, 0, 0);     \
-    acc11 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa__[SET][0].y, fb1__[SET][0].y, acc11, 0, 0, 0);     \
+    DVN_ACC01 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa__[SET][0].y, fb0__[SET][0].y, DVN_ACC01, 0, 0, 0); \
+    DVN_ACC11 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa__[SET][0].y, fb1__[SET][0].y, DVN_ACC11, 0, 0, 0); \
     acc00 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa__[SET][0].z, fb0__[SET][0].z, acc00, 0, 0, 0);     \
     acc10 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa__[SET][0].z, fb1__[SET][0].z, acc10, 0, 0, 0);     \
-    acc01 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa__[SET][0].w, fb0__[SET][0].w, acc01, 0, 0, 0);     \
-    acc11 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa__[SET][0].w, fb1__[SET][0].w, acc11, 0, 0, 0);     \
+    DVN_ACC01 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa__[SET][0].w, fb0__[SET][0].w, DVN_ACC01, 0, 0, 0); \
+    DVN_ACC11 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa__[SET][0].w, fb1__[SET][0].w, DVN_ACC11, 0, 0, 0); \
     acc00 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa__[SET][1].x, fb0__[SET][1].x, acc00, 0, 0, 0);     \
     acc10 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa__[SET][1].x, fb1__[SET][1].x, acc10, 0, 0, 0);     \
-    acc01 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa__[SET][1].y, fb0__[SET][1].y, acc01, 0, 0, 0);     \
-    acc11 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa__[SET][1].y, fb1__[SET][1].y, acc11, 0, 0, 0);     \
+    DVN_ACC01 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa__[SET][1].y, fb0__[SET][1].y, DVN_ACC01, 0, 0, 0); \
+    DVN_ACC11 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa__[SET][1].y, fb1__[SET][1].y, DVN_ACC11, 0, 0, 0); \
     acc00 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa__[SET][1].z, fb0__[SET][1].z, acc00, 0, 0, 0);     \
     acc10 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa__[SET][1].z, fb1__[SET][1].z, acc10, 0, 0, 0);     \
-    acc01 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa__[SET][1].w, fb0__[SET][1].w, acc01, 0, 0, 0);     \
-    acc11 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa__[SET][1].w, fb1__[SET][1].w, acc11, 0, 0, 0);     \
+    DVN_ACC01 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa__[SET][1].w, fb0__[SET][1].w, DVN_ACC01, 0, 0, 0); \
+    DVN_ACC11 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa__[SET][1].w, fb1__[SET][1].w, DVN_ACC11, 0, 0, 0); \
   } while (0)
 #define DVN_MMA(BUF, KT)                                                                                   \
   do {                                                                                                     \

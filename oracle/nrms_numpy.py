@@ -497,7 +497,20 @@ def dense_bn_stack_fwd(X, P, units, prefix="", training=False, drop: Drop | None
     return x, (caches, training), new_stats
 
 
-def dense_bn_stack_bwd(dx, cache, P, units, prefix=""):
+def _relu_gate(pre, layer, gate):
+    """d relu(pre) / d pre = [pre > 0] (Keras' relu gradient, nrms_docvec.py:113-130 `activation="relu"`).  `gate(layer, pre)` -- a TEST hook,
+    None in every other use -- may return a replacement boolean array: at |pre| within rounding of 0 the derivative is discontinuous and an
+    fp32 implementation's choice depends on its summation order; a parity test hands the implementation's own choice back for exactly
+    those elements (tests/test_full_size_parity.py) so that the comparison does not hinge on which side of 0 a rounding fell."""
+    g = pre > 0
+    if gate is not None:
+        alt = gate(layer, pre)
+        if alt is not None:
+            g = alt
+    return g
+
+
+def dense_bn_stack_bwd(dx, cache, P, units, prefix="", gate=None):
     caches, training = cache
     g = {}
     for l in reversed(range(len(units))):
@@ -512,7 +525,7 @@ def dense_bn_stack_bwd(dx, cache, P, units, prefix=""):
             dr = istd / R * (R * dxh - dxh.sum(0) - xh * (dxh * xh).sum(0))
         else:
             dr = dxh * istd
-        dpre_l = dr * (pre_l > 0)
+        dpre_l = dr * _relu_gate(pre_l, l, gate)
         g[f"{prefix}d{l}_W"] = x.T @ dpre_l
         g[f"{prefix}d{l}_b"] = dpre_l.sum(0)
         dx = dpre_l @ P[f"{prefix}d{l}_W"].T
@@ -528,11 +541,11 @@ def docvec_news_encoder_fwd(X, P, training=False, drop: Drop | None = None, site
     return out, (c_stack, x, pre), new_stats
 
 
-def docvec_news_encoder_bwd(dout, cache, P):
+def docvec_news_encoder_bwd(dout, cache, P, gate=None):
     c_stack, xl, pre = cache
-    dpre = dout * (pre > 0)
+    dpre = dout * _relu_gate(pre, len(P["units"]), gate)
     g = {"out_W": xl.T @ dpre, "out_b": dpre.sum(0)}
-    g_stack, dx = dense_bn_stack_bwd(dpre @ P["out_W"].T, c_stack, P, P["units"], "")
+    g_stack, dx = dense_bn_stack_bwd(dpre @ P["out_W"].T, c_stack, P, P["units"], "", gate)
     g.update(g_stack)
     return g, dx
 
@@ -551,15 +564,17 @@ def docvec_forward(his, pred, P, h, d, training=False, drop: Drop | None = None)
 
 
 def docvec_loss_and_grads(his, pred, y, P, h, d, loss="cross_entropy_loss", l2=0.0,
-                          training=True, drop: Drop | None = None):
+                          training=True, drop: Drop | None = None, relu_gate=None):
+    """relu_gate(site, layer, pre) -> bool array | None: test hook, see _relu_gate (site 0 = history rows, 1 = candidate rows; layer
+    len(units) = the output Dense)."""
     probs, s, cache = docvec_forward(his, pred, P, h, d, training, drop)
     B, H, C, ch, cc, c_user, NEc3, user, st_h, st_c = cache
     L, ds = loss_fwd_bwd(s, y, loss)
     dNEc = (ds[..., None] * user[:, None, :]).reshape(B * C, -1)
     duser = np.einsum("bc,bce->be", ds, NEc3)
     dNEh, g = user_encoder_from_news_bwd(duser, c_user)
-    g_h, _ = docvec_news_encoder_bwd(dNEh.reshape(B * H, -1), ch, P)
-    g_c, _ = docvec_news_encoder_bwd(dNEc, cc, P)
+    g_h, _ = docvec_news_encoder_bwd(dNEh.reshape(B * H, -1), ch, P, None if relu_gate is None else (lambda l, pre: relu_gate(0, l, pre)))
+    g_c, _ = docvec_news_encoder_bwd(dNEc, cc, P, None if relu_gate is None else (lambda l, pre: relu_gate(1, l, pre)))
     for k in g_h:
         g[k] = g_h[k] + g_c[k]
     # kernel_regularizer=l2(lambda) on the hidden Dense kernels only (116-122; not 130)

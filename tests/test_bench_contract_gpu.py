@@ -34,6 +34,7 @@ def test_bench_line_carries_the_contract_fields(cfg):
         assert st["bound"] == "mfma" and abs(st["frac"] - st["achieved"] / st["peak"]) < 1e-9 and 0 < st["frac"] < r["frac"]
         assert abs(st["achieved"] * 1e12 - st["flops_per_step"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * st["achieved"] * 1e12
         assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and "CpuDocVecTrainer" in c["sample"]
+        assert isinstance(st["launches_per_step"], int) and 8 <= st["launches_per_step"] <= 40 and "counted" in st["launches_note"]
         assert "tn_group" in r["kernel"] and r["algorithmic_flops_per_launch"] > 1e9
         for key in ("roofline", "roofline_gather"):
             assert d[key]["traffic_source"].startswith(("measured in this run", "not measured"))
@@ -67,6 +68,26 @@ def test_bench_line_carries_the_contract_fields(cfg):
         st = d["roofline_step"]
         assert st["bound"] == "mfma" and abs(st["frac"] - st["achieved"] / st["peak"]) < 1e-9 and 0 < st["frac"] < d["roofline"]["frac"]
         assert abs(st["achieved"] * 1e12 - st["algorithmic_flops_per_step"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * st["achieved"] * 1e12
+        assert isinstance(st["launches_per_step"], int) and 10 <= st["launches_per_step"] <= 60
+        # (round 6, verdict r5 item 1) the driver's ONE command -- no --config -- times every other BASELINE config as a leg of the line
+        legs = d["legs"]
+        assert set(legs) == {"c1", "c3", "c4", "c5"}
+        want = {"c1": ("configs[0]", 32, "32000x300"), "c3": ("configs[2]", 32, "NRMSDocVec"), "c4": ("configs[3]", 32, "history_size=50"),
+                "c5": ("configs[4]", 64, "row-sharded")}
+        for name, (idx, pb, word) in want.items():
+            leg = legs[name]
+            assert "error" not in leg and "skipped" not in leg, leg
+            assert leg["value"] > 0 and leg["n_gpus"] == 1 and leg["dtype"] == "f32" and leg["launch"] == "hipGraph replay"
+            assert idx in leg["config"]["workload"] and word in leg["config"]["workload"] and leg["config"]["per_gpu_batch"] == pb
+            assert abs(leg["value"] - pb / (leg["ms_per_step"] * 1e-3)) < 1e-6 * leg["value"] and len(leg["ms_per_step_repeats"]) == 2
+            lr, ls = leg["roofline"], leg["roofline_step"]
+            assert lr["bound"] == "mfma" and 0 < lr["frac"] < 1 and lr["avg_launch_us"] > 0 and abs(lr["frac"] - lr["achieved"] / lr["peak"]) < 1e-9
+            assert ls["bound"] == "mfma" and 0 < ls["frac"] < lr["frac"] and isinstance(ls["launches_per_step"], int)
+            assert leg["roofline_gather"]["bound"] == "hbm" and leg["roofline_gather"]["avg_launch_us"] > 0
+            if lr["traffic_source"].startswith("measured"):  # rocprofv3 could run: the kernel name is the one the profiler saw
+                assert "(" in lr["kernel"] and lr["traffic"] > 0
+        assert legs["c3"]["cpu_baseline"]["kind"] == "port" and legs["c3"]["cpu_baseline"]["value"] > 0 and "tn_group" in legs["c3"]["roofline"]["kernel"]
+        assert "cpu_baseline" not in legs["c1"] and legs["c5"]["config"]["global_batch"] == 64
 
 
 def _bench(argv, timeout, env=None):
@@ -104,6 +125,33 @@ def test_multi_rank_line_carries_the_c4_and_c5_legs_and_the_communication_librar
         assert "comm_exposed_us" in leg and leg["allreduce_bytes_per_step"] > 0
     assert legs["c4"]["config"]["per_gpu_batch"] == 32 and "history_size=50" in legs["c4"]["config"]["workload"]
     assert legs["c5"]["config"]["per_gpu_batch"] == 64 and legs["c5"]["exchange"]["world"] == 2 and "row-sharded" in legs["c5"]["config"]["workload"]
+
+
+@pytest.mark.gpu
+def test_the_multi_rank_branch_runs_end_to_end_on_a_one_rank_rccl_group():
+    """Verdict r5 item 5: every line of bench.py's `nccl` branch -- torch.distributed.run, init_process_group("nccl", device_id=...),
+    rccl_view, SegmentTrace, HangWatchdog, the engine's multi-rank launch form (graph | all-reduce | graph), run_legs with its fresh
+    rendezvous, the closing collective flag check -- executes HERE, on a group of one rank (RCCL refuses two ranks on one device),
+    before the 8-GPU node runs it; and costs the step almost nothing (the collectives are identities)."""
+    plain, _ = _bench(["--steps", "20", "--warmup", "5", "--repeats", "3", "--legs", "", "--no-cpu-baseline", "--no-fit-loop", "--no-split-leg", "--no-probe"], 900)
+    assert plain.returncode == 0, plain.stderr[-3000:]
+    ref = json.loads([l for l in plain.stdout.splitlines() if l.startswith("{")][0])
+    out, _ = _bench(["--gpus", "1", "--force-dist", "--steps", "20", "--warmup", "5", "--repeats", "3"], 1500)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    v = d["rccl_view"]
+    assert d["backend"] == "nccl" and v["backend"] == "nccl" and v["rccl_version"] and not str(v["rccl_version"]).startswith("unavailable")
+    assert v["world_size"] == 1 and v["rank_ids_allgathered"] == [0] and v["distinct_devices"] == 1
+    assert d["guard"].startswith("active") and "force-dist" in d["dist_note"] and d["n_gpus"] == 1 and d["ranks"] == 1
+    assert "comm_exposed_us" in d and d["allreduce_bytes_per_step"] > 0 and d["comm"]["overlap"] in (True, False)
+    assert set(d["legs"]) == {"c4", "c5"}
+    for name in ("c4", "c5"):
+        assert "error" not in d["legs"][name], d["legs"][name]
+        assert d["legs"][name]["value"] > 0 and d["legs"][name]["backend"] == "nccl"
+    assert d["legs"]["c5"]["exchange"]["world"] == 1
+    assert abs(d["value"] - ref["value"]) < 0.03 * ref["value"], (d["value"], ref["value"])
 
 
 @pytest.mark.gpu

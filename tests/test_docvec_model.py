@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 
 from oracle import nrms_numpy as on
-from tests.hip_testutil import assert_close
+from tests.hip_testutil import ReluTieGate, assert_close
 
 pytestmark = pytest.mark.gpu
 
@@ -82,11 +82,13 @@ def test_train_step_gradients_loss_and_moving_stats(docvec, p, l2, units, din, B
     m.model.set_weights(weight_list(P))
     rng = np.random.default_rng(2)
     his, pred, y = data(rng, B, hp.history_size, 5, hp.title_size)
-    L, _, g, stats = on.docvec_loss_and_grads(his.astype(np.float64), pred.astype(np.float64), y, P, hp.head_num, hp.head_dim,
-                                              l2=l2, training=True, drop=on.Drop(p, seed, 1) if p > 0 else None)
     got = float(m.train_step(his, pred, y).item())
-    assert abs(got - L) <= 3e-5 * max(1.0, abs(L)), (got, L)
     eng = m._engine
+    gate = ReluTieGate(eng, B * hp.history_size, B * 5)  # ReLU inputs within rounding of 0: the engine's side (order-independent comparison)
+    L, _, g, stats = on.docvec_loss_and_grads(his.astype(np.float64), pred.astype(np.float64), y, P, hp.head_num, hp.head_dim,
+                                              l2=l2, training=True, drop=on.Drop(p, seed, 1) if p > 0 else None, relu_gate=gate)
+    assert gate.fraction() < 1e-3, (gate.n_ambiguous, gate.n_total)  # (small shapes: one element of 3 x 12 x 36 would already be 8e-4)
+    assert abs(got - L) <= 3e-5 * max(1.0, abs(L)), (got, L)
     E = eng.E
     assert (eng._bufs["mlp"].get("dvn_live") is not None) == fused
     nl = len(units)

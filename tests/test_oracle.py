@@ -283,3 +283,26 @@ def test_torch_docvec_port_agrees_with_the_numpy_oracle():
     for (l, mu, var), (mu_o, var_o) in zip(stats, list(st_h) + list(st_c)):
         np.testing.assert_allclose(mu.numpy(), mu_o, rtol=1e-10)
         np.testing.assert_allclose(var.numpy(), var_o, rtol=1e-10)
+
+
+def test_relu_gate_hook_only_changes_what_it_is_told_to():
+    """oracle._relu_gate (the parity tests' order-independence hook): None / the oracle's own [pre > 0] change nothing; the hook sees every
+    ReLU of both call sites (hidden layers 0..L-1 and the output Dense L), history site first."""
+    rng = np.random.default_rng(0)
+    P = on.init_docvec_params(20, [12, 8], 2, 4, 6, seed=1)
+    his, pred = rng.standard_normal((3, 4, 20)), rng.standard_normal((3, 5, 20))
+    y = np.eye(5)[rng.integers(0, 5, 3)]
+    a = on.docvec_loss_and_grads(his, pred, y, P, 2, 4, l2=1e-3)
+    seen = []
+
+    def same(site, layer, pre):
+        seen.append((site, layer, pre.shape))
+        return pre > 0
+
+    b = on.docvec_loss_and_grads(his, pred, y, P, 2, 4, l2=1e-3, relu_gate=same)
+    c = on.docvec_loss_and_grads(his, pred, y, P, 2, 4, l2=1e-3, relu_gate=lambda s, l, pre: None)
+    for other in (b, c):
+        assert a[0] == other[0] and all(np.array_equal(a[2][k], other[2][k]) for k in a[2])
+    assert seen == [(0, 2, (12, 8)), (0, 1, (12, 8)), (0, 0, (12, 12)), (1, 2, (15, 8)), (1, 1, (15, 8)), (1, 0, (15, 12))]
+    d = on.docvec_loss_and_grads(his, pred, y, P, 2, 4, l2=1e-3, relu_gate=lambda s, l, pre: np.ones_like(pre, bool))
+    assert max(np.abs(a[2][k] - d[2][k]).max() for k in a[2]) > 1e-3  # an all-pass gate IS a different function
