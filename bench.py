@@ -515,8 +515,9 @@ def bench_docvec(args, c, world, rank, device, sync, dfields, multi=False):
     if args.kernel_probe:  # the two roofline kernels, eagerly, on the step's own buffers (what probe_kernels() wraps rocprofv3 around)
         eng.train_step(*batches[0], indexed=True)
         rk = eng.roofline_kernels(c["B"], c["C"])
-        for h_, p_, _ in batches[:4]:
-            rk["gather"](torch.cat([h_.reshape(-1), p_.reshape(-1)]).contiguous())()
+        id_sets = [torch.cat([h_.reshape(-1), p_.reshape(-1)]).contiguous() for h_, p_, _ in batches]
+        for i in range(args.probe_launches):
+            rk["gather"](id_sets[i % len(id_sets)])()
             if "dw_group" in rk:
                 rk["dw_group"]()
         sync()
@@ -858,6 +859,7 @@ def main():
     ap.add_argument("--fault-skip-collectives-on-rank", type=int, default=-1,
                     help="test hook: this rank skips its collectives in the timed region (its peers then wait for it forever): the hang "
                          "watchdog must turn that into exit code 124 within EBN_COLLECTIVE_TIMEOUT_S")
+    ap.add_argument("--probe-launches", type=int, default=24, help="internal: launches of each roofline kernel in --kernel-probe")
     ap.add_argument("--kernel-probe", action="store_true", help="internal: launch the two roofline kernels a few times on the step's "
                                                                 "buffers and exit (what probe_kernels() wraps rocprofv3 around)")
     args = ap.parse_args()
@@ -929,11 +931,12 @@ def main():
     batches = synthetic_batches(c, 8, 123 + rank, device, args.ids)
 
     if args.kernel_probe:
-        # the two roofline kernels, eagerly, on the step's own buffers: 4 launches each (the gather over 4 different id sets)
+        # the two roofline kernels, eagerly, on the step's own buffers: --probe-launches launches each (the gather cycling over the 8 batches' id sets)
         eng.train_step(*batches[0])  # allocates the step's buffers and fills X with gathered rows
         rk = eng.roofline_kernels(c["B"], c["C"])
-        for h_, p_, _ in batches[:4]:
-            rk["gather"](torch.cat([h_.reshape(-1), p_.reshape(-1)]).contiguous())()
+        id_sets = [torch.cat([h_.reshape(-1), p_.reshape(-1)]).contiguous() for h_, p_, _ in batches]
+        for i in range(args.probe_launches):  # (the first launches run on a chip that has just idled: the summary's MinNs / the later launches are the steady ones)
+            rk["gather"](id_sets[i % len(id_sets)])()
             rk["qkv_gemm"]()
         sync()
         return

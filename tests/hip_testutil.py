@@ -82,11 +82,12 @@ class ReluTieGate:
     function, but the gradient element they gate -- and every gradient upstream of it -- differs by a finite amount (measured:
     one weight-gradient column off by 1.3e-3 of the largest gradient about one step in ten at the c3 size,
     profiles/r05_tuning_notes.md).  This object is the oracle's `relu_gate` hook: for the AMBIGUOUS elements only (|z| <= rel x
-    max|z| of that layer and call site in float64) it hands the oracle the ENGINE's own choice (whether the engine's stored ReLU
+    max|z| of that layer and call site in float64; rel = 3e-6 is > 10 standard deviations of the fp32 rounding noise of a 768-deep dot product
+    relative to the layer's largest pre-activation) it hands the oracle the ENGINE's own choice (whether the engine's stored ReLU
     output is > 0); every other element keeps the oracle's [z > 0].  `fraction()` = the share of ReLU inputs that were treated
     as ambiguous (exact zeros -- zero-padded rows -- are not rounding cases and are not counted); the tests bound it."""
 
-    def __init__(self, eng, n_hist, n_cand, rel=1e-5):
+    def __init__(self, eng, n_hist, n_cand, rel=3e-6):
         mb = eng._bufs["mlp"]
         rb = eng.mlp.bufs(mb["N"])
         L = len(eng.units)
