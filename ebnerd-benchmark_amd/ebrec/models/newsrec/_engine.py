@@ -18,7 +18,6 @@ from __future__ import annotations
 
 import ctypes
 import math
-import os
 
 import numpy as np
 import torch
@@ -234,12 +233,6 @@ class NRMSEngine(StagingMixin, SegmentsMixin):
         # True: launch the multi-rank form of the step (collectives between the graph replays, the multi-rank Adam inputs) on a group of
         # ONE rank, where every collective is an identity -- `bench.py --force-dist` runs the RCCL branch end to end on a 1-GPU box
         self.force_collectives = False
-        # One-rank step: the AttLayer2 weight-gradient GEMM of the news encoder (dW = Y^T . dpre, needed only by the finishing launch)
-        # runs on a SECOND stream, forked after d(pre-activation) and joined before the finishing launch -- a parallel branch of the
-        # captured hipGraph, under the dY GEMM and the attention-core backward (the critical path to dWqkv).  Same kernels, same
-        # operands, own workspaces: same bits.  (EBN_SIDE_STREAM=0 switches it off: the A/B of profiles/r06_tuning_notes.md)
-        self.side_stream = os.environ.get("EBN_SIDE_STREAM", "1") != "0"
-        self._side, self._side_ok, self._side_pending = None, False, False
 
     @property
     def multi(self) -> bool:
@@ -947,9 +940,7 @@ class NRMSEngine(StagingMixin, SegmentsMixin):
                 return self._news_bwd_deferred(nb, ub, B, N, "p1")
             return self._news_bwd_p1(nb, N, nb.dNE)
         if part == "all" and deferred:
-            self._side_ok = True
             self._news_bwd_deferred(nb, ub, B, N, "p1")
-            self._side_ok = False
             self._news_bwd_deferred(nb, ub, B, N, "p2")
             if nb.dX is not None:
                 self._news_bwd_p3(nb, N, nb.dX)
@@ -1013,17 +1004,7 @@ class NRMSEngine(StagingMixin, SegmentsMixin):
             _hip.call("ebn_attpool_bwd_pool_f32", _hip.ptr(nb.Y), _hip.ptr(nb.w), _hip.ptr(nb.dNE), None, _hip.ptr(nb.de), N, T, E, S())
             _hip.call("ebn_attpool_bwd_dpre_f32", _hip.ptr(nb.U), _hip.ptr(pv("n_q")), _hip.ptr(nb.de), None, None, _hip.ptr(nb.partials), R, A, 0, S())
             n = ctypes.c_int32(0)
-            fork = self.side_stream and self._side_ok
-            if fork:  # parallel branch: dW on the side stream, behind everything enqueued so far (dpre is complete)
-                if self._side is None:
-                    self._side = torch.cuda.Stream(device=self.device)
-                main = torch.cuda.current_stream()
-                self._side.wait_stream(main)
-                with torch.cuda.stream(self._side):
-                    _hip.call("ebn_gemm_f32_partials", 1, 0, E, A, R, one, _hip.ptr(nb.Y), E, _hip.ptr(nb.U), A, _hip.ptr(nb.ws_dw), nb.ws_dw.numel(), ctypes.byref(n), S())
-                self._side_pending = True
-            else:
-                _hip.call("ebn_gemm_f32_partials", 1, 0, E, A, R, one, _hip.ptr(nb.Y), E, _hip.ptr(nb.U), A, _hip.ptr(nb.ws_dw), nb.ws_dw.numel(), ctypes.byref(n), S())
+            _hip.call("ebn_gemm_f32_partials", 1, 0, E, A, R, one, _hip.ptr(nb.Y), E, _hip.ptr(nb.U), A, _hip.ptr(nb.ws_dw), nb.ws_dw.numel(), ctypes.byref(n), S())
             nb.finish_jobs["dW"] = int(n.value)
             _hip.call("ebn_gemm_f32_ws", 0, 1, R, E, A, one, _hip.ptr(nb.U), A, _hip.ptr(pv("n_W")), A, zero, _hip.ptr(nb.dY), E, _hip.ptr(nb.ws), nb.ws.numel(), S())
             return
@@ -1042,9 +1023,6 @@ class NRMSEngine(StagingMixin, SegmentsMixin):
                                  ub.loss_rows.data_ptr(), self.loss_dev.data_ptr())
         jobs[2] = _hip.FinishJob(_hip.FINISH_SPLITK, nb.finish_jobs["dW"], E, A, nb.ws_dw.data_ptr(), g("n_W").data_ptr(), None, A, 0.0, 1.0, None, None)
         jobs[3] = _hip.FinishJob(_hip.FINISH_SPLITK, int(n.value), D, 3 * E, nb.ws_dwqkv.data_ptr(), g("n_Wqkv").data_ptr(), None, 3 * E, 0.0, 1.0, None, None)
-        if self._side_pending:  # join: the finishing launch sums dW's partials
-            torch.cuda.current_stream().wait_stream(self._side)
-            self._side_pending = False
         _hip.call("ebn_grad_finish_f32", jobs, 4, S())
 
     def _fwd_user_stage_kernels(self, B, C, nb, ub):
