@@ -540,7 +540,7 @@ def bench_docvec(args, c, world, rank, device, sync, dfields, multi=False):
         # document vectors themselves), the user encoder (as in step_flops) and the scorer
         fl_step = sum(2.0 * n_rows * dims[i] * dims[i + 1] * (3 if i else 2) for i in range(len(dims) - 1))
         fl_step += 3 * 2.0 * B * H * E * 3 * E + B * c["h"] * 12.0 * H * H * c["d"] + 3 * 2.0 * B * H * E * A + 3 * 2.0 * B * C * E
-        probe = None if (args.no_probe or args.no_roofline or multi) else probe_kernels("c3", 0, pick=lambda n: "gather" if "gather" in n else ("dw_group" if "tn_group" in n else None))
+        probe = None if (args.no_probe or args.no_roofline or multi) else probe_kernels("c3", 0, pick=lambda n: "gather" if "gather" in n else ("dw_group" if ("tn_finale" in n if rk.get("dw_group_is_finale") else "tn_group" in n) else None))
         line = {"metric": "training impressions/sec", **timing_fields(times, args, world, c["B"]), "unit": "impressions/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup,
                 "launch": "eager" if args.no_graph else "hipGraph replay", "higher_is_better": True, "scaling": "weak",
@@ -554,9 +554,11 @@ def bench_docvec(args, c, world, rank, device, sync, dfields, multi=False):
             if probe else "not measured (no rocprofv3 passes in this run)"
         if "dw_group" in kt:
             fl = rk["dw_group_flops"]
-            line["roofline"] = {"kernel": (probe or {}).get("dw_group", {}).get("name", "gemm_small_tn_group_kernel<64>") +
+            fin = bool(rk.get("dw_group_is_finale"))
+            line["roofline"] = {"kernel": (probe or {}).get("dw_group", {}).get("name", "gemm_small_tn_finale_kernel<64>" if fin else "gemm_small_tn_group_kernel<64>") +
                                           f" (the weight gradients of the {len(dims) - 1} Dense kernels of the news encoder as ONE grouped launch, "
-                                          f"K = {n_rows} rows: the time-dominant launch of a step that is latency-bound as a whole)", "bound": "mfma",
+                                          f"K = {n_rows} rows" + (", with the step's closing work dealt over the same workgroups: Adam on every parameter, the user head's finishing sums, the batch loss"
+                                                                  if fin else "") + ": the time-dominant launch of a step that is latency-bound as a whole)", "bound": "mfma",
                                 "achieved": fl / kt["dw_group"] / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                 "frac": fl / kt["dw_group"] / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": (probe or {}).get("dw_group", {}).get("traffic"),
                                 "traffic_source": src, "avg_launch_us": kt["dw_group"] * 1e6, "algorithmic_flops_per_launch": fl,

@@ -29,6 +29,7 @@
 // gemm_small_vec_kernel (ebn_gemm.hip).  Row tiles never straddle the two call sites (each site is tiled on its own), so a tile
 // has ONE set of statistics.
 #include "ebn_common.h"
+#include "ebn_tn_finale.h"
 
 typedef float ebn_f32x4 __attribute__((ext_vector_type(4)));
 typedef int ebn_i32x4 __attribute__((ext_vector_type(4)));
@@ -897,6 +898,53 @@ extern "C" int ebn_dvn_bwd_f32(const ebn_dvn_args* a, const ebn_step_state* st, 
     if (r != EBN_OK) return r;
   }
   return EBN_OK;
+}
+
+// The closing launch of a ONE-RANK training step (see ebn_tn_finale.h): the Dense weight gradients of ebn_gemm_tn_group_f32 with Adam in
+// the tiles' epilogues, Adam over the remaining ranges of the flat parameter buffer, the user head's finishing sums and the batch loss
+// including the L2 term (the caller ran ebn_dvn_bwd_f32 with args->loss == NULL and ebn_user_head_train_f32 with dq == db == NULL).
+extern "C" int ebn_dvn_finale_f32(const ebn_dvn_args* a, const ebn_tn_problem* problems, int32_t n, const ebn_dvn_finale* f,
+                                  const ebn_step_state* st, ebn_stream_t stream) {
+  const int rc = check_args(a);
+  if (rc != EBN_OK) return rc;
+  EBN_REQUIRE(problems != nullptr && f != nullptr && st != nullptr && a->stat != nullptr, EBN_ERR_BAD_ARG);
+  EBN_REQUIRE(f->theta && f->grad && f->m && f->v && f->numel > 0 && f->numel <= EBN_DIM_MAX * 16, EBN_ERR_BAD_ARG);
+  EBN_REQUIRE(f->n_rest >= 0 && f->n_rest <= EBN_DVN_FINALE_MAX_REST, EBN_ERR_BAD_ARG);
+  EBN_REQUIRE(f->head_partials && f->dq && f->db && f->loss_rows && f->loss_out && f->B >= 1 && f->A >= 1 && f->A < (1 << 24), EBN_ERR_BAD_ARG);
+  auto inside = [&](const float* ptr, int64_t count) {  // [ptr, ptr + count) lies in the flat gradient buffer
+    return ptr >= f->grad && count >= 0 && (ptr - f->grad) + count <= f->numel;
+  };
+  EBN_REQUIRE(n >= 1 && n <= EBN_TN_GROUP_MAX, EBN_ERR_BAD_ARG);
+  for (int i = 0; i < n; ++i) {
+    const ebn_tn_problem& q = problems[i];
+    EBN_REQUIRE(q.C != nullptr && q.M >= 1 && q.N >= 1 && q.ldc >= q.N, EBN_ERR_BAD_ARG);
+    EBN_REQUIRE(inside(q.C, (q.M - 1) * q.ldc + q.N) && (q.colsum == nullptr || inside(q.colsum, q.N)), EBN_ERR_BAD_ARG);
+  }
+  EBN_REQUIRE(inside(f->dq, f->A) && inside(f->db, f->A), EBN_ERR_BAD_ARG);
+  EbnTnFinale t{};
+  t.adam = EbnAdamFlat{f->grad, f->theta, f->m, f->v, st, static_cast<float>(1.0 - f->beta1), static_cast<float>(1.0 - f->beta2),
+                       static_cast<float>(f->eps), f->grad_scale};
+  t.n_rest = f->n_rest;
+  t.rest_total = 0;
+  for (int i = 0; i < f->n_rest; ++i) {
+    EBN_REQUIRE(f->rest_off[i] >= 0 && f->rest_len[i] >= 0 && f->rest_off[i] + f->rest_len[i] <= f->numel, EBN_ERR_BAD_ARG);
+    t.rest_off[i] = f->rest_off[i];
+    t.rest_len[i] = f->rest_len[i];
+    t.rest_total += f->rest_len[i];
+  }
+  t.head_partials = f->head_partials;
+  t.B = f->B;
+  t.A = f->A;
+  t.dq = f->dq;
+  t.db = f->db;
+  t.loss_rows = f->loss_rows;
+  t.loss_out = f->loss_out;
+  t.l2_part = l2_view(a);
+  t.n_l2 = a->l2 > 0.f ? a->n_layers : 0;
+  t.l2_slots = L2_SLOTS;
+  for (int i = 0; i < a->n_layers; ++i) t.l2_tiles[i] = (a->units[i] + TN - 1) / TN;
+  t.l2 = a->l2;
+  return ebn_tn_group_finale_launch(problems, n, t, ebn_stream(stream));
 }
 
 extern "C" int ebn_docvec_stage_gather_f32(const int32_t* idx0, int64_t n0, const int32_t* idx1, int64_t n1, const float* labels_src,

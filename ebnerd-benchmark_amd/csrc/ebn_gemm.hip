@@ -23,6 +23,7 @@
 
 #include "ebn_common.h"
 #include "ebn_finish.h"
+#include "ebn_tn_finale.h"
 
 // Buffer-load intrinsics bound by name (the __amdgpu_buffer_rsrc_t builtins make the HOST pass drop the launch stub of
 // a kernel that uses them).  Declared outside the anonymous namespace: they are external symbols of the compiler.
@@ -586,7 +587,13 @@ _Pragma("unroll")  \
           if (EPI == 1 && !split)  // 32-bit division: M < 2^31 rows
             v = fmaf(epi.rs[row], epi.cv[static_cast<int64_t>(static_cast<uint32_t>(row) / static_cast<uint32_t>(epi.L)) * epi.ldcv + col], v);
           if (EPI == 2 && !split) v = fmaxf(v + epi.bias[col], 0.f);
+#if defined(EBN_GEMM_EXP_NOSTORE)  /* tuning experiment (tools/build_variant.sh): the tile's MFMAs without its C stores */
+          if (v == 1.2345e38f) out[row * ldo + col] = v;
+#elif defined(EBN_GEMM_EXP_NT)     /* tuning experiment: non-temporal C stores */
+          __builtin_nontemporal_store(v, &out[row * ldo + col]);
+#else
           out[row * ldo + col] = v;
+#endif
         }
       }
     }
@@ -830,10 +837,12 @@ __device__ __forceinline__ void small_store_t(float* __restrict__ S, const float
   }
 }
 
-template <bool TA, bool TB, int T>
+// FIN (ebn_dvn_finale_f32): Keras-form Adam on every element this tile produces (C and the column sums), see ebn_tn_finale.h.
+template <bool TA, bool TB, int T, bool FIN = false>
 __device__ __forceinline__ void small_vec_body(int64_t M, int64_t N, int64_t K, float alpha, const float* __restrict__ A,
                                                int64_t lda, const float* __restrict__ B, int64_t ldb, float beta,
-                                               float* __restrict__ C, int64_t ldc, GemmEpi epi, int64_t tile_x, int64_t tile_y) {
+                                               float* __restrict__ C, int64_t ldc, GemmEpi epi, int64_t tile_x, int64_t tile_y,
+                                               const EbnTnFinale* fin = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float smem_small[];  // [2 buffers][A tile | B tile]
   constexpr int THREADS = T * T / 4, SPT = SBK / T, WPR = T / 16;  // float4 per thread, operand and slab; waves per tile row
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -995,22 +1004,26 @@ __device__ __forceinline__ void small_vec_body(int64_t M, int64_t N, int64_t K, 
       float t = 0.f;
       for (int r = 0; r < KR; ++r) t += sc[r * (T + 4) + tid];
       epi.colsum[n0 + tid] = t;
+      if (FIN) ebn_adam_flat_apply(fin->adam, fin->adam.st->adam_alpha, (epi.colsum + n0 + tid) - fin->adam.grad, t);
     }
   }
   // C/D map of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + r
   const int64_t col = n0 + wn * 16 + r16;
-  if (col >= N) return;
+  if (col < N) {  // (no early return: the finale's workgroups go on to their share of the step's closing work)
+    const float al = FIN ? fin->adam.st->adam_alpha : 0.f;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int64_t row = m0 + wm * 16 + 4 * kq + r;
-    if (row >= M) continue;
-    float v = alpha * acc[r];
-    if (beta != 0.f) v += beta * C[row * ldc + col];
-    if (epi.rs != nullptr)
-      v = fmaf(epi.rs[row], epi.cv[static_cast<int64_t>(static_cast<uint32_t>(row) / static_cast<uint32_t>(epi.L)) * epi.ldcv + col], v);
-    if (epi.bias != nullptr) v = fmaxf(v + epi.bias[col], 0.f);
-    if (epi.l2w != nullptr) v = fmaf(epi.two_lambda, epi.l2w[row * ldc + col], v);
-    C[row * ldc + col] = v;
+    for (int r = 0; r < 4; ++r) {
+      const int64_t row = m0 + wm * 16 + 4 * kq + r;
+      if (row >= M) continue;
+      float v = alpha * acc[r];
+      if (beta != 0.f) v += beta * C[row * ldc + col];
+      if (epi.rs != nullptr)
+        v = fmaf(epi.rs[row], epi.cv[static_cast<int64_t>(static_cast<uint32_t>(row) / static_cast<uint32_t>(epi.L)) * epi.ldcv + col], v);
+      if (epi.bias != nullptr) v = fmaxf(v + epi.bias[col], 0.f);
+      if (epi.l2w != nullptr) v = fmaf(epi.two_lambda, epi.l2w[row * ldc + col], v);
+      C[row * ldc + col] = v;
+      if (FIN) ebn_adam_flat_apply(fin->adam, al, (C + row * ldc + col) - fin->adam.grad, v);
+    }
   }
 }
 
@@ -1064,9 +1077,18 @@ struct SmallGroup {
 // T = 32: 256 threads per 32 x 32 tile; T = 64: 1024 threads (sixteen waves, one 16 x 16 block each) per 64 x 64 tile -- half the
 // operand re-streaming (a group of Dense kernel gradients with K = 800 reads 210 MB through L2 on 32 x 32 tiles, 105 MB on 64 x 64),
 // taken when the group's 64 x 64 tiles alone fill the chip.
+// Workgroup -> tile order of the grouped launches: the hardware deals consecutive workgroups round-robin to the 8 XCDs (private L2s);
+// remapped so that each XCD walks a CONTIGUOUS run of tiles -- the tiles of a run share their A column panel (K x T floats, read by
+// tiles_x neighbours) and walk the B panels of one problem, so an operand slab is fetched into one L2 instead of eight (the group of
+// c3's four Dense gradients moved 67 MB of fabric traffic for 17 MB of operands with the dispatch order as the tile order).  Bijective.
+__device__ __forceinline__ int xcd_chunked_tile(int v, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = v & 7, idx = v >> 3;
+  return ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 template <int T>
 __global__ __launch_bounds__(T * T / 4) void gemm_small_tn_group_kernel(SmallGroup g) {
-  const int b = blockIdx.x;
+  const int b = xcd_chunked_tile(blockIdx.x, gridDim.x);
   int i = 0;
   while (i + 1 < g.n && b >= g.first[i + 1]) ++i;
   const SmallProblem& p = g.p[i];
@@ -1076,6 +1098,67 @@ __global__ __launch_bounds__(T * T / 4) void gemm_small_tn_group_kernel(SmallGro
   epi.two_lambda = g.two_lambda[i];
   const int t = b - g.first[i];
   small_vec_body<true, false, T>(p.M, p.N, p.K, p.alpha, p.A, p.lda, p.B, p.ldb, p.beta, p.C, p.ldc, epi, t % p.tiles_x, t / p.tiles_x);
+}
+
+// The finale of a one-rank NRMSDocVec step: tn_group's tiles with Adam in their epilogue, then -- dealt over the same workgroups -- the
+// element-wise Adam over the ranges no tile owns and the user head's finishing sums with the batch loss.  See ebn_tn_finale.h.
+static_assert(EBN_TN_FINALE_MAX_REST == EBN_DVN_FINALE_MAX_REST, "ebn_tn_finale.h / ebnerd_hip.h");
+struct SmallGroupFin {
+  SmallGroup g;
+  EbnTnFinale f;
+};
+
+template <int T>
+__global__ __launch_bounds__(T * T / 4) void gemm_small_tn_finale_kernel(SmallGroupFin gf) {
+  extern __shared__ __attribute__((aligned(16))) float smem_small[];
+  const SmallGroup& g = gf.g;
+  const EbnTnFinale& f = gf.f;
+  const int nwg = gridDim.x, tid = threadIdx.x, b = xcd_chunked_tile(blockIdx.x, nwg);
+  constexpr int NT = T * T / 4;
+  int i = 0;
+  while (i + 1 < g.n && b >= g.first[i + 1]) ++i;
+  const SmallProblem& p = g.p[i];
+  GemmEpi epi{nullptr, nullptr, 0, 1, nullptr};
+  epi.colsum = g.colsum[i];
+  epi.l2w = g.l2w[i];
+  epi.two_lambda = g.two_lambda[i];
+  const int t = b - g.first[i];
+  small_vec_body<true, false, T, true>(p.M, p.N, p.K, p.alpha, p.A, p.lda, p.B, p.ldb, p.beta, p.C, p.ldc, epi, t % p.tiles_x, t / p.tiles_x, &f);
+  const float al = f.adam.st->adam_alpha;
+  // element-wise Adam over the remaining ranges: the concatenated index space, one contiguous share per workgroup
+  {
+    const int64_t per = (f.rest_total + nwg - 1) / nwg, e0 = static_cast<int64_t>(b) * per;
+    const int64_t e1 = e0 + per < f.rest_total ? e0 + per : f.rest_total;
+    for (int64_t e = e0 + tid; e < e1; e += NT) {
+      int64_t off = e;
+      int r = 0;
+      while (r + 1 < f.n_rest && off >= f.rest_len[r]) off -= f.rest_len[r++];
+      off += f.rest_off[r];
+      ebn_adam_flat_apply(f.adam, al, off, f.adam.grad[off]);
+    }
+  }
+  // the user head's d(q) / d(b) sums over impressions and the batch loss (+ the L2 term), then Adam on d(q) / d(b)
+  const int nh = (2 * f.A + 255) / 256 + 1;
+  if (f.head_partials != nullptr && b < nh) {  // block-uniform
+    __syncthreads();                            // the tile buffers are free (colsum's scratch included)
+    ebn_user_head_finish_body(smem_small, b, nh, f.head_partials, f.B, f.A, f.dq, f.db, f.loss_rows, f.loss_out);
+    if (b < nh - 1) {
+      const int idx = b * 256 + tid;
+      if (tid < 256 && idx < 2 * f.A) {
+        const int sidx = idx / f.A, k = idx - sidx * f.A;
+        float* gp = (sidx == 0 ? f.dq : f.db) + k;
+        ebn_adam_flat_apply(f.adam, al, gp - f.adam.grad, *gp);  // (written by this thread a moment ago)
+      }
+    } else if (tid == 0 && f.n_l2 > 0) {  // loss += l2 * sum W^2, in dvn_dbn_apply_kernel's order
+      float tot = 0.f;
+      for (int l = 0; l < f.n_l2; ++l) {
+        float tl = 0.f;
+        for (int j = 0; j < f.l2_tiles[l]; ++j) tl += f.l2_part[l * f.l2_slots + j];
+        tot += tl;
+      }
+      f.loss_out[0] += f.l2 * tot;
+    }
+  }
 }
 
 int launch_gemm_small(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda,
@@ -1500,6 +1583,53 @@ extern "C" int ebn_gemm_tn_group_f32(const ebn_tn_problem* problems, int32_t n, 
   if (T == 64) EBN_TN_GROUP(64);
   else EBN_TN_GROUP(32);
 #undef EBN_TN_GROUP
+  EBN_CHECK_LAUNCH();
+  return EBN_OK;
+}
+
+int ebn_tn_group_finale_launch(const ebn_tn_problem* problems, int32_t n, const EbnTnFinale& fin, hipStream_t s) {
+  EBN_REQUIRE(problems != nullptr && n >= 1 && n <= EBN_TN_GROUP_MAX, EBN_ERR_BAD_ARG);
+  int64_t tiles64 = 0;
+  for (int i = 0; i < n; ++i) {
+    const ebn_tn_problem& q = problems[i];
+    EBN_REQUIRE(ebn_dim_ok(q.M, q.N, q.K) && q.K >= 1 && q.M > 0 && q.N > 0, EBN_ERR_BAD_ARG);
+    EBN_REQUIRE(q.A && q.B && q.C, EBN_ERR_BAD_ARG);
+    EBN_REQUIRE(q.lda >= q.M && q.ldb >= q.N && q.ldc >= q.N, EBN_ERR_BAD_ARG);
+    EBN_REQUIRE((q.lda % 4) == 0 && (q.ldb % 4) == 0 && (q.M % 4) == 0 && (q.N % 4) == 0 && ebn_aligned16(q.A) && ebn_aligned16(q.B),
+                EBN_ERR_UNSUPPORTED);
+    EBN_REQUIRE((q.K + SBK) * (q.lda > q.ldb ? q.lda : q.ldb) * 4 + 64 * 4 < (int64_t{1} << 31), EBN_ERR_UNSUPPORTED);
+    tiles64 += ebn_ceil_div(q.M, 64) * ebn_ceil_div(q.N, 64);
+  }
+  const int T = tiles64 >= 192 ? 64 : 32;
+  SmallGroupFin gf{};
+  gf.f = fin;
+  SmallGroup& g = gf.g;
+  int64_t total = 0;
+  g.n = n;
+  for (int i = 0; i < n; ++i) {
+    const ebn_tn_problem& q = problems[i];
+    g.p[i] = SmallProblem{q.M, q.N, q.K, 1.0f, q.A, q.lda, q.B, q.ldb, 0.0f, q.C, q.ldc, static_cast<int32_t>(ebn_ceil_div(q.N, T)), 0};
+    g.p[i].tiles = g.p[i].tiles_x * static_cast<int32_t>(ebn_ceil_div(q.M, T));
+    g.colsum[i] = q.colsum;
+    g.l2w[i] = q.l2_W;
+    g.two_lambda[i] = q.two_lambda;
+    g.first[i] = static_cast<int32_t>(total);
+    total += g.p[i].tiles;
+    EBN_REQUIRE(total < (int64_t{1} << 30), EBN_ERR_UNSUPPORTED);
+  }
+  g.first[n] = static_cast<int32_t>(total);
+  EBN_REQUIRE(total >= (2 * fin.A + 255) / 256 + 1, EBN_ERR_UNSUPPORTED);  // the head's finishing blocks ride on the first workgroups
+#define EBN_TN_FINALE(TT)                                                                                                         \
+  do {                                                                                                                            \
+    constexpr size_t lds = static_cast<size_t>(2) * 2 * (TT) * SLV * sizeof(float);                                               \
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_small_tn_finale_kernel<TT>),           \
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));        \
+    if (attr != hipSuccess) return static_cast<int>(attr);                                                                        \
+    EBN_LAUNCH(gemm_small_tn_finale_kernel<TT>, dim3(static_cast<unsigned>(total)), dim3((TT) * (TT) / 4), lds, s, gf);           \
+  } while (0)
+  if (T == 64) EBN_TN_FINALE(64);
+  else EBN_TN_FINALE(32);
+#undef EBN_TN_FINALE
   EBN_CHECK_LAUNCH();
   return EBN_OK;
 }

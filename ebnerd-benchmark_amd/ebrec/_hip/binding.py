@@ -88,6 +88,18 @@ class TnProblem(ctypes.Structure):
                 ("ldc", ctypes.c_int64), ("colsum", ctypes.c_void_p), ("l2_W", ctypes.c_void_p), ("two_lambda", ctypes.c_float)]
 
 
+DVN_FINALE_MAX_REST = 12
+
+
+class DvnFinale(ctypes.Structure):
+    """ebn_dvn_finale: the closing launch of a one-rank NRMSDocVec training step (ebn_dvn_finale_f32)."""
+    _fields_ = [("theta", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("m", ctypes.c_void_p), ("v", ctypes.c_void_p), ("numel", ctypes.c_int64),
+                ("beta1", ctypes.c_double), ("beta2", ctypes.c_double), ("eps", ctypes.c_double), ("grad_scale", ctypes.c_float),
+                ("n_rest", ctypes.c_int32), ("rest_off", ctypes.c_int64 * DVN_FINALE_MAX_REST), ("rest_len", ctypes.c_int64 * DVN_FINALE_MAX_REST),
+                ("head_partials", ctypes.c_void_p), ("B", ctypes.c_int64), ("A", ctypes.c_int32), ("dq", ctypes.c_void_p), ("db", ctypes.c_void_p),
+                ("loss_rows", ctypes.c_void_p), ("loss_out", ctypes.c_void_p)]
+
+
 # ---- header parser -------------------------------------------------------
 _PROTO = re.compile(r"^(int64_t|int|const char\*)\s+(ebn_\w+)\s*\(([^;{}]*?)\)\s*;", re.M | re.S)
 

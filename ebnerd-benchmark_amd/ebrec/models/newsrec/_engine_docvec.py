@@ -44,6 +44,11 @@ class DocVecEngine:
         # True: BatchNormalization / Dropout / ReLU-backward of the news encoder ride in the Dense matmuls of a training step
         # (csrc/ebn_docvec.hip: one launch per layer and direction); False: the separate passes of csrc/ebn_dense.hip (validation form)
         self.fuse_news_mlp = True
+        # True (one rank, fused news encoder + one-launch head): the step ENDS with ebn_dvn_finale_f32 -- the Dense weight gradients with
+        # Adam in their tiles' epilogues, Adam over every other parameter, the user head's finishing sums and the batch loss in ONE
+        # launch (was: tn_group | user_head_finish | Adam, three launches of the dependent chain).  False: the separate launches
+        # (what a multi-rank step runs: the gradient all-reduce sits between the gradients and Adam; the validation form)
+        self.fuse_finale = True
         self._dvn_dirty = False  # a fused forward whose backward has not been issued yet (see _dvn)
         self.mlp = MLPStack(self.params, "", self.Din, self.units, self.device, self.l2, on_realloc=lambda: self._graphs.clear())
         self.bn_mean, self.bn_var = self.mlp.bn_mean, self.mlp.bn_var
@@ -180,7 +185,9 @@ class DocVecEngine:
             return None
         # the cached argument block freezes raw pointers AND the scalars p / l2: they are part of the key, so that changing
         # `eng.p` or `eng.l2` between steps reaches the fused launches as it reaches the per-pass kernels
-        key = ("dvn", n_hist, n_cand, self.p, self.l2)
+        fin_args = self._finale_args() if self._finale_live(n_cand // max(n_hist // self.H, 1) if n_hist else 0) else None
+        fin = fin_args is not None
+        key = ("dvn", n_hist, n_cand, self.p, self.l2, fin)
         a = mb.get(key)
         if a is None:
             L, N, pv, g, b = len(self.units), mb["N"], self.params.view, self.params.g, self.mlp.bufs(mb["N"])
@@ -196,7 +203,7 @@ class DocVecEngine:
                 mb["dvn_dY"] = [f(N, u) for u in self.units]
                 mb["dvn_dP"] = [f(N, u) for u in self.units] + [f(N, self.E)]
             # the scratch is sized by the row tiling of (n_hist, n_cand): one per shape
-            mb[("dvn_stat", n_hist, n_cand, self.p, self.l2)] = stat = torch.zeros(int(_hip.lib().ebn_dvn_stat_floats(ctypes.byref(a))), device=self.device)
+            mb[("dvn_stat", n_hist, n_cand, self.p, self.l2, fin)] = stat = torch.zeros(int(_hip.lib().ebn_dvn_stat_floats(ctypes.byref(a))), device=self.device)
             for l in range(L):
                 a.W[l], a.b[l] = pv(f"d{l}_W").data_ptr(), pv(f"d{l}_b").data_ptr()
                 a.gamma[l], a.beta[l] = pv(f"bn{l}_g").data_ptr(), pv(f"bn{l}_b").data_ptr()
@@ -205,7 +212,8 @@ class DocVecEngine:
                 a.dY[l], a.dP[l] = mb["dvn_dY"][l].data_ptr(), mb["dvn_dP"][l].data_ptr()
                 a.ggamma[l], a.gbeta[l] = g(f"bn{l}_g").data_ptr(), g(f"bn{l}_b").data_ptr()
             a.W[L], a.b[L], a.dP[L] = pv("out_W").data_ptr(), pv("out_b").data_ptr(), mb["dvn_dP"][L].data_ptr()
-            a.X0, a.NE, a.dNE, a.stat, a.loss = mb["X0"].data_ptr(), mb["NE"].data_ptr(), mb["dNE"].data_ptr(), stat.data_ptr(), self.loss_dev.data_ptr()
+            a.X0, a.NE, a.dNE, a.stat = mb["X0"].data_ptr(), mb["NE"].data_ptr(), mb["dNE"].data_ptr(), stat.data_ptr()
+            a.loss = None if fin else self.loss_dev.data_ptr()  # the finale forms the whole batch loss, L2 term included
             # weight gradients of all L + 1 Dense kernels as ONE launch: dW_l = Xn_{l-1}^T . dP_l, bias gradient = column sums
             # of dP_l, + 2 l2 W_l for the regularised (hidden) kernels
             probs = (_hip.TnProblem * (L + 1))()
@@ -219,9 +227,42 @@ class DocVecEngine:
                 q.C, q.ldc, q.colsum = g(wn).data_ptr(), dims[l + 1], g(bn).data_ptr()
                 if l < L and self.l2 > 0:
                     q.l2_W, q.two_lambda = pv(wn).data_ptr(), 2.0 * self.l2
-            a._probs, a._stat = probs, stat
+            a._probs, a._stat, a._finale = probs, stat, fin_args
             mb[key] = a
         return a or None
+
+    def _finale_live(self, C=None) -> bool:
+        """whether a training step of this engine ends with ebn_dvn_finale_f32 (see `fuse_finale`)"""
+        if not (self.fuse_finale and self.fuse_news_mlp and self.fuse_user_head and self.units and not self.multi):
+            return False
+        L = _hip.lib()
+        if C is not None and int(L.ebn_user_head_supported(self.H, int(C), self.E, self.A)) == 0:
+            return False
+        return int(L.ebn_attn_bwd_pooled_supported(self.H, self.d)) != 0
+
+    def _finale_args(self):
+        """ebn_dvn_finale of this engine's flat parameter buffers: the `rest` ranges are every parameter whose gradient no tile of the
+        weight-gradient group and not the head's finishing sums produce -- the BatchNormalization scales / offsets and the user encoder's
+        projection and AttLayer2 kernels."""
+        P = self.params
+        owned = {f"d{l}_{s}" for l in range(len(self.units)) for s in ("W", "b")} | {"out_W", "out_b", "u_q", "u_b"}
+        rest = sorted((P.offsets[k], int(np.prod(P.shapes[k]))) for k in P.shapes if k not in owned)
+        merged = []
+        for off, n in rest:
+            if merged and merged[-1][0] + merged[-1][1] == off:
+                merged[-1][1] += n
+            else:
+                merged.append([off, n])
+        if len(merged) > _hip.DVN_FINALE_MAX_REST:
+            return None
+        f = _hip.DvnFinale()
+        f.theta, f.grad, f.m, f.v, f.numel = P.data.data_ptr(), P.grad.data_ptr(), P.m.data_ptr(), P.v.data_ptr(), P.numel
+        f.beta1, f.beta2, f.eps, f.grad_scale = BETA1, BETA2, ADAM_EPS, 1.0
+        f.n_rest = len(merged)
+        for i, (off, n) in enumerate(merged):
+            f.rest_off[i], f.rest_len[i] = off, n
+        f.A, f.dq, f.db, f.loss_out = self.A, P.g("u_q").data_ptr(), P.g("u_b").data_ptr(), self.loss_dev.data_ptr()
+        return f
 
     def _news_forward(self, mb, n_hist, n_cand, train):
         """MLP over the N = n_hist + n_cand rows already in mb['X0'] -> mb['NE'][:N]."""
@@ -245,7 +286,12 @@ class DocVecEngine:
         a = mb.get("dvn_live")
         if a is not None:
             _hip.call("ebn_dvn_bwd_f32", ctypes.byref(a), _hip.ptr(self.state), _hip.stream_handle())
-            _hip.call("ebn_gemm_tn_group_f32", a._probs, len(a._probs), _hip.stream_handle())
+            if a._finale is not None:  # gradients, the head's finishing sums, the loss and Adam: the step's last launch
+                ub, f = self._user_bufs(n_hist // self.H), a._finale
+                f.head_partials, f.loss_rows, f.B = ub.head_partials.data_ptr(), ub.loss_rows.data_ptr(), n_hist // self.H
+                _hip.call("ebn_dvn_finale_f32", ctypes.byref(a), a._probs, len(a._probs), ctypes.byref(f), _hip.ptr(self.state), _hip.stream_handle())
+            else:
+                _hip.call("ebn_gemm_tn_group_f32", a._probs, len(a._probs), _hip.stream_handle())
             self._dvn_dirty = False
             return
         prev, x_last = self.mlp.out_dim, mb["x_last"]
@@ -438,26 +484,36 @@ class DocVecEngine:
         if self.use_graph:
             # graph(forward + backward) -> gradient all-reduce over RCCL (eager, data-parallel only) -> graph(Adam)
             adv = self._advanced
-            gkey = (B, C, adv, bool(self.fuse_news_mlp), self.p, self.l2)  # a captured graph freezes the launch form and its scalars
+            gkey = (B, C, adv, bool(self.fuse_news_mlp), self.p, self.l2, bool(self.fuse_finale), bool(self.multi))  # a captured graph freezes the launch form and its scalars
             g = self._graphs.get(gkey)
             if g is None:
                 torch.cuda.synchronize()
                 g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
                 with _hip.capture(g1):
                     self._fwd_bwd_kernels(B, C, adv)
-                with _hip.capture(g2, pool=g1.pool()):
-                    self._optimizer_kernels()
+                if self._step_applied_adam(mb):  # one rank, the finale: the optimizer ran inside the step's last launch
+                    g2 = None
+                else:
+                    with _hip.capture(g2, pool=g1.pool()):
+                        self._optimizer_kernels()
                 g = self._graphs[gkey] = (g1, g2)
             g[0].replay()
-            self._allreduce_grads()
-            g[1].replay()
+            if g[1] is not None:
+                self._allreduce_grads()
+                g[1].replay()
         else:
             self._fwd_bwd_kernels(B, C, self._advanced)
-            self._allreduce_grads()
-            self._optimizer_kernels()
+            if not self._step_applied_adam(mb):
+                self._allreduce_grads()
+                self._optimizer_kernels()
         if return_probs:
             return self.loss_dev, mb["probs"][: B * C].view(B, C), mb["labels"][: B * C].view(B, C)
         return self.loss_dev
+
+    @staticmethod
+    def _step_applied_adam(mb) -> bool:
+        a = mb.get("dvn_live")
+        return a is not None and a._finale is not None
 
     def _fwd_bwd_kernels(self, B, C, advanced=False):
         E = self.E
@@ -468,6 +524,11 @@ class DocVecEngine:
         if not advanced:
             _hip.call("ebn_step_advance", st, BETA1, BETA2, S())
         self._news_forward(mb, n_hist, n_cand, True)
+        a = mb.get("dvn_live")
+        if a is not None and a._finale is not None:
+            self._user_stage_deferred(B, C, mb, ub)
+            self._news_backward(mb, n_hist, n_cand)
+            return
         dims, params, acts = self._enc(ub, B, mb["NE"])
         cand = mb["NE"][n_hist:]
         g = self.params.g
@@ -482,6 +543,30 @@ class DocVecEngine:
                   _hip.ptr(ub.head_partials) if self.fuse_user_head else None, _hip.ptr(mb["dNE"]), C, self.loss_kind,
                   ctypes.c_float(1.0 / B), st, S())
         self._news_backward(mb, n_hist, n_cand)
+
+    def _user_stage_deferred(self, B, C, mb, ub):
+        """ebn_user_stage_train_f32's fused branch (csrc/ebn_encoder.hip) kernel by kernel, with the head's finishing launch left to
+        the step's finale (dq == db == NULL): user encoder forward up to the AttLayer2 matmul, the one-launch head, the two
+        gradient-GEMM pairs around the attention backward.  Writes d(cand) = dNE[n_hist:], d(history news vectors) = dNE[:n_hist],
+        the user encoder's kernel gradients, and the per-impression partials / loss rows the finale sums."""
+        S, H, E, A = _hip.stream_handle, self.H, self.E, self.A
+        R = B * H
+        pv, g = self.params.view, self.params.g
+        ws, wsn = _hip.ptr(ub.ws), ub.ws.numel()
+        one, zero = ctypes.c_float(1.0), ctypes.c_float(0.0)
+        X, cand, dcand = mb["NE"], mb["NE"][R:], mb["dNE"][R:]
+        _hip.call("ebn_gemm_f32_site", 0, 0, R, 3 * E, E, one, _hip.ptr(X), E, _hip.ptr(pv("u_Wqkv")), 3 * E, zero, _hip.ptr(ub.QKV), 3 * E, ws, wsn, 1, S())
+        _hip.call("ebn_attn_fwd_f32", _hip.ptr(ub.QKV), 3 * E, _hip.ptr(ub.Y), E, B, H, self.h, self.d, None, -1, zero, S())
+        _hip.call("ebn_gemm_f32_ws", 0, 0, R, A, E, one, _hip.ptr(ub.Y), E, _hip.ptr(pv("u_W")), A, zero, _hip.ptr(ub.U), A, ws, wsn, S())
+        _hip.call("ebn_user_head_train_f32", _hip.ptr(ub.U), _hip.ptr(pv("u_b")), _hip.ptr(pv("u_q")), _hip.ptr(ub.Y), _hip.ptr(cand), _hip.ptr(mb["labels"]),
+                  _hip.ptr(ub.w), _hip.ptr(ub.out), _hip.ptr(mb["scores"]), _hip.ptr(mb["probs"]), _hip.ptr(ub.loss_rows), _hip.ptr(self.loss_dev), _hip.ptr(dcand),
+                  _hip.ptr(ub.duser), _hip.ptr(ub.de), None, None, _hip.ptr(ub.head_partials), B, H, C, E, A, self.loss_kind, ctypes.c_float(1.0 / B), S())
+        _hip.call("ebn_dense_bwd_pair_f32", R, E, A, _hip.ptr(ub.Y), E, _hip.ptr(ub.U), A, _hip.ptr(pv("u_W")), A, zero, _hip.ptr(g("u_W")), A,
+                  _hip.ptr(ub.dY), E, ws, wsn, S())
+        _hip.call("ebn_attn_bwd_pooled_f32", _hip.ptr(ub.QKV), 3 * E, _hip.ptr(ub.dY), E, _hip.ptr(ub.w), _hip.ptr(ub.duser), E, _hip.ptr(ub.dQKV), 3 * E,
+                  B, H, self.h, self.d, None, -1, zero, S())
+        _hip.call("ebn_dense_bwd_pair_f32", R, E, 3 * E, _hip.ptr(X), E, _hip.ptr(ub.dQKV), 3 * E, _hip.ptr(pv("u_Wqkv")), 3 * E, zero, _hip.ptr(g("u_Wqkv")),
+                  3 * E, _hip.ptr(mb["dNE"]), E, ws, wsn, S())
 
     def _allreduce_grads(self):
         if self.multi:
@@ -512,10 +597,23 @@ class DocVecEngine:
         out = {"gather": make_gather}
         a = self._dvn(mb, B * self.H, B * C)
         if a is not None:
-            # the time-dominant launch of the fused step: the weight gradients of all Dense kernels as one grouped TN product
-            out["dw_group"] = lambda: _hip.call("ebn_gemm_tn_group_f32", a._probs, len(a._probs), S())
+            # the time-dominant launch of the fused step: the weight gradients of all Dense kernels as one grouped TN product -- on one
+            # rank the step's closing launch (ebn_dvn_finale_f32: the same tiles + Adam + the head's finishing sums).  The probe runs
+            # it with Adam pointed at SHADOW copies of the parameter / moment buffers: same traffic, the model is left alone
             out["dw_group_flops"] = float(sum(2.0 * q.M * q.N * q.K for q in a._probs))
             out["dw_group_bytes"] = float(sum(4.0 * (q.K * (q.M + q.N) + q.M * q.N) for q in a._probs))
+            if a._finale is not None:
+                P, f = self.params, _hip.DvnFinale()
+                ctypes.memmove(ctypes.byref(f), ctypes.byref(a._finale), ctypes.sizeof(f))
+                shadow = mb.setdefault("finale_shadow", [P.data.clone(), P.m.clone(), P.v.clone()])
+                f.theta, f.m, f.v = (t.data_ptr() for t in shadow)
+                ub = self._user_bufs(B)
+                f.head_partials, f.loss_rows, f.B = ub.head_partials.data_ptr(), ub.loss_rows.data_ptr(), B
+                out["dw_group"] = lambda: _hip.call("ebn_dvn_finale_f32", ctypes.byref(a), a._probs, len(a._probs), ctypes.byref(f), _hip.ptr(self.state), S())
+                out["dw_group_bytes"] += 4.0 * 7 * P.numel  # Adam: theta, m, v read and written, the gradient re-read for the ranges no tile owns (upper bound)
+                out["dw_group_is_finale"] = True
+            else:
+                out["dw_group"] = lambda: _hip.call("ebn_gemm_tn_group_f32", a._probs, len(a._probs), S())
         return out
 
     def check_oob(self):

@@ -560,6 +560,39 @@ typedef struct ebn_tn_problem {
 } ebn_tn_problem;
 int ebn_gemm_tn_group_f32(const ebn_tn_problem* problems, int32_t n, ebn_stream_t stream);
 
+/* The closing launch of a ONE-RANK NRMSDocVec training step (nrms_docvec.py:99-188 backward + nrms.py:69-80): the Dense weight
+ * gradients of ebn_gemm_tn_group_f32 (`problems`: every C_i / colsum_i must lie inside the flat gradient buffer `grad`) and, dealt over
+ * the same workgroups instead of launches of their own, (1) Keras-form Adam -- in the epilogue of the tile that has just produced a
+ * gradient element, and element-wise over the `rest` ranges (offset, length in floats) of the flat buffers, i.e. every parameter no
+ * tile owns; theta / grad / m / v are the flat parameter, gradient and moment buffers with identical offsets, `numel` floats each --
+ * (2) the user head's finishing sums (ebn_user_head_train_f32 called with dq == db == NULL leaves `head_partials`, `loss_rows`):
+ * d(q), d(b) over the B impressions and loss_out[0] = sum(loss_rows) + l2 * sum_l sum(W[l]^2) (ebn_dvn_bwd_f32 called with
+ * args->loss == NULL leaves the L2 term to this call), then Adam on d(q) / d(b).  Same arithmetic, element by element, as
+ * ebn_gemm_tn_group_f32 + ebn_user_head_train_f32's finishing pass + ebn_adam_keras_step_f32.  With world > 1 the gradient all-reduce
+ * sits between the gradients and Adam: the separate calls stay.                                                                       */
+#define EBN_DVN_FINALE_MAX_REST 12
+typedef struct ebn_dvn_finale {
+  float* theta;
+  const float* grad;
+  float* m;
+  float* v;
+  int64_t numel;
+  double beta1, beta2, eps;
+  float grad_scale;
+  int32_t n_rest;
+  int64_t rest_off[EBN_DVN_FINALE_MAX_REST];
+  int64_t rest_len[EBN_DVN_FINALE_MAX_REST];
+  const float* head_partials;
+  int64_t B;
+  int32_t A;
+  float* dq;
+  float* db;
+  const float* loss_rows;
+  float* loss_out;
+} ebn_dvn_finale;
+int ebn_dvn_finale_f32(const ebn_dvn_args* args, const ebn_tn_problem* problems, int32_t n, const ebn_dvn_finale* fin,
+                       const ebn_step_state* st, ebn_stream_t stream);
+
 /* Step prologue: copy up to three device buffers (history ids, candidate ids, labels of a batch handed over as device
  * tensors -- the inputs of nrms.py:170-176) into the step's static buffers with ONE launch; n_i in bytes, multiples
  * of 4; a NULL source or n_i = 0 skips that pair.                                                                   */

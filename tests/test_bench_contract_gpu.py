@@ -35,7 +35,7 @@ def test_bench_line_carries_the_contract_fields(cfg):
         assert abs(st["achieved"] * 1e12 - st["flops_per_step"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * st["achieved"] * 1e12
         assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and "CpuDocVecTrainer" in c["sample"]
         assert isinstance(st["launches_per_step"], int) and 8 <= st["launches_per_step"] <= 40 and "counted" in st["launches_note"]
-        assert "tn_group" in r["kernel"] and r["algorithmic_flops_per_launch"] > 1e9
+        assert ("tn_finale" in r["kernel"] or "tn_group" in r["kernel"]) and r["algorithmic_flops_per_launch"] > 1e9
         for key in ("roofline", "roofline_gather"):
             assert d[key]["traffic_source"].startswith(("measured in this run", "not measured"))
             if d[key]["traffic_source"].startswith("measured"):
@@ -86,7 +86,7 @@ def test_bench_line_carries_the_contract_fields(cfg):
             assert leg["roofline_gather"]["bound"] == "hbm" and leg["roofline_gather"]["avg_launch_us"] > 0
             if lr["traffic_source"].startswith("measured"):  # rocprofv3 could run: the kernel name is the one the profiler saw
                 assert "(" in lr["kernel"] and lr["traffic"] > 0
-        assert legs["c3"]["cpu_baseline"]["kind"] == "port" and legs["c3"]["cpu_baseline"]["value"] > 0 and "tn_group" in legs["c3"]["roofline"]["kernel"]
+        assert legs["c3"]["cpu_baseline"]["kind"] == "port" and legs["c3"]["cpu_baseline"]["value"] > 0 and "tn_finale" in legs["c3"]["roofline"]["kernel"]
         assert "cpu_baseline" not in legs["c1"] and legs["c5"]["config"]["global_batch"] == 64
 
 

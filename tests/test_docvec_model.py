@@ -222,3 +222,37 @@ def test_a_step_that_stopped_between_forward_and_backward_does_not_poison_the_ne
         assert not eng._dvn_dirty
         grads.append(eng.params.grad.cpu().numpy().copy())
     assert np.array_equal(grads[0], grads[1])
+
+
+@pytest.mark.parametrize("units,din,B,graphs", [([48, 40], 64, 8, False), ([512, 512, 512], 768, 32, True), ([36], 20, 3, True)])
+def test_the_one_launch_finale_equals_the_three_launches_it_replaces(docvec, units, din, B, graphs):
+    """ebn_dvn_finale_f32 (the weight-gradient group with Adam in its epilogue + Adam over every other parameter + the user head's
+    finishing sums + the batch loss incl. the L2 term, ONE launch) against tn_group | user_head_finish | adam_keras: the same loss
+    bits, the same gradients, the same weights and Adam moments after three steps (dropout on, l2 on), eager and as graph replays;
+    64 x 64 tiles of 1024 threads (the c3 shape) and 32 x 32 tiles of 256."""
+    import torch
+
+    full = units == [512, 512, 512]
+    hp = make_hp(title_size=din, newsencoder_units_per_layer=units, history_size=20 if full else 7, **({} if full else dict(head_num=4, head_dim=8, attention_hidden_dim=12)))
+    P = oracle_params(hp, 9)
+    rng = np.random.default_rng(2)
+    batches = [data(rng, B, hp.history_size, 5, hp.title_size) for _ in range(3)]
+    out = []
+    for finale in (True, False):
+        m = docvec(hp, seed=5)
+        m.model.set_weights(weight_list(P))
+        eng = m._engine
+        eng.fuse_finale = finale
+        eng.enable_graphs(graphs)
+        losses = [float(m.train_step(*b).item()) for b in batches]
+        torch.cuda.synchronize()
+        assert eng._step_applied_adam(eng._bufs["mlp"]) == finale
+        out.append((losses, eng.params.grad.cpu().numpy().copy(), eng.params.data.cpu().numpy().copy(), eng.params.m.cpu().numpy().copy(),
+                    eng.params.v.cpu().numpy().copy(), [t.cpu().numpy().copy() for t in eng.bn_mean + eng.bn_var], int(eng.read_state().step)))
+    a, b = out
+    assert a[0] == b[0], (a[0], b[0])  # the loss: same rows, same fixed-order sums, same L2 term
+    assert a[6] == b[6] == 3
+    for x, y, what in zip(a[1:5], b[1:5], ("gradients", "weights", "Adam m", "Adam v")):
+        assert_close(x, y, rtol=2e-6, atol=1e-9, what=f"finale vs separate launches: {what}")
+    for x, y in zip(a[5], b[5]):
+        assert np.array_equal(x, y)
