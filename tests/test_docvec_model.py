@@ -233,7 +233,7 @@ def test_the_one_launch_finale_equals_the_three_launches_it_replaces(docvec, uni
     import torch
 
     full = units == [512, 512, 512]
-    hp = make_hp(title_size=din, newsencoder_units_per_layer=units, history_size=20 if full else 7, **({} if full else dict(head_num=4, head_dim=8, attention_hidden_dim=12)))
+    hp = make_hp(title_size=din, newsencoder_units_per_layer=units, history_size=20 if full else 7, **({} if full else dict(head_num=2, head_dim=16, attention_hidden_dim=12)))  # (head_dim 16 / 20 / 32: the attention core's MFMA path, which the one-launch head needs)
     P = oracle_params(hp, 9)
     rng = np.random.default_rng(2)
     batches = [data(rng, B, hp.history_size, 5, hp.title_size) for _ in range(3)]
