@@ -174,6 +174,11 @@ struct GemmEpi {
   const int32_t* rowmap = nullptr;
   int64_t rowmap_rows = 0;
   int32_t* oob = nullptr;
+#ifdef EBN_GEMM_EXP_STAGGER
+  // tuning experiment (tools/build_variant.sh -DEBN_GEMM_EXP_STAGGER, EBN_GEMM_STAGGER_PCT at run time): the three workgroups that
+  // share a CU in the first dispatch round start a third of a tile's duration apart (percent of that third)
+  uint32_t stagger_pct = 0;
+#endif
 };
 
 // TA: A stored [K,M]; TB: B stored [N,K].
@@ -348,6 +353,13 @@ __global__ __launch_bounds__(GEMM_THREADS, GEMM_WPE) void gemm_f32_kernel(
     }
   };
   tile_setup(vb);
+#ifdef EBN_GEMM_EXP_STAGGER
+  if (epi.stagger_pct != 0u && vb < 768) {  // 256 consecutive workgroups go one per CU: b, b + 256, b + 512 share a CU
+    // one tile on a CU shared by three = nk slabs x 3 x 2048 cycles; a third of that = nk x 2048 cycles = nk / 2 sleeps of 4096
+    const uint32_t n = (static_cast<uint32_t>(vb >> 8) % 3u) * static_cast<uint32_t>(nk) * epi.stagger_pct / 200u;
+    for (uint32_t i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(64);
+  }
+#endif
   // LDS float offset of the 1 KB that instruction q of this wave fills
 #define EBN_GLDS_A_DST(Q) (A_KC ? ((Q) * 4 + wave) * 256 : (wave * A_IPW + (Q)) * A_RPI * BM)
 #define EBN_GLDS_B_DST(Q) (B_KC ? ((Q) * 4 + wave) * 256 : (wave * B_IPW + (Q)) * B_RPI * BN)
@@ -629,6 +641,10 @@ int launch_gemm(int transA, int transB, int64_t M, int64_t N, int64_t K, float a
   dim3 grid(static_cast<unsigned>(ebn_ceil_div(N, BN)), static_cast<unsigned>(ebn_ceil_div(M, BM)),
             static_cast<unsigned>(splits));
   dim3 block(GEMM_THREADS);
+#ifdef EBN_GEMM_EXP_STAGGER
+  static const uint32_t stagger_pct = getenv("EBN_GEMM_STAGGER_PCT") ? static_cast<uint32_t>(atoi(getenv("EBN_GEMM_STAGGER_PCT"))) : 0u;
+  epi.stagger_pct = splits == 1 ? stagger_pct : 0u;
+#endif
 #define EBN_GEMM_LAUNCH(TA, TB)                                                                            \
   do {                                                                                                    \
     if (vecA && vecB)                                                                                     \

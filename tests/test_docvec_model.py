@@ -250,7 +250,9 @@ def test_the_one_launch_finale_equals_the_three_launches_it_replaces(docvec, uni
         out.append((losses, eng.params.grad.cpu().numpy().copy(), eng.params.data.cpu().numpy().copy(), eng.params.m.cpu().numpy().copy(),
                     eng.params.v.cpu().numpy().copy(), [t.cpu().numpy().copy() for t in eng.bn_mean + eng.bn_var], int(eng.read_state().step)))
     a, b = out
-    assert a[0] == b[0], (a[0], b[0])  # the loss: same rows, same fixed-order sums, same L2 term
+    # the loss: same rows, same fixed-order sums, same L2 term -- bit-identical on the first step; later steps start from weights that
+    # agree to an ulp (the compiler contracts the two Adam kernels' arithmetic differently), so their losses agree to ~1e-7
+    assert a[0][0] == b[0][0] and np.allclose(a[0], b[0], rtol=2e-6, atol=0), (a[0], b[0])
     assert a[6] == b[6] == 3
     for x, y, what in zip(a[1:5], b[1:5], ("gradients", "weights", "Adam m", "Adam v")):
         assert_close(x, y, rtol=2e-6, atol=1e-9, what=f"finale vs separate launches: {what}")
