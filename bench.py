@@ -498,6 +498,8 @@ def bench_docvec(args, c, world, rank, device, sync, dfields, multi=False):
                                                     attention_hidden_dim=c["A"], newsencoder_units_per_layer=c["units"]))
     model = NRMSDocVec(hp, seed=42, device=device)
     eng = model._engine
+    if args.no_adam_in_finish:
+        eng.fuse_finale = False
     rng = np.random.default_rng(42)
     matrix = rng.standard_normal((c["n_articles"], c["doc"]), dtype=np.float32)
     matrix[0] = 0
@@ -857,6 +859,8 @@ def main():
                          "rccl_view, SegmentTrace, HangWatchdog, the engine's multi-rank launch form (collectives between the graph replays -- identities "
                          "on one rank), run_legs with its fresh rendezvous and the closing collective flag check: what the 8-GPU node will run, executed "
                          "on a 1-GPU box")
+    ap.add_argument("--no-adam-in-finish", action="store_true",
+                    help="A/B: Adam on the dense parameters as a launch of its own instead of inside the step's finishing launch (the one-rank default)")
     ap.add_argument("--leg", action="store_true", help="internal: this process is one rank of a leg started by run_legs()")
     ap.add_argument("--fault-skip-collectives-on-rank", type=int, default=-1,
                     help="test hook: this rank skips its collectives in the timed region (its peers then wait for it forever): the hang "
@@ -944,6 +948,8 @@ def main():
         return
 
     eng.atomic_table_grad = bool(args.atomic_table_grad)
+    if args.no_adam_in_finish:
+        eng.adam_in_finish = False
     eng.enable_graphs(not args.no_graph)
     eng.trace = trace  # N > 1: an event behind every segment of every step, so that a hang can be named (None at N = 1: nothing recorded)
     if args.force_dist and world == 1:

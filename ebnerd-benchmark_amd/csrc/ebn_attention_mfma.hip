@@ -1113,6 +1113,10 @@ static void allow_lds(K kernel, size_t bytes) {
 
 template <class K>
 static void launch_waves(K kernel, size_t lds, const MfmaAttnArgs& a, hipStream_t s) {
+#ifdef EBN_ATTN_EXP_PAD_LDS  /* tuning experiment (tools/build_variant.sh): EBN_ATTN_PAD_LDS bytes of unused LDS per workgroup = fewer resident waves per CU */
+  static const size_t pad = getenv("EBN_ATTN_PAD_LDS") ? static_cast<size_t>(atol(getenv("EBN_ATTN_PAD_LDS"))) : 0;
+  lds += pad;
+#endif
   allow_lds(kernel, lds);
   EBN_LAUNCH(kernel, dim3(static_cast<unsigned>(ebn_ceil_div(a.n_prob, ATT_WAVES))), dim3(64 * ATT_WAVES), lds, s, a);
 }

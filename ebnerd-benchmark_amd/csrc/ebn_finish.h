@@ -1,6 +1,7 @@
 // Device bodies of the small finishing passes of a training step's backward -- each is the second stage of a deterministic
 // reduction (fixed summation order) -- shared by their own kernels and by the merged pass ebn_grad_finish_f32 (ebn_finish.hip).
 #pragma once
+#include "ebn_adam_flat.h"
 #include "ebn_common.h"
 
 // C[row][col] = sum_z part[z][row][col] (+ beta * C) for the flattened elements i = first, first + stride, ...  (total = M * N
@@ -9,7 +10,7 @@
 static __device__ __forceinline__ void ebn_splitk_sum_body(uint32_t first, uint32_t stride, const float* __restrict__ part, int splits,
                                                            uint32_t total, uint32_t n32, float beta, float* __restrict__ C, int64_t ldc,
                                                            const float* __restrict__ rs, const float* __restrict__ cv, int64_t ldcv,
-                                                           int32_t L, const float* __restrict__ bias) {
+                                                           int32_t L, const float* __restrict__ bias, const EbnAdamFlat* ad = nullptr) {
   for (uint32_t i = first; i < total; i += stride) {
     float s = 0.f;
     int z = 0;
@@ -27,7 +28,9 @@ static __device__ __forceinline__ void ebn_splitk_sum_body(uint32_t first, uint3
     float* c = C + static_cast<int64_t>(row) * ldc + col;
     if (rs != nullptr) s = fmaf(rs[row], cv[static_cast<int64_t>(row / static_cast<uint32_t>(L)) * ldcv + col], s);
     if (bias != nullptr) s = fmaxf(s + bias[col], 0.f);
-    *c = (beta != 0.f) ? (s + beta * *c) : s;
+    const float g = (beta != 0.f) ? (s + beta * *c) : s;
+    *c = g;
+    if (ad != nullptr) ebn_adam_flat_apply(*ad, ad->st->adam_alpha, c - ad->grad, g);  // (ebn_grad_finish_adam_f32: the optimizer where the gradient is formed)
   }
 }
 

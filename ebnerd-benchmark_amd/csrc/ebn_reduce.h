@@ -1,6 +1,7 @@
 // Deterministic two-stage column reductions: stage 1 (op-specific) writes
 // partials[row_block][s][col] for up to 2 reduction kinds; stage 2 sums over the row blocks.
 #pragma once
+#include "ebn_adam_flat.h"
 #include "ebn_common.h"
 
 // Row blocks of stage 1: 32 rows each (capped), so that even a few hundred rows (one TimeDistributed call
@@ -53,7 +54,8 @@ static inline void ebn_colred_stage1(F f, float* partials, int64_t R, int C, hip
 // 1024-thread block among the blocks of THIS reduction, `sm` = 32 x 33 floats of LDS)
 static __device__ __forceinline__ void ebn_reduce_partials_body(float (*sm)[33], int blk, const float* __restrict__ partials, int nblk, int S, int A,
                                                               float scale, float* __restrict__ out0, float* __restrict__ out1, int accumulate,
-                                                              float* __restrict__ site0, float* __restrict__ site1) {
+                                                              float* __restrict__ site0, float* __restrict__ site1,
+                                                              const EbnAdamFlat* ad = nullptr) {
   const int col = threadIdx.x & 31, part = threadIdx.x >> 5;
   const int idx = blk * 32 + col;  // flattened (s, k)
   const bool ok = idx < S * A;
@@ -83,7 +85,11 @@ static __device__ __forceinline__ void ebn_reduce_partials_body(float (*sm)[33],
     t *= scale;
     const int s = idx / A, k = idx - s * A;
     float* o = (s == 0) ? out0 : out1;
-    if (o != nullptr) o[k] = accumulate ? (o[k] + t) : t;
+    if (o != nullptr) {
+      const float g = accumulate ? (o[k] + t) : t;
+      o[k] = g;
+      if (ad != nullptr) ebn_adam_flat_apply(*ad, ad->st->adam_alpha, (o + k) - ad->grad, g);
+    }
     float* st = (s == 0) ? site0 : site1;
     if (st != nullptr) st[k] = t;
   }

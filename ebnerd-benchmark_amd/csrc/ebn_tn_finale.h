@@ -6,34 +6,8 @@
 //     element-wise pass over the remaining ranges of the flat parameter buffer (was adam_keras_kernel).
 // Shared between ebn_gemm.hip (the kernel) and ebn_docvec.hip (the entry point, which knows the layout of the step's scratch).
 #pragma once
+#include "ebn_adam_flat.h"
 #include "ebn_common.h"
-
-// Adam on the flat parameter buffers: an element is addressed by the ADDRESS of its gradient (grad + offset).
-struct EbnAdamFlat {
-  const float* grad;  // base of the flat gradient buffer
-  float* theta;
-  float* m;
-  float* v;
-  const ebn_step_state* st;
-  float omb1, omb2, eps, gscale;
-};
-
-// the update of adam_keras_kernel (ebn_score_optim.hip), one element
-#define EBN_ADAM_ELEMENT(T, G, M, V, ALPHA, OMB1, OMB2, EPS, GSCALE) \
-  {                                                                  \
-    const float gg__ = (G) * (GSCALE);                               \
-    (M) = (M) + (gg__ - (M)) * (OMB1);                               \
-    (V) = (V) + (gg__ * gg__ - (V)) * (OMB2);                        \
-    (T) = (T) - (ALPHA) * (M) / (sqrtf(V) + (EPS));                  \
-  }
-
-static __device__ __forceinline__ void ebn_adam_flat_apply(const EbnAdamFlat& ad, float alpha, int64_t off, float g) {
-  float t = ad.theta[off], mm = ad.m[off], vv = ad.v[off];
-  EBN_ADAM_ELEMENT(t, g, mm, vv, alpha, ad.omb1, ad.omb2, ad.eps, ad.gscale)
-  ad.theta[off] = t;
-  ad.m[off] = mm;
-  ad.v[off] = vv;
-}
 
 constexpr int EBN_TN_FINALE_MAX_REST = 12;
 

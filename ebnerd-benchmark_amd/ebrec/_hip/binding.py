@@ -89,6 +89,15 @@ class TnProblem(ctypes.Structure):
 
 
 DVN_FINALE_MAX_REST = 12
+ADAM_FLAT_MAX_REST = 12
+
+
+class AdamFlat(ctypes.Structure):
+    """ebn_adam_flat: the optimizer inside a one-rank step's finishing launch (ebn_grad_finish_adam_f32)."""
+    _fields_ = [("theta", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("m", ctypes.c_void_p), ("v", ctypes.c_void_p), ("numel", ctypes.c_int64),
+                ("beta1", ctypes.c_double), ("beta2", ctypes.c_double), ("eps", ctypes.c_double), ("grad_scale", ctypes.c_float),
+                ("n_rest", ctypes.c_int32), ("rest_off", ctypes.c_int64 * ADAM_FLAT_MAX_REST), ("rest_len", ctypes.c_int64 * ADAM_FLAT_MAX_REST)]
+
 
 
 class DvnFinale(ctypes.Structure):

@@ -233,6 +233,13 @@ class NRMSEngine(StagingMixin, SegmentsMixin):
         # True: launch the multi-rank form of the step (collectives between the graph replays, the multi-rank Adam inputs) on a group of
         # ONE rank, where every collective is an identity -- `bench.py --force-dist` runs the RCCL branch end to end on a 1-GPU box
         self.force_collectives = False
+        # True (one rank, the standard configuration of `_deferred`): Keras-form Adam on the dense parameters runs INSIDE the step's
+        # finishing launch (ebn_grad_finish_adam_f32: each gradient element gets its update from the thread that has just summed it,
+        # the user encoder's kernels -- whose gradients earlier launches wrote -- in blocks behind) instead of as a launch of its own.
+        # With a trainable table the finishing launch then runs AFTER the input-gradient GEMM (which reads Wqkv).  False: the two
+        # launches (what a multi-rank step runs: the all-reduce sits between them; the validation form)
+        self.adam_in_finish = True
+        self._adam_done_in_finish = False  # set by the step's backward when its finishing launch has applied the dense Adam
 
     @property
     def multi(self) -> bool:
@@ -925,6 +932,8 @@ class NRMSEngine(StagingMixin, SegmentsMixin):
         st = _hip.ptr(self.state)
         site1, p1 = (1, self.p) if self.p > 0 else (-1, 0.0)
         deferred = self._deferred(C)
+        if part in ("all", "a"):
+            self._adam_done_in_finish = False
         if part == "b":
             if deferred:
                 return self._news_bwd_deferred(nb, ub, B, N, "p2")
@@ -941,9 +950,16 @@ class NRMSEngine(StagingMixin, SegmentsMixin):
             return self._news_bwd_p1(nb, N, nb.dNE)
         if part == "all" and deferred:
             self._news_bwd_deferred(nb, ub, B, N, "p1")
-            self._news_bwd_deferred(nb, ub, B, N, "p2")
-            if nb.dX is not None:
-                self._news_bwd_p3(nb, N, nb.dX)
+            self._adam_done_in_finish = self._adam_fused(C)
+            if self._adam_done_in_finish:  # the finishing launch carries the optimizer: it runs after the last reader of the weights
+                self._news_bwd_deferred(nb, ub, B, N, "p2a")
+                if nb.dX is not None:
+                    self._news_bwd_p3(nb, N, nb.dX)
+                self._news_bwd_deferred(nb, ub, B, N, "p2b")
+            else:
+                self._news_bwd_deferred(nb, ub, B, N, "p2")
+                if nb.dX is not None:
+                    self._news_bwd_p3(nb, N, nb.dX)
         elif part == "all":
             self._encoder_bwd("n", nb, N, nb.X, nb.dNE, nb.dX, B * H)
         elif nb.dX is not None:  # part "c"
@@ -957,6 +973,25 @@ class NRMSEngine(StagingMixin, SegmentsMixin):
         return bool(self.defer_finish and self.mlp is None and self.precision == "exact" and self.fuse_user_head
                     and self._fold_pooling(self.T) and self._fold_pooling(self.H)
                     and int(L.ebn_user_head_supported(self.H, C, self.E, self.A)) != 0)
+
+    def _adam_fused(self, C) -> bool:
+        """this step's finishing launch applies Adam to the dense parameters (one rank, the deferred launch form)"""
+        return bool(self.adam_in_finish and not self.multi and self._deferred(C))
+
+    def _adam_flat_args(self):
+        """ebn_adam_flat over this engine's flat buffers; `rest` = the parameters no finishing job produces: the user encoder's kernels"""
+        a = getattr(self, "_adam_flat", None)
+        if a is None:
+            P = self.params
+            a = _hip.AdamFlat()
+            a.theta, a.grad, a.m, a.v, a.numel = P.data.data_ptr(), P.grad.data_ptr(), P.m.data_ptr(), P.v.data_ptr(), P.numel
+            a.beta1, a.beta2, a.eps, a.grad_scale = BETA1, BETA2, ADAM_EPS, 1.0
+            rest = sorted((P.offsets[k], int(np.prod(P.shapes[k]))) for k in ("u_Wqkv", "u_W"))
+            a.n_rest = len(rest)
+            for i, (off, n) in enumerate(rest):
+                a.rest_off[i], a.rest_len[i] = off, n
+            self._adam_flat = a
+        return a
 
     def _defer_bufs(self, nb):
         if getattr(nb, "ws_dw", None) is None:
@@ -993,7 +1028,8 @@ class NRMSEngine(StagingMixin, SegmentsMixin):
     def _news_bwd_deferred(self, nb, ub, B, N, part):
         """The news encoder's backward (the kernels of ebn_encoder_bwd_f32 in its order) with the combining passes of its three
         reductions left out, then -- after the last weight gradient -- ONE finishing launch for them and for the user head's.
-        part: "p1" AttLayer2 backward | "p2" attention core + dWqkv + the finishing launch."""
+        part: "p1" AttLayer2 backward | "p2" attention core + dWqkv + the finishing launch | "p2a" / "p2b": p2's two halves (the
+        finishing launch with the optimizer inside runs after the input-gradient GEMM of a trainable table)."""
         S, E, A, T, D = _hip.stream_handle, self.E, self.A, self.T, self.D
         R = N * T
         pv, g = self.params.view, self.params.g
@@ -1009,11 +1045,15 @@ class NRMSEngine(StagingMixin, SegmentsMixin):
             _hip.call("ebn_gemm_f32_ws", 0, 1, R, E, A, one, _hip.ptr(nb.U), A, _hip.ptr(pv("n_W")), A, zero, _hip.ptr(nb.dY), E, _hip.ptr(nb.ws), nb.ws.numel(), S())
             return
         site, p = (1, self.p) if self.p > 0 else (-1, 0.0)
-        _hip.call("ebn_attn_bwd_pooled_f32", _hip.ptr(nb.QKV), 3 * E, _hip.ptr(nb.dY), E, _hip.ptr(nb.w), _hip.ptr(nb.dNE), E, _hip.ptr(nb.dQKV), 3 * E,
-                  N, T, self.h, self.d, _hip.ptr(self.state), site, ctypes.c_float(p), S())
-        n = ctypes.c_int32(0)
-        _hip.call("ebn_gemm_f32_partials", 1, 0, D, 3 * E, R, one, _hip.ptr(nb.X), D, _hip.ptr(nb.dQKV), 3 * E, _hip.ptr(nb.ws_dwqkv), nb.ws_dwqkv.numel(),
-                  ctypes.byref(n), S())
+        if part in ("p2", "p2a"):
+            _hip.call("ebn_attn_bwd_pooled_f32", _hip.ptr(nb.QKV), 3 * E, _hip.ptr(nb.dY), E, _hip.ptr(nb.w), _hip.ptr(nb.dNE), E, _hip.ptr(nb.dQKV), 3 * E,
+                      N, T, self.h, self.d, _hip.ptr(self.state), site, ctypes.c_float(p), S())
+            n = ctypes.c_int32(0)
+            _hip.call("ebn_gemm_f32_partials", 1, 0, D, 3 * E, R, one, _hip.ptr(nb.X), D, _hip.ptr(nb.dQKV), 3 * E, _hip.ptr(nb.ws_dwqkv), nb.ws_dwqkv.numel(),
+                      ctypes.byref(n), S())
+            nb.finish_jobs["dWqkv"] = int(n.value)
+            if part == "p2a":
+                return
         # the latency-bound jobs FIRST (a few blocks each walking a long chain of partials): blocks are dispatched in order, and behind
         # the 1200 blocks of the dWqkv sum they would only start when it is nearly done (measured: 16 us that way, the sum alone 8)
         jobs = (_hip.FinishJob * 4)()
@@ -1022,8 +1062,11 @@ class NRMSEngine(StagingMixin, SegmentsMixin):
         jobs[1] = _hip.FinishJob(_hip.FINISH_HEAD, 1, B, A, ub.head_partials.data_ptr(), g("u_q").data_ptr(), g("u_b").data_ptr(), A, 0.0, 1.0,
                                  ub.loss_rows.data_ptr(), self.loss_dev.data_ptr())
         jobs[2] = _hip.FinishJob(_hip.FINISH_SPLITK, nb.finish_jobs["dW"], E, A, nb.ws_dw.data_ptr(), g("n_W").data_ptr(), None, A, 0.0, 1.0, None, None)
-        jobs[3] = _hip.FinishJob(_hip.FINISH_SPLITK, int(n.value), D, 3 * E, nb.ws_dwqkv.data_ptr(), g("n_Wqkv").data_ptr(), None, 3 * E, 0.0, 1.0, None, None)
-        _hip.call("ebn_grad_finish_f32", jobs, 4, S())
+        jobs[3] = _hip.FinishJob(_hip.FINISH_SPLITK, nb.finish_jobs["dWqkv"], D, 3 * E, nb.ws_dwqkv.data_ptr(), g("n_Wqkv").data_ptr(), None, 3 * E, 0.0, 1.0, None, None)
+        if part == "p2b":  # the optimizer rides in the finishing launch (one rank)
+            _hip.call("ebn_grad_finish_adam_f32", jobs, 4, ctypes.byref(self._adam_flat_args()), _hip.ptr(self.state), S())
+        else:
+            _hip.call("ebn_grad_finish_f32", jobs, 4, S())
 
     def _fwd_user_stage_kernels(self, B, C, nb, ub):
         H, E = self.H, self.E
@@ -1084,8 +1127,9 @@ class NRMSEngine(StagingMixin, SegmentsMixin):
         st = _hip.ptr(self.state)
         gs = ctypes.c_float(1.0 / self.world)
         P = self.params
-        _hip.call("ebn_adam_keras_step_f32", _hip.ptr(P.data), _hip.ptr(P.grad), _hip.ptr(P.m), _hip.ptr(P.v), P.numel,
-                  st, BETA1, BETA2, ADAM_EPS, gs, S())
+        if not self._adam_done_in_finish:
+            _hip.call("ebn_adam_keras_step_f32", _hip.ptr(P.data), _hip.ptr(P.grad), _hip.ptr(P.m), _hip.ptr(P.v), P.numel,
+                      st, BETA1, BETA2, ADAM_EPS, gs, S())
         if self.train_embedding and from_acc:
             # the gradient goes from the fixed-point accumulator into Adam in a single sweep over the table
             _hip.call("ebn_adam_keras_step_fixed_f32", _hip.ptr(self.table), _hip.ptr(self.table_acc), _hip.ptr(self.table_m),

@@ -220,6 +220,29 @@ typedef struct {
 } ebn_finish_job;
 int ebn_grad_finish_f32(const ebn_finish_job* jobs, int32_t n_jobs, ebn_stream_t stream);
 
+/* ONE-RANK steps: the same finishing launch with the optimizer inside (nrms.py:69-80; with world > 1 the gradient all-reduce sits
+ * between the gradients and Adam: ebn_grad_finish_f32 + ebn_adam_keras_step_f32 stay).  theta / grad / m / v: the flat parameter,
+ * gradient and Adam-moment buffers (identical offsets, numel floats each); every out0 / out1 of `jobs` must point into `grad`.
+ * Keras-form Adam (the arithmetic of ebn_adam_keras_step_f32, element by element) is applied to each gradient element a job finishes,
+ * by the thread that has just written it, and -- in blocks behind the jobs' -- to the `rest` ranges (offset, length in floats) of the
+ * flat buffers: the parameters whose gradients earlier launches of the step wrote complete.  Together the jobs' outputs and the rest
+ * ranges must cover every parameter exactly once (the caller's contract; nothing checks it).                                      */
+#define EBN_ADAM_FLAT_MAX_REST 12
+typedef struct ebn_adam_flat {
+  float* theta;
+  const float* grad;
+  float* m;
+  float* v;
+  int64_t numel;
+  double beta1, beta2, eps;
+  float grad_scale;
+  int32_t n_rest;
+  int64_t rest_off[EBN_ADAM_FLAT_MAX_REST];
+  int64_t rest_len[EBN_ADAM_FLAT_MAX_REST];
+} ebn_adam_flat;
+int ebn_grad_finish_adam_f32(const ebn_finish_job* jobs, int32_t n_jobs, const ebn_adam_flat* adam, const ebn_step_state* st,
+                             ebn_stream_t stream);
+
 /* Same again; `site` is accepted and ignored (rounds 1-4 used it to label the kernel instantiation of the encoders' Q|K|V
  * projection for per-kernel profiler summaries; the instantiations it doubled are gone).                        */
 int ebn_gemm_f32_site(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K, float alpha,

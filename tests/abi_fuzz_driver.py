@@ -17,7 +17,7 @@ from ebrec._hip import binding as B  # noqa: E402  (header parser + struct mirro
 
 HOST_STRUCTS = {"ebn_encoder_dims": B.EncoderDims, "ebn_encoder_params": B.EncoderParams, "ebn_encoder_acts": B.EncoderActs,
                 "ebn_encoder_grads": B.EncoderGrads, "ebn_encoder_scratch": B.EncoderScratch, "ebn_finish_job": B.FinishJob * B.FINISH_MAX_JOBS,
-                "ebn_dvn_args": B.DvnArgs, "ebn_tn_problem": B.TnProblem * B.TN_GROUP_MAX, "ebn_dvn_finale": B.DvnFinale}
+                "ebn_dvn_args": B.DvnArgs, "ebn_tn_problem": B.TnProblem * B.TN_GROUP_MAX, "ebn_dvn_finale": B.DvnFinale, "ebn_adam_flat": B.AdamFlat}
 FAKE_DEV = 0x7E0000000000  # a 16-byte-aligned address no host mapping uses: device pointers are never dereferenced on the host
 SIZES = [0, 1, 2, 3, 5, 7, 16, 20, 30, 31, 32, 33, 50, 63, 64, 65, 100, 127, 128, 200, 255, 256, 257, 300, 400, 512, 768, 1000, 1024, 1200,
          4096, 24000, 32000, 52800, 250002, 1 << 20, (1 << 24) + 1, (1 << 31) - 1, 1 << 31, (1 << 31) + 7, 1 << 33, 1 << 40, (1 << 62) + 3]

@@ -632,6 +632,7 @@ def test_one_finishing_launch_of_the_backward_changes_no_bit_of_a_training_run(h
     a = NRMSModel(hp, word2vec_embedding=emb, seed=5, train_embedding=train_embedding)
     b = NRMSModel(hp, word2vec_embedding=emb, seed=5, train_embedding=train_embedding)
     assert a._engine.defer_finish and a._engine._deferred(5)
+    a._engine.adam_in_finish = False  # (this test isolates the finishing launch; the optimizer riding in it has its own test below)
     b._engine.defer_finish = False
     assert not b._engine._deferred(5)
     if graph:
@@ -644,3 +645,38 @@ def test_one_finishing_launch_of_the_backward_changes_no_bit_of_a_training_run(h
         assert torch.equal(a._engine.params.grad, b._engine.params.grad), t
     for wa, wb in zip(a.model.get_weights(), b.model.get_weights()):
         assert np.array_equal(wa, wb)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("train_embedding,graph", [(False, True), (True, False), (True, True)])
+def test_adam_inside_the_finishing_launch_equals_the_separate_optimizer_launch(hip, train_embedding, graph):
+    """engine.adam_in_finish (default, one rank): ebn_grad_finish_adam_f32 applies Keras-form Adam to each dense gradient element in the
+    thread that has just summed it (and to the user encoder's kernels in blocks behind) instead of a launch of its own; with a trainable
+    table the finishing launch moves behind the input-gradient GEMM, which reads Wqkv.  Same arithmetic element by element: the first
+    step's loss and every gradient are bit-identical, weights and moments agree to fp32 rounding over three steps."""
+    from ebrec.models.newsrec import NRMSModel
+
+    hp = make_hp(dropout=0.2, learning_rate=1e-3)
+    rng = np.random.default_rng(3)
+    V, D = 700, 128
+    emb = rng.standard_normal((V, D)).astype(np.float32)
+    a = NRMSModel(hp, word2vec_embedding=emb, seed=5, train_embedding=train_embedding)
+    b = NRMSModel(hp, word2vec_embedding=emb, seed=5, train_embedding=train_embedding)
+    assert a._engine.adam_in_finish and a._engine._adam_fused(5)
+    b._engine.adam_in_finish = False
+    if graph:
+        a._engine.enable_graphs()
+        b._engine.enable_graphs()
+    for t in range(3):
+        his, pred, y = batch(rng, 40, hp.history_size, 5, hp.title_size, V)
+        la, lb = float(a.train_step(his, pred, y).item()), float(b.train_step(his, pred, y).item())
+        assert a._engine._adam_done_in_finish and not b._engine._adam_done_in_finish
+        if t == 0:
+            assert la == lb and torch.equal(a._engine.params.grad, b._engine.params.grad)
+        assert abs(la - lb) <= 2e-6 * abs(lb), (t, la, lb)
+        assert_close(a._engine.params.grad.cpu().numpy(), b._engine.params.grad.cpu().numpy(), rtol=1e-4, atol=1e-7, what=f"gradients, step {t}")
+    for what in ("data", "m", "v"):
+        assert_close(getattr(a._engine.params, what).cpu().numpy(), getattr(b._engine.params, what).cpu().numpy(), rtol=2e-5, atol=1e-9, what=f"dense {what}")
+    for wa, wb in zip(a.model.get_weights(), b.model.get_weights()):
+        assert_close(wa, wb, rtol=2e-5, atol=1e-8, what="weights after three steps")
+    assert int(a._engine.read_state().step) == int(b._engine.read_state().step) == 3
