@@ -244,17 +244,22 @@ def test_the_one_launch_finale_equals_the_three_launches_it_replaces(docvec, uni
         eng = m._engine
         eng.fuse_finale = finale
         eng.enable_graphs(graphs)
-        losses = [float(m.train_step(*b).item()) for b in batches]
+        losses, g1 = [], None
+        for i, bt in enumerate(batches):
+            losses.append(float(m.train_step(*bt).item()))
+            if i == 0:
+                g1 = eng.params.grad.cpu().numpy().copy()
         torch.cuda.synchronize()
         assert eng._step_applied_adam(eng._bufs["mlp"]) == finale
-        out.append((losses, eng.params.grad.cpu().numpy().copy(), eng.params.data.cpu().numpy().copy(), eng.params.m.cpu().numpy().copy(),
+        out.append((losses, g1, eng.params.data.cpu().numpy().copy(), eng.params.m.cpu().numpy().copy(),
                     eng.params.v.cpu().numpy().copy(), [t.cpu().numpy().copy() for t in eng.bn_mean + eng.bn_var], int(eng.read_state().step)))
     a, b = out
     # the loss: same rows, same fixed-order sums, same L2 term -- bit-identical on the first step; later steps start from weights that
     # agree to an ulp (the compiler contracts the two Adam kernels' arithmetic differently), so their losses agree to ~1e-7
     assert a[0][0] == b[0][0] and np.allclose(a[0], b[0], rtol=2e-6, atol=0), (a[0], b[0])
     assert a[6] == b[6] == 3
-    for x, y, what in zip(a[1:5], b[1:5], ("gradients", "weights", "Adam m", "Adam v")):
-        assert_close(x, y, rtol=2e-6, atol=1e-9, what=f"finale vs separate launches: {what}")
+    assert np.array_equal(a[1], b[1])  # every gradient of the first step (same weights going in): the same bits
+    for x, y, what in zip(a[2:5], b[2:5], ("weights", "Adam m", "Adam v")):
+        assert_close(x, y, rtol=2e-5, atol=1e-8, what=f"finale vs separate launches after three steps: {what}")
     for x, y in zip(a[5], b[5]):
-        assert np.array_equal(x, y)
+        assert_close(x, y, rtol=1e-5, atol=1e-7, what="moving statistics")
