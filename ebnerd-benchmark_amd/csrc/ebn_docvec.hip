@@ -49,8 +49,9 @@ constexpr int TILE_A = TM * LD, TILE_B = TN * LD;
 constexpr int MAX_K = 1024;     // widest layer whose per-column constants fit next to the tiles in LDS
 constexpr int MAX_TILES = 4096;  // row tiles of both sites together (131 072 rows: only the launch geometry bounds it)
 // fixed-point scales of the accumulators: forward sums of relu outputs / of their squares, backward sums of gradients.  Ranges: |sum x| <
-// 2^31, sum x^2 < 2^35, |sum dy| < 2^23 per call site and column -- orders of magnitude beyond a model that has not diverged (a diverged one
-// shows in the activations themselves: NaN / Inf travel through the data path, only the statistics are formed from the integer sums)
+// 2^31, sum x^2 < 2^35, |sum dy| < 2^23 per call site and column -- orders of magnitude beyond a model that has not diverged.  A tile sum
+// outside the range, or not finite, is NOT added: it raises args->range_flag (sticky; fix_addend below) and the host layer raises
+// FloatingPointError at its next flag check -- the statistics never silently wrap
 constexpr float FIX_SUM = 4294967296.0f /* 2^32 */, FIX_SQ = 268435456.0f /* 2^28 */, FIX_GRAD = 1099511627776.0f /* 2^40 */;
 constexpr int L2_SLOTS = MAX_K / 64;  // column tiles of the widest regularised kernel
 
@@ -101,7 +102,19 @@ struct PanelArgs {
   float* l2_part;          // forward of a regularised Dense: sum of squares of the weight columns of column tile tx (may be null)
   float* zero;             // a span this launch re-zeroes for later launches of the step (nobody reads it meanwhile); may be null
   int zero_n;
+  int32_t* range_flag;     // set when a tile's column sum leaves the accumulators' range or is not finite (may be null)
 };
+
+// One tile's contribution to a fixed-point accumulator: the scaled sum as a 64-bit integer -- or 0 and the sticky range flag when it is
+// not finite or so large that `tiles` such addends could wrap the 64-bit total (the run has diverged: the statistics formed from the
+// integer sums would be garbage where the separate-pass kernels propagate NaN; the host layer raises FloatingPointError on the flag).
+__device__ __forceinline__ unsigned long long fix_addend(float scaled, float limit, int32_t* flag) {
+  if (!(fabsf(scaled) < limit)) {
+    if (flag != nullptr) *flag = 1;
+    return 0ull;
+  }
+  return static_cast<unsigned long long>(__float2ll_rn(scaled));
+}
 
 // swizzled column of the LDS image: whole float4s move, by the row's (row >> 2) & 7 (tools/lds/bank_sim.py)
 __device__ __forceinline__ int swz(int row) { return ((row >> 2) & 7) << 2; }
@@ -535,21 +548,20 @@ __global__ __launch_bounds__(NTHR) void dvn_panel_kernel(PanelArgs p) {
     red[128 + wm * 64 + cl0 + 16] = s1[1];
   }
   __syncthreads();
+  const float fix_limit = 4.0e18f / static_cast<float>(gridDim.y);  // 2^62 / (row tiles of the launch): the totals cannot wrap
   if (EPI == EPI_DY) {
     if (tid < TN && n0c + tid < Nout) {
       long long* acc = p.out_acc + site * Nout + n0c + tid;
-      atomicAdd(reinterpret_cast<unsigned long long*>(acc), static_cast<unsigned long long>(__float2ll_rn((red[tid] + red[64 + tid]) * FIX_GRAD)));
-      atomicAdd(reinterpret_cast<unsigned long long*>(acc + 2 * Nout),
-                static_cast<unsigned long long>(__float2ll_rn((red[128 + tid] + red[192 + tid]) * FIX_GRAD)));
+      atomicAdd(reinterpret_cast<unsigned long long*>(acc), fix_addend((red[tid] + red[64 + tid]) * FIX_GRAD, fix_limit, p.range_flag));
+      atomicAdd(reinterpret_cast<unsigned long long*>(acc + 2 * Nout), fix_addend((red[128 + tid] + red[192 + tid]) * FIX_GRAD, fix_limit, p.range_flag));
     }
     return;
   }
   // EPI_RELU_STATS: the tile's sum and sum of squares (32 addends each in fp32; the totals are exact integer sums of these)
   if (tid < TN && n0c + tid < Nout) {
     long long* acc = p.out_acc + site * Nout + n0c + tid;
-    atomicAdd(reinterpret_cast<unsigned long long*>(acc), static_cast<unsigned long long>(__float2ll_rn((red[tid] + red[64 + tid]) * FIX_SUM)));
-    atomicAdd(reinterpret_cast<unsigned long long*>(acc + 2 * Nout),
-              static_cast<unsigned long long>(__float2ll_rn((red[128 + tid] + red[192 + tid]) * FIX_SQ)));
+    atomicAdd(reinterpret_cast<unsigned long long*>(acc), fix_addend((red[tid] + red[64 + tid]) * FIX_SUM, fix_limit, p.range_flag));
+    atomicAdd(reinterpret_cast<unsigned long long*>(acc + 2 * Nout), fix_addend((red[128 + tid] + red[192 + tid]) * FIX_SQ, fix_limit, p.range_flag));
   }
 }
 
@@ -795,6 +807,7 @@ extern "C" int ebn_dvn_fwd_train_f32(const ebn_dvn_args* a, const ebn_step_state
     p.ldb = p.Nout;
     p.bias = a->b[l];
     p.C = l < L ? a->R[l] : a->NE;
+    p.range_flag = a->range_flag;
     EBN_REQUIRE(p.C != nullptr, EBN_ERR_BAD_ARG);
     if (l < L) p.out_acc = stat_view(a, l).fwd;
     if (l < L && a->l2 > 0.f) p.l2_part = l2_view(a) + l * L2_SLOTS;
@@ -856,6 +869,7 @@ static int dvn_bwd_layer(const ebn_dvn_args* a, int32_t l, const ebn_step_state*
     p.key_out = d_out.key_ptr;
     p.thresh = d_out.thresh;
     p.scale = d_out.scale;
+    p.range_flag = a->range_flag;
     EBN_REQUIRE(p.B && p.C && p.Aout && p.Rout, EBN_ERR_BAD_ARG);
     if (l == L) {
       p.A = a->dNE;

@@ -78,7 +78,7 @@ class DvnArgs(ctypes.Structure):
                  ("NE", ctypes.c_void_p), ("stat", ctypes.c_void_p), ("dNE", ctypes.c_void_p),
                  ("dY", ctypes.c_void_p * DVN_MAX_LAYERS), ("dP", ctypes.c_void_p * (DVN_MAX_LAYERS + 1)),
                  ("ggamma", ctypes.c_void_p * DVN_MAX_LAYERS), ("gbeta", ctypes.c_void_p * DVN_MAX_LAYERS),
-                 ("loss", ctypes.c_void_p)])
+                 ("loss", ctypes.c_void_p), ("range_flag", ctypes.c_void_p)])
 
 
 class TnProblem(ctypes.Structure):

@@ -141,6 +141,14 @@ class LockStepGuard:
         return f"active (c10d store rendezvous, timeout {self._resolve_timeout():.0f} s)"
 
     def enter(self, what: str) -> None:
+        """Rendezvous of call number n of this group.  PASSING and GIVING UP are made consistent across the ranks by a shared
+        `passed` counter: a rank passes only after it has (1) seen every rank's mark, (2) bumped `passed`, (3) seen every mark
+        AGAIN; a rank that times out withdraws its mark and then reads `passed` -- if a peer has bumped it, everyone had arrived
+        and the peer is about to pass (or is waiting in (3) for this rank's mark to come back), so this rank puts its mark back
+        and goes on polling instead of raising.  Without that, a rank timing out in the instant a late peer arrives raised alone
+        while the peer passed and advanced its call counter: every later guarded call of the two then met on different keys
+        (round-5 ADVICE).  The poll backs off from 20 ms to 250 ms after the first second: `world` store reads per poll, for up
+        to the group's own timeout, must not load the store."""
         if not self.ensure():
             return
         import time
@@ -148,25 +156,55 @@ class LockStepGuard:
         timeout = self._resolve_timeout()
         n = LockStepGuard._calls.get(self._gkey, 0)
         key = f"{self._prefix}/{n}"
-        mine = f"{key}/r{self.rank}"
+        mine, passed = f"{key}/r{self.rank}", f"{key}/passed"
         marks = [f"{key}/r{r}" for r in self._ranks]
         st = self._store
-        st.add(mine, 1)
-        deadline = time.monotonic() + timeout
-        while True:
+        grace = max(1.0, 20 * self.poll_s)  # how long a rank in step (3) waits for a withdrawn mark to come back
+
+        def all_here():
             here = [int(st.add(m, 0)) > 0 for m in marks]
-            if all(here):
-                if n:  # everyone is at call n, so everyone has left call n-1: its mark can go
+            return all(here), here
+
+        def done():
+            if n:  # everyone is at call n, so everyone has left call n-1: its keys can go
+                for k in (f"{self._prefix}/{n - 1}/r{self.rank}",) + ((f"{self._prefix}/{n - 1}/passed",) if self.rank == self._ranks[0] else ()):
                     try:
-                        st.delete_key(f"{self._prefix}/{n - 1}/r{self.rank}")
+                        st.delete_key(k)
                     except Exception:
                         pass
-                LockStepGuard._calls[self._gkey] = n + 1
-                return
-            if time.monotonic() >= deadline:
+            LockStepGuard._calls[self._gkey] = n + 1
+
+        st.add(mine, 1)
+        t0 = time.monotonic()
+        deadline = t0 + timeout
+        here = []
+        while True:
+            ok, here = all_here()
+            if ok:
+                st.add(passed, 1)
+                t1 = time.monotonic()
+                while True:  # (3): still everyone?  A mark missing now belongs to a rank that is giving up: it will see `passed`
+                    ok2, here = all_here()
+                    if ok2:
+                        done()
+                        return
+                    if time.monotonic() - t1 >= grace:
+                        break
+                    time.sleep(self.poll_s)
+                st.add(passed, -1)  # the peer gave up for good before it could see this rank's bump: this rank gives up as well
                 break
-            time.sleep(self.poll_s)
-        st.add(mine, -1)  # withdraw: the next enter() every rank makes starts from a clean slate
+            now = time.monotonic()
+            if now >= deadline:
+                st.add(mine, -1)  # withdraw ...
+                if int(st.add(passed, 0)) > 0:  # ... unless a peer has seen everyone and is passing: stay in
+                    st.add(mine, 1)
+                    deadline = now + grace
+                    continue
+                mine = None
+                break
+            time.sleep(self.poll_s if now - t0 < 1.0 else max(self.poll_s, 0.25))
+        if mine is not None:
+            st.add(mine, -1)  # withdraw: the next enter() every rank makes starts from a clean slate
         missing = [r for r, h in zip(self._ranks, here) if not h]
         raise RuntimeError(f"{what} is a COLLECTIVE when world > 1 ({self.world} ranks): every rank of the group must call it at the "
                            f"same point.  Rank {self.rank} entered it, but rank(s) {missing} did not within {timeout:.0f} s -- a call "

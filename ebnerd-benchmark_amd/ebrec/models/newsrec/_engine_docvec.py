@@ -60,6 +60,7 @@ class DocVecEngine:
         self._bufs = {}
         self.loss_dev = torch.zeros(1, device=self.device)
         self.reg_dev = torch.zeros(1, device=self.device)
+        self.range_flag = torch.zeros(1, dtype=torch.int32, device=self.device)  # a fused launch's column sum left the fixed-point range / was not finite
         self.world = 1
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
@@ -214,6 +215,7 @@ class DocVecEngine:
             a.W[L], a.b[L], a.dP[L] = pv("out_W").data_ptr(), pv("out_b").data_ptr(), mb["dvn_dP"][L].data_ptr()
             a.X0, a.NE, a.dNE, a.stat = mb["X0"].data_ptr(), mb["NE"].data_ptr(), mb["dNE"].data_ptr(), stat.data_ptr()
             a.loss = None if fin else self.loss_dev.data_ptr()  # the finale forms the whole batch loss, L2 term included
+            a.range_flag = self.range_flag.data_ptr()
             # weight gradients of all L + 1 Dense kernels as ONE launch: dW_l = Xn_{l-1}^T . dP_l, bias gradient = column sums
             # of dP_l, + 2 l2 W_l for the regularised (hidden) kernels
             probs = (_hip.TnProblem * (L + 1))()
@@ -620,9 +622,20 @@ class DocVecEngine:
         """Article-row numbers outside the document-vector matrix raise (device-resident batches are checked here,
         once per epoch, not per step)."""
         oob = getattr(self, "_oob", None)
-        if oob is not None and int(oob.item()) != 0:
+        flags = torch.cat([oob if oob is not None else torch.zeros(1, dtype=torch.int32, device=self.device), self.range_flag])
+        if self.world > 1:  # every rank raises together: a rank raising alone would leave its peers in the next collective
+            torch.distributed.all_reduce(flags, op=torch.distributed.ReduceOp.MAX, group=self.pg)
+        bad_rows, bad_range = (int(v) != 0 for v in flags.cpu().tolist())
+        if bad_rows and oob is not None:
             oob.zero_()
+        if bad_range:  # (both words cleared before anything is raised)
+            self.range_flag.zero_()
+            self._dvn_dirty = True  # the accumulators hold a partial step: zero them before the next one
+        if bad_rows:
             raise IndexError(f"article row out of range [0, {self.article_matrix.shape[0]}) for the document-vector matrix")
+        if bad_range:
+            raise FloatingPointError("a column sum of the news encoder's BatchNormalization left the range of its fixed-point accumulator or was not "
+                                     "finite: the run has diverged (fuse_news_mlp=False runs the separate passes, which propagate NaN instead)")
 
     def sync_moving_statistics(self) -> None:
         """world > 1 with BatchNormalization layers: average the moving mean / variance over the ranks (a COLLECTIVE; fit() calls it

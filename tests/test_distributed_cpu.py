@@ -283,6 +283,41 @@ def _guard_default_timeout_worker(rank, world):
     assert group_timeout_s(sub) == 77.0
 
 
+def _guard_race_worker(rank, world):
+    """Round-5 ADVICE: a rank timing out in the instant its late peer arrives.  Whatever the timing, the ranks must AGREE (both pass
+    or both raise) and stay in step: the next guarded call both make passes at once."""
+    import time
+
+    from ebrec.models.newsrec._dist import LockStepGuard
+
+    g = LockStepGuard(timeout_s=1.0)
+    g.enter("warm-up")  # store connection, key prefix
+    outcomes = []
+    for delay in (0.93, 0.97, 1.0, 1.03, 1.07, 1.4):
+        dist.barrier()
+        if rank == 1:
+            time.sleep(delay)
+        try:
+            g.enter(f"model.fit() [late peer, {delay}]")
+            mine = 1
+        except RuntimeError:
+            mine = 0
+        both = [None, None]
+        dist.all_gather_object(both, mine)
+        assert both[0] == both[1], (delay, both)  # never one rank through and the other one raising
+        outcomes.append(both[0])
+        if rank == 0 and not mine:
+            time.sleep(0.3)
+        t0 = time.time()
+        g.enter("the call after")  # counters in step: passes as soon as both are here
+        assert time.time() - t0 < 0.9, (delay, time.time() - t0)
+    assert outcomes[-1] == 0  # 1.4 s late against a 1 s deadline (+ nobody to have bumped `passed`): both raise
+
+
+def test_a_rank_timing_out_while_its_peer_arrives_never_splits_the_ranks():
+    _run(_guard_race_worker, 2)
+
+
 def test_lock_step_guard_default_timeout_is_the_process_groups_own():
     _run(_guard_default_timeout_worker, 2)
 

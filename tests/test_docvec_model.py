@@ -263,3 +263,38 @@ def test_the_one_launch_finale_equals_the_three_launches_it_replaces(docvec, uni
         assert_close(x, y, rtol=2e-5, atol=1e-8, what=f"finale vs separate launches after three steps: {what}")
     for x, y in zip(a[5], b[5]):
         assert_close(x, y, rtol=1e-5, atol=1e-7, what="moving statistics")
+
+
+def test_fused_column_sums_outside_the_fixed_point_range_raise_instead_of_wrapping(docvec):
+    """Round-5 ADVICE: the fused launches keep their BatchNormalization column sums in 64-bit fixed-point accumulators; a tile sum that is
+    not finite or could wrap the total is not added -- it raises a sticky flag and check_oob() raises FloatingPointError -- instead of
+    silently yielding garbage statistics.  Large but in-range activations (x 30) agree with the separate-pass form; a diverged input
+    (x 1e6, then NaN) raises, and the engine trains normally afterwards (the accumulators are re-zeroed)."""
+    hp = make_hp(title_size=64, newsencoder_units_per_layer=[48, 40], head_num=2, head_dim=16, attention_hidden_dim=12, history_size=7, dropout=0.0,
+                 newsencoder_l2_regularization=0.0)
+    P = oracle_params(hp, 9)
+    rng = np.random.default_rng(2)
+    his, pred, y = data(rng, 8, hp.history_size, 5, hp.title_size)
+    grads = []
+    for fused in (True, False):
+        m = docvec(hp, seed=5)
+        m.model.set_weights(weight_list(P))
+        m._engine.fuse_news_mlp = fused
+        m.train_step(30.0 * his, 30.0 * pred, y)
+        m._engine.check_oob()  # in range: nothing raised
+        grads.append(m._engine.params.grad.cpu().numpy().astype(np.float64))
+    assert_close(grads[0], grads[1], rtol=2e-3, atol=1e-6 + 2e-4 * np.abs(grads[1]).max(), what="x30 activations, fused vs separate passes")
+    m = docvec(hp, seed=5)
+    m.model.set_weights(weight_list(P))
+    eng = m._engine
+    for bad in (1e6 * his, np.where(np.arange(his.size).reshape(his.shape) == 5, np.nan, his).astype(np.float32)):
+        m.train_step(bad, pred, y)
+        with pytest.raises(FloatingPointError, match="fixed-point accumulator"):
+            eng.check_oob()
+        eng.check_oob()  # the flag is cleared by the raise
+        m.model.set_weights(weight_list(P))  # (the diverged step has moved / poisoned the weights)
+    loss = float(m.train_step(his, pred, y).item())
+    eng.check_oob()
+    fresh = docvec(hp, seed=5)
+    fresh.model.set_weights(weight_list(P))
+    assert loss == float(fresh.train_step(his, pred, y).item())  # the accumulators were re-zeroed: the same statistics as a fresh engine's
