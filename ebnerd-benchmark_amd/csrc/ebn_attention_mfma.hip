@@ -24,21 +24,7 @@
 
 #include "ebn_common.h"
 
-typedef float ebn_nt_f32x4 __attribute__((ext_vector_type(4)));
-typedef int ebn_i32x4nt __attribute__((ext_vector_type(4)));
-__device__ ebn_nt_f32x4 nt_buffer_load_x4(ebn_i32x4nt rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
-
 namespace {
-
-__device__ __forceinline__ ebn_i32x4nt nt_rsrc(const float* base) {
-  const unsigned long long a = reinterpret_cast<unsigned long long>(base);
-  ebn_i32x4nt r;
-  r.x = static_cast<int>(static_cast<uint32_t>(a));
-  r.y = static_cast<int>(static_cast<uint32_t>(a >> 32) & 0xFFFFu);
-  r.z = -1;
-  r.w = 0x00020000;
-  return r;
-}
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -1125,233 +1111,6 @@ static void allow_lds(K kernel, size_t bytes) {
   if (bytes > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
 }
 
-// ---- the news encoder's tail as ONE launch per step (verdict r5 item 2; nrms.py:137-156, layers.py:55-81, 231-252) ------------------
-// One workgroup per TITLE keeps Y = dropout(P^T V) of the title in LDS from the attention core through AttLayer2:
-//   phase 1  the attention core of the title's heads, one wave per head at a time (the code path of attn_mfma_fwd_kernel); the output tile
-//            goes to global memory once (backward needs Y) AND into the LDS image Y[30][E + 4];
-//   phase 2  U = tanh(Y . W + b) on 16 x 16 x 4 MFMAs: A fragments from the LDS image, B fragments (a k-contiguous copy W^T [A][E] of the
-//            AttLayer2 kernel) straight from L2 as in gemm_direct16_kernel; wave w owns row block w / 3 and 5 | 4 | 4 column blocks;
-//            U leaves for global memory (backward needs it), e = U . q as per-wave partial row sums through LDS;
-//   phase 3  a = exp(e) (no max subtraction), w = a / (sum a + 1e-7), pooled = sum_t w_t Y_t from the LDS image.
-// Replaces attn_mfma_fwd_kernel + gemm_direct16_kernel<3,7,false,2> + attpool_fwd_vec_kernel and two of the three HBM round trips of Y / U.
-constexpr int NT_WAVES = 6;      // 2 row blocks x 3 column groups in phase 2; heads dealt round-robin in phase 1
-constexpr int NT_NC = 5;         // column blocks per wave (at most)
-constexpr int NT_PAD = 4;        // Y image row stride E + 4: the 16 rows of an A-fragment read start in 16 different bank quads
-typedef float nt_f32x4 __attribute__((ext_vector_type(4)));
-
-struct NewsTailArgs {
-  const float* qkv;   // (n_seq * L, 3E)
-  const float* Wt;    // (A, E): the AttLayer2 kernel, k-contiguous
-  const float* b;     // (A)
-  const float* q;     // (A)
-  float* Y;           // (n_seq * L, E)  dropout(P^T V)
-  float* U;           // (n_seq * L, A)  tanh(Y W + b)
-  float* w;           // (n_seq * L)
-  float* out;         // (n_seq, E)
-  int32_t h, A;
-  const uint32_t* key_ptr;
-  uint32_t thresh;
-  float scale;
-};
-
-// phase 2 of news_tail_fwd_kernel for one wave: row block rb (16 rows of the LDS image) x NC column blocks starting at block cb0
-template <int NC, int L>
-__device__ __forceinline__ void nt_gemm_tanh(const NewsTailArgs& a, const float* __restrict__ yimg, int LDY, int E, int A, int64_t row0, int rb,
-                                             int cb0, int lane, float* __restrict__ ep) {
-  const int i16 = lane & 15, kq = lane >> 4;
-  const int arow = (rb * 16 + i16 < L) ? rb * 16 + i16 : 0;  // rows >= L are clamped: they feed outputs nobody stores
-  const float* ap = yimg + arow * LDY + 4 * kq;
-  uint32_t ob[NC];
-#pragma unroll
-  for (int c = 0; c < NC; ++c) {
-    int col = (cb0 + c) * 16 + i16;
-    col = col < A ? col : A - 1;
-    ob[c] = static_cast<uint32_t>((col * E + 4 * kq) * 4);
-  }
-  const ebn_i32x4nt wrsrc = nt_rsrc(a.Wt);
-  nt_f32x4 acc[NC];
-#pragma unroll
-  for (int c = 0; c < NC; ++c) acc[c] = nt_f32x4{0.f, 0.f, 0.f, 0.f};
-  const int ng = E / 16;  // E % 16 == 0 (checked by the launcher)
-  nt_f32x4 fa0, fa1, fb0[NC], fb1[NC];
-#define NT_FETCH(FA, FB, G)                                                                            \
-  do {                                                                                                 \
-    FA = *reinterpret_cast<const nt_f32x4*>(ap + 16 * (G));                                            \
-    _Pragma("unroll") for (int c = 0; c < NC; ++c) FB[c] = nt_buffer_load_x4(wrsrc, static_cast<int>(ob[c]), 64 * (G), 0); \
-  } while (0)
-#define NT_MMA(FA, FB)                                                                                 \
-  do {                                                                                                 \
-    _Pragma("unroll") for (int sidx = 0; sidx < 4; ++sidx)                                             \
-      _Pragma("unroll") for (int c = 0; c < NC; ++c)                                                   \
-        acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(FA[sidx], FB[c][sidx], acc[c], 0, 0, 0);        \
-    __builtin_amdgcn_sched_barrier(0);                                                                 \
-  } while (0)
-  NT_FETCH(fa0, fb0, 0);
-  int g = 0;
-#pragma unroll 1
-  for (; g + 2 <= ng - 1; g += 2) {
-    NT_FETCH(fa1, fb1, g + 1);
-    NT_MMA(fa0, fb0);
-    NT_FETCH(fa0, fb0, g + 2);
-    NT_MMA(fa1, fb1);
-  }
-  if (g + 1 < ng) {  // two groups left: g in set 0
-    NT_FETCH(fa1, fb1, g + 1);
-    NT_MMA(fa0, fb0);
-    NT_MMA(fa1, fb1);
-  } else {
-    NT_MMA(fa0, fb0);
-  }
-#undef NT_FETCH
-#undef NT_MMA
-  // epilogue: C/D map of the 16 x 16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + r
-  float part[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int c = 0; c < NC; ++c) {
-    const int col = (cb0 + c) * 16 + i16;
-    const bool cok = col < A;
-    const float bb = a.b[cok ? col : 0], qq = cok ? a.q[col] : 0.f;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int rr = rb * 16 + 4 * kq + r;
-      const float u = tanhf(acc[c][r] + bb);
-      if (cok && rr < L) a.U[(row0 + rr) * A + col] = u;
-      part[r] = fmaf(u, qq, part[r]);
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-#pragma unroll
-    for (int off = 8; off > 0; off >>= 1) part[r] += __shfl_xor(part[r], off, 64);
-  }
-  if (i16 == 0) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) ep[4 * kq + r] = part[r];  // row inside this wave's row block
-  }
-}
-
-template <int D, int LC>
-__host__ __device__ constexpr int news_tail_lds_floats(int E) {
-  return LC * (E + NT_PAD) + NT_WAVES * fwd_wave_floats<D>(LC) + NT_WAVES * 32 + 32;
-}
-
-template <int D, int LC>
-__global__ __launch_bounds__(64 * NT_WAVES, 3) void news_tail_fwd_kernel(NewsTailArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int L = LC;
-  const int E = a.h * D, A = a.A, LDY = E + NT_PAD;
-  float* yimg = smem;                                        // [L][LDY]
-  float* stage = yimg + L * LDY;                             // [NT_WAVES][fwd_wave_floats]
-  float* epart = stage + NT_WAVES * fwd_wave_floats<D>(L);   // [NT_WAVES][32]
-  float* wsm = epart + NT_WAVES * 32;                        // [32]
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int64_t seq = blockIdx.x, row0 = seq * L;
-  const int row = lane & 31, hi = lane >> 5;
-  const bool drop = a.key_ptr != nullptr;
-  const uint32_t key = drop ? *a.key_ptr : 0u;
-  const int64_t ld_qkv = 3 * static_cast<int64_t>(E);
-
-  // ---- phase 1: attention core, heads wv, wv + NT_WAVES, ... -------------------------------------------------------------------
-  {
-    float* sv = stage + wv * fwd_wave_floats<D>(L);
-    const float inv2 = 1.44269504088896341f / sqrtf(static_cast<float>(D));
-    for (int head = wv; head < a.h; head += NT_WAVES) {
-      const float* qb = a.qkv + row0 * ld_qkv + head * D;
-      float qr[D / 2], kr[D / 2];
-      {
-        Staged<D> tv;
-        stage_load<D>(tv, qb + 2 * E, static_cast<uint32_t>(ld_qkv), L, lane);
-        global_row_form<D>(qr, qb, static_cast<uint32_t>(ld_qkv), L, row, hi);
-        global_row_form<D>(kr, qb + E, static_cast<uint32_t>(ld_qkv), L, row, hi);
-        stage_store<D, false>(sv, tv, L, lane, 0u, 0u, 0, 0u, 0.f);
-      }
-      wave_lds_sync();
-      float vc[16];
-      lds_col_form<D>(vc, sv, L, row, hi);
-      f32x16 P = mm_rows<D / 2>(kr, qr);
-      softmax_in_lane(P, L, hi, inv2);
-      wave_lds_sync();
-      tile_transpose(P, sv, L, row, hi);
-      const f32x16 O = mm_col_tile(vc, P);  // O^T[c][j]: lane j, regs c
-      // out: lane (row, hi) owns the 16-byte pieces at columns 8g + 4hi of its row: dropout, then global Y and the LDS image
-      if (row < L) {
-        float* yg = a.Y + (row0 + row) * E + head * D;
-        float* yl = yimg + row * LDY + head * D;
-        const uint64_t e0 = static_cast<uint64_t>(row0) * E + head * D;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int c0 = 8 * g + 4 * hi;
-          if (c0 < D) {
-            float4 y = make_float4(O[4 * g], O[4 * g + 1], O[4 * g + 2], O[4 * g + 3]);
-            if (drop) {
-              const uint64_t pr = (e0 >> 1) + ((static_cast<uint32_t>(row) * static_cast<uint32_t>(E) + static_cast<uint32_t>(c0)) >> 1);
-              const uint32_t h0 = ebn_dropout_pair_hash(key, pr), h1 = ebn_dropout_pair_hash(key, pr + 1);
-              y.x *= ((h0 & 0xFFFFu) >= a.thresh) ? a.scale : 0.f;
-              y.y *= ((h0 >> 16) >= a.thresh) ? a.scale : 0.f;
-              y.z *= ((h1 & 0xFFFFu) >= a.thresh) ? a.scale : 0.f;
-              y.w *= ((h1 >> 16) >= a.thresh) ? a.scale : 0.f;
-            }
-            *reinterpret_cast<float4*>(yg + c0) = y;
-            *reinterpret_cast<float4*>(yl + c0) = y;
-          }
-        }
-      }
-      wave_lds_sync();  // the transpose buffer is read: the next head may stage into it
-    }
-  }
-  __syncthreads();
-
-  // ---- phase 2: U = tanh(Y . W + b), e partials ----------------------------------------------------------------------------------
-  {
-    const int rb = wv / 3, cg = wv - rb * 3;
-    const int ncb = (A + 15) / 16;                    // column blocks of 16 (13 for A = 200)
-    const int base = ncb / 3, extra = ncb - base * 3;  // groups 0 .. extra-1 hold base + 1 blocks
-    const int nc = base + (cg < extra ? 1 : 0);
-    const int cb0 = cg * base + (cg < extra ? cg : extra);
-    float* ep = epart + wv * 32;
-    // wave-uniform dispatch on the block count: every instantiation has literal accumulator indices and no guards around its MFMAs
-    switch (nc) {
-      case 5: nt_gemm_tanh<5, LC>(a, yimg, LDY, E, A, row0, rb, cb0, lane, ep); break;
-      case 4: nt_gemm_tanh<4, LC>(a, yimg, LDY, E, A, row0, rb, cb0, lane, ep); break;
-      case 3: nt_gemm_tanh<3, LC>(a, yimg, LDY, E, A, row0, rb, cb0, lane, ep); break;
-      case 2: nt_gemm_tanh<2, LC>(a, yimg, LDY, E, A, row0, rb, cb0, lane, ep); break;
-      case 1: nt_gemm_tanh<1, LC>(a, yimg, LDY, E, A, row0, rb, cb0, lane, ep); break;
-      default:  // no block for this wave: its partial row sums are zero
-        if ((lane & 15) == 0) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) ep[4 * (lane >> 4) + r] = 0.f;
-        }
-        break;
-    }
-  }
-  __syncthreads();
-
-  // ---- phase 3: attention weights over the title's tokens and the pooled vector ------------------------------------------------
-  if (wv == 0) {
-    const int t = lane;
-    float av = 0.f;
-    if (t < L) {
-      const int rb = t >> 4, rr = t & 15;
-      const float e = (epart[(rb * 3 + 0) * 32 + rr] + epart[(rb * 3 + 1) * 32 + rr]) + epart[(rb * 3 + 2) * 32 + rr];
-      av = expf(e);  // no max subtraction (layers.py:71-77)
-    }
-    const float ssum = ebn_wave_sum(av) + 1e-7f;
-    if (t < L) {
-      const float wl = av / ssum;
-      wsm[t] = wl;
-      a.w[row0 + t] = wl;
-    }
-  }
-  __syncthreads();
-  for (int c = tid; c < E; c += 64 * NT_WAVES) {
-    float acc = 0.f;
-#pragma unroll 6
-    for (int l = 0; l < L; ++l) acc = fmaf(wsm[l], yimg[l * LDY + c], acc);
-    a.out[seq * E + c] = acc;
-  }
-}
-
 template <class K>
 static void launch_waves(K kernel, size_t lds, const MfmaAttnArgs& a, hipStream_t s) {
 #ifdef EBN_ATTN_EXP_PAD_LDS  /* tuning experiment (tools/build_variant.sh): EBN_ATTN_PAD_LDS bytes of unused LDS per workgroup = fewer resident waves per CU */
@@ -1460,32 +1219,6 @@ int ebn_attn_mfma_bwd(const float* qkv, int64_t ld_qkv, const float* dout, int64
   else if (d == 20 && L == 20) launch_waves(attn_mfma_bwd_kernel<20, 20>, wb * bwd_wave_floats<20>(L), a, s);
   else if (d == 20) launch_waves(attn_mfma_bwd_kernel<20, 0>, wb * bwd_wave_floats<20>(L), a, s);
   else launch_waves(attn_mfma_bwd_kernel<32, 0>, wb * bwd_wave_floats<32>(L), a, s);
-  EBN_CHECK_LAUNCH();
-  return EBN_OK;
-}
-
-
-// ---- a3 + a4 of the news encoder as one launch per training step (see news_tail_fwd_kernel) ------------------------------------------
-extern "C" int ebn_news_tail_supported(int32_t L, int32_t h, int32_t d, int32_t A) {
-  if (L != 30 || d != 20 || h < 1 || A < 16 || (A % 4) != 0) return 0;
-  const int E = h * d;
-  if ((E % 16) != 0 || (A + 15) / 16 > 3 * NT_NC) return 0;
-  return static_cast<size_t>(news_tail_lds_floats<20, 30>(E)) * sizeof(float) <= 80 * 1024 ? 1 : 0;  // two workgroups per CU
-}
-
-extern "C" int ebn_news_tail_fwd_f32(const float* qkv, const float* Wt, const float* b, const float* q, float* Y, float* U, float* w,
-                                     float* out, int64_t n_seq, int32_t L, int32_t h, int32_t d, int32_t A, const ebn_step_state* st,
-                                     int32_t site, float drop_p, ebn_stream_t stream) {
-  EBN_REQUIRE(qkv && Wt && b && q && Y && U && w && out && n_seq >= 0, EBN_ERR_BAD_ARG);
-  EBN_REQUIRE(ebn_news_tail_supported(L, h, d, A) != 0, EBN_ERR_UNSUPPORTED);
-  EBN_REQUIRE(ebn_aligned16(qkv) && ebn_aligned16(Wt) && ebn_aligned16(Y), EBN_ERR_ALIGN);
-  EBN_REQUIRE(n_seq < (int64_t{1} << 31) / (3 * h * d * L + 1), EBN_ERR_UNSUPPORTED);
-  if (n_seq == 0) return EBN_OK;
-  const EbnDrop dr = ebn_make_drop(st, site, drop_p);
-  NewsTailArgs a{qkv, Wt, b, q, Y, U, w, out, h, A, dr.key_ptr, dr.thresh, dr.scale};
-  const size_t lds = static_cast<size_t>(news_tail_lds_floats<20, 30>(h * d)) * sizeof(float);
-  allow_lds(news_tail_fwd_kernel<20, 30>, lds);
-  EBN_LAUNCH((news_tail_fwd_kernel<20, 30>), dim3(static_cast<unsigned>(n_seq)), dim3(64 * NT_WAVES), lds, ebn_stream(stream), a);
   EBN_CHECK_LAUNCH();
   return EBN_OK;
 }

@@ -18,7 +18,6 @@ from __future__ import annotations
 
 import ctypes
 import math
-import os
 
 import numpy as np
 import torch
@@ -240,9 +239,6 @@ class NRMSEngine(StagingMixin, SegmentsMixin):
         # With a trainable table the finishing launch then runs AFTER the input-gradient GEMM (which reads Wqkv).  False: the two
         # launches (what a multi-rank step runs: the all-reduce sits between them; the validation form)
         self.adam_in_finish = True
-        # the news encoder's attention core + AttLayer2 forward as one launch per step (ebn_news_tail_fwd_f32); EBN_NEWS_TAIL=1 / the
-        # attribute switch it on for the A/B of profiles/r06_tuning_notes.md
-        self.fuse_news_tail = os.environ.get("EBN_NEWS_TAIL", "0") == "1"
         self._adam_done_in_finish = False  # set by the step's backward when its finishing launch has applied the dense Adam
 
     @property
@@ -455,18 +451,6 @@ class NRMSEngine(StagingMixin, SegmentsMixin):
             return self._news_encoder_fwd_mlp(b, n_seq, X, train, n_seq if n_first is None else n_first)
         if pre == "n" and self.precision == "split":
             return self._news_encoder_fwd_split(b, n_seq, X, st, site, p)
-        if pre == "n" and train and self.fuse_news_tail and int(_hip.lib().ebn_news_tail_supported(b.L, self.h, self.d, self.A)) != 0:
-            # the news encoder after its projection as ONE launch: attention core -> Dropout -> AttLayer2 with Y kept in LDS per title
-            S, E, A = _hip.stream_handle, self.E, self.A
-            pv = self.params.view
-            _hip.call("ebn_gemm_f32_site", 0, 0, n_seq * b.L, 3 * E, b.Din, ctypes.c_float(1.0), _hip.ptr(X), b.Din, _hip.ptr(pv("n_Wqkv")), 3 * E,
-                      ctypes.c_float(0.0), _hip.ptr(b.QKV), 3 * E, _hip.ptr(b.ws), b.ws.numel(), 1, S())
-            if getattr(b, "Wt", None) is None:
-                b.Wt = torch.empty(A, E, device=self.device)
-            b.Wt.copy_(pv("n_W").t())  # the AttLayer2 kernel, k-contiguous (refreshed every step: Adam moves it)
-            _hip.call("ebn_news_tail_fwd_f32", _hip.ptr(b.QKV), _hip.ptr(b.Wt), _hip.ptr(pv("n_b")), _hip.ptr(pv("n_q")), _hip.ptr(b.Y), _hip.ptr(b.U),
-                      _hip.ptr(b.w), _hip.ptr(b.out), n_seq, b.L, self.h, self.d, A, st, site, ctypes.c_float(p), S())
-            return
         dims, params, acts = self._enc_structs(pre, b, n_seq, X, site, p)
         _hip.call("ebn_encoder_fwd_f32", ctypes.byref(dims), ctypes.byref(params), ctypes.byref(acts),
                   ctypes.byref(self._fwd_scratch(b)), st, _hip.stream_handle())

@@ -259,15 +259,6 @@ int ebn_gemm_f32_site(int32_t transA, int32_t transB, int64_t M, int64_t N, int6
 int ebn_attn_fwd_f32(const float* qkv, int64_t ld_qkv, float* out, int64_t ld_out, int64_t n_seq,
                      int32_t L, int32_t h, int32_t d, const ebn_step_state* st, int32_t site,
                      float drop_p, ebn_stream_t stream);
-/* a3 + a4 of the NEWS encoder as one launch per training step (nrms.py:137-156: SelfAttention core -> Dropout -> AttLayer2): one
- * workgroup per title keeps Y = dropout(P^T V) in LDS from the attention core through AttLayer2.  Wt = the AttLayer2 kernel W (E, A)
- * stored k-contiguous, (A, E).  Writes Y (n_seq*L, E), U = tanh(Y W + b) (n_seq*L, A), the attention weights w (n_seq*L) and the
- * pooled news vectors out (n_seq, E): exactly what ebn_attn_fwd_f32 + ebn_gemm_f32 + ebn_attpool_fwd_f32 leave, to fp32 summation
- * order.  ebn_news_tail_supported: L == 30, d == 20, E % 16 == 0, A <= 240 (title_size 30, head_dim 20: BASELINE.json's configs).   */
-int ebn_news_tail_supported(int32_t L, int32_t h, int32_t d, int32_t A);
-int ebn_news_tail_fwd_f32(const float* qkv, const float* Wt, const float* b, const float* q, float* Y, float* U, float* w,
-                          float* out, int64_t n_seq, int32_t L, int32_t h, int32_t d, int32_t A, const ebn_step_state* st,
-                          int32_t site, float drop_p, ebn_stream_t stream);
 /* dqkv (same layout as qkv) from d(out); the dropout multiplier is re-derived.     */
 int ebn_attn_bwd_f32(const float* qkv, int64_t ld_qkv, const float* dout, int64_t ld_dout,
                      float* dqkv, int64_t ld_dqkv, int64_t n_seq, int32_t L, int32_t h, int32_t d,

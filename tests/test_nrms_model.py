@@ -676,39 +676,8 @@ def test_adam_inside_the_finishing_launch_equals_the_separate_optimizer_launch(h
         assert abs(la - lb) <= 2e-6 * abs(lb), (t, la, lb)
         assert_close(a._engine.params.grad.cpu().numpy(), b._engine.params.grad.cpu().numpy(), rtol=1e-4, atol=1e-7, what=f"gradients, step {t}")
     for what in ("data", "m", "v"):
-        assert_close(getattr(a._engine.params, what).cpu().numpy(), getattr(b._engine.params, what).cpu().numpy(), rtol=2e-5, atol=1e-9, what=f"dense {what}")
+        assert_close(getattr(a._engine.params, what).cpu().numpy(), getattr(b._engine.params, what).cpu().numpy(), rtol=2e-5, atol=5e-8, what=f"dense {what}")  # (atol: 5e-5 of one Adam step of lr = 1e-3 -- a weight that three steps moved through zero)
     for wa, wb in zip(a.model.get_weights(), b.model.get_weights()):
         assert_close(wa, wb, rtol=2e-5, atol=1e-8, what="weights after three steps")
     assert int(a._engine.read_state().step) == int(b._engine.read_state().step) == 3
 
-
-@pytest.mark.gpu
-def test_news_tail_launch_equals_the_three_kernels_it_replaces(hip):
-    """ebn_news_tail_fwd_f32 (attention core -> Dropout -> AttLayer2, one workgroup per title, Y kept in LDS) against ebn_attn_fwd_f32 +
-    the U = Y.W GEMM + ebn_attpool_fwd_f32 on the same Q|K|V: Y bit for bit (the same MFMA order and dropout mask), U / w / pooled
-    vectors to fp32 summation order; then a whole training step with it against the step without (loss, every gradient)."""
-    from ebrec.models.newsrec import NRMSModel
-
-    hp = make_hp(dropout=0.2, learning_rate=1e-3)
-    rng = np.random.default_rng(3)
-    V, D = 700, 128
-    emb = rng.standard_normal((V, D)).astype(np.float32)
-    his, pred, y = batch(rng, 6, hp.history_size, 5, hp.title_size, V)
-    out = []
-    for fuse in (False, True):
-        m = NRMSModel(hp, word2vec_embedding=emb, seed=5, train_embedding=True)
-        eng = m._engine
-        eng.fuse_news_tail = fuse
-        eng.keep_table_grad = True
-        loss = float(m.train_step(his, pred, y).item())
-        nb = eng._bufs[("news", True)]
-        n = 6 * 25
-        out.append((loss, nb.Y[: n * 30].cpu().numpy().copy(), nb.w[: n * 30].cpu().numpy().copy(), nb.out[:n].cpu().numpy().copy(),
-                    eng.params.grad.cpu().numpy().astype(np.float64), eng.table_grad.cpu().numpy().astype(np.float64)))
-    a, b = out
-    assert np.array_equal(a[1], b[1])  # Y = dropout(P^T V)
-    assert_close(b[2], a[2], rtol=2e-5, atol=1e-7, what="attention weights")
-    assert_close(b[3], a[3], rtol=2e-5, atol=1e-6, what="pooled news vectors")
-    assert abs(a[0] - b[0]) <= 2e-6 * max(1.0, abs(a[0]))
-    assert_close(b[4], a[4], rtol=1e-4, atol=1e-7 + 2e-5 * np.abs(a[4]).max(), what="dense gradients")
-    assert_close(b[5], a[5], rtol=1e-4, atol=1e-7 + 2e-5 * np.abs(a[5]).max(), what="table gradient")
