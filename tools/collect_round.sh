@@ -5,12 +5,18 @@
 # --pmc passes are separate runs with --kernel-trace only (no sys/hip/hsa trace domains), as the pool requires.
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
-tag=${1:-r05}
+tag=${1:-r06}
 out=gpurun_out/$tag
 mkdir -p $out
+# the probe-only summaries behind every roofline* figure (bench.py keeps them when asked): per config, rocprofv3 --kernel-trace --stats and the
+# FETCH_SIZE / WRITE_SIZE passes over `bench.py --kernel-probe` -- only the two roofline kernels' launches, no calibration copies
+export EBN_PROBE_KEEP_DIR=$PWD/$out/probe
 timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -5 > $out/pytest_gpu.log
-# the driver's command first (c2, CPU baseline included), then every other config
-python bench.py --steps 20 --warmup 5 > $out/bench_c2.json 2> $out/bench_c2.err
+# the driver's command first (c2 headline with the c1 / c3 / c4 / c5 legs, CPU baseline included), then every other config on its own
+python bench.py > $out/bench_default.json 2> $out/bench_default.err
+python bench.py --steps 20 --warmup 5 --legs "" > $out/bench_c2.json 2> $out/bench_c2.err
+# the multi-rank branch on a one-rank RCCL group (what the 8-GPU node will run, executed here)
+timeout 900 python bench.py --gpus 1 --force-dist --steps 20 --warmup 5 > $out/bench_c2_force_dist_1rank_rccl.json 2> $out/bench_c2_force_dist.err
 for c in c1 c3 c4 c5 c5h50; do
   nocpu=--no-cpu-baseline; [ $c = c3 ] && nocpu=   # c3 carries its own cpu_baseline leg (a second of CPU work)
   python bench.py --config $c --steps 20 --warmup 5 $nocpu --no-split-leg > $out/bench_$c.json 2> $out/bench_$c.err

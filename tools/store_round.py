@@ -9,7 +9,7 @@ import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
-tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
 G, P = ROOT / "gpurun_out" / tag, ROOT / "profiles"
 
 
@@ -46,6 +46,16 @@ for d in (G / "pmc_mfma_a", G / "pmc_mfma_b"):
         shutil.copy(src, d / "b_counter_collection.csv")
 subprocess.run([sys.executable, str(ROOT / "tools" / "summarize_mfma_pmc.py"), str(G / "pmc_mfma_a"), str(G / "pmc_mfma_b"),
                 str(P / f"{tag}_pmc" / "mfma_utilisation_bench_c2.json")], check=True)
+# ---- probe-only summaries (the figures behind roofline / roofline_gather of every config, recomputable from profiles/ alone)
+if (G / "probe").exists():
+    (P / f"{tag}_probe").mkdir(exist_ok=True)
+    for f in sorted((G / "probe").iterdir()):
+        shutil.copy(f, P / f"{tag}_probe" / f.name)
+for name in ("bench_default", "bench_c2_force_dist_1rank_rccl"):
+    src = G / f"{name}.json"
+    line = last_json(src) if src.exists() else None
+    if line is not None:
+        (P / f"{tag}_{name}.json").write_text(json.dumps(line) + "\n")
 # ---- kernel statistics + bench lines
 traffic = json.loads((P / "traffic.json").read_text())["c2"]
 for c in ("c1", "c2", "c3", "c4", "c5", "c5h50"):
