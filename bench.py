@@ -356,7 +356,7 @@ def fit_loop_leg(model, c, n_steps=100):
 
 
 def split_precision_leg(c, make_model, batches, args, sync, device, exact_ms):
-    """The opt-in second precision of the projection GEMMs (every fp32 operand split exactly into three bf16 values, six
+    """The opt-in second precision of the projection GEMMs (profiles/HISTORY.md section 4a: every fp32 operand split exactly into three bf16 values, six
     bf16 MFMA cross products, fp32 accumulate), timed in the SAME run as the exact-fp32 headline so that the driver's line carries
     it: K steps x R repeats of the same batches on a second engine, and the accuracy evidence next to it -- the max abs error of
     the Q|K|V projection of one real step (this run's gathered, dropped-out X and this model's Wqkv) against float64, for the
@@ -850,7 +850,7 @@ def main():
                          "fp32 accumulate), an opt-in second precision with its own line")
     ap.add_argument("--atomic-table-grad", action="store_true",
                     help="trainable table: one 64-bit atomic per gradient element instead of combining the duplicate ids of every 64 consecutive "
-                         "tokens first (same bits; the A/B behind DESIGN's choice, see --ids zipf)")
+                         "tokens first (same bits; the A/B behind the default (profiles/HISTORY.md), see --ids zipf)")
     ap.add_argument("--legs", default=None, help="on the default config: also measure these configs as sub-records of the line, each in its own (set of) child "
                                                   "process(es) under its own timeout ('' = none).  Default: N = 1 -> c1,c3,c4,c5 (every other BASELINE.json config at "
                                                   "its single-GPU / per-rank shape, with its own roofline objects); N > 1 -> c4,c5 (configs[3] / configs[4])")
