@@ -420,7 +420,10 @@ def probe_kernels(config, batch, precision="exact", ids="uniform", pick=None):
     try:
         for tag, flags in (("stats", ["--kernel-trace", "--stats"]), ("fetch", ["--pmc", "FETCH_SIZE", "--kernel-trace"]),
                            ("write", ["--pmc", "WRITE_SIZE", "--kernel-trace"])):
-            r = subprocess.run([exe] + flags + ["--output-format", "csv", "-d", f"{tmp}/{tag}", "-o", "p", "--"] + probe,
+            # the statistics pass launches each kernel 300 times back to back (the chip reaches its steady clocks after ~50 ms of load: its
+            # AVERAGE then is the steady figure of `avg_launch_us`); the counter passes serialise every dispatch and need only a few
+            n_launch = ["--probe-launches", "300" if tag == "stats" else "24"]
+            r = subprocess.run([exe] + flags + ["--output-format", "csv", "-d", f"{tmp}/{tag}", "-o", "p", "--"] + probe + n_launch,
                                cwd=tmp, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=150)  # a pass takes ~15 s; a hung profiler (seen: 15 min after an aborted pass) falls back to the static labels
             if r.returncode != 0:
                 return None
@@ -519,9 +522,10 @@ def bench_docvec(args, c, world, rank, device, sync, dfields, multi=False):
         rk = eng.roofline_kernels(c["B"], c["C"])
         id_sets = [torch.cat([h_.reshape(-1), p_.reshape(-1)]).contiguous() for h_, p_, _ in batches]
         for i in range(args.probe_launches):
-            rk["gather"](id_sets[i % len(id_sets)])()
             if "dw_group" in rk:
                 rk["dw_group"]()
+        for i in range(args.probe_launches):
+            rk["gather"](id_sets[i % len(id_sets)])()
         sync()
         return
     eng.enable_graphs(not args.no_graph)
@@ -941,9 +945,10 @@ def main():
         eng.train_step(*batches[0])  # allocates the step's buffers and fills X with gathered rows
         rk = eng.roofline_kernels(c["B"], c["C"])
         id_sets = [torch.cat([h_.reshape(-1), p_.reshape(-1)]).contiguous() for h_, p_, _ in batches]
-        for i in range(args.probe_launches):  # (the first launches run on a chip that has just idled: the summary's MinNs / the later launches are the steady ones)
-            rk["gather"](id_sets[i % len(id_sets)])()
+        for i in range(args.probe_launches):  # each kernel back to back, as bench.py's own HIP-event timing runs them
             rk["qkv_gemm"]()
+        for i in range(args.probe_launches):
+            rk["gather"](id_sets[i % len(id_sets)])()
         sync()
         return
 
