@@ -1261,3 +1261,133 @@ def test_docvec_step_prologue_in_one_launch(hip):
              None, 0.9, 0.999, S())
     torch.cuda.synchronize()
     assert int(flag.item()) == 1 and not host(X0)[n0 + 3].any()
+
+
+# ---------------------------------------------------------------- round 6: the optimizer inside a one-rank step's closing launch
+def _flat_buffers(rng, segs):
+    """flat theta / grad / m / v of the named segments (name -> element count), 64-element aligned like the engines' FlatParams"""
+    off, offs = 0, {}
+    for k, n in segs.items():
+        offs[k] = off
+        off += -(-n // 64) * 64
+    th, m, v = rng.standard_normal(off), rng.standard_normal(off) * 0.1, rng.random(off) * 0.01
+    return offs, off, th, m, v
+
+
+def test_finishing_launch_with_adam_inside_against_float64(hip):
+    """ebn_grad_finish_adam_f32: a split-K sum, a column-partials sum and a head sum whose outputs live in a flat gradient buffer, plus two `rest`
+    ranges whose gradients are already there -- every gradient against float64 sums, and theta / m / v of EVERY parameter against the
+    oracle's Keras-form Adam (two steps: the second one starts from non-trivial moments); elements no job and no range owns stay untouched."""
+    rng = np.random.default_rng(5)
+    M, N, parts, A, nblk, B = 96, 72, 5, 40, 37, 9
+    offs, numel, th, m, v = _flat_buffers(rng, {"W": M * N, "q": A, "b": A, "uq": A, "ub": A, "r0": 1000, "gap": 100, "r1": 333})
+    th_d, m_d, v_d, g_d = dev(th), dev(m), dev(v), torch.zeros(numel, device="cuda")
+    st = make_state(seed=0, step=0, lr=1e-3)
+    for t in (1, 2):
+        Wp = rng.standard_normal((parts, M, N)).astype(np.float32)
+        cp = rng.standard_normal((nblk, 2, A)).astype(np.float32)
+        hp_, rows = rng.standard_normal((B, 2, A)).astype(np.float32), rng.standard_normal(B).astype(np.float32)
+        g_rest = {k: rng.standard_normal(n).astype(np.float32) for k, n in (("r0", 1000), ("r1", 333))}
+        for k, a_ in g_rest.items():
+            g_d[offs[k]: offs[k] + a_.size] = dev(a_)
+        view = lambda k, n: g_d[offs[k]: offs[k] + n]
+        loss = torch.zeros(1, device="cuda")
+        jobs = (hip.FinishJob * 3)(
+            _finish_job(hip, hip.FINISH_COLRED, nblk, 1, A, dev(cp), view("q", A), view("b", A), ld=A),
+            _finish_job(hip, hip.FINISH_HEAD, 1, B, A, dev(hp_), view("uq", A), view("ub", A), ld=A, loss_rows=dev(rows), loss_out=loss),
+            _finish_job(hip, hip.FINISH_SPLITK, parts, M, N, dev(Wp), view("W", M * N), ld=N))
+        ad = hip.AdamFlat()
+        ad.theta, ad.grad, ad.m, ad.v, ad.numel = th_d.data_ptr(), g_d.data_ptr(), m_d.data_ptr(), v_d.data_ptr(), numel
+        ad.beta1, ad.beta2, ad.eps, ad.grad_scale, ad.n_rest = 0.9, 0.999, 1e-7, 1.0, 2
+        ad.rest_off[0], ad.rest_len[0], ad.rest_off[1], ad.rest_len[1] = offs["r0"], 1000, offs["r1"], 333
+        hip.call("ebn_step_advance", P(st), 0.9, 0.999, S())
+        hip.call("ebn_grad_finish_adam_f32", jobs, 3, ctypes.byref(ad), P(st), S())
+        g = np.zeros(numel)
+        g[offs["W"]: offs["W"] + M * N] = Wp.astype(np.float64).sum(0).reshape(-1)
+        g[offs["q"]: offs["q"] + A], g[offs["b"]: offs["b"] + A] = cp.astype(np.float64).sum(0)
+        g[offs["uq"]: offs["uq"] + A], g[offs["ub"]: offs["ub"] + A] = hp_.astype(np.float64).sum(0)
+        for k, a_ in g_rest.items():
+            g[offs[k]: offs[k] + a_.size] = a_
+        owned = g != 0
+        assert_close(host(g_d)[owned], g[owned], rtol=1e-5, atol=1e-5, what=f"gradients, step {t}")
+        assert abs(float(loss.item()) - rows.astype(np.float64).sum()) < 1e-5
+        th2, m2, v2 = th.copy(), m.copy(), v.copy()
+        on.adam_keras_step(th2, g, m2, v2, t, lr=1e-3)
+        th[owned], m[owned], v[owned] = th2[owned], m2[owned], v2[owned]  # parameters nobody owns (the gap, the alignment padding) do not move
+        assert_close(host(th_d), th, rtol=1e-5, atol=2e-6, what=f"theta, step {t}")
+        assert_close(host(m_d), m, rtol=1e-5, atol=1e-6, what=f"m, step {t}")
+        assert_close(host(v_d), v, rtol=1e-5, atol=1e-7, what=f"v, step {t}")
+    bad = hip.AdamFlat()
+    assert hip.lib().ebn_grad_finish_adam_f32(jobs, 3, ctypes.byref(bad), P(st), S()) == -1  # no buffers
+
+
+@pytest.mark.parametrize("shapes", [[(48, 40, 96), (20, 36, 96)], [(768, 512, 800), (512, 512, 800), (512, 512, 800), (512, 256, 800)]])
+def test_docvec_finale_against_float64(hip, shapes):
+    """ebn_dvn_finale_f32 at the kernel level: the grouped weight gradients (+ column sums + L2 term) written into a flat gradient buffer,
+    Adam on them in the tiles' epilogues, Adam over a `rest` range, the head's d(q) / d(b) sums + Adam, and the batch loss = sum(loss rows)
+    + l2 * sum of the L2 column-tile sums the forward launches leave in `stat` -- all against float64 (32 x 32 and 64 x 64 tiles)."""
+    from ebrec import _hip
+
+    rng = np.random.default_rng(11 + len(shapes))
+    A_, B_ = 24, 7
+    segs = {}
+    for i, (M, N, K) in enumerate(shapes):
+        segs[f"W{i}"], segs[f"b{i}"] = M * N, N
+    segs.update({"uq": A_, "ub": A_, "rest": 777})
+    offs, numel, th, m, v = _flat_buffers(rng, segs)
+    th_d, m_d, v_d, g_d = dev(th), dev(m), dev(v), torch.zeros(numel, device="cuda")
+    L = len(shapes) - 1  # hidden layers of the pretend encoder: units = the N of every problem but the last
+    a = _hip.DvnArgs()
+    a.n_layers, a.din, a.e_out, a.n0, a.n1, a.drop_p, a.l2 = L, shapes[0][0], shapes[-1][1], shapes[0][2] - 16, 16, 0.0, 0.01
+    for l in range(L):
+        a.units[l] = shapes[l][1]
+    stat = torch.zeros(int(_hip.lib().ebn_dvn_stat_floats(ctypes.byref(a))), device="cuda")
+    a.stat = stat.data_ptr()
+    l2_tiles = [(-(-shapes[l][1] // 64)) for l in range(L)]
+    l2_vals = [rng.random(nt).astype(np.float32) for nt in l2_tiles]
+    l2_base = 20 * sum(shapes[l][1] for l in range(L))
+    for l, vals in enumerate(l2_vals):  # the L2 column-tile sums live behind the accumulators: [EBN_DVN_MAX_LAYERS][1024 / 64]
+        stat[l2_base + l * 16: l2_base + l * 16 + len(vals)] = dev(vals)
+    probs = (_hip.TnProblem * len(shapes))()
+    keep, g = [], np.zeros(numel)
+    for i, (M, N, K) in enumerate(shapes):
+        A, B, W = (rng.standard_normal(s).astype(np.float32) for s in ((K, M), (K, N), (M, N)))
+        dA, dB, dW = dev(A), dev(B), dev(W)
+        q = probs[i]
+        q.M, q.N, q.K, q.A, q.lda, q.B, q.ldb, q.ldc = M, N, K, dA.data_ptr(), M, dB.data_ptr(), N, N
+        q.C, q.colsum = g_d.data_ptr() + 4 * offs[f"W{i}"], g_d.data_ptr() + 4 * offs[f"b{i}"]
+        lam = 0.02 if i < L else 0.0
+        if lam:
+            q.l2_W, q.two_lambda = dW.data_ptr(), lam
+        keep += [dA, dB, dW]
+        g[offs[f"W{i}"]: offs[f"W{i}"] + M * N] = (A.astype(np.float64).T @ B.astype(np.float64) + lam * W).reshape(-1)
+        g[offs[f"b{i}"]: offs[f"b{i}"] + N] = B.astype(np.float64).sum(0)
+    hp_, rows = rng.standard_normal((B_, 2, A_)).astype(np.float32), rng.standard_normal(B_).astype(np.float32)
+    g_rest = rng.standard_normal(777).astype(np.float32)
+    g_d[offs["rest"]: offs["rest"] + 777] = dev(g_rest)
+    g[offs["rest"]: offs["rest"] + 777] = g_rest
+    g[offs["uq"]: offs["uq"] + A_], g[offs["ub"]: offs["ub"] + A_] = hp_.astype(np.float64).sum(0)
+    loss = torch.zeros(1, device="cuda")
+    f = _hip.DvnFinale()
+    f.theta, f.grad, f.m, f.v, f.numel = th_d.data_ptr(), g_d.data_ptr(), m_d.data_ptr(), v_d.data_ptr(), numel
+    f.beta1, f.beta2, f.eps, f.grad_scale, f.n_rest = 0.9, 0.999, 1e-7, 1.0, 1
+    f.rest_off[0], f.rest_len[0] = offs["rest"], 777
+    hp_d, rows_d = dev(hp_), dev(rows)
+    f.head_partials, f.B, f.A, f.dq, f.db = hp_d.data_ptr(), B_, A_, g_d.data_ptr() + 4 * offs["uq"], g_d.data_ptr() + 4 * offs["ub"]
+    f.loss_rows, f.loss_out = rows_d.data_ptr(), loss.data_ptr()
+    st = make_state(seed=0, step=0, lr=1e-3)
+    hip.call("ebn_step_advance", P(st), 0.9, 0.999, S())
+    hip.call("ebn_dvn_finale_f32", ctypes.byref(a), probs, len(shapes), ctypes.byref(f), P(st), S())
+    owned = g != 0
+    assert_close(host(g_d)[owned], g[owned], rtol=2e-5, atol=2e-5 * np.abs(g).max(), what="gradients")
+    want_loss = rows.astype(np.float64).sum() + 0.01 * sum(float(x.astype(np.float64).sum()) for x in l2_vals)
+    assert abs(float(loss.item()) - want_loss) < 1e-5 * max(1.0, abs(want_loss))
+    g_eng = host(g_d)  # Adam is checked on the gradients the launch itself formed (fp32), so that the comparison isolates the optimizer
+    th2, m2, v2 = th.copy(), m.copy(), v.copy()
+    on.adam_keras_step(th2, g_eng, m2, v2, 1, lr=1e-3)
+    th[owned], m[owned], v[owned] = th2[owned], m2[owned], v2[owned]
+    assert_close(host(th_d), th, rtol=1e-5, atol=2e-6, what="theta")
+    assert_close(host(m_d), m, rtol=1e-5, atol=1e-6, what="m")
+    assert_close(host(v_d), v, rtol=1e-5, atol=1e-6 * max(1.0, float(np.abs(v).max())), what="v")
+    f.numel = 10  # a gradient pointer outside the flat buffer is refused
+    assert hip.lib().ebn_dvn_finale_f32(ctypes.byref(a), probs, len(shapes), ctypes.byref(f), P(st), S()) == -1
