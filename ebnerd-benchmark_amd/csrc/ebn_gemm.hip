@@ -1208,14 +1208,6 @@ int launch_gemm_small(int transA, int transB, int64_t M, int64_t N, int64_t K, f
     if (vecA && vecB && fits32) EBN_SMALL_VEC(TA, TB); \
     else EBN_SMALL_ONE(TA, TB, false, false);          \
   } while (0)
-#ifdef EBN_GEMM_EXP_SMALL_NN_T64  /* tuning experiment (tools/build_variant.sh): NN small-output products whose 64 x 64 tiles fit one dispatch round */
-  if (!transA && !transB && vecA && vecB && fits32 && (M % 4) == 0 && (N % 4) == 0 &&
-      ebn_ceil_div(M, 64) * ebn_ceil_div(N, 64) <= 256 && ebn_ceil_div(M, 64) * ebn_ceil_div(N, 64) >= 96) {
-    EBN_SMALL_VEC_T(false, false, 64);
-    EBN_CHECK_LAUNCH();
-    return EBN_OK;
-  }
-#endif
   if (!transA && !transB) EBN_SMALL(false, false);
   else if (!transA && transB) EBN_SMALL(false, true);
   else if (transA && !transB) EBN_SMALL(true, false);
